@@ -1,0 +1,198 @@
+// extern "C" entry points of libgs2m_raster.so (see include/gs2m_raster.h for the contract
+// and the reference interfaces each one replaces).  Orchestration mirrors
+// CudaRasterizer::Rasterizer::forward/backward (cuda_rasterizer/rasterizer_impl.cu:185-438)
+// with the pipeline described in binning.hip.
+#include "common.h"
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) return GS2M_ERR_HIP; \
+    } while (0)
+
+namespace {
+
+// getHigherMsb (rasterizer_impl.cu:31-44): number of key bits that cover the tile ids
+uint32_t higher_msb(uint32_t n) {
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// pinned landing zone for num_rendered, one per host thread (never freed: the HIP runtime
+// may already be gone when thread-local destructors run)
+struct Pinned {
+    uint32_t* p = nullptr;
+};
+thread_local Pinned t_pinned;
+
+}  // namespace
+
+extern "C" {
+
+const char* gs2m_version(void) { return "gs2m_raster 0.1 (gfx950, round 1)"; }
+
+int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
+                        void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* features,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, int feature_count, float* out_color, int* out_radii,
+                        int* out_observe, float* out_buffer, void* stream_) {
+    (void)prefiltered;
+    hipStream_t s = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
+    if (!geometry_alloc || !binning_alloc || !image_alloc || !out_color || !out_buffer || !background) return GS2M_ERR_INVALID_ARG;
+    if (P > 0 && (!means3D || !opacities || !out_radii || !out_observe || !viewmatrix || !projmatrix)) return GS2M_ERR_INVALID_ARG;
+    if (P > 0 && ((shs == nullptr) == (colors_precomp == nullptr))) return GS2M_ERR_INVALID_ARG;
+    if (P > 0 && (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))) return GS2M_ERR_INVALID_ARG;
+    if (P > 0 && shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1) || !cam_pos)) return GS2M_ERR_INVALID_ARG;
+    if (P > 0 && feature_count > 0 && !features) return GS2M_ERR_INVALID_ARG;
+    if (width > 16 * 65535 || height > 16 * 65535) return GS2M_ERR_UNSUPPORTED;
+
+    const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
+    const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    const size_t Pn = P > 0 ? (size_t)P : 1;
+    const size_t gtemp = gs2m_geom_temp_bytes(Pn);
+    GeomState gsz = gs2m_carve_geom(nullptr, Pn, gtemp);
+    char* gbase = geometry_alloc(gsz.total_bytes, geometry_user);
+    if (!gbase) return GS2M_ERR_ALLOC;
+    GeomState g = gs2m_carve_geom(gbase, Pn, gtemp);
+
+    ImageState isz = gs2m_carve_image(nullptr, N, tiles);
+    char* ibase = image_alloc(isz.total_bytes, image_user);
+    if (!ibase) return GS2M_ERR_ALLOC;
+    ImageState im = gs2m_carve_image(ibase, N, tiles);
+
+    int R = 0;
+    if (P > 0) {
+        gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                               colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
+                               tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, s);
+        // 1. depth order of the Gaussians themselves (stable: ties keep id order)
+        HIP_TRY(gs2m_sort_pairs_u32(g.temp, g.temp_bytes, g.depth_key, g.depth_key_sorted, g.gid_iota, g.sorted_gid, (size_t)P, 0, 32, s));
+        // 2. emission offsets in that order
+        gs2m_launch_gather_tt(P, g, s);
+        HIP_TRY(gs2m_exclusive_scan_u32(g.temp, g.temp_bytes, g.sorted_tt, g.sorted_off, (size_t)P, s));
+        gs2m_launch_total(P, g, s);
+        if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the reference has the same sync point (rasterizer_impl.cu:269-270)
+        R = (int)t_pinned.p[0];
+    }
+
+    const int tile_bits = (int)higher_msb((uint32_t)tiles);
+    const size_t Rn = R > 0 ? (size_t)R : 1;
+    const size_t btemp = gs2m_binning_temp_bytes(Rn, tile_bits);
+    BinningState bsz = gs2m_carve_binning(nullptr, Rn, btemp);
+    char* bbase = binning_alloc(bsz.total_bytes, binning_user);
+    if (!bbase) return GS2M_ERR_ALLOC;
+    BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
+
+    HIP_TRY(hipMemsetAsync(im.ranges, 0, tiles * sizeof(uint2), s));
+    if (R > 0) {
+        gs2m_launch_emit(P, tiles_x, g, b, s);
+        HIP_TRY(gs2m_sort_pairs_u32(b.temp, b.temp_bytes, b.keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0, tile_bits, s));
+        gs2m_launch_ranges(R, b, im, s);
+        HIP_TRY(hipMemsetAsync(b.inst_obs, 0, (size_t)R * sizeof(uint32_t), s));
+    }
+    gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
+    if (P > 0) gs2m_launch_observe(P, g, b, out_observe, s);
+    HIP_TRY(hipGetLastError());
+    return R;
+}
+
+int gs2m_raster_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* features, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         float tan_fovx, float tan_fovy, const int* radii, const float* buffer, char* geom_buffer,
+                         char* binning_buffer, char* image_buffer, int feature_count, const float* grad_colors,
+                         const float* grad_buffer, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                         float* dL_drots, float* dL_dfeatures, gs2m_alloc_fn scratch_alloc, void* scratch_user,
+                         void* stream_) {
+    (void)buffer; (void)features;
+    hipStream_t s = (hipStream_t)stream_;
+    if (P == 0) return GS2M_OK;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !scratch_alloc || !grad_colors || !radii) return GS2M_ERR_INVALID_ARG;
+    if (feature_count > 0 && !grad_buffer) return GS2M_ERR_INVALID_ARG;
+    if (!dL_dmeans2D || !dL_dopacities || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drots || !dL_dfeatures) return GS2M_ERR_INVALID_ARG;
+    if (shs && M > 0 && !dL_dshs) return GS2M_ERR_INVALID_ARG;
+
+    const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
+    const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
+    const size_t Rn = R > 0 ? (size_t)R : 1;
+    GeomState g = gs2m_carve_geom(geom_buffer, (size_t)P, gs2m_geom_temp_bytes((size_t)P));
+    BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    ImageState im = gs2m_carve_image(image_buffer, N, tiles);
+
+    const int rowf = gs2m_row_floats(feature_count);
+    const size_t rows_bytes = gs2m_align_up(Rn * (size_t)rowf * sizeof(float));
+    const size_t valid_bytes = gs2m_align_up(Rn);
+    char* sbase = scratch_alloc(rows_bytes + valid_bytes + 2 * GS2M_ALIGN, scratch_user);
+    if (!sbase) return GS2M_ERR_ALLOC;
+    char* al = (char*)gs2m_align_up((size_t)(uintptr_t)sbase);
+    float* rows = (float*)al;
+    uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
+
+    HIP_TRY(hipMemsetAsync(row_valid, 0, Rn, s));
+    if (R > 0)
+        gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors, grad_buffer,
+                              rows, row_valid, s);
+    gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                             viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
+                             rows, row_valid, rowf, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
+                             dL_dcov3D, dL_dshs, dL_dscales, dL_drots, dL_dfeatures, s);
+    HIP_TRY(hipGetLastError());
+    return GS2M_OK;
+}
+
+int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                             uint8_t* present, void* stream_) {
+    (void)projmatrix;
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if (P == 0) return GS2M_OK;
+    if (!means3D || !viewmatrix || !present) return GS2M_ERR_INVALID_ARG;
+    gs2m_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
+    HIP_TRY(hipGetLastError());
+    return GS2M_OK;
+}
+
+int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out) {
+    if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return GS2M_ERR_INVALID_ARG;
+    const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
+    const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
+    const size_t Pn = P > 0 ? (size_t)P : 1, Rn = R > 0 ? (size_t)R : 1;
+    GeomState g = gs2m_carve_geom(nullptr, Pn, gs2m_geom_temp_bytes(Pn));
+    BinningState b = gs2m_carve_binning(nullptr, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    ImageState im = gs2m_carve_image(nullptr, N, tiles);
+    out->geom_bytes = g.total_bytes;
+    out->rec = (uint64_t)(uintptr_t)g.rec;
+    out->tiles_touched = (uint64_t)(uintptr_t)g.tiles_touched;
+    out->depth_key = (uint64_t)(uintptr_t)g.depth_key;
+    out->sorted_gid = (uint64_t)(uintptr_t)g.sorted_gid;
+    out->sorted_off = (uint64_t)(uintptr_t)g.sorted_off;
+    out->clamped = (uint64_t)(uintptr_t)g.clamped;
+    out->binning_bytes = b.total_bytes;
+    out->point_list = (uint64_t)(uintptr_t)b.point_list;
+    out->tile_keys = (uint64_t)(uintptr_t)b.tile_keys;
+    out->inst_obs = (uint64_t)(uintptr_t)b.inst_obs;
+    out->image_bytes = im.total_bytes;
+    out->final_T = (uint64_t)(uintptr_t)im.final_T;
+    out->n_contrib = (uint64_t)(uintptr_t)im.n_contrib;
+    out->ranges = (uint64_t)(uintptr_t)im.ranges;
+    return GS2M_OK;
+}
+
+}  // extern "C"

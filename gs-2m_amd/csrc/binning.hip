@@ -1,0 +1,214 @@
+// Tile binning for gfx950.
+//
+// The reference (cuda_rasterizer/rasterizer_impl.cu:63-103, 265-305) expands every visible
+// Gaussian into (tile<<32 | depth) u64 keys and runs one 45-bit radix sort over all R
+// instances.  Here the work is split so that far fewer bytes move through HBM:
+//   1. depth sort of the P Gaussians themselves (u32 fp32-bit key, id payload), stable;
+//   2. exclusive scan of tiles_touched in that order  -> emission offsets, R;
+//   3. load-balanced emit: instance (tile id, Gaussian id) pairs in depth order, every wave
+//      writes 64 consecutive slots per step (the reference loops serially per thread);
+//   4. stable sort of the R pairs on the tile bits only (13 bits at 1080p instead of 45).
+// Stable sort by tile of a depth-ordered list == sort by (tile, depth) with ties kept in
+// Gaussian-id order, i.e. exactly the reference's sorted list.
+// Sort/scan primitives: rocPRIM device radix sort / scan (library baseline for round 1).
+#include "common.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
+    GeomState g;
+    size_t off = base ? (gs2m_align_up((size_t)(uintptr_t)base) - (size_t)(uintptr_t)base) : 0;
+    auto take = [&](size_t bytes) {  // base == nullptr: the returned "pointers" are byte offsets
+        char* p = (char*)((uintptr_t)base + off);
+        off = gs2m_align_up(off + bytes);
+        return p;
+    };
+    g.rec = (float4*)take(P * REC_Q * sizeof(float4));
+    g.tiles_touched = (uint32_t*)take(P * 4);
+    g.depth_key = (uint32_t*)take(P * 4);
+    g.gid_iota = (uint32_t*)take(P * 4);
+    g.depth_key_sorted = (uint32_t*)take(P * 4);
+    g.sorted_gid = (uint32_t*)take(P * 4);
+    g.sorted_tt = (uint32_t*)take(P * 4);
+    g.sorted_off = (uint32_t*)take(P * 4);
+    g.clamped = (uint8_t*)take(P);
+    g.counters = (uint32_t*)take(64 * 4);
+    g.temp = take(temp_bytes);
+    g.temp_bytes = temp_bytes;
+    g.total_bytes = off + GS2M_ALIGN;
+    return g;
+}
+
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
+    BinningState b;
+    size_t off = base ? (gs2m_align_up((size_t)(uintptr_t)base) - (size_t)(uintptr_t)base) : 0;
+    auto take = [&](size_t bytes) {  // base == nullptr: the returned "pointers" are byte offsets
+        char* p = (char*)((uintptr_t)base + off);
+        off = gs2m_align_up(off + bytes);
+        return p;
+    };
+    b.keys_unsorted = (uint32_t*)take(R * 4);
+    b.vals_unsorted = (uint32_t*)take(R * 4);
+    b.tile_keys = (uint32_t*)take(R * 4);
+    b.point_list = (uint32_t*)take(R * 4);
+    b.inst_obs = (uint32_t*)take(R * 4);
+    b.temp = take(temp_bytes);
+    b.temp_bytes = temp_bytes;
+    b.total_bytes = off + GS2M_ALIGN;
+    return b;
+}
+
+ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
+    ImageState im;
+    size_t off = base ? (gs2m_align_up((size_t)(uintptr_t)base) - (size_t)(uintptr_t)base) : 0;
+    auto take = [&](size_t bytes) {  // base == nullptr: the returned "pointers" are byte offsets
+        char* p = (char*)((uintptr_t)base + off);
+        off = gs2m_align_up(off + bytes);
+        return p;
+    };
+    im.final_T = (float*)take(N * 4);
+    im.n_contrib = (uint32_t*)take(N * 4);
+    im.ranges = (uint2*)take(tiles * sizeof(uint2));
+    im.total_bytes = off + GS2M_ALIGN;
+    return im;
+}
+
+size_t gs2m_geom_temp_bytes(size_t P) {
+    size_t a = 0, b = 0;
+    uint32_t* n = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, P, 0, 32, (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, b, n, n, 0u, P, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return gs2m_align_up(a > b ? a : b) + GS2M_ALIGN;
+}
+
+size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) {
+    size_t a = 0;
+    uint32_t* n = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R, 0, (unsigned)tile_bits, (hipStream_t)0);
+    return gs2m_align_up(a) + GS2M_ALIGN;
+}
+
+hipError_t gs2m_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
+                               const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
+                               hipStream_t s) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
+}
+
+hipError_t gs2m_exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
+                                   hipStream_t s) {
+    return rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+}
+
+namespace {
+
+__global__ void gather_tt_kernel(int P, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ tiles_touched,
+                                 uint32_t* __restrict__ sorted_tt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) sorted_tt[i] = tiles_touched[sorted_gid[i]];
+}
+
+__global__ void total_kernel(int P, const uint32_t* __restrict__ sorted_tt, const uint32_t* __restrict__ sorted_off,
+                             uint32_t* __restrict__ counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[0] = P > 0 ? sorted_off[P - 1] + sorted_tt[P - 1] : 0u;
+}
+
+// Load-balanced expansion (replaces duplicateWithKeys, rasterizer_impl.cu:63-103).
+// One wave owns 64 depth-sorted Gaussians whose instances occupy one contiguous slot range;
+// each step the wave writes 64 consecutive slots, each lane locating its source Gaussian by
+// binary search in the wave's prefix sums.  Also stores the emission offset into the record.
+__global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uint32_t* __restrict__ sorted_gid,
+                                                   const uint32_t* __restrict__ sorted_tt,
+                                                   const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
+                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_pref[4][GS2M_WAVE];
+    __shared__ uint32_t s_gid[4][GS2M_WAVE];
+    __shared__ uint32_t s_rmin[4][GS2M_WAVE];
+    __shared__ uint32_t s_rw[4][GS2M_WAVE];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t cnt = 0, gid = 0, off = 0, rmin = 0, rw = 1;
+    if (i < P) {
+        gid = sorted_gid[i];
+        cnt = sorted_tt[i];
+        off = sorted_off[i];
+    }
+    if (cnt > 0) {
+        float4* r = rec + (size_t)gid * REC_Q + REC_BIN;
+        const float4 bin = *r;
+        rmin = f2u(bin.y);
+        rw = f2u(bin.z) & 0xFFFFu;
+        reinterpret_cast<uint32_t*>(r)[0] = off;
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t base = __shfl(off, 0, 64);
+    s_pref[wave][lane] = incl - cnt;
+    s_gid[wave][lane] = gid;
+    s_rmin[wave][lane] = rmin;
+    s_rw[wave][lane] = rw;
+    __syncthreads();
+    for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
+        const uint32_t j = k + lane;
+        if (j < total) {
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always
+            const uint32_t t = j - s_pref[wave][lo];
+            const uint32_t w = s_rw[wave][lo];
+            const uint32_t ry = t / w, rx = t - ry * w;
+            const uint32_t rm = s_rmin[wave][lo];
+            keys_out[base + j] = ((rm >> 16) + ry) * (uint32_t)tiles_x + (rm & 0xFFFFu) + rx;
+            vals_out[base + j] = s_gid[wave][lo];
+        }
+    }
+}
+
+// identifyTileRanges (rasterizer_impl.cu:108-129) on the sorted tile ids.
+__global__ void ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = tile_keys[idx];
+    if (idx == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = tile_keys[idx - 1];
+        if (cur != prev) {
+            ranges[prev].y = idx;
+            ranges[cur].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+// observe[g] = sum of the per-instance counts the forward blend stored in emission order
+// (replaces the per-pixel atomicAdd at forward.cu:348-350).
+__global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ sorted_tt,
+                               const uint32_t* __restrict__ sorted_off, const uint32_t* __restrict__ inst_obs,
+                               int* __restrict__ observe) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t n = sorted_tt[i], off = sorted_off[i];
+    uint32_t sum = 0;
+    for (uint32_t t = 0; t < n; t++) sum += inst_obs[off + t];
+    observe[sorted_gid[i]] = (int)sum;
+}
+
+}  // namespace
+
+void gs2m_launch_gather_tt(int P, const GeomState& g, hipStream_t s) {
+    gather_tt_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.tiles_touched, g.sorted_tt);
+}
+void gs2m_launch_total(int P, const GeomState& g, hipStream_t s) {
+    total_kernel<<<1, 64, 0, s>>>(P, g.sorted_tt, g.sorted_off, g.counters);
+}
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s) {
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
+                                                b.vals_unsorted);
+}
+void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s) {
+    if (R > 0) ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, b.tile_keys, im.ranges);
+}
+void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s) {
+    observe_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, b.inst_obs, out_observe);
+}

@@ -1,0 +1,256 @@
+// Per-tile back-to-front gradient pass (backward of the alpha compositing) for gfx950.
+//
+// Semantics: renderCUDA, diff-gaussian-rasterization/cuda_rasterizer/backward.cu:413-598.
+// The reference issues (11 + fc) float atomicAdds per contributing pixel x Gaussian pair.  On
+// MI355X global float atomics run at ~1.3 TB/s of added bytes and an order of magnitude
+// slower when 64 lanes hit 64 rows, so that shape cannot be carried over.  This kernel uses
+// NO global atomics:
+//   * each wave (one 8x8 pixel quadrant) reduces the 11 + fc partial values of an instance
+//     over its 64 lanes with DPP adds (quad_perm / row_mirror / row_bcast), only for
+//     instances that survive the quadrant rectangle test AND have a contributing lane;
+//   * the four waves' sums are combined in LDS in a fixed order and the workgroup stores one
+//     row per (tile, Gaussian) instance with plain coalesced stores, addressed by the
+//     instance's EMISSION slot, so all rows of one Gaussian are contiguous in HBM;
+//   * gaussian_bwd.hip then sums each Gaussian's contiguous rows (a streaming read) while it
+//     runs the rest of the per-Gaussian backward.  Gradients are bitwise reproducible.
+// The per-pixel recurrence is restated with one scalar suffix sum: with gc = <g, c_i> over
+// the 3 colour + fc feature channels, w_i = alpha_i*T_i and Sg_i = sum_{j>i} gc_j*w_j
+// (+ T_final*<bg, g_colour>), dL/dalpha_i = T_i*gc_i - Sg_i/(1 - alpha_i), which equals
+// backward.cu:541-566 (accum_rec/last_color per channel) term by term.
+#include "common.h"
+
+namespace {
+
+constexpr int BB = 64;  // instances per batch: one per lane in the quadrant test
+
+template <int FQ>
+__global__ void __launch_bounds__(256) blend_bwd_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, int W,
+    int H, int tiles_x, const float* __restrict__ bg, int fc, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
+    const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
+    constexpr int NQ = 4 + FQ;
+    constexpr int NV = ROW_FEAT + 4 * FQ;  // values reduced per instance (row length in floats)
+    constexpr int RQ = NV / 4 + ((NV % 4) ? 1 : 0);
+    constexpr int ROWF = RQ * 4;
+    __shared__ float4 s_v[NQ][BB];
+    __shared__ float4 s_orig[BB];  // A, B, C (unscaled conic), opacity
+    __shared__ uint32_t s_gid[BB];
+    __shared__ uint32_t s_slot[BB];
+    __shared__ __align__(16) float s_acc[4][BB][ROWF];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ uint32_t s_max;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int px = tile_x * GS2M_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tile_y * GS2M_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)(tile_x * GS2M_TILE + (wave & 1) * 8), bx1 = bx0 + 7.0f;
+    const float by0 = (float)(tile_y * GS2M_TILE + (wave >> 1) * 8), by1 = by0 + 7.0f;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+
+    const uint2 range = ranges[tile];
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float T = T_final;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float4 gf[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; q++) gf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) {
+        g0 = grad_color[pix];
+        g1 = grad_color[HW + pix];
+        g2 = grad_color[2 * HW + pix];
+        float t[12];
+#pragma unroll
+        for (int ch = 0; ch < 12; ch++) t[ch] = (ch < fc && ch < 4 * FQ) ? grad_buffer[ch * HW + pix] : 0.f;
+#pragma unroll
+        for (int q = 0; q < FQ; q++) gf[q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+    }
+    // suffix sum seeded with the background term (backward.cu:562-566)
+    float Sg = T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // entries past the tile's largest n_contrib are never touched by any pixel
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    {
+        uint32_t m = last;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    const int maxc = (int)s_max;
+    const int nb = (maxc + BB - 1) / BB;
+    int prev_cnt = 0;
+
+    for (int b = nb - 1; b >= -1; b--) {
+        __syncthreads();  // (S1) previous batch fully accumulated
+        if (prev_cnt > 0) {
+            // write the rows of the previous batch: 8 lanes x 16 B per row, fixed wave order
+            unsigned long long any = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+            const int q = tid & 7;
+#pragma unroll
+            for (int r = 0; r < BB / 32; r++) {
+                const int row = r * 32 + (tid >> 3);
+                if (row < prev_cnt && ((any >> row) & 1ull)) {
+                    const uint32_t slot = s_slot[row];
+                    if (q < RQ) {
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            if ((s_mask[w] >> row) & 1ull) {
+                                const float4 v = *reinterpret_cast<const float4*>(&s_acc[w][row][4 * q]);
+                                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                            }
+                        }
+                        reinterpret_cast<float4*>(rows + (size_t)slot * ROWF)[q] = acc;
+                    }
+                    if (q == 7) row_valid[slot] = 1;
+                }
+            }
+        }
+        if (b < 0) break;
+        const int base = b * BB;
+        const int cnt = min(BB, maxc - base);
+        if (tid < cnt) s_gid[tid] = point_list[range.x + base + tid];
+        __syncthreads();  // (S2)
+        {
+            const int q = tid & 7;
+            if (q < NQ) {
+#pragma unroll
+                for (int r = 0; r < BB / 32; r++) {
+                    const int row = r * 32 + (tid >> 3);
+                    if (row < cnt) {
+                        float4 v = rec[(size_t)s_gid[row] * REC_Q + q];
+                        if (q == REC_GEO0) {
+                            s_orig[row].x = v.z;
+                            s_orig[row].y = v.w;
+                            v.z *= (-0.5f * GS2M_LOG2E);
+                            v.w *= (-GS2M_LOG2E);
+                        } else if (q == REC_GEO1) {
+                            s_orig[row].z = v.x;
+                            s_orig[row].w = v.y;
+                            v.x *= (-0.5f * GS2M_LOG2E);
+                        } else if (q == REC_BIN) {
+                            const uint32_t off = f2u(v.x), rm = f2u(v.y), rw = f2u(v.z) & 0xFFFFu;
+                            s_slot[row] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
+                        }
+                        s_v[q][row] = v;
+                    }
+                }
+            }
+            if (tid < 4) s_mask[tid] = 0ull;
+        }
+        __syncthreads();  // (S3)
+        prev_cnt = cnt;
+
+        bool hit = false;
+        if (lane < cnt) {
+            const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
+            hit = (a.x + c.z >= bx0) && (a.x - c.z <= bx1) && (a.y + c.w >= by0) && (a.y - c.w <= by1);
+        }
+        unsigned long long mask = __ballot(hit);
+        unsigned long long wrote = 0ull;
+        while (mask) {
+            const int jj = 63 - __builtin_clzll(mask);  // back to front
+            mask &= ~(1ull << jj);
+            const uint32_t pos = (uint32_t)(base + jj + 1);  // 1-based list position
+            const float4 a = s_v[REC_GEO0][jj], c = s_v[REC_GEO1][jj];
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float p2 = gs2m_power2(dx, dy, a.z, a.w, c.x);
+            const float G = gs2m_exp2(p2);
+            const float alpha = fminf(0.99f, c.y * G);
+            const bool contrib = (pos <= last) && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
+            if (__ballot(contrib) == 0ull) continue;
+
+            float v[NV];
+            if (contrib) {
+                const float inv1ma = 1.0f / (1.f - alpha);
+                T = T * inv1ma;
+                const float w = alpha * T;
+                const float4 col = s_v[REC_RGB][jj];
+                float gc = col.x * g0;
+                gc = __builtin_fmaf(col.y, g1, gc);
+                gc = __builtin_fmaf(col.z, g2, gc);
+                v[ROW_COL + 0] = w * g0;
+                v[ROW_COL + 1] = w * g1;
+                v[ROW_COL + 2] = w * g2;
+#pragma unroll
+                for (int q = 0; q < FQ; q++) {
+                    const float4 f = s_v[REC_FEAT + q][jj];
+                    gc = __builtin_fmaf(f.x, gf[q].x, gc);
+                    gc = __builtin_fmaf(f.y, gf[q].y, gc);
+                    gc = __builtin_fmaf(f.z, gf[q].z, gc);
+                    gc = __builtin_fmaf(f.w, gf[q].w, gc);
+                    v[ROW_FEAT + 4 * q + 0] = w * gf[q].x;
+                    v[ROW_FEAT + 4 * q + 1] = w * gf[q].y;
+                    v[ROW_FEAT + 4 * q + 2] = w * gf[q].z;
+                    v[ROW_FEAT + 4 * q + 3] = w * gf[q].w;
+                }
+                const float dL_dalpha = T * gc - Sg * inv1ma;
+                Sg = __builtin_fmaf(gc, w, Sg);
+                const float4 o = s_orig[jj];  // A, B, C, opacity
+                const float dL_dG = o.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * o.x - gdy * o.y;
+                const float dG_ddely = -gdy * o.z - gdx * o.y;
+                const float mx = dL_dG * dG_ddelx * ddelx_dx;
+                const float my = dL_dG * dG_ddely * ddely_dy;
+                v[0] = mx;
+                v[1] = my;
+                v[2] = fabsf(mx);
+                v[3] = fabsf(my);
+                v[4] = -0.5f * gdx * dx * dL_dG;
+                v[5] = -0.5f * gdx * dy * dL_dG;
+                v[6] = -0.5f * gdy * dy * dL_dG;
+                v[7] = G * dL_dalpha;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; k++) v[k] = 0.f;
+            }
+            // 64-lane sums; totals are valid in lanes 48..63, lane 48+k keeps value k (mod 16)
+            float o0 = 0.f, o1 = 0.f;
+            const int l16 = lane - 48;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const float tot = wave_sum_row3(v[k]);
+                if (k < 16) o0 = (l16 == k) ? tot : o0;
+                else o1 = (l16 == k - 16) ? tot : o1;
+            }
+            if (l16 >= 0) {
+                s_acc[wave][jj][l16] = o0;
+                if (NV > 16 && l16 < ROWF - 16) s_acc[wave][jj][16 + l16] = o1;
+            }
+            wrote |= (1ull << jj);
+        }
+        if (lane == 0) s_mask[wave] = wrote;
+    }
+}
+
+}  // namespace
+
+int gs2m_row_floats(int fc) {
+    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
+    const int nv = ROW_FEAT + 4 * fq;
+    return ((nv + 3) / 4) * 4;
+}
+
+void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                           const BinningState& b, const ImageState& im, const float* grad_color,
+                           const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s) {
+    const int tiles = tiles_x * tiles_y;
+    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
+#define GS2M_BWD(FQ)                                                                                              \
+    blend_bwd_kernel<FQ><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, im.final_T, \
+                                               im.n_contrib, grad_color, grad_buffer, rows, row_valid)
+    if (fq == 1) GS2M_BWD(1);
+    else if (fq == 2) GS2M_BWD(2);
+    else GS2M_BWD(3);
+#undef GS2M_BWD
+}

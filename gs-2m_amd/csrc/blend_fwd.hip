@@ -1,0 +1,186 @@
+// Per-tile front-to-back alpha compositing (forward) for gfx950.
+//
+// Semantics: renderCUDA, diff-gaussian-rasterization/cuda_rasterizer/forward.cu:246-372.
+// One 256-thread workgroup per 16x16 tile as in the reference, but organised for 64-lane
+// wavefronts: each of the 4 waves owns one 8x8 pixel quadrant.  Per batch of 256 sorted
+// instances the workgroup gathers the 128-B blend records cooperatively (8 lanes x 16 B per
+// record, full-line reads) into LDS -- geometry AND colour/feature rows, the reference only
+// stages geometry and re-reads colours from global per pixel.  Each wave then tests 64
+// instances at a time (one per lane) against its quadrant's rectangle, takes a 64-bit
+// ballot, and walks only the set bits; the per-instance data is then read from LDS with a
+// wave-uniform address (broadcast).  Skipped instances cannot contribute (alpha < 1/255
+// over the whole quadrant, see preprocess.hip), so results are unchanged.
+// `observe` is accumulated per instance in LDS (one popcount of a ballot per wave) and stored
+// once per instance in emission order -- no global atomics (forward.cu:348-350 uses one
+// atomicAdd per pixel); binning.hip:observe_kernel reduces them per Gaussian.
+#include "common.h"
+
+namespace {
+
+constexpr int BATCH = 256;
+
+template <int FQ>  // number of float4 feature quads staged (1..3)
+__global__ void __launch_bounds__(256) blend_fwd_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, int W,
+    int H, int tiles_x, const float* __restrict__ bg, int fc, float* __restrict__ out_color,
+    float* __restrict__ out_buffer, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    uint32_t* __restrict__ inst_obs) {
+    constexpr int NQ = 4 + FQ;  // record quads staged: geo0, geo1, bin, rgb, feat...
+    __shared__ float4 s_v[NQ][BATCH];
+    __shared__ uint32_t s_gid[BATCH];
+    __shared__ uint32_t s_slot[BATCH];
+    __shared__ int s_obs[BATCH];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int px = tile_x * GS2M_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tile_y * GS2M_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)(tile_x * GS2M_TILE + (wave & 1) * 8), bx1 = bx0 + 7.0f;
+    const float by0 = (float)(tile_y * GS2M_TILE + (wave >> 1) * 8), by1 = by0 + 7.0f;
+
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float4 F[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; q++) F[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool done = !inside;
+    int prev_cnt = 0;
+
+    for (int base = 0; base < len; base += BATCH) {
+        // (S1) everyone finished the previous batch; vote on early exit (forward.cu:300-302)
+        const int num_done = __syncthreads_count(done);
+        if (prev_cnt > 0 && tid < prev_cnt) {
+            const int o = s_obs[tid];
+            if (o != 0) inst_obs[s_slot[tid]] = (uint32_t)o;
+        }
+        prev_cnt = 0;
+        if (num_done == 256) break;
+        const int cnt = min(BATCH, len - base);
+        if (tid < cnt) s_gid[tid] = point_list[range.x + base + tid];
+        __syncthreads();  // (S2) s_obs/s_slot of the previous batch consumed, gids visible
+        {
+            const int q = tid & 7;
+            if (q < NQ) {
+#pragma unroll
+                for (int r = 0; r < BATCH / 32; r++) {
+                    const int row = r * 32 + (tid >> 3);
+                    if (row < cnt) {
+                        float4 v = rec[(size_t)s_gid[row] * REC_Q + q];
+                        if (q == REC_GEO0) {
+                            v.z *= (-0.5f * GS2M_LOG2E);
+                            v.w *= (-GS2M_LOG2E);
+                        } else if (q == REC_GEO1) {
+                            v.x *= (-0.5f * GS2M_LOG2E);
+                        } else if (q == REC_BIN) {
+                            const uint32_t off = f2u(v.x), rm = f2u(v.y), rw = f2u(v.z) & 0xFFFFu;
+                            s_slot[row] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
+                        }
+                        s_v[q][row] = v;
+                    }
+                }
+            }
+            s_obs[tid] = 0;
+        }
+        __syncthreads();  // (S3) batch staged
+        prev_cnt = cnt;
+
+        if (__ballot(!done) != 0ull) {
+            for (int sub = 0; sub < cnt; sub += GS2M_WAVE) {
+                const int j = sub + lane;
+                bool hit = false;
+                if (j < cnt) {
+                    const float4 a = s_v[REC_GEO0][j], b = s_v[REC_GEO1][j];
+                    hit = (a.x + b.z >= bx0) && (a.x - b.z <= bx1) && (a.y + b.w >= by0) && (a.y - b.w <= by1);
+                }
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int bit = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int jj = sub + bit;  // wave-uniform
+                    const float4 a = s_v[REC_GEO0][jj], b = s_v[REC_GEO1][jj];
+                    const float dx = a.x - pxf, dy = a.y - pyf;
+                    const float p2 = gs2m_power2(dx, dy, a.z, a.w, b.x);
+                    const float alpha = fminf(0.99f, b.y * gs2m_exp2(p2));
+                    bool contrib = !done && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                    const float test_T = T * (1.0f - alpha);
+                    if (contrib && test_T < 0.0001f) {
+                        done = true;
+                        contrib = false;
+                    }
+                    if (contrib) {
+                        const float w = alpha * T;
+                        const float4 c = s_v[REC_RGB][jj];
+                        C0 = __builtin_fmaf(c.x, w, C0);
+                        C1 = __builtin_fmaf(c.y, w, C1);
+                        C2 = __builtin_fmaf(c.z, w, C2);
+#pragma unroll
+                        for (int q = 0; q < FQ; q++) {
+                            const float4 f = s_v[REC_FEAT + q][jj];
+                            F[q].x = __builtin_fmaf(f.x, w, F[q].x);
+                            F[q].y = __builtin_fmaf(f.y, w, F[q].y);
+                            F[q].z = __builtin_fmaf(f.z, w, F[q].z);
+                            F[q].w = __builtin_fmaf(f.w, w, F[q].w);
+                        }
+                        last_contributor = (uint32_t)(base + jj + 1);
+                    }
+                    const unsigned long long seen = __ballot(contrib && T > 0.5f);
+                    if (seen != 0ull && lane == 0) atomicAdd(&s_obs[jj], (int)__popcll(seen));
+                    if (contrib) T = test_T;
+                    if (__ballot(!done) == 0ull) {
+                        mask = 0ull;
+                        sub = cnt;  // leave both loops
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (prev_cnt > 0 && tid < prev_cnt) {
+        const int o = s_obs[tid];
+        if (o != 0) inst_obs[s_slot[tid]] = (uint32_t)o;
+    }
+
+    if (inside) {
+        const size_t HW = (size_t)H * W;
+        const size_t pix = (size_t)py * W + px;
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        float f[12];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q < FQ) {
+                f[4 * q] = F[q].x; f[4 * q + 1] = F[q].y; f[4 * q + 2] = F[q].z; f[4 * q + 3] = F[q].w;
+            } else {
+                f[4 * q] = f[4 * q + 1] = f[4 * q + 2] = f[4 * q + 3] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < GS2M_NUM_FEATURES; ch++) out_buffer[ch * HW + pix] = ch < fc ? f[ch] : 0.0f;
+    }
+}
+
+}  // namespace
+
+void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                           const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
+                           hipStream_t s) {
+    const int tiles = tiles_x * tiles_y;
+    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
+#define GS2M_FWD(FQ)                                                                                              \
+    blend_fwd_kernel<FQ><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, out_color, \
+                                               out_buffer, im.final_T, im.n_contrib, b.inst_obs)
+    if (fq == 1) GS2M_FWD(1);
+    else if (fq == 2) GS2M_FWD(2);
+    else GS2M_FWD(3);
+#undef GS2M_FWD
+}

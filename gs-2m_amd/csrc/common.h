@@ -1,0 +1,157 @@
+// Internal declarations shared by the HIP translation units of libgs2m_raster.so.
+// gfx950 (MI355X) only: wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gs2m_raster.h"
+
+#define GS2M_ALIGN 256
+#define GS2M_WAVE 64
+
+// ---- blend record: 8 x float4 = 128 B per Gaussian (one aligned HBM line) -------------
+// q0: x, y, A, B          pixel-space mean, conic (A = conic.x, B = conic.y)
+// q1: C, opacity, hx, hy  conic.z, opacity, half extents of the alpha >= 1/255 ellipse
+// q2: off, rmin, rwh, z   u32 emission offset, tile rect min (x | y << 16), rect (w | h << 16), depth
+// q3: r, g, b, -          colour (SH-evaluated or precomputed)
+// q4..q6: features[0..9], 2 pad floats
+// q7: unused
+#define REC_Q 8
+#define REC_GEO0 0
+#define REC_GEO1 1
+#define REC_BIN 2
+#define REC_RGB 3
+#define REC_FEAT 4
+
+// per tile-instance partial-gradient row produced by the blend backward (floats):
+// 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature
+#define ROW_GEOM 8
+#define ROW_COL 8
+#define ROW_FEAT 11
+
+static inline size_t gs2m_align_up(size_t x, size_t a = GS2M_ALIGN) { return (x + a - 1) & ~(a - 1); }
+
+struct GeomState {
+    float4* rec;             // P * 8
+    uint32_t* tiles_touched; // P (by Gaussian id)
+    uint32_t* depth_key;     // P
+    uint32_t* gid_iota;      // P
+    uint32_t* depth_key_sorted; // P
+    uint32_t* sorted_gid;    // P
+    uint32_t* sorted_tt;     // P
+    uint32_t* sorted_off;    // P
+    uint8_t* clamped;        // P
+    uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
+    char* temp;              // rocPRIM temporary storage
+    size_t temp_bytes;
+    size_t total_bytes;      // including alignment slack
+};
+struct BinningState {
+    uint32_t* keys_unsorted; // R
+    uint32_t* vals_unsorted; // R
+    uint32_t* tile_keys;     // R (sorted)
+    uint32_t* point_list;    // R (sorted Gaussian ids)
+    uint32_t* inst_obs;      // R
+    char* temp;
+    size_t temp_bytes;
+    size_t total_bytes;
+};
+struct ImageState {
+    float* final_T;      // N
+    uint32_t* n_contrib; // N
+    uint2* ranges;       // tiles
+    size_t total_bytes;
+};
+
+// carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
+GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes);
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
+ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
+
+// rocPRIM-backed primitives (binning.hip)
+size_t gs2m_geom_temp_bytes(size_t P);
+size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
+hipError_t gs2m_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
+                               const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
+                               hipStream_t s);
+hipError_t gs2m_exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
+                                   hipStream_t s);
+
+// kernel launchers
+void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                            const float* rotations, const float* opacities, const float* shs,
+                            const float* cov3D_precomp, const float* colors_precomp, const float* features,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
+                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
+                            int* radii, const GeomState& g, hipStream_t s);
+void gs2m_launch_gather_tt(int P, const GeomState& g, hipStream_t s);
+void gs2m_launch_total(int P, const GeomState& g, hipStream_t s);
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s);
+void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
+void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                           const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
+                           hipStream_t s);
+void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s);
+int gs2m_row_floats(int fc);
+void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                           const BinningState& b, const ImageState& im, const float* grad_color,
+                           const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
+void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
+                              int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
+                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                              float* dL_drots, float* dL_dfeatures, hipStream_t s);
+void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+
+#ifdef __HIPCC__
+// ---- device helpers -----------------------------------------------------------------
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// DPP cross-lane move (gfx9 encodings).  Lanes masked off by row_mask/bank_mask get 0.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+#define DPP_QUAD_XOR1 0xB1     // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E     // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_ROW_SHR(n) (0x110 + (n))
+
+// Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (row 3).
+__device__ __forceinline__ float wave_sum_row3(float v) {
+    v += dpp_mov0<DPP_QUAD_XOR1>(v);
+    v += dpp_mov0<DPP_QUAD_XOR2>(v);
+    v += dpp_mov0<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov0<DPP_ROW_MIRROR>(v);
+    v += dpp_mov0<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_mov0<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave (u32).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// alpha evaluation shared bit-for-bit by the forward and backward blend kernels.
+// a2, b2, c2 are the conic pre-scaled by -0.5*log2(e), -log2(e), -0.5*log2(e) so that
+// exp(power) = exp2(p2);  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy  (CR/forward.cu:326-337).
+#define GS2M_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float gs2m_power2(float dx, float dy, float a2, float b2, float c2) {
+    float t = __builtin_fmaf(b2, dy, a2 * dx);
+    return __builtin_fmaf(c2 * dy, dy, t * dx);
+}
+__device__ __forceinline__ float gs2m_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif

@@ -1,0 +1,336 @@
+// Per-Gaussian backward for gfx950: one pass that (1) sums the Gaussian's contiguous
+// partial-gradient rows written by blend_bwd.hip, (2) back-propagates conic -> 2D covariance ->
+// 3D covariance and view-space mean, (3) the projection of the 2D mean, (4) SH colour and
+// (5) scale / rotation, and writes EVERY element of every gradient tensor (zeros for culled
+// Gaussians), so the caller does not have to pre-zero 344 B per Gaussian as the reference's
+// binding does (rasterize_points.cu:150-159).
+//
+// Semantics: computeCov2DCUDA backward.cu:153-281, preprocessCUDA (bwd) backward.cu:352-410,
+// computeColorFromSH (bwd) backward.cu:23-148, computeCov3D (bwd) backward.cu:285-347 of
+// diff-gaussian-rasterization/cuda_rasterizer, including the quirks listed in SURVEY.md A.5
+// (+0.3 low-pass only here, clamp masks, no quaternion normalisation).
+#include "common.h"
+
+namespace {
+
+struct M3 {
+    float m[3][3];  // m[col][row]
+};
+__device__ __forceinline__ M3 m3_cols(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+    M3 r;
+    r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
+    r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+    r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+    return r;
+}
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+    return R;
+}
+
+__constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                             0.5462742152960396f};
+__constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                             -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+__global__ void __launch_bounds__(256) gaussian_bwd_kernel(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ vm,
+    const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
+    float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
+    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ rows,
+    const uint8_t* __restrict__ row_valid, int rowf, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
+    float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const bool visible = radii[idx] > 0;
+
+    float acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0.f;
+    if (visible) {
+        const uint32_t off = f2u(rec[(size_t)idx * REC_Q + REC_BIN].x);
+        const uint32_t n = tiles_touched[idx];
+        const int rq = rowf >> 2;
+        for (uint32_t t = 0; t < n; t++) {
+            if (!row_valid[off + t]) continue;
+            const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t) * rowf);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q < rq) {
+                    const float4 v = r4[q];
+                    acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                }
+            }
+        }
+    }
+    // ---- gradients that are plain sums of the rows ----
+    reinterpret_cast<float4*>(dL_dmeans2D)[idx] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (dL_dconics) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(acc[4], acc[5], 0.f, acc[6]);
+    dL_dopacities[idx] = acc[7];
+    dL_dcolors[3 * idx] = acc[ROW_COL]; dL_dcolors[3 * idx + 1] = acc[ROW_COL + 1]; dL_dcolors[3 * idx + 2] = acc[ROW_COL + 2];
+#pragma unroll
+    for (int ch = 0; ch < GS2M_NUM_FEATURES; ch++)
+        dL_dfeatures[(size_t)idx * GS2M_NUM_FEATURES + ch] = ch < fc ? acc[ROW_FEAT + ch] : 0.f;
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (visible) {
+        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+        // ---- 3D covariance (recomputed exactly as preprocess.hip does) ----
+        float c3[6];
+        float sx = 0.f, sy = 0.f, sz = 0.f, qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        M3 R, Mm;
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
+        } else {
+            sx = scale_modifier * scales[3 * idx]; sy = scale_modifier * scales[3 * idx + 1];
+            sz = scale_modifier * scales[3 * idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            const float r = qr, x = qx, y = qy, z = qz;
+            M3 S = m3_cols(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+            R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+            Mm = m3_mul(S, R);
+            M3 Sig = m3_mul(m3_t(Mm), Mm);
+            c3[0] = Sig.m[0][0]; c3[1] = Sig.m[0][1]; c3[2] = Sig.m[0][2];
+            c3[3] = Sig.m[1][1]; c3[4] = Sig.m[1][2]; c3[5] = Sig.m[2][2];
+        }
+        // ---- computeCov2DCUDA ----
+        const float dcx = acc[4], dcy = acc[5], dcz = acc[6];
+        float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float tz_ = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float txtz = tx / tz_, tytz = ty / tz_;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        M3 J = m3_cols(h_x / tz_, 0.0f, -(h_x * tx) / (tz_ * tz_), 0.0f, h_y / tz_, -(h_y * ty) / (tz_ * tz_), 0.f, 0.f, 0.f);
+        M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+        M3 Vrk = m3_cols(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        M3 T = m3_mul(Wm, J);
+        M3 cov2D = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+        const float a = cov2D.m[0][0] + 0.3f;  // low-pass appears only in the backward (backward.cu:205-207)
+        const float b = cov2D.m[0][1];
+        const float c = cov2D.m[1][1] + 0.3f;
+        const float denom = a * c - b * b;
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define TT(i, j) T.m[i][j]
+#define VV(i, j) Vrk.m[i][j]
+#define WW(i, j) Wm.m[i][j]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        }
+        const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                              (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                              (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                              (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                              (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                              (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                              (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+        const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+        const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+        const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+        const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef TT
+#undef VV
+#undef WW
+        const float tz = 1.f / tz_;
+        const float tz2 = tz * tz;
+        const float tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 + (2 * h_y * ty) * tz3 * dL_dJ12;
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+        // ---- projection of the 2D mean (backward.cu:376-392) ----
+        {
+            const float m_hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+            const float m_w = 1.0f / (m_hw + 0.0000001f);
+            const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+            const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+            const float gx = acc[0], gy = acc[1];
+            dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
+            dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
+            dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
+        }
+
+        // ---- SH colour backward (backward.cu:23-148) ----
+        if (shs != nullptr) {
+            const float ox = mx - campos[0], oy = my - campos[1], oz = mz - campos[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+            const float* sh = shs + (size_t)idx * M * 3;
+            float* dsh = dL_dshs + (size_t)idx * M * 3;
+            const uint8_t cl = clamped[idx];
+            float g[3] = {acc[ROW_COL] * ((cl & 1) ? 0.f : 1.f), acc[ROW_COL + 1] * ((cl & 2) ? 0.f : 1.f),
+                          acc[ROW_COL + 2] * ((cl & 4) ? 0.f : 1.f)};
+            float dRdx[3] = {0.f, 0.f, 0.f}, dRdy[3] = {0.f, 0.f, 0.f}, dRdz[3] = {0.f, 0.f, 0.f};
+#define SHv(k, c_) sh[(k) * 3 + (c_)]
+#define DSH(k, val)                                           \
+    do {                                                      \
+        const float v_ = (val);                               \
+        dsh[(k) * 3 + 0] = v_ * g[0];                         \
+        dsh[(k) * 3 + 1] = v_ * g[1];                         \
+        dsh[(k) * 3 + 2] = v_ * g[2];                         \
+    } while (0)
+            DSH(0, SH_C0);
+            if (D > 0) {
+                DSH(1, -SH_C1 * y);
+                DSH(2, SH_C1 * z);
+                DSH(3, -SH_C1 * x);
+#pragma unroll
+                for (int c_ = 0; c_ < 3; c_++) {
+                    dRdx[c_] = -SH_C1 * SHv(3, c_);
+                    dRdy[c_] = -SH_C1 * SHv(1, c_);
+                    dRdz[c_] = SH_C1 * SHv(2, c_);
+                }
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    DSH(4, kC2[0] * xy);
+                    DSH(5, kC2[1] * yz);
+                    DSH(6, kC2[2] * (2.f * zz - xx - yy));
+                    DSH(7, kC2[3] * xz);
+                    DSH(8, kC2[4] * (xx - yy));
+#pragma unroll
+                    for (int c_ = 0; c_ < 3; c_++) {
+                        dRdx[c_] += kC2[0] * y * SHv(4, c_) + kC2[2] * 2.f * -x * SHv(6, c_) + kC2[3] * z * SHv(7, c_) + kC2[4] * 2.f * x * SHv(8, c_);
+                        dRdy[c_] += kC2[0] * x * SHv(4, c_) + kC2[1] * z * SHv(5, c_) + kC2[2] * 2.f * -y * SHv(6, c_) + kC2[4] * 2.f * -y * SHv(8, c_);
+                        dRdz[c_] += kC2[1] * y * SHv(5, c_) + kC2[2] * 2.f * 2.f * z * SHv(6, c_) + kC2[3] * x * SHv(7, c_);
+                    }
+                    if (D > 2) {
+                        DSH(9, kC3[0] * y * (3.f * xx - yy));
+                        DSH(10, kC3[1] * xy * z);
+                        DSH(11, kC3[2] * y * (4.f * zz - xx - yy));
+                        DSH(12, kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                        DSH(13, kC3[4] * x * (4.f * zz - xx - yy));
+                        DSH(14, kC3[5] * z * (xx - yy));
+                        DSH(15, kC3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+                        for (int c_ = 0; c_ < 3; c_++) {
+                            dRdx[c_] += (kC3[0] * SHv(9, c_) * 3.f * 2.f * xy + kC3[1] * SHv(10, c_) * yz +
+                                         kC3[2] * SHv(11, c_) * -2.f * xy + kC3[3] * SHv(12, c_) * -3.f * 2.f * xz +
+                                         kC3[4] * SHv(13, c_) * (-3.f * xx + 4.f * zz - yy) +
+                                         kC3[5] * SHv(14, c_) * 2.f * xz + kC3[6] * SHv(15, c_) * 3.f * (xx - yy));
+                            dRdy[c_] += (kC3[0] * SHv(9, c_) * 3.f * (xx - yy) + kC3[1] * SHv(10, c_) * xz +
+                                         kC3[2] * SHv(11, c_) * (-3.f * yy + 4.f * zz - xx) +
+                                         kC3[3] * SHv(12, c_) * -3.f * 2.f * yz + kC3[4] * SHv(13, c_) * -2.f * xy +
+                                         kC3[5] * SHv(14, c_) * -2.f * yz + kC3[6] * SHv(15, c_) * -3.f * 2.f * xy);
+                            dRdz[c_] += (kC3[1] * SHv(10, c_) * xy + kC3[2] * SHv(11, c_) * 4.f * 2.f * yz +
+                                         kC3[3] * SHv(12, c_) * 3.f * (2.f * zz - xx - yy) +
+                                         kC3[4] * SHv(13, c_) * 4.f * 2.f * xz + kC3[5] * SHv(14, c_) * (xx - yy));
+                        }
+                    }
+                }
+            }
+            // coefficients above the active degree receive no gradient
+            for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+#undef SHv
+#undef DSH
+            const float ddx = dRdx[0] * g[0] + dRdx[1] * g[1] + dRdx[2] * g[2];
+            const float ddy = dRdy[0] * g[0] + dRdy[1] * g[1] + dRdy[2] * g[2];
+            const float ddz = dRdz[0] * g[0] + dRdz[1] * g[1] + dRdz[2] * g[2];
+            // dnormvdv (auxiliary.h:111-120)
+            const float sum2 = ox * ox + oy * oy + oz * oz;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+            dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+            dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+        }
+
+        // ---- scale / rotation backward (backward.cu:285-347) ----
+        if (scales != nullptr) {
+            const float r = qr, x = qx, y = qy, z = qz;
+            M3 dSig = m3_cols(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                              0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+            M3 M2;
+#pragma unroll
+            for (int c_ = 0; c_ < 3; c_++)
+#pragma unroll
+                for (int r_ = 0; r_ < 3; r_++) M2.m[c_][r_] = Mm.m[c_][r_] * 2.0f;
+            M3 dM = m3_mul(M2, dSig);
+            M3 Rt = m3_t(R);
+            M3 dMt = m3_t(dM);
+            dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+            dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+            dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { dMt.m[0][j] *= sx; dMt.m[1][j] *= sy; dMt.m[2][j] *= sz; }
+#define Dm(i, j) dMt.m[i][j]
+            drot[0] = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
+            drot[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
+            drot[2] = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
+            drot[3] = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
+#undef Dm
+        }
+    } else if (shs != nullptr && M > 0) {
+        float* dsh = dL_dshs + (size_t)idx * M * 3;
+        for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+    }
+
+    dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+    dL_dscales[3 * idx] = dscale[0]; dL_dscales[3 * idx + 1] = dscale[1]; dL_dscales[3 * idx + 2] = dscale[2];
+    reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+}  // namespace
+
+void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
+                              int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
+                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                              float* dL_drots, float* dL_dfeatures, hipStream_t s) {
+    const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
+    gaussian_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,
+        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drots,
+        dL_dfeatures);
+}

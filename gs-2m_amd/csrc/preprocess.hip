@@ -1,0 +1,242 @@
+// Per-Gaussian forward preprocessing for gfx950: cull, project, 3D->2D covariance, conic,
+// radius, tile rectangle, SH->RGB, and the 128-byte blend record the tile kernels gather.
+//
+// Behaviour follows the reference kernel preprocessCUDA
+// (diff-gaussian-rasterization/cuda_rasterizer/forward.cu:145-241 with computeCov3D :109-142,
+// computeCov2D :70-104, computeColorFromSH :20-67, in_frustum auxiliary.h:140-162,
+// ndc2Pix/getRect auxiliary.h:40-53) but the data layout is different: instead of six SoA
+// arrays it emits ONE aligned 128-B record per visible Gaussian (common.h) plus the
+// fp32-bit depth key used by the depth sort.  This file is compiled with
+// -ffp-contract=off: the values that decide integers (radius, tile rect, depth key) are
+// evaluated in exactly the written order.
+#include "common.h"
+
+namespace {
+
+struct M3 {  // column-major 3x3, m[col][row]
+    float m[3][3];
+};
+__device__ __forceinline__ M3 m3_cols(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+    M3 r;
+    r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
+    r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+    r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+    return r;
+}
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+    return R;
+}
+
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
+
+__global__ void __launch_bounds__(256) preprocess_kernel(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
+    const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+    int tiles_x, int tiles_y, int* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ gid_iota, uint8_t* __restrict__ clamped) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+
+    int out_radius = 0;
+    uint32_t out_tt = 0;
+    uint32_t out_key = 0xFFFFFFFFu;
+
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    // view-space point (transformPoint4x3), near-plane cull at 0.2
+    const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+    const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    if (vz > 0.2f) {
+        const float hx_ = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+        const float hy_ = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+        const float hw_ = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+        const float p_w = 1.0f / (hw_ + 0.0000001f);
+        const float projx = hx_ * p_w, projy = hy_ * p_w;
+
+        float c3[6];
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
+        } else {
+            const float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1],
+                        sz = scale_modifier * scales[3 * idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            M3 S = m3_cols(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+            M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                           2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                           2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+            M3 Mm = m3_mul(S, R);
+            M3 Sig = m3_mul(m3_t(Mm), Mm);
+            c3[0] = Sig.m[0][0]; c3[1] = Sig.m[0][1]; c3[2] = Sig.m[0][2];
+            c3[3] = Sig.m[1][1]; c3[4] = Sig.m[1][2]; c3[5] = Sig.m[2][2];
+        }
+        // EWA projection of the covariance (no +0.3 low-pass in this fork's forward)
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        M3 J = m3_cols(focal_x / vz, 0.0f, -(focal_x * tx) / (vz * vz), 0.0f, focal_y / vz, -(focal_y * ty) / (vz * vz),
+                       0.f, 0.f, 0.f);
+        M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+        M3 T = m3_mul(Wm, J);
+        M3 Vrk = m3_cols(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        M3 cov = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+        const float cova = cov.m[0][0], covb = cov.m[0][1], covc = cov.m[1][1];
+        const float det = cova * covc - covb * covb;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float cA = covc * det_inv, cB = -covb * det_inv, cC = cova * det_inv;
+            const float mid = 0.5f * (cova + covc);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix is evaluated in double in the reference (auxiliary.h:40-42)
+            const float pix = (float)((((double)projx + 1.0) * (double)W - 1.0) * 0.5);
+            const float piy = (float)((((double)projy + 1.0) * (double)H - 1.0) * 0.5);
+            const int mr = (int)radius;
+            const int rminx = clampi((int)((pix - mr) / GS2M_TILE), 0, tiles_x);
+            const int rminy = clampi((int)((piy - mr) / GS2M_TILE), 0, tiles_y);
+            const int rmaxx = clampi((int)((pix + mr + GS2M_TILE - 1) / GS2M_TILE), 0, tiles_x);
+            const int rmaxy = clampi((int)((piy + mr + GS2M_TILE - 1) / GS2M_TILE), 0, tiles_y);
+            const uint32_t rw = (uint32_t)(rmaxx - rminx), rh = (uint32_t)(rmaxy - rminy);
+            if (rw * rh != 0) {
+                float cr, cg, cb;
+                uint8_t cl = 0;
+                if (colors_precomp == nullptr) {
+                    float dx = px - cam_pos[0], dy = py - cam_pos[1], dz = pz - cam_pos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len; dy = dy / len; dz = dz / len;
+                    const float x = dx, y = dy, z = dz;
+                    const float* sh = shs + (size_t)idx * M * 3;
+                    float res[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float r_ = SH_C0 * sh[c];
+                        if (D > 0) {
+                            r_ = r_ - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+                            if (D > 1) {
+                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                r_ = r_ + kSH_C2[0] * xy * sh[12 + c] + kSH_C2[1] * yz * sh[15 + c] +
+                                     kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] + kSH_C2[3] * xz * sh[21 + c] +
+                                     kSH_C2[4] * (xx - yy) * sh[24 + c];
+                                if (D > 2) {
+                                    r_ = r_ + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] +
+                                         kSH_C3[1] * xy * z * sh[30 + c] +
+                                         kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] +
+                                         kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                                         kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] +
+                                         kSH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                                         kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+                                }
+                            }
+                        }
+                        r_ += 0.5f;
+                        if (r_ < 0) cl |= (uint8_t)(1u << c);
+                        res[c] = fmaxf(r_, 0.0f);
+                    }
+                    cr = res[0]; cg = res[1]; cb = res[2];
+                } else {
+                    cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+                }
+                clamped[idx] = cl;
+
+                // Half extents of the region where alpha = opacity*exp(power) can reach 1/255,
+                // used by the blend kernels to skip 8x8 pixel blocks.  Must never under-estimate:
+                // evaluated in double from the very conic the blend kernels use, inflated, and
+                // switched off (infinite) for ill-conditioned or indefinite conics.
+                const float op = opacities[idx];
+                float ex, ey;
+                if (op < 1.0f / 255.0f) {
+                    ex = ey = -1.0f;  // alpha <= opacity < 1/255 everywhere: never contributes
+                } else {
+                    const double dA = cA, dB = cB, dC = cC;
+                    const double ddet = dA * dC - dB * dB;
+                    if (!(ddet > 0.0) || !(dA > 0.0) || !(dC > 0.0) || dA * dC > 1.0e4 * ddet) {
+                        ex = ey = __builtin_inff();
+                    } else {
+                        const double tau2 = 2.0 * fmax(0.0, log(255.0 * (double)op) + 1.0e-3);
+                        ex = (float)(sqrt(tau2 * dC / ddet) * 1.001 + 0.01);
+                        ey = (float)(sqrt(tau2 * dA / ddet) * 1.001 + 0.01);
+                    }
+                }
+                float4* r4 = rec + (size_t)idx * REC_Q;
+                r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
+                r4[REC_GEO1] = make_float4(cC, op, ex, ey);
+                r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)rminx | ((uint32_t)rminy << 16)), u2f(rw | (rh << 16)), vz);
+                r4[REC_RGB] = make_float4(cr, cg, cb, 0.f);
+                if (features != nullptr) {
+                    const float2* f2 = reinterpret_cast<const float2*>(features + (size_t)idx * GS2M_NUM_FEATURES);
+                    const float2 a = f2[0], b = f2[1], c = f2[2], d = f2[3], e = f2[4];
+                    r4[REC_FEAT + 0] = make_float4(a.x, a.y, b.x, b.y);
+                    r4[REC_FEAT + 1] = make_float4(c.x, c.y, d.x, d.y);
+                    r4[REC_FEAT + 2] = make_float4(e.x, e.y, 0.f, 0.f);
+                } else {
+                    r4[REC_FEAT + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    r4[REC_FEAT + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    r4[REC_FEAT + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                out_radius = mr;
+                out_tt = rw * rh;
+                out_key = f2u(vz);
+            }
+        }
+    }
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tt;
+    depth_key[idx] = out_key;
+    gid_iota[idx] = (uint32_t)idx;
+}
+
+// markVisible / checkFrustum (rasterizer_impl.cu:48-59, 132-143)
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm,
+                                    uint8_t* __restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    present[idx] = vz <= 0.2f ? 0 : 1;
+}
+
+}  // namespace
+
+void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                            const float* rotations, const float* opacities, const float* shs,
+                            const float* cov3D_precomp, const float* colors_precomp, const float* features,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
+                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
+                            int* radii, const GeomState& g, hipStream_t s) {
+    preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                                                      cov3D_precomp, colors_precomp, features, viewmatrix, projmatrix,
+                                                      cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, tiles_x,
+                                                      tiles_y, radii, g.rec, g.tiles_touched, g.depth_key, g.gid_iota,
+                                                      g.clamped);
+}
+
+void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, viewmatrix, present);
+}

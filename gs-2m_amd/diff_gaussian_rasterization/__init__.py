@@ -1,0 +1,249 @@
+"""MI355X-native drop-in for the reference's `diff_gaussian_rasterization` package.
+
+Same public surface as /root/reference/submodules/diff-gaussian-rasterization/
+diff_gaussian_rasterization/__init__.py:
+  GaussianRasterizationSettings (NamedTuple, 12 fields, :143-155)
+  GaussianRasterizer(nn.Module).forward(...) -> (color, radii, observe, buffer) and
+  .markVisible(positions) (:157-218)
+  rasterize_gaussians / _RasterizeGaussians (autograd.Function, 10 inputs, 9 grads + None,
+  :17-141)
+and a `_C` namespace with the three functions of the reference's pybind module
+(ext.cpp:15-19; rasterize_points.cu:30-219), implemented on top of the C ABI in
+include/gs2m_raster.h through ctypes.  PyTorch only provides device memory and the stream.
+There is no fallback: tensors must live on a HIP device and the HIP library must be built.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+import gs2m_native as _native
+
+NUM_CHANNELS = 3
+NUM_FEATURES = 10
+
+
+def _ptr(t):
+    """Device pointer or NULL for the reference's 'missing optional' encoding (an empty tensor)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _f32c(t, name):
+    if t is None or t.numel() == 0:
+        return t
+    if not t.is_cuda:
+        raise RuntimeError(f"gs2m rasterizer: `{name}` must be on a HIP (cuda) device; there is no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"gs2m rasterizer: `{name}` must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _Alloc:
+    """Scratch allocator handed to the C ABI (mirrors resizeFunctional, rasterize_points.cu:22-28)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _native.ALLOC_FN(self._alloc)
+
+    def _alloc(self, nbytes, _user):
+        try:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # out of memory -> NULL, reported as GS2M_ERR_ALLOC
+            return 0
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _CModule:
+    """Function-for-function mirror of the reference's `_C` extension module."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                            features, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                            campos, prefiltered, featureCount):
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:52-54
+        L = _native.lib()
+        means3D = _f32c(means3D, "means3D")
+        device = means3D.device
+        background = _f32c(background, "bg"); colors = _f32c(colors, "colors_precomp")
+        opacities = _f32c(opacities, "opacities"); scales = _f32c(scales, "scales")
+        rotations = _f32c(rotations, "rotations"); cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp")
+        features = _f32c(features, "features"); viewmatrix = _f32c(viewmatrix, "viewmatrix")
+        projmatrix = _f32c(projmatrix, "projmatrix"); sh = _f32c(sh, "shs"); campos = _f32c(campos, "campos")
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        # outputs need no zero fill: the kernels write every element
+        out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
+        out_buffer = torch.empty((NUM_FEATURES, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        observe = torch.empty((P,), dtype=torch.int32, device=device)
+        geom, binning, img = _Alloc(device), _Alloc(device), _Alloc(device)
+        with torch.cuda.device(device):
+            rendered = L.gs2m_raster_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
+                _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacities), _ptr(scales), float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), _ptr(features), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), int(featureCount), _ptr(out_color),
+                _ptr(radii), _ptr(observe), _ptr(out_buffer), _stream())
+        _native.check(rendered, "gs2m_raster_forward")
+        return rendered, out_color, radii, observe, out_buffer, geom.tensor, binning.tensor, img.tensor
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, features, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_colors,
+                                     grad_buffer, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                     featureCount, return_conics=False):
+        L = _native.lib()
+        device = means3D.device
+        means3D = _f32c(means3D, "means3D")
+        P = means3D.size(0)
+        H, W = grad_colors.size(1), grad_colors.size(2)
+        M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        grad_colors = _f32c(grad_colors, "grad_colors"); grad_buffer = _f32c(grad_buffer, "grad_buffer")
+        mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=device)) if P == 0 else \
+             (lambda *s: torch.empty(s, dtype=torch.float32, device=device))
+        dL_dmeans3D = mk(P, 3); dL_dmeans2D = mk(P, 4); dL_dcolors = mk(P, NUM_CHANNELS)
+        dL_dfeatures = mk(P, NUM_FEATURES); dL_dopacities = mk(P, 1); dL_dcov3D = mk(P, 6)
+        dL_dshs = mk(P, M, 3); dL_dscales = mk(P, 3); dL_drotations = mk(P, 4)
+        dL_dconics = mk(P, 2, 2) if return_conics else None
+        scratch = _Alloc(device)
+        with torch.cuda.device(device):
+            rc = L.gs2m_raster_backward(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(features),
+                _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii),
+                _ptr(buffer), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), int(featureCount),
+                _ptr(grad_colors), _ptr(grad_buffer), _ptr(dL_dmeans2D), _ptr(dL_dconics), _ptr(dL_dopacities),
+                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dshs), _ptr(dL_dscales),
+                _ptr(dL_drotations), _ptr(dL_dfeatures), scratch.cb, None, _stream())
+        _native.check(rc, "gs2m_raster_backward")
+        out = (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drotations,
+               dL_dfeatures)
+        return out + (dL_dconics,) if return_conics else out
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        L = _native.lib()
+        means3D = _f32c(means3D, "means3D")
+        P = means3D.size(0)
+        present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+        if P != 0:
+            with torch.cuda.device(means3D.device):
+                rc = L.gs2m_raster_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
+                                                _ptr(_f32c(projmatrix, "projmatrix")), present.data_ptr(), _stream())
+            _native.check(rc, "gs2m_raster_mark_visible")
+        return present
+
+
+_C = _CModule()
+
+
+def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, features, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
+                raster_settings):
+        args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, features, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
+                raster_settings.image_height, raster_settings.image_width, shs, raster_settings.sh_degree,
+                raster_settings.campos, raster_settings.prefiltered, raster_settings.feature_count)
+        num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
+                              geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii, observe)
+        return color, radii, observe, buffer
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_radii, grad_out_observe, grad_out_buffer):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs, geomBuffer,
+         binningBuffer, imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros_like(buffer[:NUM_CHANNELS])
+        if grad_out_buffer is None:
+            grad_out_buffer = torch.zeros_like(buffer)
+        args = (raster_settings.bg, means3D, radii, buffer, colors_precomp, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, features, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
+                grad_out_buffer, shs, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
+                binningBuffer, imgBuffer, raster_settings.feature_count)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_features) = _C.rasterize_gaussians_backward(*args)
+
+        def opt(g, x):  # gradients for absent optionals (empty placeholder tensors) are dropped
+            return g if (x is not None and x.numel() != 0) else None
+
+        return (grad_means3D, grad_means2D, opt(grad_sh, shs), opt(grad_colors_precomp, colors_precomp), grad_opacities,
+                opt(grad_scales, scales), opt(grad_rotations, rotations), opt(grad_cov3Ds_precomp, cov3Ds_precomp),
+                opt(grad_features, features), None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    feature_count: int
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, features=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        if features is None:
+            features = torch.Tensor([])
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   features, raster_settings)

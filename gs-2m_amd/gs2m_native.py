@@ -1,0 +1,78 @@
+"""Loader for the HIP/C-ABI library (csrc/libgs2m_raster.so, include/gs2m_raster.h).
+
+There is NO CPU or PyTorch fallback: if the shared library is missing or cannot be
+loaded, every entry point raises.  The library is built in-tree by `build()` (hipcc,
+--offload-arch=gfx950) so that it travels with the repository snapshot.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgs2m_raster.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
+           "gs2m_debug_layout", "gs2m_version")
+
+_lib = None
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "geom_bytes", "rec", "tiles_touched", "depth_key", "sorted_gid", "sorted_off", "clamped",
+        "binning_bytes", "point_list", "tile_keys", "inst_obs",
+        "image_bytes", "final_T", "n_contrib", "ranges")]
+
+
+def build(jobs=8, force=False):
+    """Compile every HIP translation unit for gfx950 and link libgs2m_raster.so."""
+    cmd = ["make", "-C", CSRC, "-j", str(jobs)]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"gs2m: HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    p, i, f = C.c_void_p, C.c_int, C.c_float
+    L.gs2m_raster_forward.restype = i
+    L.gs2m_raster_forward.argtypes = [ALLOC_FN, p, ALLOC_FN, p, ALLOC_FN, p, i, i, i, p, i, i, p, p, p, p, p, f, p, p,
+                                      p, p, p, p, f, f, i, i, p, p, p, p, p]
+    L.gs2m_raster_backward.restype = i
+    L.gs2m_raster_backward.argtypes = [i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, p, f, f, p, p, p, p, p, i,
+                                       p, p, p, p, p, p, p, p, p, p, p, p, ALLOC_FN, p, p]
+    L.gs2m_raster_mark_visible.restype = i
+    L.gs2m_raster_mark_visible.argtypes = [i, p, p, p, p, p]
+    L.gs2m_knn_dist2.restype = i
+    L.gs2m_knn_dist2.argtypes = [i, p, p, ALLOC_FN, p, p]
+    L.gs2m_debug_layout.restype = i
+    L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
+    L.gs2m_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocation failed", -4: "unsupported size"}
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"gs2m: {what} failed: {ERRORS.get(rc, rc)}")
+    return rc
+
+
+def debug_layout(P, R, W, H):
+    lay = Layout()
+    check(lib().gs2m_debug_layout(P, R, W, H, C.byref(lay)), "gs2m_debug_layout")
+    return lay

@@ -1,0 +1,172 @@
+/*
+ * gs2m_raster.h -- C ABI of the MI355X-native (gfx950) GS-2M rasterizer hot path.
+ *
+ * Drop-in boundary: these entry points take exactly what the reference's native seam
+ * takes (raw device pointers, sizes, allocator callbacks) so that a binding written
+ * against CudaRasterizer::Rasterizer can bind them one for one.  Reference interface
+ * replaced (paths relative to /root/reference/submodules/):
+ *
+ *   gs2m_raster_forward       <- CudaRasterizer::Rasterizer::forward
+ *                                diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:31-59
+ *                                (impl rasterizer_impl.cu:185-330; torch caller rasterize_points.cu:30-113)
+ *   gs2m_raster_backward      <- CudaRasterizer::Rasterizer::backward
+ *                                cuda_rasterizer/rasterizer.h:61-88 (impl rasterizer_impl.cu:334-438;
+ *                                torch caller rasterize_points.cu:115-200)
+ *   gs2m_raster_mark_visible  <- CudaRasterizer::Rasterizer::markVisible
+ *                                cuda_rasterizer/rasterizer.h:23-29 (impl rasterizer_impl.cu:132-143)
+ *   gs2m_knn_dist2            <- SimpleKNN::knn  simple-knn/simple_knn.h, simple_knn.cu:169-204
+ *                                (torch caller spatial.cu:15-24, python name distCUDA2)
+ *
+ * Differences from the reference seam, all additive:
+ *   - every call takes the HIP stream to launch on (the reference uses the default stream);
+ *   - allocator callbacks are plain function pointers + a user pointer instead of
+ *     std::function<char*(size_t)>;
+ *   - backward takes one extra scratch allocator (per tile-instance partial-gradient rows:
+ *     the reference accumulates with float atomics and needs no scratch);
+ *   - int status / num_rendered return codes instead of C++ exceptions.
+ *
+ * All pointers are DEVICE pointers to contiguous fp32 / int32 data unless stated.  Null
+ * pointers select the same alternatives as in the reference (shs vs colors_precomp,
+ * scales+rotations vs cov3D_precomp).  Output tensors out_color (3,H,W), out_radii (P),
+ * out_observe (P), out_buffer (10,H,W) and all gradient tensors must be allocated by the
+ * caller; they do NOT have to be zero-filled (the kernels write every element).
+ * The three scratch buffers returned by the forward callbacks must be kept alive and
+ * passed unchanged to backward; their layout is private to this library.
+ */
+#ifndef GS2M_RASTER_H
+#define GS2M_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS2M_NUM_CHANNELS 3  /* cuda_rasterizer/config.h:15 */
+#define GS2M_NUM_FEATURES 10 /* cuda_rasterizer/config.h:16 */
+#define GS2M_TILE 16         /* cuda_rasterizer/config.h:17-18 */
+
+/* error codes (negative returns) */
+#define GS2M_OK 0
+#define GS2M_ERR_INVALID_ARG (-1)
+#define GS2M_ERR_HIP (-2)
+#define GS2M_ERR_ALLOC (-3)
+#define GS2M_ERR_UNSUPPORTED (-4)
+
+/* Scratch allocator: must return a DEVICE pointer to at least `bytes` bytes (any
+ * alignment; the library aligns internally) that stays valid until the matching
+ * backward has run.  Mirrors resizeFunctional, rasterize_points.cu:22-28. */
+typedef char* (*gs2m_alloc_fn)(size_t bytes, void* user);
+
+/* Returns num_rendered (>= 0, number of Gaussian/tile instances) or a negative error. */
+int gs2m_raster_forward(
+    gs2m_alloc_fn geometry_alloc, void* geometry_user,
+    gs2m_alloc_fn binning_alloc, void* binning_user,
+    gs2m_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* features,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    int feature_count,
+    float* out_color,
+    int* out_radii,
+    int* out_observe,
+    float* out_buffer,
+    void* stream);
+
+/* Returns GS2M_OK or a negative error.  dL_dconics may be NULL (it is an internal
+ * temporary in the reference, rasterize_points.cu:154). */
+int gs2m_raster_backward(
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* features,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    const float* buffer, /* unused, as in the reference (backward.cu:428) */
+    char* geom_buffer,
+    char* binning_buffer,
+    char* image_buffer,
+    int feature_count,
+    const float* grad_colors,
+    const float* grad_buffer,
+    float* dL_dmeans2D,   /* (P,4) */
+    float* dL_dconics,    /* (P,2,2) or NULL */
+    float* dL_dopacities, /* (P,1) */
+    float* dL_dcolors,    /* (P,3) */
+    float* dL_dmeans3D,   /* (P,3) */
+    float* dL_dcov3D,     /* (P,6) */
+    float* dL_dshs,       /* (P,M,3) */
+    float* dL_dscales,    /* (P,3) */
+    float* dL_drots,      /* (P,4) */
+    float* dL_dfeatures,  /* (P,10) */
+    gs2m_alloc_fn scratch_alloc, void* scratch_user,
+    void* stream);
+
+/* present: P bytes (bool). */
+int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                             const float* projmatrix, uint8_t* present, void* stream);
+
+/* points (P,3) fp32 -> mean_dists (P) fp32: mean squared distance to the 3 nearest
+ * other points.  scratch_alloc provides temporary device memory. */
+int gs2m_knn_dist2(int P, const float* points, float* mean_dists,
+                   gs2m_alloc_fn scratch_alloc, void* scratch_user, void* stream);
+
+/* ---- introspection used by the parity tests (not part of the reference seam) ---- */
+
+/* Byte offsets of the private arrays inside the three scratch buffers, relative to the
+ * 256-byte-aligned base of each buffer.  Filled by gs2m_debug_layout. */
+typedef struct gs2m_layout {
+    /* geometry buffer */
+    uint64_t geom_bytes;
+    uint64_t rec;           /* P x 32 floats: blend records, see DESIGN.md */
+    uint64_t tiles_touched; /* P u32 */
+    uint64_t depth_key;     /* P u32: fp32 bits of view-space depth, 0xFFFFFFFF if culled */
+    uint64_t sorted_gid;    /* P u32: Gaussian ids in (depth, id) order */
+    uint64_t sorted_off;    /* P u32: exclusive scan of tiles_touched in that order */
+    uint64_t clamped;       /* P u8 bit mask (bit c = SH channel c clamped) */
+    /* binning buffer */
+    uint64_t binning_bytes;
+    uint64_t point_list;    /* R u32: Gaussian ids sorted by (tile, depth, id) */
+    uint64_t tile_keys;     /* R u32: tile id of each sorted instance */
+    uint64_t inst_obs;      /* R u32: per-instance observe partial counts (emission order) */
+    /* image buffer */
+    uint64_t image_bytes;
+    uint64_t final_T;       /* W*H f32 */
+    uint64_t n_contrib;     /* W*H u32 */
+    uint64_t ranges;        /* tiles x uint2 */
+} gs2m_layout;
+
+int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
+
+/* Library version / build info string (static storage). */
+const char* gs2m_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS2M_RASTER_H */
