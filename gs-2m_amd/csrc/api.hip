@@ -31,6 +31,41 @@ struct Pinned {
 };
 thread_local Pinned t_pinned;
 
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
+// mode 0: off; 1: the two blend kernels only; 2: every stage.
+static_assert(GS2M_NUM_STAGES == 10, "stage table");
+enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_OBSERVE,
+             ST_BLEND_BWD, ST_GAUSSIAN_BWD, ST_COUNT };
+constexpr int kMaxRecords = 8192;
+struct Prof {
+    int mode = 0;
+    int n = 0;
+    hipEvent_t ev[kMaxRecords][2];
+    int stage[kMaxRecords];
+    int created = 0;
+};
+Prof g_prof;
+
+struct StageTimer {
+    hipStream_t s;
+    int slot = -1;
+    StageTimer(int stage, hipStream_t s_) : s(s_) {
+        const bool blend = stage == ST_BLEND_FWD || stage == ST_BLEND_BWD;
+        if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || g_prof.n >= kMaxRecords) return;
+        slot = g_prof.n++;
+        if (slot >= g_prof.created) {
+            (void)hipEventCreate(&g_prof.ev[slot][0]);
+            (void)hipEventCreate(&g_prof.ev[slot][1]);
+            g_prof.created = slot + 1;
+        }
+        g_prof.stage[slot] = stage;
+        (void)hipEventRecord(g_prof.ev[slot][0], s);
+    }
+    ~StageTimer() {
+        if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], s);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -75,15 +110,22 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
 
     int R = 0;
     if (P > 0) {
-        gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
-                               colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                               tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, s);
-        // 1. depth order of the Gaussians themselves (stable: ties keep id order)
-        HIP_TRY(gs2m_sort_pairs_u32(g.temp, g.temp_bytes, g.depth_key, g.depth_key_sorted, g.gid_iota, g.sorted_gid, (size_t)P, 0, 32, s));
-        // 2. emission offsets in that order
-        gs2m_launch_gather_tt(P, g, s);
-        HIP_TRY(gs2m_exclusive_scan_u32(g.temp, g.temp_bytes, g.sorted_tt, g.sorted_off, (size_t)P, s));
-        gs2m_launch_total(P, g, s);
+        {
+            StageTimer t(ST_PREPROCESS, s);
+            gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                                   colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, s);
+        }
+        {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
+            StageTimer t(ST_DEPTH_SORT, s);
+            HIP_TRY(gs2m_sort_pairs_u32(g.temp, g.temp_bytes, g.depth_key, g.depth_key_sorted, g.gid_iota, g.sorted_gid, (size_t)P, 0, 32, s));
+        }
+        {   // 2. emission offsets in that order
+            StageTimer t(ST_SCAN, s);
+            gs2m_launch_gather_tt(P, g, s);
+            HIP_TRY(gs2m_exclusive_scan_u32(g.temp, g.temp_bytes, g.sorted_tt, g.sorted_off, (size_t)P, s));
+            gs2m_launch_total(P, g, s);
+        }
         if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
         HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));  // the reference has the same sync point (rasterizer_impl.cu:269-270)
@@ -100,13 +142,28 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
 
     HIP_TRY(hipMemsetAsync(im.ranges, 0, tiles * sizeof(uint2), s));
     if (R > 0) {
-        gs2m_launch_emit(P, tiles_x, g, b, s);
-        HIP_TRY(gs2m_sort_pairs_u32(b.temp, b.temp_bytes, b.keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0, tile_bits, s));
-        gs2m_launch_ranges(R, b, im, s);
-        HIP_TRY(hipMemsetAsync(b.inst_obs, 0, (size_t)R * sizeof(uint32_t), s));
+        {
+            StageTimer t(ST_EMIT, s);
+            gs2m_launch_emit(P, tiles_x, g, b, s);
+        }
+        {
+            StageTimer t(ST_TILE_SORT, s);
+            HIP_TRY(gs2m_sort_pairs_u32(b.temp, b.temp_bytes, b.keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0, tile_bits, s));
+        }
+        {
+            StageTimer t(ST_RANGES, s);
+            gs2m_launch_ranges(R, b, im, s);
+            HIP_TRY(hipMemsetAsync(b.inst_obs, 0, (size_t)R * sizeof(uint32_t), s));
+        }
     }
-    gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
-    if (P > 0) gs2m_launch_observe(P, g, b, out_observe, s);
+    {
+        StageTimer t(ST_BLEND_FWD, s);
+        gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
+    }
+    if (P > 0) {
+        StageTimer t(ST_OBSERVE, s);
+        gs2m_launch_observe(P, g, b, out_observe, s);
+    }
     HIP_TRY(hipGetLastError());
     return R;
 }
@@ -147,9 +204,12 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
 
     HIP_TRY(hipMemsetAsync(row_valid, 0, Rn, s));
-    if (R > 0)
+    if (R > 0) {
+        StageTimer t(ST_BLEND_BWD, s);
         gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors, grad_buffer,
                               rows, row_valid, s);
+    }
+    StageTimer tg(ST_GAUSSIAN_BWD, s);
     gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
                              rows, row_valid, rowf, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
@@ -166,6 +226,27 @@ int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatri
     if (!means3D || !viewmatrix || !present) return GS2M_ERR_INVALID_ARG;
     gs2m_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
     HIP_TRY(hipGetLastError());
+    return GS2M_OK;
+}
+
+int gs2m_profile_mode(int mode) {
+    if (mode < 0 || mode > 2) return GS2M_ERR_INVALID_ARG;
+    g_prof.mode = mode;
+    g_prof.n = 0;
+    return GS2M_OK;
+}
+
+int gs2m_profile_collect(float* stage_ms, int* stage_count, int n_stages) {
+    if (!stage_ms || !stage_count || n_stages < GS2M_NUM_STAGES) return GS2M_ERR_INVALID_ARG;
+    for (int i = 0; i < n_stages; i++) { stage_ms[i] = 0.f; stage_count[i] = 0; }
+    for (int r = 0; r < g_prof.n; r++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(g_prof.ev[r][1]));
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[r][0], g_prof.ev[r][1]));
+        stage_ms[g_prof.stage[r]] += ms;
+        stage_count[g_prof.stage[r]] += 1;
+    }
+    g_prof.n = 0;
     return GS2M_OK;
 }
 

@@ -1,0 +1,142 @@
+"""`render()` -- the caller of the rasterizer hot path, reproducing the reference's
+gaussian_renderer/__init__.py:21-165 call for call on PyTorch-ROCm: same arguments, same
+feature-row packing and feature_count rule (:86-96), same settings construction (:98-110),
+same post-processing (:126-141) and the same 14(+1)-entry output dict (:143-163).
+
+`pc` is any object with the reference GaussianModel's accessors (scene/gaussian_model.py:113-172):
+get_xyz, get_opacity, get_albedo, get_roughness, get_metallic, get_scaling, get_rotation,
+get_features, get_normals(camera_center), get_covariance(), active_sh_degree, max_sh_degree.
+`viewpoint_camera` needs FoVx, FoVy, image_height, image_width, world_view_transform,
+full_proj_transform, camera_center, get_rays(), get_calib_matrix_nerf() (scene/cameras.py).
+gs2m_scene.py provides minimal implementations of both.
+"""
+import math
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from gs2m_scene import eval_sh, normal_from_depth_image
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=False, material_stage=False,
+           sobel_normal=False, blend_metallic=False):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    device = pc.get_xyz.device
+    # zero tensor whose gradient carries the 2D (screen-space) mean gradients: the first two columns as
+    # in 3DGS, the last two accumulate absolute values (GR:38-43)
+    screenspace_points = torch.zeros((pc.get_xyz.shape[0], 4), dtype=pc.get_xyz.dtype, requires_grad=True,
+                                     device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+
+    means3D = pc.get_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    albedo = pc.get_albedo
+    roughness = pc.get_roughness
+    metallic = pc.get_metallic
+
+    scales = None
+    rotations = None
+    cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance()
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+
+    shs = None
+    colors_precomp = None
+    if pipe.convert_SHs_python:
+        shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        dir_pp = (pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1))
+        dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+        colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+    else:
+        shs = pc.get_features
+
+    normals = pc.get_normals(viewpoint_camera.camera_center)  # world space
+    cam_normals = normals @ viewpoint_camera.world_view_transform[:3, :3]
+    cam_points = means3D @ viewpoint_camera.world_view_transform[:3, :3] + viewpoint_camera.world_view_transform[3, :3]
+
+    feature_count = 9 if material_stage else 5 if geometry_stage else 1
+    features = torch.zeros((means3D.shape[0], 10), dtype=torch.float32, device=device)
+    features[:, 0] = 1.0  # alpha
+    features[:, 1] = cam_points[:, 2] if pipe.z_depth else (cam_normals * cam_points).sum(dim=-1).abs()  # distance
+    features[:, 2:5] = normals
+    features[:, 5:8] = albedo
+    features[:, 8:9] = roughness
+    if blend_metallic:
+        feature_count += 1
+        features[:, 9:10] = metallic
+
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx,
+        tanfovy=tanfovy,
+        bg=bg_color,
+        scale_modifier=1.0,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        feature_count=feature_count)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    rendered_image, radii, observe, buffer = rasterizer(
+        means3D=means3D, means2D=means2D, opacities=opacity, shs=shs, colors_precomp=colors_precomp,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, features=features)
+
+    normal_map = buffer[2:5, ...]  # (3, H, W)
+    normal_mask = (normal_map != 0).all(0, keepdim=True).detach()
+
+    local_normals = normal_map.permute(1, 2, 0).view(-1, 3)  # (H*W, 3)
+    local_normals = local_normals @ viewpoint_camera.world_view_transform[:3, :3]
+    H, W = viewpoint_camera.image_height, viewpoint_camera.image_width
+    local_normal_map = local_normals.reshape(H, W, 3).permute(2, 0, 1)
+
+    depth_map = buffer[1:2, ...]
+    distance_map = None
+    if not pipe.z_depth:
+        distance_map = buffer[1:2, ...]
+        rays = viewpoint_camera.get_rays().view(-1, 3)
+        denoms = torch.sum(local_normals * rays, dim=-1).view(1, H, W)
+        depth_map = distance_map / -(denoms + 1e-8)
+
+    out = {
+        "render": rendered_image,
+        "viewspace_points": screenspace_points,
+        "visibility_filter": radii > 0,
+        "radii": radii,
+        "observe": observe,
+        "alpha_map": buffer[0:1, ...],
+        "distance_map": distance_map if not pipe.z_depth else None,
+        "depth_map": depth_map,
+        "normal_map": normal_map,
+        "albedo_map": buffer[5:8, ...],
+        "roughness_map": buffer[8:9, ...],
+        "metallic_map": buffer[9:10, ...],
+        "normal_mask": normal_mask,
+        "local_normal_map": local_normal_map,
+    }
+    if sobel_normal:
+        depth = out["depth_map"].squeeze(0)
+        out["sobel_map"] = render_normal_from_depth_map(viewpoint_camera, depth, bg_color, out["alpha_map"][0])
+    return out
+
+
+def render_normal_from_depth_map(viewpoint_cam, depth, bg_color, alpha_map):
+    """depth (H,W), bg_color (3), alpha (H,W) -> (3,H,W); GR:167-175."""
+    intrinsic, extrinsic = viewpoint_cam.get_calib_matrix_nerf()
+    normal_ref = normal_from_depth_image(depth, intrinsic.to(depth.device), extrinsic.to(depth.device), view_space=False)
+    background = bg_color[None, None, ...]
+    normal_ref = normal_ref * alpha_map[..., None] + background * (1. - alpha_map[..., None])
+    return normal_ref.permute(2, 0, 1)

@@ -15,7 +15,10 @@ LIB_PATH = os.path.join(CSRC, "libgs2m_raster.so")
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_version")
+           "gs2m_debug_layout", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
+
+STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
+          "gaussian_bwd")
 
 _lib = None
 
@@ -58,6 +61,10 @@ def lib():
     L.gs2m_knn_dist2.argtypes = [i, p, p, ALLOC_FN, p, p]
     L.gs2m_debug_layout.restype = i
     L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
+    L.gs2m_profile_mode.restype = i
+    L.gs2m_profile_mode.argtypes = [i]
+    L.gs2m_profile_collect.restype = i
+    L.gs2m_profile_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), i]
     L.gs2m_version.restype = C.c_char_p
     _lib = L
     return L
@@ -76,3 +83,17 @@ def debug_layout(P, R, W, H):
     lay = Layout()
     check(lib().gs2m_debug_layout(P, R, W, H, C.byref(lay)), "gs2m_debug_layout")
     return lay
+
+
+def profile_mode(mode):
+    """0 off, 1 blend kernels only, 2 every stage (HIP events on the launch stream)."""
+    check(lib().gs2m_profile_mode(int(mode)), "gs2m_profile_mode")
+
+
+def profile_collect():
+    """-> {stage: (total_ms, launches)} since the last collect."""
+    n = len(STAGES)
+    ms = (C.c_float * n)()
+    cnt = (C.c_int * n)()
+    check(lib().gs2m_profile_collect(ms, cnt, n), "gs2m_profile_collect")
+    return {STAGES[k]: (float(ms[k]), int(cnt[k])) for k in range(n)}

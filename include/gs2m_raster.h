@@ -163,6 +163,16 @@ typedef struct gs2m_layout {
 
 int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
 
+/* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
+ * mode 0 = off, 1 = the two blend kernels only, 2 = every stage.  Setting the mode clears
+ * the records.  gs2m_profile_collect waits for the recorded events and returns, per
+ * stage, the summed milliseconds and the number of launches since the last collect.
+ * Stage order: preprocess, depth_sort, scan, emit, tile_sort, ranges, blend_fwd, observe,
+ * blend_bwd, gaussian_bwd. */
+#define GS2M_NUM_STAGES 10
+int gs2m_profile_mode(int mode);
+int gs2m_profile_collect(float* stage_ms, int* stage_count, int n_stages);
+
 /* Library version / build info string (static storage). */
 const char* gs2m_version(void);
 
