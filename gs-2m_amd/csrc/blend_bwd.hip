@@ -6,8 +6,11 @@
 // slower when 64 lanes hit 64 rows, so that shape cannot be carried over.  This kernel uses
 // NO global atomics:
 //   * each wave (one 8x8 pixel quadrant) reduces the 11 + fc partial values of an instance
-//     over its 64 lanes with DPP adds (quad_perm / row_mirror / row_bcast), only for
-//     instances that survive the quadrant rectangle test AND have a contributing lane;
+//     over its 64 lanes with a TRANSPOSED reduction: v_permlane32_swap / v_permlane16_swap
+//     halve the register count while doubling the lanes each sum covers (N -> N/4 registers,
+//     each 16-lane row then owning different values), followed by 4 DPP adds per remaining
+//     register -- ~3 instructions per value instead of 6-10 for independent butterflies;
+//     only for instances that survive the quadrant rectangle test AND have a contributing lane;
 //   * the four waves' sums are combined in LDS in a fixed order and the workgroup stores one
 //     row per (tile, Gaussian) instance with plain coalesced stores, addressed by the
 //     instance's EMISSION slot, so all rows of one Gaussian are contiguous in HBM;
@@ -23,16 +26,41 @@ namespace {
 
 constexpr int BB = 64;  // instances per batch: one per lane in the quadrant test
 
-template <int FQ>
+// Sum N (multiple of 4) per-lane values over the 64 lanes of the wave.  On return r[q]
+// (q < N/4) holds, in every lane of 16-lane row `row`, the total of value q + (N/4)*row.
+template <int N>
+__device__ __forceinline__ void wave_reduce_transposed(float (&v)[N], float (&r)[N / 4]) {
+    static_assert(N % 4 == 0, "N must be a multiple of 4");
+    constexpr int H = N / 2, Q = N / 4;
+    float u[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {  // lanes 0-31 <- value i, lanes 32-63 <- value i + H (each summed over l, l^32)
+        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + H]), false, false);
+        u[i] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; i++) {  // row0 <- i, row1 <- i + Q, row2 <- i + H, row3 <- i + H + Q
+        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[i]), __float_as_uint(u[i + Q]), false, false);
+        float w = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        w += dpp_mov0<DPP_QUAD_XOR1>(w);
+        w += dpp_mov0<DPP_QUAD_XOR2>(w);
+        w += dpp_mov0<DPP_ROW_HALF_MIRROR>(w);
+        w += dpp_mov0<DPP_ROW_MIRROR>(w);
+        r[i] = w;
+    }
+}
+
+template <int FC>  // feature channels blended (compile time); runtime fc <= FC
 __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, int W,
     int H, int tiles_x, const float* __restrict__ bg, int fc, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
     const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
+    constexpr int FQ = (FC + 3) / 4;
     constexpr int NQ = 4 + FQ;
-    constexpr int NV = ROW_FEAT + 4 * FQ;  // values reduced per instance (row length in floats)
-    constexpr int RQ = NV / 4 + ((NV % 4) ? 1 : 0);
-    constexpr int ROWF = RQ * 4;
+    constexpr int NV = ROW_FEAT + FC;  // values reduced per instance
+    constexpr int RQ = (NV + 3) / 4;
+    constexpr int ROWF = RQ * 4;       // row length in floats (zero padded)
     __shared__ float4 s_v[NQ][BB];
     __shared__ float4 s_orig[BB];  // A, B, C (unscaled conic), opacity
     __shared__ uint32_t s_gid[BB];
@@ -67,7 +95,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         g2 = grad_color[2 * HW + pix];
         float t[12];
 #pragma unroll
-        for (int ch = 0; ch < 12; ch++) t[ch] = (ch < fc && ch < 4 * FQ) ? grad_buffer[ch * HW + pix] : 0.f;
+        for (int ch = 0; ch < 12; ch++) t[ch] = (ch < fc && ch < FC) ? grad_buffer[ch * HW + pix] : 0.f;
 #pragma unroll
         for (int q = 0; q < FQ; q++) gf[q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
     }
@@ -169,9 +197,11 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             const bool contrib = (pos <= last) && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
             if (__ballot(contrib) == 0ull) continue;
 
-            float v[NV];
+            float v[ROWF];
+#pragma unroll
+            for (int k = 0; k < ROWF; k++) v[k] = 0.f;
             if (contrib) {
-                const float inv1ma = 1.0f / (1.f - alpha);
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = T * inv1ma;
                 const float w = alpha * T;
                 const float4 col = s_v[REC_RGB][jj];
@@ -184,14 +214,15 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 #pragma unroll
                 for (int q = 0; q < FQ; q++) {
                     const float4 f = s_v[REC_FEAT + q][jj];
-                    gc = __builtin_fmaf(f.x, gf[q].x, gc);
-                    gc = __builtin_fmaf(f.y, gf[q].y, gc);
-                    gc = __builtin_fmaf(f.z, gf[q].z, gc);
-                    gc = __builtin_fmaf(f.w, gf[q].w, gc);
-                    v[ROW_FEAT + 4 * q + 0] = w * gf[q].x;
-                    v[ROW_FEAT + 4 * q + 1] = w * gf[q].y;
-                    v[ROW_FEAT + 4 * q + 2] = w * gf[q].z;
-                    v[ROW_FEAT + 4 * q + 3] = w * gf[q].w;
+                    const float fa[4] = {f.x, f.y, f.z, f.w};
+                    const float ga[4] = {gf[q].x, gf[q].y, gf[q].z, gf[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (4 * q + e < FC) {
+                            gc = __builtin_fmaf(fa[e], ga[e], gc);
+                            v[ROW_FEAT + 4 * q + e] = w * ga[e];
+                        }
+                    }
                 }
                 const float dL_dalpha = T * gc - Sg * inv1ma;
                 Sg = __builtin_fmaf(gc, w, Sg);
@@ -210,23 +241,15 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 v[5] = -0.5f * gdx * dy * dL_dG;
                 v[6] = -0.5f * gdy * dy * dL_dG;
                 v[7] = G * dL_dalpha;
-            } else {
+            }
+            // transposed 64-lane sums: lane (row, c) with c < RQ ends up owning value c + RQ*row
+            float r[RQ];
+            wave_reduce_transposed<ROWF>(v, r);
+            const int c16 = lane & 15, row = lane >> 4;
+            float outv = r[0];
 #pragma unroll
-                for (int k = 0; k < NV; k++) v[k] = 0.f;
-            }
-            // 64-lane sums; totals are valid in lanes 48..63, lane 48+k keeps value k (mod 16)
-            float o0 = 0.f, o1 = 0.f;
-            const int l16 = lane - 48;
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-                const float tot = wave_sum_row3(v[k]);
-                if (k < 16) o0 = (l16 == k) ? tot : o0;
-                else o1 = (l16 == k - 16) ? tot : o1;
-            }
-            if (l16 >= 0) {
-                s_acc[wave][jj][l16] = o0;
-                if (NV > 16 && l16 < ROWF - 16) s_acc[wave][jj][16 + l16] = o1;
-            }
+            for (int q = 1; q < RQ; q++) outv = (c16 == q) ? r[q] : outv;
+            if (c16 < RQ) s_acc[wave][jj][c16 + RQ * row] = outv;
             wrote |= (1ull << jj);
         }
         if (lane == 0) s_mask[wave] = wrote;
@@ -235,22 +258,22 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 
 }  // namespace
 
-int gs2m_row_floats(int fc) {
-    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
-    const int nv = ROW_FEAT + 4 * fq;
-    return ((nv + 3) / 4) * 4;
-}
+static int fc_template(int fc) { return fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10)); }
+
+int gs2m_row_floats(int fc) { return ((ROW_FEAT + fc_template(fc) + 3) / 4) * 4; }
 
 void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, const float* grad_color,
                            const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s) {
     const int tiles = tiles_x * tiles_y;
-    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
-#define GS2M_BWD(FQ)                                                                                              \
-    blend_bwd_kernel<FQ><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, im.final_T, \
+#define GS2M_BWD(FC)                                                                                              \
+    blend_bwd_kernel<FC><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, im.final_T, \
                                                im.n_contrib, grad_color, grad_buffer, rows, row_valid)
-    if (fq == 1) GS2M_BWD(1);
-    else if (fq == 2) GS2M_BWD(2);
-    else GS2M_BWD(3);
+    switch (fc_template(fc)) {
+        case 1: GS2M_BWD(1); break;
+        case 5: GS2M_BWD(5); break;
+        case 9: GS2M_BWD(9); break;
+        default: GS2M_BWD(10); break;
+    }
 #undef GS2M_BWD
 }

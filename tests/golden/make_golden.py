@@ -1,0 +1,88 @@
+"""Generates the committed golden vectors.  Run in the BUILD container only:
+
+    python tests/golden/make_golden.py
+
+(1) ref_helpers.npz -- outputs of the reference's own pure-Python helpers, imported from
+    /root/reference (they cannot travel to the GPU box, the vectors can):
+      utils/sh_utils.py:eval_sh (:57-112), utils/graphics_utils.py:getWorld2View2 /
+      getProjectionMatrix (:38-71), utils/normal_utils.py:normal_from_depth_image (:65-72).
+    These pin the oracle's SH forward, the synthetic-camera matrices and render()'s Sobel path.
+(2) raster_small.npz -- inputs and the CPU oracle's outputs/gradients for one small scene; a
+    regression anchor for the oracle and a fixed vector for the HIP path.  (The reference has no
+    runnable rasterizer here -- CUDA only -- so this file is NOT reference output; it says so.)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "gs-2m_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def ref_helpers():
+    sys.path.insert(0, "/root/reference")
+    from utils.sh_utils import eval_sh
+    from utils.graphics_utils import getWorld2View2, getProjectionMatrix
+    from utils.normal_utils import normal_from_depth_image
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    # SH: (P, 3, 16) coefficients, unit directions
+    sh = torch.randn(257, 3, 16, generator=g)
+    dirs = torch.nn.functional.normalize(torch.randn(257, 3, generator=g), dim=1)
+    out["sh_coeffs"] = sh.numpy()
+    out["sh_dirs"] = dirs.numpy()
+    for deg in range(4):
+        out[f"sh_eval_deg{deg}"] = eval_sh(deg, sh, dirs).numpy()
+    # cameras
+    Rs, Ts, views, projs = [], [], [], []
+    for i in range(6):
+        q = torch.nn.functional.normalize(torch.randn(4, generator=g), dim=0).numpy().astype(np.float64)
+        r, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                      [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                      [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+        T = torch.randn(3, generator=g).numpy().astype(np.float64) * 3
+        fovx, fovy = 0.6 + 0.1 * i, 0.4 + 0.07 * i
+        Rs.append(R); Ts.append(T)
+        views.append(getWorld2View2(R, T))
+        projs.append(getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).numpy())
+    out["cam_R"] = np.stack(Rs); out["cam_T"] = np.stack(Ts)
+    out["cam_fov"] = np.array([[0.6 + 0.1 * i, 0.4 + 0.07 * i] for i in range(6)])
+    out["cam_view"] = np.stack(views); out["cam_proj"] = np.stack(projs)
+    # normals from depth
+    depth = 2.0 + torch.rand(37, 53, generator=g)
+    K = torch.tensor([[60.0, 0, 26.5], [0, 55.0, 18.5], [0, 0, 1]])
+    E = torch.tensor(views[0])
+    out["nd_depth"] = depth.numpy(); out["nd_K"] = K.numpy(); out["nd_E"] = E.numpy()
+    out["nd_world"] = normal_from_depth_image(depth, K, E, view_space=False).numpy()
+    out["nd_view"] = normal_from_depth_image(depth, K, E, view_space=True).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"), **out)
+    print("wrote ref_helpers.npz")
+
+
+def raster_small():
+    import helpers as Hh
+    from oracle import oracle
+    sc = Hh.make_scene(400, 64, 48, seed=77, fc=10, scale_hi=0.08, bg=(0.1, 0.4, 0.7))
+    f, gr = Hh.run_oracle(oracle, sc)
+    cam = sc["cam"]
+    out = dict(W=64, H=48, fc=10, sh_degree=3, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+               viewmatrix=cam["viewmatrix"].numpy(), projmatrix=cam["projmatrix"].numpy(), campos=cam["campos"].numpy(),
+               bg=sc["bg"].numpy(), Gc=sc["Gc"].numpy().astype(np.float32), Gb=sc["Gb"].numpy().astype(np.float32),
+               color=f.color, buffer=f.buffer, radii=f.radii, observe=f.observe, n_contrib=f.n_contrib,
+               final_T=f.final_T, num_rendered=f.num_rendered, vals_sorted=f.vals_sorted, ranges=f.ranges)
+    for k, v in sc["g"].items():
+        out["in_" + k] = v.numpy()
+    for k, v in gr.items():
+        out["grad_" + k] = v
+    np.savez_compressed(os.path.join(HERE, "raster_small.npz"), **out)
+    print("wrote raster_small.npz", f.num_rendered)
+
+
+if __name__ == "__main__":
+    ref_helpers()
+    raster_small()

@@ -115,3 +115,98 @@ def assert_image_close(name, got, ref, tol=ABS_TOL_BUFFERS, scale=None, max_outl
 def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS):
     e = rel_err(got, ref)
     assert e <= rel, f"{name}: relative error {e:.3e} > {rel:g}"
+
+
+# ---------------------------------------------------------------------------------------
+# golden fixtures
+def scene_from_golden(z):
+    cam = dict(W=int(z["W"]), H=int(z["H"]), tanfovx=float(z["tanfovx"]), tanfovy=float(z["tanfovy"]),
+               viewmatrix=torch.tensor(z["viewmatrix"]), projmatrix=torch.tensor(z["projmatrix"]),
+               campos=torch.tensor(z["campos"]))
+    g = {k: torch.tensor(z["in_" + k]) for k in ("means3D", "scales", "rotations", "opacities", "shs", "features")}
+    return dict(cam=cam, g=g, Gc=torch.tensor(z["Gc"]), Gb=torch.tensor(z["Gb"]), W=cam["W"], H=cam["H"],
+                fc=int(z["fc"]), sh_degree=int(z["sh_degree"]), bg=torch.tensor(z["bg"]))
+
+
+# ---------------------------------------------------------------------------------------
+# oracle-backed stand-in for GaussianRasterizer on CPU tensors (TEST ONLY): lets the very same
+# render() code run around the oracle so that pre/post-processing and end-to-end autograd can be
+# compared with the device path.
+class _OracleRasterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, oracle, st, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, features):
+        n = lambda t: None if t is None else t.detach().cpu().numpy()
+        f = oracle.forward(n(means3D), n(opacities), shs=n(shs), colors_precomp=n(colors_precomp), scales=n(scales),
+                           rotations=n(rotations), cov3D_precomp=n(cov3D_precomp), features=n(features), bg=n(st.bg),
+                           viewmatrix=n(st.viewmatrix), projmatrix=n(st.projmatrix), campos=n(st.campos),
+                           W=st.image_width, H=st.image_height, tanfovx=st.tanfovx, tanfovy=st.tanfovy,
+                           sh_degree=st.sh_degree, scale_modifier=st.scale_modifier, feature_count=st.feature_count)
+        ctx.f, ctx.oracle = f, oracle
+        ctx.has = [t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp, features)]
+        radii, observe = torch.tensor(f.radii), torch.tensor(f.observe)
+        ctx.mark_non_differentiable(radii, observe)
+        return torch.tensor(f.color), radii, observe, torch.tensor(f.buffer)
+
+    @staticmethod
+    def backward(ctx, gc, gr, go, gb):
+        f = ctx.f
+        gc = torch.zeros(3, f.H, f.W) if gc is None else gc
+        gb = torch.zeros(10, f.H, f.W) if gb is None else gb
+        g = ctx.oracle.backward(f, gc.numpy(), gb.numpy())
+        t = lambda k, on=True: torch.tensor(g[k]) if on else None
+        h = ctx.has
+        return (None, None, t("means3D"), t("means2D"), t("opacities"), t("shs", h[0]), t("colors", h[1]),
+                t("scales", h[2]), t("rotations", h[3]), t("cov3D", h[4]), t("features", h[5]))
+
+
+def oracle_rasterizer_class(oracle):
+    class OracleRasterizer:
+        def __init__(self, raster_settings):
+            self.raster_settings = raster_settings
+
+        def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                     cov3D_precomp=None, features=None):
+            return _OracleRasterFn.apply(oracle, self.raster_settings, means3D, means2D, opacities, shs, colors_precomp,
+                                         scales, rotations, cov3D_precomp, features)
+    return OracleRasterizer
+
+
+def model_from_scene(sc, device, requires_grad=False):
+    import gs2m_scene
+    g = sc["g"]
+    f = g["features"]
+    args = [g["means3D"], g["shs"], g["scales"], g["rotations"], g["opacities"],
+            f[:, 5:8].clamp(0.02, 0.98), f[:, 8:9].clamp(0.02, 0.98), f[:, 9:10].clamp(0.02, 0.98)]
+    pc = gs2m_scene.GaussianParams.from_activated(*[a.clone().to(device) for a in args], active_sh_degree=sc["sh_degree"])
+    if requires_grad:
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_albedo",
+                     "_roughness", "_metallic"):
+            setattr(pc, name, getattr(pc, name).detach().clone().requires_grad_(True))
+    return pc
+
+
+def render_pair(oracle, sc, grads=False, **kw):
+    """render() on the device (HIP op) and on the CPU (same code, oracle-backed op)."""
+    import gaussian_renderer
+    import gs2m_scene
+    res = []
+    for device in ("cuda", "cpu"):
+        pc = model_from_scene(sc, device, requires_grad=grads)
+        cam = gs2m_scene.Camera(sc["cam"], device)
+        saved = gaussian_renderer.GaussianRasterizer
+        if device == "cpu":
+            gaussian_renderer.GaussianRasterizer = oracle_rasterizer_class(oracle)
+        try:
+            out = gaussian_renderer.render(cam, pc, gs2m_scene.PipelineParams(), sc["bg"].to(device), **kw)
+            if grads:
+                loss = (out["render"] * sc["Gc"].to(device)).sum() + (out["depth_map"] * sc["Gb"][1:2].to(device)).sum() \
+                    + (out["normal_map"] * sc["Gb"][2:5].to(device)).sum() + (out["albedo_map"] * sc["Gb"][5:8].to(device)).sum()
+                loss.backward()
+        finally:
+            gaussian_renderer.GaussianRasterizer = saved
+        o = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+        if grads:
+            o["param_grads"] = [p.grad.detach().cpu().numpy() for p in pc.parameters()]
+            o["viewspace_grad"] = out["viewspace_points"].grad.detach().cpu().numpy()
+        res.append(o)
+    return res[0], res[1]

@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/*.h declares.
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = []
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if not fn.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", fn)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"^\s*(?:const\s+)?(?:int|char\s*\*|void)\s*\*?\s*(gs2m_\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for n in ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    import gs2m_native
+    if not os.path.exists(gs2m_native.LIB_PATH):
+        gs2m_native.build()
+    lib = ctypes.CDLL(gs2m_native.LIB_PATH)
+    for n in _declared_functions():
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+    assert set(gs2m_native.EXPORTS) <= set(_declared_functions())
+    assert b"gfx950" in ctypes.cast(lib.gs2m_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_product_package_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under gs-2m_amd/ may import, include or link it."""
+    pkg = os.path.join(ROOT, "gs-2m_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "gs2m_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_op_fails_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import helpers as Hh
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = Hh.make_scene(8, 32, 32)
+    r = GaussianRasterizer(Hh.settings_for(sc, "cpu"))
+    g = sc["g"]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(g["means3D"], torch.zeros(8, 4), g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+          features=g["features"])
