@@ -62,7 +62,6 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     constexpr int RQ = (NV + 3) / 4;
     constexpr int ROWF = RQ * 4;       // row length in floats (zero padded)
     __shared__ float4 s_v[NQ][BB];
-    __shared__ float4 s_orig[BB];  // A, B, C (unscaled conic), opacity
     __shared__ uint32_t s_gid[BB];
     __shared__ uint32_t s_slot[BB];
     __shared__ __align__(16) float s_acc[4][BB][ROWF];
@@ -156,16 +155,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                     const int row = r * 32 + (tid >> 3);
                     if (row < cnt) {
                         float4 v = rec[(size_t)s_gid[row] * REC_Q + q];
-                        if (q == REC_GEO0) {
-                            s_orig[row].x = v.z;
-                            s_orig[row].y = v.w;
-                            v.z *= (-0.5f * GS2M_LOG2E);
-                            v.w *= (-GS2M_LOG2E);
-                        } else if (q == REC_GEO1) {
-                            s_orig[row].z = v.x;
-                            s_orig[row].w = v.y;
-                            v.x *= (-0.5f * GS2M_LOG2E);
-                        } else if (q == REC_BIN) {
+                        if (q == REC_BIN) {
                             const uint32_t off = f2u(v.x), rm = f2u(v.y), rw = f2u(v.z) & 0xFFFFu;
                             s_slot[row] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
                         }
@@ -191,8 +181,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             const uint32_t pos = (uint32_t)(base + jj + 1);  // 1-based list position
             const float4 a = s_v[REC_GEO0][jj], c = s_v[REC_GEO1][jj];
             const float dx = a.x - pxf, dy = a.y - pyf;
-            const float p2 = gs2m_power2(dx, dy, a.z, a.w, c.x);
-            const float G = gs2m_exp2(p2);
+            const float p2 = gs2m_power(dx, dy, a.z, a.w, c.x);
+            const float G = gs2m_exp(p2);
             const float alpha = fminf(0.99f, c.y * G);
             const bool contrib = (pos <= last) && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
             if (__ballot(contrib) == 0ull) continue;
@@ -226,11 +216,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 }
                 const float dL_dalpha = T * gc - Sg * inv1ma;
                 Sg = __builtin_fmaf(gc, w, Sg);
-                const float4 o = s_orig[jj];  // A, B, C, opacity
-                const float dL_dG = o.w * dL_dalpha;
+                const float dL_dG = c.y * dL_dalpha;  // a = x, y, A, B;  c = C, opacity, hx, hy
                 const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * o.x - gdy * o.y;
-                const float dG_ddely = -gdy * o.z - gdx * o.y;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * c.x - gdx * a.w;
                 const float mx = dL_dG * dG_ddelx * ddelx_dx;
                 const float my = dL_dG * dG_ddely * ddely_dy;
                 v[0] = mx;

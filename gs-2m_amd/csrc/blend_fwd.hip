@@ -73,12 +73,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                     const int row = r * 32 + (tid >> 3);
                     if (row < cnt) {
                         float4 v = rec[(size_t)s_gid[row] * REC_Q + q];
-                        if (q == REC_GEO0) {
-                            v.z *= (-0.5f * GS2M_LOG2E);
-                            v.w *= (-GS2M_LOG2E);
-                        } else if (q == REC_GEO1) {
-                            v.x *= (-0.5f * GS2M_LOG2E);
-                        } else if (q == REC_BIN) {
+                        if (q == REC_BIN) {
                             const uint32_t off = f2u(v.x), rm = f2u(v.y), rw = f2u(v.z) & 0xFFFFu;
                             s_slot[row] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
                         }
@@ -106,8 +101,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                     const int jj = sub + bit;  // wave-uniform
                     const float4 a = s_v[REC_GEO0][jj], b = s_v[REC_GEO1][jj];
                     const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float p2 = gs2m_power2(dx, dy, a.z, a.w, b.x);
-                    const float alpha = fminf(0.99f, b.y * gs2m_exp2(p2));
+                    const float p2 = gs2m_power(dx, dy, a.z, a.w, b.x);
+                    const float alpha = fminf(0.99f, b.y * gs2m_exp(p2));
                     bool contrib = !done && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
                     const float test_T = T * (1.0f - alpha);
                     if (contrib && test_T < 0.0001f) {

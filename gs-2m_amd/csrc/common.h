@@ -145,13 +145,20 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane
     return v;
 }
 
-// alpha evaluation shared bit-for-bit by the forward and backward blend kernels.
-// a2, b2, c2 are the conic pre-scaled by -0.5*log2(e), -log2(e), -0.5*log2(e) so that
-// exp(power) = exp2(p2);  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy  (CR/forward.cu:326-337).
+// alpha evaluation shared bit-for-bit by the forward and backward blend kernels:
+//   power = -0.5f * (A*dx*dx + C*dy*dy) - B*dx*dy      (CR/forward.cu:326-329)
+// evaluated UNFUSED and in the reference's written order.  For splats hundreds of pixels long
+// the three terms are O(1e2..1e3) and cancel to O(1); keeping the written order makes the
+// rounding of `power` identical to the CPU oracle's, so parity does not degrade with the
+// conditioning of the conic (only exp() differs, by ~1 ulp).  Costs 4 VALU ops per evaluated
+// pixel x Gaussian pair over a pre-scaled FMA form.
 #define GS2M_LOG2E 1.4426950408889634f
-__device__ __forceinline__ float gs2m_power2(float dx, float dy, float a2, float b2, float c2) {
-    float t = __builtin_fmaf(b2, dy, a2 * dx);
-    return __builtin_fmaf(c2 * dy, dy, t * dx);
+__device__ __forceinline__ float gs2m_power(float dx, float dy, float A, float B, float C) {
+    const float t1 = (A * dx) * dx;
+    const float t2 = (C * dy) * dy;
+    const float t3 = (B * dx) * dy;
+    return (-0.5f * (t1 + t2)) - t3;
 }
-__device__ __forceinline__ float gs2m_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// exp(x) for x <= 0 through v_exp_f32
+__device__ __forceinline__ float gs2m_exp(float x) { return __builtin_amdgcn_exp2f(x * GS2M_LOG2E); }
 #endif

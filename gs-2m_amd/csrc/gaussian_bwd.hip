@@ -48,6 +48,7 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f
 
+template <bool SH_LDS>
 __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
@@ -59,9 +60,32 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
+    // SH rows in and dL/dSH rows out go through LDS so that every global access of the two
+    // (P,16,3) tensors is a coalesced stream (see preprocess.hip); row stride 49 floats.
+    __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const bool visible = radii[idx] > 0;
+    if (SH_LDS) {
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
+        const float4* g4 = reinterpret_cast<const float4*>(shs);
+        float4 t[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + threadIdx.x + 256 * i;
+            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e = 4 * (threadIdx.x + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            float* d = s_sh + row * 49 + col;
+            d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
+        }
+        __syncthreads();
+    }
+    const bool in_range = idx < P;
+    const bool visible = in_range && radii[idx] > 0;
+    if (!SH_LDS && !in_range) return;
+    if (in_range) {
 
     float acc[24];
 #pragma unroll
@@ -202,8 +226,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             const float ox = mx - campos[0], oy = my - campos[1], oz = mz - campos[2];
             const float len = sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox / len, y = oy / len, z = oz / len;
-            const float* sh = shs + (size_t)idx * M * 3;
-            float* dsh = dL_dshs + (size_t)idx * M * 3;
+            const float* sh = SH_LDS ? (s_sh + threadIdx.x * 49) : (shs + (size_t)idx * M * 3);
+            float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
             const uint8_t cl = clamped[idx];
             float g[3] = {acc[ROW_COL] * ((cl & 1) ? 0.f : 1.f), acc[ROW_COL + 1] * ((cl & 2) ? 0.f : 1.f),
                           acc[ROW_COL + 2] * ((cl & 4) ? 0.f : 1.f)};
@@ -216,11 +240,9 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
         dsh[(k) * 3 + 1] = v_ * g[1];                         \
         dsh[(k) * 3 + 2] = v_ * g[2];                         \
     } while (0)
-            DSH(0, SH_C0);
+            // pass 1: everything that READS the coefficients (the dL/dSH row may alias the SH row in LDS)
+            float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
             if (D > 0) {
-                DSH(1, -SH_C1 * y);
-                DSH(2, SH_C1 * z);
-                DSH(3, -SH_C1 * x);
 #pragma unroll
                 for (int c_ = 0; c_ < 3; c_++) {
                     dRdx[c_] = -SH_C1 * SHv(3, c_);
@@ -228,12 +250,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
                     dRdz[c_] = SH_C1 * SHv(2, c_);
                 }
                 if (D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    DSH(4, kC2[0] * xy);
-                    DSH(5, kC2[1] * yz);
-                    DSH(6, kC2[2] * (2.f * zz - xx - yy));
-                    DSH(7, kC2[3] * xz);
-                    DSH(8, kC2[4] * (xx - yy));
+                    xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z;
 #pragma unroll
                     for (int c_ = 0; c_ < 3; c_++) {
                         dRdx[c_] += kC2[0] * y * SHv(4, c_) + kC2[2] * 2.f * -x * SHv(6, c_) + kC2[3] * z * SHv(7, c_) + kC2[4] * 2.f * x * SHv(8, c_);
@@ -241,13 +258,6 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
                         dRdz[c_] += kC2[1] * y * SHv(5, c_) + kC2[2] * 2.f * 2.f * z * SHv(6, c_) + kC2[3] * x * SHv(7, c_);
                     }
                     if (D > 2) {
-                        DSH(9, kC3[0] * y * (3.f * xx - yy));
-                        DSH(10, kC3[1] * xy * z);
-                        DSH(11, kC3[2] * y * (4.f * zz - xx - yy));
-                        DSH(12, kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                        DSH(13, kC3[4] * x * (4.f * zz - xx - yy));
-                        DSH(14, kC3[5] * z * (xx - yy));
-                        DSH(15, kC3[6] * x * (xx - 3.f * yy));
 #pragma unroll
                         for (int c_ = 0; c_ < 3; c_++) {
                             dRdx[c_] += (kC3[0] * SHv(9, c_) * 3.f * 2.f * xy + kC3[1] * SHv(10, c_) * yz +
@@ -262,6 +272,29 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
                                          kC3[3] * SHv(12, c_) * 3.f * (2.f * zz - xx - yy) +
                                          kC3[4] * SHv(13, c_) * 4.f * 2.f * xz + kC3[5] * SHv(14, c_) * (xx - yy));
                         }
+                    }
+                }
+            }
+            // pass 2: dL/dSH_k = basis_k(dir) * dL/dRGB
+            DSH(0, SH_C0);
+            if (D > 0) {
+                DSH(1, -SH_C1 * y);
+                DSH(2, SH_C1 * z);
+                DSH(3, -SH_C1 * x);
+                if (D > 1) {
+                    DSH(4, kC2[0] * xy);
+                    DSH(5, kC2[1] * yz);
+                    DSH(6, kC2[2] * (2.f * zz - xx - yy));
+                    DSH(7, kC2[3] * xz);
+                    DSH(8, kC2[4] * (xx - yy));
+                    if (D > 2) {
+                        DSH(9, kC3[0] * y * (3.f * xx - yy));
+                        DSH(10, kC3[1] * xy * z);
+                        DSH(11, kC3[2] * y * (4.f * zz - xx - yy));
+                        DSH(12, kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                        DSH(13, kC3[4] * x * (4.f * zz - xx - yy));
+                        DSH(14, kC3[5] * z * (xx - yy));
+                        DSH(15, kC3[6] * x * (xx - 3.f * yy));
                     }
                 }
             }
@@ -306,7 +339,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 #undef Dm
         }
     } else if (shs != nullptr && M > 0) {
-        float* dsh = dL_dshs + (size_t)idx * M * 3;
+        float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
     }
 
@@ -315,6 +348,20 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
     dL_dscales[3 * idx] = dscale[0]; dL_dscales[3 * idx + 1] = dscale[1]; dL_dscales[3 * idx + 2] = dscale[2];
     reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }  // in_range
+    if (SH_LDS) {
+        __syncthreads();  // every thread has replaced its LDS row by its dL/dSH row
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
+        float4* o4 = reinterpret_cast<float4*>(dL_dshs);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + threadIdx.x + 256 * i;
+            const int e = 4 * (threadIdx.x + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            const float* d = s_sh + row * 49 + col;
+            if (k < lim4) o4[k] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
 }
 
 }  // namespace
@@ -328,9 +375,14 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
-    gaussian_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
-        P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
-        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,
-        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drots,
-        dL_dfeatures);
+#define GS2M_GB(LDS)                                                                                                    \
+    gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
+        P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, \
+        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,      \
+        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drots,      \
+        dL_dfeatures)
+    const bool lds = shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0 && (((uintptr_t)dL_dshs) & 15) == 0;
+    if (lds) GS2M_GB(true);
+    else GS2M_GB(false);
+#undef GS2M_GB
 }

@@ -50,6 +50,7 @@ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
 
+template <bool SH_LDS>
 __global__ void __launch_bounds__(256) preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -58,7 +59,31 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ gid_iota, uint8_t* __restrict__ clamped) {
+    // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian read has a 192-B lane
+    // stride.  The block instead streams its 256 rows (48 KiB, contiguous) with coalesced float4
+    // loads into LDS (row stride 49 floats: conflict-free column reads) and each thread then reads
+    // its own row from LDS.  Other M fall back to direct loads.
+    __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (SH_LDS) {
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12;                 // float4 index of the block's first row
+        const size_t lim4 = (size_t)P * 12;
+        const float4* g4 = reinterpret_cast<const float4*>(shs);
+        float4 t[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + threadIdx.x + 256 * i;
+            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e = 4 * (threadIdx.x + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            float* d = s_sh + row * 49 + col;
+            d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
+        }
+        __syncthreads();
+    }
     if (idx >= P) return;
 
     int out_radius = 0;
@@ -132,7 +157,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                     dx = dx / len; dy = dy / len; dz = dz / len;
                     const float x = dx, y = dy, z = dz;
-                    const float* sh = shs + (size_t)idx * M * 3;
+                    const float* sh = SH_LDS ? (s_sh + threadIdx.x * 49) : (shs + (size_t)idx * M * 3);
                     float res[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
@@ -230,11 +255,16 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, const GeomState& g, hipStream_t s) {
-    preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                                                      cov3D_precomp, colors_precomp, features, viewmatrix, projmatrix,
-                                                      cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, tiles_x,
-                                                      tiles_y, radii, g.rec, g.tiles_touched, g.depth_key, g.gid_iota,
-                                                      g.clamped);
+#define GS2M_PRE(LDS)                                                                                                  \
+    preprocess_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, \
+                                                           shs, cov3D_precomp, colors_precomp, features, viewmatrix,      \
+                                                           projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
+                                                           focal_y, tiles_x, tiles_y, radii, g.rec, g.tiles_touched,     \
+                                                           g.depth_key, g.gid_iota, g.clamped)
+    const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;
+    if (lds) GS2M_PRE(true);
+    else GS2M_PRE(false);
+#undef GS2M_PRE
 }
 
 void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
