@@ -45,6 +45,7 @@ struct Prof {
     int created = 0;
 };
 Prof g_prof;
+int g_reference_binning = 0;
 
 struct StageTimer {
     hipStream_t s;
@@ -114,7 +115,7 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_PREPROCESS, s);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, s);
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, g_reference_binning ? 0 : 1, s);
         }
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s);
@@ -226,6 +227,11 @@ int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatri
     if (!means3D || !viewmatrix || !present) return GS2M_ERR_INVALID_ARG;
     gs2m_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
     HIP_TRY(hipGetLastError());
+    return GS2M_OK;
+}
+
+int gs2m_set_reference_binning(int on) {
+    g_reference_binning = on ? 1 : 0;
     return GS2M_OK;
 }
 

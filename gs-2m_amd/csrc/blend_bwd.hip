@@ -187,13 +187,17 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             const bool contrib = (pos <= last) && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
             if (__ballot(contrib) == 0ull) continue;
 
+            // Branch-free payload: non-contributing lanes run with alpha = 0 and G = 0, which makes every
+            // reduced value exactly 0 and leaves T and Sg unchanged (rcp(1) = 1, fma(gc, 0, Sg) = Sg).
             float v[ROWF];
 #pragma unroll
-            for (int k = 0; k < ROWF; k++) v[k] = 0.f;
-            if (contrib) {
-                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+            for (int k = NV; k < ROWF; k++) v[k] = 0.f;
+            {
+                const float am = contrib ? alpha : 0.f;
+                const float Gm = contrib ? G : 0.f;
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - am);
                 T = T * inv1ma;
-                const float w = alpha * T;
+                const float w = am * T;
                 const float4 col = s_v[REC_RGB][jj];
                 float gc = col.x * g0;
                 gc = __builtin_fmaf(col.y, g1, gc);
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 const float dL_dalpha = T * gc - Sg * inv1ma;
                 Sg = __builtin_fmaf(gc, w, Sg);
                 const float dL_dG = c.y * dL_dalpha;  // a = x, y, A, B;  c = C, opacity, hx, hy
-                const float gdx = G * dx, gdy = G * dy;
+                const float gdx = Gm * dx, gdy = Gm * dy;
                 const float dG_ddelx = -gdx * a.z - gdy * a.w;
                 const float dG_ddely = -gdy * c.x - gdx * a.w;
                 const float mx = dL_dG * dG_ddelx * ddelx_dx;
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 v[4] = -0.5f * gdx * dx * dL_dG;
                 v[5] = -0.5f * gdx * dy * dL_dG;
                 v[6] = -0.5f * gdy * dy * dL_dG;
-                v[7] = G * dL_dalpha;
+                v[7] = Gm * dL_dalpha;
             }
             // transposed 64-lane sums: lane (row, c) with c < RQ ends up owning value c + RQ*row
             float r[RQ];

@@ -83,7 +83,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, hipStream_t s);
+                            int* radii, const GeomState& g, int shrink, hipStream_t s);
 void gs2m_launch_gather_tt(int P, const GeomState& g, hipStream_t s);
 void gs2m_launch_total(int P, const GeomState& g, hipStream_t s);
 void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s);

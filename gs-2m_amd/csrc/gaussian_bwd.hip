@@ -87,21 +87,39 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     if (!SH_LDS && !in_range) return;
     if (in_range) {
 
+    // independent loads first, so that their latency overlaps the dependent row-summing chain
+    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+    const uint32_t off = f2u(rec[(size_t)idx * REC_Q + REC_BIN].x);  // garbage for culled Gaussians: unused
+    const uint32_t n = visible ? tiles_touched[idx] : 0u;
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s_in[3] = {0.f, 0.f, 0.f};
+    if (scales != nullptr) {
+        q_in = reinterpret_cast<const float4*>(rotations)[idx];
+        s_in[0] = scales[3 * idx]; s_in[1] = scales[3 * idx + 1]; s_in[2] = scales[3 * idx + 2];
+    }
+
     float acc[24];
 #pragma unroll
     for (int k = 0; k < 24; k++) acc[k] = 0.f;
-    if (visible) {
-        const uint32_t off = f2u(rec[(size_t)idx * REC_Q + REC_BIN].x);
-        const uint32_t n = tiles_touched[idx];
+    {
         const int rq = rowf >> 2;
-        for (uint32_t t = 0; t < n; t++) {
-            if (!row_valid[off + t]) continue;
-            const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t) * rowf);
+        for (uint32_t t = 0; t < n; t += 4) {  // up to 4 rows in flight
+            uint8_t vld[4];
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
-                if (q < rq) {
-                    const float4 v = r4[q];
-                    acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+            for (int u = 0; u < 4; u++) vld[u] = (t + u < n) ? row_valid[off + t + u] : (uint8_t)0;
+            float4 rv[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t + u) * rowf);
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    rv[u][q] = (vld[u] && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // fixed summation order: bitwise reproducible
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
                 }
             }
         }
@@ -121,7 +139,6 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
     if (visible) {
-        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
         // ---- 3D covariance (recomputed exactly as preprocess.hip does) ----
         float c3[6];
         float sx = 0.f, sy = 0.f, sz = 0.f, qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
@@ -130,10 +147,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
         } else {
-            sx = scale_modifier * scales[3 * idx]; sy = scale_modifier * scales[3 * idx + 1];
-            sz = scale_modifier * scales[3 * idx + 2];
-            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            sx = scale_modifier * s_in[0]; sy = scale_modifier * s_in[1]; sz = scale_modifier * s_in[2];
+            qr = q_in.x; qx = q_in.y; qy = q_in.z; qz = q_in.w;
             const float r = qr, x = qx, y = qy, z = qz;
             M3 S = m3_cols(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
             R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),

@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int tiles_x, int tiles_y, int* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+    int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, float4* __restrict__ rec,
+    uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ gid_iota, uint8_t* __restrict__ clamped) {
     // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian read has a 192-B lane
     // stride.  The block instead streams its 256 rows (48 KiB, contiguous) with coalesced float4
@@ -209,10 +210,31 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                         ey = (float)(sqrt(tau2 * dA / ddet) * 1.001 + 0.01);
                     }
                 }
+                // Tile rectangle actually emitted: the reference's radius rectangle intersected with
+                // the tiles the alpha >= 1/255 ellipse's bounding box can reach (pixel centres of tile t
+                // are 16t .. 16t+15).  Dropped tiles hold no contributing pixel, so every output is
+                // unchanged while ~30 % fewer instances are sorted, staged and reduced.  `radii` keeps
+                // the reference value.  shrink = 0 reproduces the reference's lists exactly.
+                int ex0 = rminx, ex1 = rmaxx, ey0 = rminy, ey1 = rmaxy;
+                if (shrink) {
+                    if (ex < 0.f) {
+                        ex1 = ex0; ey1 = ey0;
+                    } else {
+                        const float lx = ceilf((pix - ex - 15.0f) * 0.0625f), hx2 = floorf((pix + ex) * 0.0625f) + 1.0f;
+                        const float ly = ceilf((piy - ey - 15.0f) * 0.0625f), hy2 = floorf((piy + ey) * 0.0625f) + 1.0f;
+                        ex0 = max(ex0, (int)fminf(fmaxf(lx, -1.0f), 70000.0f));
+                        ex1 = min(ex1, (int)fminf(fmaxf(hx2, -1.0f), 70000.0f));
+                        ey0 = max(ey0, (int)fminf(fmaxf(ly, -1.0f), 70000.0f));
+                        ey1 = min(ey1, (int)fminf(fmaxf(hy2, -1.0f), 70000.0f));
+                        if (ex1 < ex0) ex1 = ex0;
+                        if (ey1 < ey0) ey1 = ey0;
+                    }
+                }
+                const uint32_t ew = (uint32_t)(ex1 - ex0), eh = (uint32_t)(ey1 - ey0);
                 float4* r4 = rec + (size_t)idx * REC_Q;
                 r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
                 r4[REC_GEO1] = make_float4(cC, op, ex, ey);
-                r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)rminx | ((uint32_t)rminy << 16)), u2f(rw | (rh << 16)), vz);
+                r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), vz);
                 r4[REC_RGB] = make_float4(cr, cg, cb, 0.f);
                 if (features != nullptr) {
                     const float2* f2 = reinterpret_cast<const float2*>(features + (size_t)idx * GS2M_NUM_FEATURES);
@@ -226,7 +248,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                     r4[REC_FEAT + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 out_radius = mr;
-                out_tt = rw * rh;
+                out_tt = ew * eh;  // 0 is possible: visible (radii > 0) but nothing to emit
                 out_key = f2u(vz);
             }
         }
@@ -254,13 +276,13 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, hipStream_t s) {
+                            int* radii, const GeomState& g, int shrink, hipStream_t s) {
 #define GS2M_PRE(LDS)                                                                                                  \
     preprocess_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, \
                                                            shs, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
-                                                           focal_y, tiles_x, tiles_y, radii, g.rec, g.tiles_touched,     \
-                                                           g.depth_key, g.gid_iota, g.clamped)
+                                                           focal_y, tiles_x, tiles_y, shrink, radii, g.rec,             \
+                                                           g.tiles_touched, g.depth_key, g.gid_iota, g.clamped)
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;
     if (lds) GS2M_PRE(true);
     else GS2M_PRE(false);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libgs2m_raster.so")
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
+           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
           "gaussian_bwd")
@@ -61,6 +61,8 @@ def lib():
     L.gs2m_knn_dist2.argtypes = [i, p, p, ALLOC_FN, p, p]
     L.gs2m_debug_layout.restype = i
     L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
+    L.gs2m_set_reference_binning.restype = i
+    L.gs2m_set_reference_binning.argtypes = [i]
     L.gs2m_profile_mode.restype = i
     L.gs2m_profile_mode.argtypes = [i]
     L.gs2m_profile_collect.restype = i
@@ -97,3 +99,9 @@ def profile_collect():
     cnt = (C.c_int * n)()
     check(lib().gs2m_profile_collect(ms, cnt, n), "gs2m_profile_collect")
     return {STAGES[k]: (float(ms[k]), int(cnt[k])) for k in range(n)}
+
+
+def set_reference_binning(on):
+    """True: emit exactly the reference's tile rectangles (bit-identical sorted lists, for the parity tests
+    of the integer artefacts); False (default): drop tiles the alpha >= 1/255 ellipse cannot reach."""
+    check(lib().gs2m_set_reference_binning(1 if on else 0), "gs2m_set_reference_binning")

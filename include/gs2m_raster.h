@@ -163,6 +163,14 @@ typedef struct gs2m_layout {
 
 int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
 
+/* Binning mode.  Default (0): each Gaussian's tile rectangle is the reference's radius rectangle
+ * intersected with the tiles its alpha >= 1/255 ellipse can reach; the dropped tiles cannot
+ * contribute to any pixel, so every output is identical while fewer instances are processed
+ * (num_rendered and the private tile lists shrink).  1: emit exactly the reference's rectangle
+ * (cuda_rasterizer/auxiliary.h:44-53), giving bit-identical sorted lists / ranges / num_rendered;
+ * used by the parity tests of the integer artefacts. */
+int gs2m_set_reference_binning(int on);
+
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage.  Setting the mode clears
  * the records.  gs2m_profile_collect waits for the recorded events and returns, per

@@ -138,6 +138,14 @@ def test_binning_artefacts_bit_exact(oracle_lib):
     _require_gpu()
     import gs2m_native
     import diff_gaussian_rasterization as dgr
+    gs2m_native.set_reference_binning(True)
+    try:
+        _binning_bit_exact(oracle_lib, gs2m_native, dgr)
+    finally:
+        gs2m_native.set_reference_binning(False)
+
+
+def _binning_bit_exact(oracle_lib, gs2m_native, dgr):
     sc = Hh.make_scene(6000, 320, 200, seed=9, fc=9, scale_hi=0.06)
     m = sc["g"]["means3D"]
     m[:, 2] = torch.round(m[:, 2] * 4) / 4  # many exactly equal depths -> ties resolved by Gaussian id
@@ -173,6 +181,50 @@ def test_binning_artefacts_bit_exact(oracle_lib):
     nc = view(imgB, lay.n_contrib, W * H, np.uint32).reshape(H, W)
     assert (nc != f.n_contrib).mean() <= 1e-4
     assert np.all(nc <= (f.ranges[:, 1] - f.ranges[:, 0]).reshape(f.tiles_y, f.tiles_x).repeat(16, 0).repeat(16, 1)[:H, :W])
+
+
+def test_default_binning_is_a_safe_subset(oracle_lib):
+    """default mode drops tiles a Gaussian cannot reach with alpha >= 1/255: each tile list must be a
+    subsequence of the reference's list (same order) that still holds every instance with at least one
+    contributing pixel (so all outputs are unchanged -- checked by every other test in this file)."""
+    _require_gpu()
+    import gs2m_native
+    import diff_gaussian_rasterization as dgr
+    P, W, H = 3000, 160, 112
+    sc = Hh.make_scene(P, W, H, seed=15, fc=9, scale_lo=0.003, scale_hi=0.08)
+    f, _ = Hh.run_oracle(oracle_lib, sc, backward=False)
+    g = {k: v.cuda() for k, v in sc["g"].items()}
+    st = Hh.settings_for(sc, "cuda")
+    e = torch.Tensor([])
+    R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
+        st.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
+        st.projmatrix, st.tanfovx, st.tanfovy, H, W, g["shs"], 3, st.campos, False, 9)
+    torch.cuda.synchronize()
+    assert 0 < R <= f.num_rendered
+    assert np.array_equal(radii.cpu().numpy(), f.radii), "radii keep the reference value"
+    lay = gs2m_native.debug_layout(P, R, W, H)
+    al = lambda t: (-t.data_ptr()) % 256
+    view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
+    pl = view(binB, lay.point_list, R, np.uint32)
+    Tn = f.tiles_x * f.tiles_y
+    rg = view(imgB, lay.ranges, 2 * Tn, np.uint32).reshape(Tn, 2)
+    dropped = 0
+    for t in range(Tn):
+        ref = f.vals_sorted[f.ranges[t, 0]:f.ranges[t, 1]]
+        mine = pl[rg[t, 0]:rg[t, 1]]
+        it = iter(ref.tolist())
+        assert all(any(x == y for y in it) for x in mine.tolist()), f"tile {t}: not a subsequence of the reference list"
+        gone = np.setdiff1d(ref, mine)
+        dropped += len(gone)
+        if len(gone):  # the dropped instances must not contribute anywhere in this tile
+            tx, ty = t % f.tiles_x, t // f.tiles_x
+            px, py = np.meshgrid(np.arange(tx * 16, min(tx * 16 + 16, W)), np.arange(ty * 16, min(ty * 16 + 16, H)))
+            xy = f.means2D[gone].astype(np.float64); co = f.conic_opacity[gone].astype(np.float64)
+            dx = xy[:, 0, None, None] - px[None]; dy = xy[:, 1, None, None] - py[None]
+            power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+            alpha = np.minimum(0.99, co[:, 3, None, None] * np.exp(np.minimum(power, 0)))
+            assert not ((power <= 0) & (alpha >= 1.0 / 255.0 * (1 - 1e-4))).any(), f"tile {t}: dropped a contributing instance"
+    assert dropped > 0, "the scene should exercise the tile-rectangle shrink"
 
 
 def test_mark_visible(oracle_lib):
