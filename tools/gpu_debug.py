@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--scale_hi", type=float, default=0.05)
     a = ap.parse_args()
     print(gs2m_native.lib().gs2m_version())
+    gs2m_native.set_reference_binning(True)  # compare the integer artefacts in reference mode
     sc = Hh.make_scene(a.P, a.W, a.H, seed=a.seed, fc=a.fc, scale_hi=a.scale_hi, bg=(0.1, 0.2, 0.3))
     f, gr = Hh.run_oracle(oracle, sc)
     dev = "cuda"
