@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1],
+                    help="backward blend implementation (default: the library's default)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,6 +82,8 @@ def main():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, rasterize_gaussians
     from gs2m_dp import GradReducer
 
+    if a.bwd_impl is not None:
+        gs2m_native.set_bwd_impl(a.bwd_impl)
     P, W, H, fc = a.gaussians, a.width, a.height, a.fc
     if world == 1:
         cam = S.make_camera(W, H)

@@ -46,6 +46,7 @@ struct Prof {
 };
 Prof g_prof;
 int g_reference_binning = 0;
+int g_bwd_impl = 0;  // 0: pixel-per-lane + permlane reduction (blend_bwd.hip), 1: survivor-per-lane + MFMA
 
 struct StageTimer {
     hipStream_t s;
@@ -195,25 +196,30 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
-    const int rowf = gs2m_row_floats(feature_count);
-    const size_t rows_bytes = gs2m_align_up(Rn * (size_t)rowf * sizeof(float));
-    const size_t valid_bytes = gs2m_align_up(Rn);
+    const int rpi = g_bwd_impl == 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
+    const int rowf = g_bwd_impl == 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
+    const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rowf * sizeof(float));
+    const size_t valid_bytes = gs2m_align_up(Rn * rpi);
     char* sbase = scratch_alloc(rows_bytes + valid_bytes + 2 * GS2M_ALIGN, scratch_user);
     if (!sbase) return GS2M_ERR_ALLOC;
     char* al = (char*)gs2m_align_up((size_t)(uintptr_t)sbase);
     float* rows = (float*)al;
     uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
 
-    HIP_TRY(hipMemsetAsync(row_valid, 0, Rn, s));
+    HIP_TRY(hipMemsetAsync(row_valid, 0, Rn * rpi, s));
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s);
-        gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors, grad_buffer,
-                              rows, row_valid, s);
+        if (g_bwd_impl == 1)
+            gs2m_launch_blend_bwd_mfma(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
+                                       grad_buffer, rows, row_valid, s);
+        else
+            gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
+                                  grad_buffer, rows, row_valid, s);
     }
     StageTimer tg(ST_GAUSSIAN_BWD, s);
     gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
-                             rows, row_valid, rowf, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
+                             rows, row_valid, rowf, rpi, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
                              dL_dcov3D, dL_dshs, dL_dscales, dL_drots, dL_dfeatures, s);
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
@@ -232,6 +238,12 @@ int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatri
 
 int gs2m_set_reference_binning(int on) {
     g_reference_binning = on ? 1 : 0;
+    return GS2M_OK;
+}
+
+int gs2m_set_bwd_impl(int impl) {
+    if (impl != 0 && impl != 1) return GS2M_ERR_INVALID_ARG;
+    g_bwd_impl = impl;
     return GS2M_OK;
 }
 

@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int BATCH = 256;
+constexpr int BATCH = 128;
 
 template <int FQ>  // number of float4 feature quads staged (1..3)
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                     }
                 }
             }
-            s_obs[tid] = 0;
+            if (tid < BATCH) s_obs[tid] = 0;
         }
         __syncthreads();  // (S3) batch staged
         prev_cnt = cnt;

@@ -96,12 +96,16 @@ int gs2m_row_floats(int fc);
 void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, const float* grad_color,
                            const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
+int gs2m_row_floats_mfma(int fc);
+void gs2m_launch_blend_bwd_mfma(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                                const BinningState& b, const ImageState& im, const float* grad_color,
+                                const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
                               int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s);
 void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
     const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ rows,
-    const uint8_t* __restrict__ row_valid, int rowf, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
+    const uint8_t* __restrict__ row_valid, int rowf, int rpi, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
@@ -103,23 +103,46 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     for (int k = 0; k < 24; k++) acc[k] = 0.f;
     {
         const int rq = rowf >> 2;
-        for (uint32_t t = 0; t < n; t += 4) {  // up to 4 rows in flight
-            uint8_t vld[4];
+        if (rpi == 1) {
+            for (uint32_t t = 0; t < n; t += 4) {  // up to 4 rows in flight
+                uint8_t vld[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) vld[u] = (t + u < n) ? row_valid[off + t + u] : (uint8_t)0;
-            float4 rv[4][6];
+                for (int u = 0; u < 4; u++) vld[u] = (t + u < n) ? row_valid[off + t + u] : (uint8_t)0;
+                float4 rv[4][6];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t + u) * rowf);
+                for (int u = 0; u < 4; u++) {
+                    const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t + u) * rowf);
 #pragma unroll
-                for (int q = 0; q < 6; q++)
-                    rv[u][q] = (vld[u] && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q = 0; q < 6; q++)
+                        rv[u][q] = (vld[u] && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {  // fixed summation order: bitwise reproducible
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
+                    }
+                }
             }
+        } else {  // one row per (instance, quadrant): the 4 valid bytes of an instance form one word
+            const uint32_t* valid4 = reinterpret_cast<const uint32_t*>(row_valid);
+            for (uint32_t t = 0; t < n; t++) {
+                const uint32_t vm4 = valid4[off + t];
+                float4 rv[4][6];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {  // fixed summation order: bitwise reproducible
+                for (int u = 0; u < 4; u++) {
+                    const bool on = ((vm4 >> (8 * u)) & 0xFFu) != 0;
+                    const float4* r4 = reinterpret_cast<const float4*>(rows + ((size_t)(off + t) * 4 + u) * rowf);
 #pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
+                    for (int q = 0; q < 6; q++)
+                        rv[u][q] = (on && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
+                    }
                 }
             }
         }
@@ -386,7 +409,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
                               int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
@@ -394,6 +417,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
     gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
         P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, \
         campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,      \
+        rows_per_inst,                                                                                                  \
         dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drots,      \
         dL_dfeatures)
     const bool lds = shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0 && (((uintptr_t)dL_dshs) & 15) == 0;

@@ -10,12 +10,12 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgs2m_raster.so")
+LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  # GS2M_LIB: A/B builds
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
+           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
           "gaussian_bwd")
@@ -63,6 +63,8 @@ def lib():
     L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
     L.gs2m_set_reference_binning.restype = i
     L.gs2m_set_reference_binning.argtypes = [i]
+    L.gs2m_set_bwd_impl.restype = i
+    L.gs2m_set_bwd_impl.argtypes = [i]
     L.gs2m_profile_mode.restype = i
     L.gs2m_profile_mode.argtypes = [i]
     L.gs2m_profile_collect.restype = i
@@ -105,3 +107,8 @@ def set_reference_binning(on):
     """True: emit exactly the reference's tile rectangles (bit-identical sorted lists, for the parity tests
     of the integer artefacts); False (default): drop tiles the alpha >= 1/255 ellipse cannot reach."""
     check(lib().gs2m_set_reference_binning(1 if on else 0), "gs2m_set_reference_binning")
+
+
+def set_bwd_impl(impl):
+    """0 (default): pixel-per-lane backward blend with permlane/DPP reductions; 1: survivor-per-lane + fp32 MFMA (experimental)."""
+    check(lib().gs2m_set_bwd_impl(int(impl)), "gs2m_set_bwd_impl")

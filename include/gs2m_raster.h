@@ -171,6 +171,12 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
  * used by the parity tests of the integer artefacts. */
 int gs2m_set_reference_binning(int on);
 
+/* Backward blend implementation: 0 (default) = pixel-per-lane with permlane/DPP reductions
+ * (csrc/blend_bwd.hip); 1 = survivor-per-lane layout with fp32 MFMA reductions
+ * (csrc/blend_bwd_mfma.hip, experimental: fewer vector instructions, currently slower end to end).
+ * Same results within fp32 rounding; both are covered by the parity tests. */
+int gs2m_set_bwd_impl(int impl);
+
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage.  Setting the mode clears
  * the records.  gs2m_profile_collect waits for the recorded events and returns, per

@@ -11,6 +11,17 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["bwd_permlane", "bwd_mfma"])
+def bwd_impl(request):
+    """every test runs against both backward blend implementations"""
+    import gs2m_native
+    if torch.cuda.is_available():
+        gs2m_native.set_bwd_impl(request.param)
+    yield request.param
+    if torch.cuda.is_available():
+        gs2m_native.set_bwd_impl(0)
+
+
 def _require_gpu():
     assert torch.cuda.is_available(), "these tests need a HIP device"
     import gs2m_native
