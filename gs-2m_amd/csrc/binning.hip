@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
     s_gid[wave][lane] = gid;
     s_rmin[wave][lane] = rmin;
     s_rw[wave][lane] = rw;
-    __syncthreads();
+    gs2m_sync();
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
         const uint32_t j = k + lane;
         if (j < total) {

@@ -104,20 +104,20 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 
     // entries past the tile's largest n_contrib are never touched by any pixel
     if (tid == 0) s_max = 0;
-    __syncthreads();
+    gs2m_sync();
     {
         uint32_t m = last;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
         if (lane == 0) atomicMax(&s_max, m);
     }
-    __syncthreads();
+    gs2m_sync();
     const int maxc = (int)s_max;
     const int nb = (maxc + BB - 1) / BB;
     int prev_cnt = 0;
 
     for (int b = nb - 1; b >= -1; b--) {
-        __syncthreads();  // (S1) previous batch fully accumulated
+        gs2m_sync();  // (S1) previous batch fully accumulated
         if (prev_cnt > 0) {
             // write the rows of the previous batch: 8 lanes x 16 B per row, fixed wave order
             unsigned long long any = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         const int base = b * BB;
         const int cnt = min(BB, maxc - base);
         if (tid < cnt) s_gid[tid] = point_list[range.x + base + tid];
-        __syncthreads();  // (S2)
+        gs2m_sync();  // (S2)
         {
             const int q = tid & 7;
             if (q < NQ) {
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             }
             if (tid < 4) s_mask[tid] = 0ull;
         }
-        __syncthreads();  // (S3)
+        gs2m_sync();  // (S3)
         prev_cnt = cnt;
 
         bool hit = false;

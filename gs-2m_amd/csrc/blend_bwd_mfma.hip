@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     const int maxc = (int)m;  // entries past the quadrant's largest n_contrib are never touched
     const int nb = (maxc + BB - 1) / BB;
-    __syncthreads();
+    gs2m_sync();
 
     // ---- survivor-per-lane state ----
     const int j = lane & 15, r = lane >> 4;
@@ -181,13 +181,13 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             U1 = h;
         }
         // ---- epilogue: lane (j, r) holds D[4r + rr][j], rr = 0..3 ----
-        __syncthreads();
+        gs2m_sync();
 #pragma unroll
         for (int rr = 0; rr < 4; rr++)
             if (j < 6) s_d[4 * r + rr][j] = acc2[rr];
         if (r == 0) s_d[j][6] = U1;
         if (r == 2) s_d[j][7] = U1;
-        __syncthreads();
+        gs2m_sync();
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
             const int i = 4 * r + rr;
@@ -215,9 +215,9 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     for (int bi = nb - 1; bi >= 0; bi--) {
         const int base = bi * BB;
         const int cnt = min(BB, maxc - base);
-        __syncthreads();
+        gs2m_sync();
         if (lane < cnt) s_gid[lane] = point_list[range.x + base + lane];
-        __syncthreads();
+        gs2m_sync();
         {
             const int q = lane & 7;
             if (q < NQ) {
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 }
             }
         }
-        __syncthreads();
+        gs2m_sync();
         bool hit = false;
         if (lane < cnt) {
             const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
         // back to front: the hit with the highest list position gets rank 0
         if (hit) s_list[lane == 63 ? 0 : (int)__popcll(mask >> (lane + 1))] = (uint32_t)lane;
         const int nh = (int)__popcll(mask);
-        __syncthreads();
+        gs2m_sync();
         int taken = 0;
         while (taken < nh) {
             const int n = min(16 - nfill, nh - taken);

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 
     for (int base = 0; base < len; base += BATCH) {
         // (S1) everyone finished the previous batch; vote on early exit (forward.cu:300-302)
-        const int num_done = __syncthreads_count(done);
+        const int num_done = gs2m_sync_count(done);
         if (prev_cnt > 0 && tid < prev_cnt) {
             const int o = s_obs[tid];
             if (o != 0) inst_obs[s_slot[tid]] = (uint32_t)o;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         if (num_done == 256) break;
         const int cnt = min(BATCH, len - base);
         if (tid < cnt) s_gid[tid] = point_list[range.x + base + tid];
-        __syncthreads();  // (S2) s_obs/s_slot of the previous batch consumed, gids visible
+        gs2m_sync();  // (S2) s_obs/s_slot of the previous batch consumed, gids visible
         {
             const int q = tid & 7;
             if (q < NQ) {
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
             }
             if (tid < BATCH) s_obs[tid] = 0;
         }
-        __syncthreads();  // (S3) batch staged
+        gs2m_sync();  // (S3) batch staged
         prev_cnt = cnt;
 
         if (__ballot(!done) != 0ull) {
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
             }
         }
     }
-    __syncthreads();
+    gs2m_sync();
     if (prev_cnt > 0 && tid < prev_cnt) {
         const int o = s_obs[tid];
         if (o != 0) inst_obs[s_slot[tid]] = (uint32_t)o;

@@ -139,6 +139,25 @@ __device__ __forceinline__ float wave_sum_row3(float v) {
     return v;
 }
 
+// Workgroup barrier that is safe at loop headers.  hipcc (ROCm 7.2, gfx950) emitted a bare
+// `s_barrier` for a __syncthreads() at the top of a loop whose back edge ends in LDS stores: the
+// release half (s_waitcnt lgkmcnt(0)) was missing, so other waves could pass the barrier and read
+// LDS before this wave's ds_writes had landed (seen as run-to-run differences in ~0.04 % of the
+// gradient rows at 1M Gaussians; tests/test_fullsize_gpu.py).  The inline-asm wait is invisible to
+// the waitcnt pass and therefore always kept.
+__device__ __forceinline__ void gs2m_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ int gs2m_sync_count(bool pred) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return __syncthreads_count(pred);
+}
+__device__ __forceinline__ int gs2m_sync_or(bool pred) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return __syncthreads_or(pred);
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave (u32).
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 #pragma unroll

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             float* d = s_sh + row * 49 + col;
             d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
         }
-        __syncthreads();
+        gs2m_sync();
     }
     const bool in_range = idx < P;
     const bool visible = in_range && radii[idx] > 0;
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     }  // in_range
     if (SH_LDS) {
-        __syncthreads();  // every thread has replaced its LDS row by its dL/dSH row
+        gs2m_sync();  // every thread has replaced its LDS row by its dL/dSH row
         const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
         float4* o4 = reinterpret_cast<float4*>(dL_dshs);
 #pragma unroll

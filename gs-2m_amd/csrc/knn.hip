@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) aabb_kernel(int n, const float* __restric
     m.mnx = wave_min(m.mnx); m.mny = wave_min(m.mny); m.mnz = wave_min(m.mnz);
     m.mxx = wave_max(m.mxx); m.mxy = wave_max(m.mxy); m.mxz = wave_max(m.mxz);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
-    __syncthreads();
+    gs2m_sync();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) {
             m.mnx = fminf(m.mnx, s[w].mnx); m.mny = fminf(m.mny, s[w].mny); m.mnz = fminf(m.mnz, s[w].mnz);
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) box_kernel(int P, const float4* __restric
     m.mnx = wave_min(m.mnx); m.mny = wave_min(m.mny); m.mnz = wave_min(m.mnz);
     m.mxx = wave_max(m.mxx); m.mxy = wave_max(m.mxy); m.mxz = wave_max(m.mxz);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
-    __syncthreads();
+    gs2m_sync();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) {
             m.mnx = fminf(m.mnx, s[w].mnx); m.mny = fminf(m.mny, s[w].mny); m.mnz = fminf(m.mnz, s[w].mnz);
@@ -165,10 +165,10 @@ __global__ void __launch_bounds__(256) knn_kernel(int P, const float4* __restric
             const float d = dist_box_point(box, point);
             want = !(d > reject || d > best[2]);
         }
-        if (__syncthreads_or(want)) {
+        if (gs2m_sync_or(want)) {
             const int start = b * BOX, n = min(BOX, P - start);
             for (int k = threadIdx.x; k < n; k += 256) s_pts[k] = sorted[start + k];
-            __syncthreads();
+            gs2m_sync();
             if (want) {
                 for (int k = 0; k < n; k++) {
                     if (start + k == idx) continue;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) knn_kernel(int P, const float4* __restric
                 }
             }
         }
-        __syncthreads();
+        gs2m_sync();
     }
     if (valid) dists[order[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
 }

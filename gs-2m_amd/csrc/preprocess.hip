@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             float* d = s_sh + row * 49 + col;
             d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
         }
-        __syncthreads();
+        gs2m_sync();
     }
     if (idx >= P) return;
 

@@ -287,3 +287,15 @@ def test_render_counterpart_matches_oracle(oracle_lib):
     assert set(out_dev.keys()) >= {"render", "viewspace_points", "visibility_filter", "radii", "observe", "alpha_map",
                                    "distance_map", "depth_map", "normal_map", "albedo_map", "roughness_map",
                                    "metallic_map", "normal_mask", "local_normal_map", "sobel_map"}
+
+
+def test_render_end_to_end_gradients(oracle_lib):
+    """autograd through render()'s pre/post-processing AND the rasterizer: raw-parameter gradients on the
+    device vs the same Python code around the oracle-backed op on the CPU."""
+    _require_gpu()
+    sc = Hh.make_scene(2000, 128, 96, seed=14, fc=9, scale_hi=0.06)
+    dev, ref = Hh.render_pair(oracle_lib, sc, grads=True, material_stage=True, blend_metallic=True)
+    names = ["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic"]
+    for n, a, b in zip(names, dev["param_grads"], ref["param_grads"]):
+        assert Hh.rel_err(a, b) < 2e-3, (n, Hh.rel_err(a, b))
+    assert Hh.rel_err(dev["viewspace_grad"], ref["viewspace_grad"]) < 1e-3
