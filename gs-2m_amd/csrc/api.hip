@@ -120,13 +120,13 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s);
-            HIP_TRY(gs2m_sort_pairs_u32(g.temp, g.temp_bytes, g.depth_key, g.depth_key_sorted, g.gid_iota, g.sorted_gid, (size_t)P, 0, 32, s));
+            HIP_TRY(gs2m_radix_sort_pairs(g.temp, g.temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
+                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, s));
         }
         {   // 2. emission offsets in that order
             StageTimer t(ST_SCAN, s);
-            gs2m_launch_gather_tt(P, g, s);
-            HIP_TRY(gs2m_exclusive_scan_u32(g.temp, g.temp_bytes, g.sorted_tt, g.sorted_off, (size_t)P, s));
-            gs2m_launch_total(P, g, s);
+            HIP_TRY(gs2m_scan_tiles_touched(g.temp, g.temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
+                                            g.sorted_off, g.counters, s));
         }
         if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
         HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -150,7 +150,8 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
         {
             StageTimer t(ST_TILE_SORT, s);
-            HIP_TRY(gs2m_sort_pairs_u32(b.temp, b.temp_bytes, b.keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0, tile_bits, s));
+            HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
+                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, s));
         }
         {
             StageTimer t(ST_RANGES, s);

@@ -10,10 +10,8 @@
 //   4. stable sort of the R pairs on the tile bits only (13 bits at 1080p instead of 45).
 // Stable sort by tile of a depth-ordered list == sort by (tile, depth) with ties kept in
 // Gaussian-id order, i.e. exactly the reference's sorted list.
-// Sort/scan primitives: rocPRIM device radix sort / scan (library baseline for round 1).
+// Sort/scan primitives: radix_sort.hip (hand-written onesweep radix sort and look-back scan).
 #include "common.h"
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     GeomState g;
@@ -26,7 +24,8 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     g.rec = (float4*)take(P * REC_Q * sizeof(float4));
     g.tiles_touched = (uint32_t*)take(P * 4);
     g.depth_key = (uint32_t*)take(P * 4);
-    g.gid_iota = (uint32_t*)take(P * 4);
+    g.sort_keyA = (uint32_t*)take(P * 4);
+    g.sort_valA = (uint32_t*)take(P * 4);
     g.depth_key_sorted = (uint32_t*)take(P * 4);
     g.sorted_gid = (uint32_t*)take(P * 4);
     g.sorted_tt = (uint32_t*)take(P * 4);
@@ -49,6 +48,8 @@ BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
     };
     b.keys_unsorted = (uint32_t*)take(R * 4);
     b.vals_unsorted = (uint32_t*)take(R * 4);
+    b.sort_keyA = (uint32_t*)take(R * 4);
+    b.sort_valA = (uint32_t*)take(R * 4);
     b.tile_keys = (uint32_t*)take(R * 4);
     b.point_list = (uint32_t*)take(R * 4);
     b.inst_obs = (uint32_t*)take(R * 4);
@@ -74,43 +75,13 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
 }
 
 size_t gs2m_geom_temp_bytes(size_t P) {
-    size_t a = 0, b = 0;
-    uint32_t* n = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, P, 0, 32, (hipStream_t)0);
-    (void)rocprim::exclusive_scan(nullptr, b, n, n, 0u, P, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    const size_t a = gs2m_radix_temp_bytes(P, 32), b = gs2m_scan_temp_bytes(P);
     return gs2m_align_up(a > b ? a : b) + GS2M_ALIGN;
 }
 
-size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) {
-    size_t a = 0;
-    uint32_t* n = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R, 0, (unsigned)tile_bits, (hipStream_t)0);
-    return gs2m_align_up(a) + GS2M_ALIGN;
-}
-
-hipError_t gs2m_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
-                               const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
-                               hipStream_t s) {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
-}
-
-hipError_t gs2m_exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
-                                   hipStream_t s) {
-    return rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
-}
+size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) { return gs2m_align_up(gs2m_radix_temp_bytes(R, tile_bits)) + GS2M_ALIGN; }
 
 namespace {
-
-__global__ void gather_tt_kernel(int P, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ tiles_touched,
-                                 uint32_t* __restrict__ sorted_tt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) sorted_tt[i] = tiles_touched[sorted_gid[i]];
-}
-
-__global__ void total_kernel(int P, const uint32_t* __restrict__ sorted_tt, const uint32_t* __restrict__ sorted_off,
-                             uint32_t* __restrict__ counters) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) counters[0] = P > 0 ? sorted_off[P - 1] + sorted_tt[P - 1] : 0u;
-}
 
 // Load-balanced expansion (replaces duplicateWithKeys, rasterizer_impl.cu:63-103).
 // One wave owns 64 depth-sorted Gaussians whose instances occupy one contiguous slot range;
@@ -196,12 +167,6 @@ __global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, c
 
 }  // namespace
 
-void gs2m_launch_gather_tt(int P, const GeomState& g, hipStream_t s) {
-    gather_tt_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.tiles_touched, g.sorted_tt);
-}
-void gs2m_launch_total(int P, const GeomState& g, hipStream_t s) {
-    total_kernel<<<1, 64, 0, s>>>(P, g.sorted_tt, g.sorted_off, g.counters);
-}
 void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
                                                 b.vals_unsorted);

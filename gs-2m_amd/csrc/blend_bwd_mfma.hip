@@ -42,11 +42,6 @@ __device__ __forceinline__ float row_scan_add(float x) {  // inclusive prefix su
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_ROW_SHR(8), 0xF, 0xF, false));
     return x;
 }
-// value of lane 15 of each 16-lane row, in every lane of that row (ds_swizzle bit mode:
-// lane' = (lane & 0x10) | 0x0F inside each group of 32)
-__device__ __forceinline__ float row_last(float x) {
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x1F0));
-}
 
 template <int FC>
 __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(

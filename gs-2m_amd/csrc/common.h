@@ -35,20 +35,23 @@ struct GeomState {
     float4* rec;             // P * 8
     uint32_t* tiles_touched; // P (by Gaussian id)
     uint32_t* depth_key;     // P
-    uint32_t* gid_iota;      // P
+    uint32_t* sort_keyA;     // P (radix sort ping buffer)
+    uint32_t* sort_valA;     // P
     uint32_t* depth_key_sorted; // P
     uint32_t* sorted_gid;    // P
     uint32_t* sorted_tt;     // P
     uint32_t* sorted_off;    // P
     uint8_t* clamped;        // P
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
-    char* temp;              // rocPRIM temporary storage
+    char* temp;              // radix sort / scan temporary storage
     size_t temp_bytes;
     size_t total_bytes;      // including alignment slack
 };
 struct BinningState {
     uint32_t* keys_unsorted; // R
     uint32_t* vals_unsorted; // R
+    uint32_t* sort_keyA;     // R (radix sort ping buffer)
+    uint32_t* sort_valA;     // R
     uint32_t* tile_keys;     // R (sorted)
     uint32_t* point_list;    // R (sorted Gaussian ids)
     uint32_t* inst_obs;      // R
@@ -68,14 +71,16 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes);
 BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
 ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 
-// rocPRIM-backed primitives (binning.hip)
+// hand-written radix sort / scan (radix_sort.hip)
 size_t gs2m_geom_temp_bytes(size_t P);
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
-hipError_t gs2m_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
-                               const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
-                               hipStream_t s);
-hipError_t gs2m_exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
-                                   hipStream_t s);
+size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
+hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, hipStream_t s);
+size_t gs2m_scan_temp_bytes(size_t n);
+hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
+                                   const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
+                                   uint32_t* counters, hipStream_t s);
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -84,8 +89,6 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, const GeomState& g, int shrink, hipStream_t s);
-void gs2m_launch_gather_tt(int P, const GeomState& g, hipStream_t s);
-void gs2m_launch_total(int P, const GeomState& g, hipStream_t s);
 void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s);
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

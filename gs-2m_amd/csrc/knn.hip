@@ -11,8 +11,6 @@
 // box with one ballot whether ANY of its points needs it, then stages the box's 1024
 // points in LDS once for the whole workgroup instead of 1024 dependent gathers per thread.
 #include "common.h"
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <cfloat>
 
 namespace {
@@ -73,7 +71,7 @@ __device__ __forceinline__ uint32_t prep_morton(uint32_t x) {
 }
 
 __global__ void morton_kernel(int P, const float* __restrict__ pts, const MinMax* __restrict__ aabb,
-                              uint32_t* __restrict__ codes, uint32_t* __restrict__ iota) {
+                              uint32_t* __restrict__ codes) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
     const MinMax b = *aabb;
@@ -82,7 +80,6 @@ __global__ void morton_kernel(int P, const float* __restrict__ pts, const MinMax
     const uint32_t my = prep_morton((uint32_t)(((y - b.mny) / (b.mxy - b.mny)) * ((1 << 10) - 1)));
     const uint32_t mz = prep_morton((uint32_t)(((z - b.mnz) / (b.mxz - b.mnz)) * ((1 << 10) - 1)));
     codes[idx] = mx | (my << 1) | (mz << 2);
-    iota[idx] = (uint32_t)idx;
 }
 
 __global__ void gather_points_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
@@ -192,12 +189,11 @@ extern "C" int gs2m_knn_dist2(int P, const float* points, float* mean_dists, gs2
     const size_t n = (size_t)P;
     const int num_boxes = (P + BOX - 1) / BOX;
     const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    size_t sort_bytes = 0;
-    uint32_t* nul = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, nul, nul, nul, nul, n, 0, 32, (hipStream_t)0);
+    const size_t sort_bytes = gs2m_radix_temp_bytes(n, 32);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = gs2m_align_up(off + bytes); return o; };
     const size_t o_codes = take(n * 4), o_iota = take(n * 4), o_codes_s = take(n * 4), o_order = take(n * 4);
+    const size_t o_kA = take(n * 4);
     const size_t o_sorted = take(n * sizeof(float4)), o_boxes = take((size_t)num_boxes * sizeof(MinMax));
     const size_t o_part = take((size_t)nblk * sizeof(MinMax)), o_aabb = take(sizeof(MinMax)), o_temp = take(sort_bytes);
     char* base = scratch_alloc(off + GS2M_ALIGN, scratch_user);
@@ -210,8 +206,9 @@ extern "C" int gs2m_knn_dist2(int P, const float* points, float* mean_dists, gs2
 
     aabb_kernel<<<nblk, 256, 0, s>>>(P, points, 3, 0, part);
     aabb_kernel<<<1, 256, 0, s>>>(nblk, reinterpret_cast<const float*>(part), 0, 1, aabb);
-    morton_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, aabb, codes, iota);
-    if (rocprim::radix_sort_pairs(base + o_temp, sort_bytes, codes, codes_s, iota, order, n, 0, 32, s) != hipSuccess) return GS2M_ERR_HIP;
+    morton_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, aabb, codes);
+    // 30-bit Morton codes; values implicit (index); iota doubles as the ping value buffer
+    if (gs2m_radix_sort_pairs(base + o_temp, sort_bytes, codes, nullptr, (uint32_t*)(base + o_kA), iota, codes_s, order, n, 32, s) != hipSuccess) return GS2M_ERR_HIP;
     gather_points_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, order, sorted);
     box_kernel<<<num_boxes, 256, 0, s>>>(P, sorted, boxes);
     knn_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, sorted, order, boxes, num_boxes, mean_dists);

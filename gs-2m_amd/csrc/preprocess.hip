@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, float4* __restrict__ rec,
     uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ gid_iota, uint8_t* __restrict__ clamped) {
+    uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped) {
     // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian read has a 192-B lane
     // stride.  The block instead streams its 256 rows (48 KiB, contiguous) with coalesced float4
     // loads into LDS (row stride 49 floats: conflict-free column reads) and each thread then reads
@@ -256,7 +256,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     radii[idx] = out_radius;
     tiles_touched[idx] = out_tt;
     depth_key[idx] = out_key;
-    gid_iota[idx] = (uint32_t)idx;
 }
 
 // markVisible / checkFrustum (rasterizer_impl.cu:48-59, 132-143)
@@ -282,7 +281,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                                                            shs, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, g.rec,             \
-                                                           g.tiles_touched, g.depth_key, g.gid_iota, g.clamped)
+                                                           g.tiles_touched, g.depth_key, g.clamped)
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;
     if (lds) GS2M_PRE(true);
     else GS2M_PRE(false);

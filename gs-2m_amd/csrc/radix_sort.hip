@@ -1,0 +1,338 @@
+// Stable LSD radix sort of (u32 key, u32 value) pairs for gfx950, onesweep style
+// (Adinets & Merrill 2022): ONE histogram kernel reads the keys once and counts every digit of
+// every pass; then one kernel per pass ranks and scatters a 4096-key tile per workgroup, obtaining
+// the number of equal digits in all preceding tiles by decoupled look-back instead of a separate
+// scan pass.  Used for (1) the depth order of the Gaussians (32-bit fp32 depth keys) and (2) the
+// stable tile sort of the emitted instances (13 key bits at 1080p) -- the two places where the
+// reference calls cub::DeviceRadixSort (cuda_rasterizer/rasterizer_impl.cu:291-296 sorts R 64-bit
+// keys over 45 bits in one go).
+//
+// MI355X specifics:
+//  * 64-lane ranking: the lanes holding the same digit are found with BITS ballots (match-any);
+//    rank = popcount of the lower peers; the lowest peer bumps the wave's digit counter in LDS.
+//    Items of a lane are visited in index order, waves own contiguous key ranges, so the sort is
+//    stable by construction.
+//  * look-back across workgroups that may sit on different XCDs (non-coherent L2s): every status
+//    word carries flag and count together in ONE naturally aligned 32-bit word, written and polled
+//    with relaxed AGENT-scope atomics (sc1, served by the memory side), so no fence and no separate
+//    payload are needed; tile ids are handed out by an atomic ticket, so a tile only ever waits for
+//    tiles that were started before it (forward progress without co-residency assumptions).
+#include "common.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_MAXPASS = 4;
+constexpr uint32_t FLAG_AGG = 1u << 30, FLAG_PFX = 2u << 30, VAL_MASK = (1u << 30) - 1;
+
+struct SortPlan {
+    int npass;
+    int bits[RS_MAXPASS];
+    int shift[RS_MAXPASS];
+};
+
+SortPlan make_plan(int total_bits) {
+    SortPlan p;
+    if (total_bits < 1) total_bits = 1;
+    p.npass = total_bits <= 16 ? 2 : 4;  // even: the result lands back in the input buffers
+    const int per = (total_bits + p.npass - 1) / p.npass;
+    int s = 0;
+    for (int i = 0; i < p.npass; i++) {
+        int b = total_bits - s;
+        if (b > per) b = per;
+        if (b < 0) b = 0;
+        p.bits[i] = b;
+        p.shift[i] = s;
+        s += b;
+    }
+    return p;
+}
+
+// ---- histogram of every digit of every pass, one read of the keys ----
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npass,
+                                                             int4 bits, int4 shift, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t s_h[RS_MAXPASS][256];
+    const int tid = threadIdx.x;
+    for (int p = 0; p < RS_MAXPASS; p++) s_h[p][tid] = 0;
+    gs2m_sync();
+    const int b[4] = {bits.x, bits.y, bits.z, bits.w}, sh[4] = {shift.x, shift.y, shift.z, shift.w};
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = base + k * RS_THREADS + tid;
+        if (i < n) {
+            const uint32_t key = keys[i];
+            for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key >> sh[p]) & ((1u << b[p]) - 1u)], 1u);
+        }
+    }
+    gs2m_sync();
+    for (int p = 0; p < npass; p++) {
+        const uint32_t c = s_h[p][tid];
+        if (c) atomicAdd(&ghist[p * 256 + tid], c);
+    }
+}
+
+// ---- one pass: rank + look-back + scatter ----
+template <int BITS>
+__global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ ghist, uint32_t* ticket,
+    uint32_t* status /* [tiles][256] */) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t s_cnt[4][BINS];  // per-wave digit counters, later per-wave local bases
+    __shared__ uint32_t s_gbase[256];    // global position of local index i with digit d: s_gbase[d] + i
+    __shared__ uint32_t s_w[2][4];
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_key[RS_TILE], s_val[RS_TILE];  // tile reordered by digit: coalesced runs on the way out
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = tid; i < 4 * BINS; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    gs2m_sync();
+    const uint32_t tile = s_tile;
+    const uint32_t tile_base = tile * RS_TILE;
+    const uint32_t tile_count = min((uint32_t)RS_TILE, n - tile_base);
+    const uint32_t segbase = tile_base + wave * (64 * RS_ITEMS);
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = segbase + k * 64 + lane;
+        key[k] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        val[k] = i < n ? (vals_in ? vals_in[i] : i) : 0u;  // vals_in == nullptr: the value is the index
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const bool valid = segbase + k * 64 + lane < n;
+        const uint32_t d = (key[k] >> shift) & (BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t old = s_cnt[wave][d];  // every peer reads before the leader's write (in-order LDS)
+        const unsigned long long below = peers & lt;
+        rank[k] = old + (uint32_t)__popcll(below);
+        if (valid && below == 0ull) s_cnt[wave][d] = old + (uint32_t)__popcll(peers);
+    }
+    gs2m_sync();
+
+    // per digit: tile total, exclusive scans over the digits of (a) the tile totals (local layout) and
+    // (b) the global histogram (digit bases), then the look-back for the tiles in front
+    uint32_t tot = 0, c0 = 0, c1 = 0, c2 = 0, gh = 0;
+    if (tid < BINS) {
+        c0 = s_cnt[0][tid]; c1 = s_cnt[1][tid]; c2 = s_cnt[2][tid];
+        tot = c0 + c1 + c2 + s_cnt[3][tid];
+        gh = ghist[tid];
+    }
+    const uint32_t inclA = wave_inclusive_scan_u32(tot, lane), inclB = wave_inclusive_scan_u32(gh, lane);
+    if (lane == 63) {
+        s_w[0][wave] = inclA;
+        s_w[1][wave] = inclB;
+    }
+    gs2m_sync();
+    uint32_t tile_excl = inclA - tot, digit_base = inclB - gh;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (w < wave) {
+            tile_excl += s_w[0][w];
+            digit_base += s_w[1][w];
+        }
+    if (tid < BINS) {
+        uint32_t* my = status + (size_t)tile * 256 + tid;
+        uint32_t excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(my, FLAG_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(my, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int p = (int)tile - 1;
+            while (true) {
+                const uint32_t w = __hip_atomic_load(status + (size_t)p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t f = w & ~VAL_MASK;
+                if (f == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += w & VAL_MASK;
+                if (f == FLAG_PFX) break;
+                p--;
+            }
+            __hip_atomic_store(my, FLAG_PFX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gbase[tid] = digit_base + excl - tile_excl;
+        s_cnt[0][tid] = tile_excl;
+        s_cnt[1][tid] = tile_excl + c0;
+        s_cnt[2][tid] = tile_excl + c0 + c1;
+        s_cnt[3][tid] = tile_excl + c0 + c1 + c2;
+    }
+    gs2m_sync();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        if (segbase + k * 64 + lane < n) {
+            const uint32_t d = (key[k] >> shift) & (BINS - 1);
+            const uint32_t lp = s_cnt[wave][d] + rank[k];
+            s_key[lp] = key[k];
+            s_val[lp] = val[k];
+        }
+    }
+    gs2m_sync();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = k * RS_THREADS + tid;
+        if (i < tile_count) {
+            const uint32_t kk = s_key[i];
+            const uint32_t pos = s_gbase[(kk >> shift) & (BINS - 1)] + i;
+            keys_out[pos] = kk;
+            vals_out[pos] = s_val[i];
+        }
+    }
+}
+
+template <int BITS>
+void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
+                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s) {
+    rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist, ticket, status);
+}
+
+}  // namespace
+
+// temp layout: [ghist 4x256][tickets 4 (padded to 256 B)][status npass x tiles x 256]
+size_t gs2m_radix_temp_bytes(size_t n, int total_bits) {
+    const SortPlan p = make_plan(total_bits);
+    const size_t tiles = (n + RS_TILE - 1) / RS_TILE;
+    return gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4 + 2 * GS2M_ALIGN;
+}
+
+// Sorts n pairs by key bits [0, total_bits), stable.  The input (kin, vin) is only read (vin may be
+// nullptr: values are then the indices 0..n-1); passes alternate between (kA, vA) and (kB, vB) and the
+// number of passes is even, so the result is in (kB, vB).
+hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const SortPlan p = make_plan(total_bits);
+    const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
+    if (temp_bytes < gs2m_radix_temp_bytes(n, total_bits)) return hipErrorInvalidValue;
+    char* base = (char*)gs2m_align_up((size_t)(uintptr_t)temp);
+    uint32_t* ghist = (uint32_t*)base;
+    uint32_t* tickets = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4));
+    uint32_t* status = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN);
+    const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
+    hipError_t e = hipMemsetAsync(base, 0, zero_bytes, s);
+    if (e != hipSuccess) return e;
+    rs_hist_kernel<<<tiles, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
+                                                make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist);
+    const uint32_t *ki = kin, *vi = vin;
+    for (int i = 0; i < p.npass; i++) {
+        uint32_t* ko = (i & 1) ? kB : kA;
+        uint32_t* vo = (i & 1) ? vB : vA;
+        uint32_t* st = status + (size_t)i * tiles * 256;
+        const uint32_t* gh = ghist + i * 256;
+        switch (p.bits[i]) {
+#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s); break;
+            RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+#undef RS_CASE
+            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s); break;  // 0 bits: stable copy
+        }
+        ki = ko;
+        vi = vo;
+    }
+    return hipGetLastError();
+}
+
+// ---- exclusive scan of tiles_touched in depth order, single pass with decoupled look-back ----
+// out: sorted_tt[i] = tiles_touched[sorted_gid[i]], sorted_off[i] = exclusive prefix, counters[0] = total.
+namespace {
+constexpr int SC_ITEMS = 16;
+__global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t* __restrict__ sorted_gid,
+                                                      const uint32_t* __restrict__ tiles_touched,
+                                                      uint32_t* __restrict__ sorted_tt, uint32_t* __restrict__ sorted_off,
+                                                      uint32_t* __restrict__ counters, uint32_t* ticket, uint32_t* status) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile, s_base;
+    __shared__ uint32_t s_t[256 * SC_ITEMS + 128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    gs2m_sync();
+    const uint32_t tile = s_tile;
+    // coalesced gather (element k*256 + tid), transposed through LDS so that each thread then owns 16
+    // consecutive elements; index + index/32 padding keeps both access patterns conflict-free
+    const uint32_t tbase = tile * (256 * SC_ITEMS);
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t e = k * 256 + tid, i = tbase + e;
+        s_t[e + (e >> 5)] = i < n ? tiles_touched[sorted_gid[i]] : 0u;
+    }
+    gs2m_sync();
+    const uint32_t i0 = tbase + tid * SC_ITEMS;
+    uint32_t v[SC_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t e = tid * SC_ITEMS + k;
+        v[k] = s_t[e + (e >> 5)];
+        sum += v[k];
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(sum, lane);
+    if (lane == 63) s_w[wave] = incl;
+    gs2m_sync();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) wbase += s_w[w];
+        total += s_w[w];
+    }
+    if (tid == 0) {
+        uint32_t excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(status, FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(status + tile, FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int p = (int)tile - 1;
+            while (true) {
+                const uint32_t w = __hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t f = w & ~VAL_MASK;
+                if (f == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += w & VAL_MASK;
+                if (f == FLAG_PFX) break;
+                p--;
+            }
+            __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_base = excl;
+        if ((tile + 1) * (256 * SC_ITEMS) >= n) counters[0] = excl + total;  // last tile: num_rendered
+    }
+    gs2m_sync();
+    uint32_t run = s_base + wbase + (incl - sum);
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t i = i0 + k;
+        if (i < n) {
+            sorted_tt[i] = v[k];
+            sorted_off[i] = run;
+        }
+        run += v[k];
+    }
+}
+}  // namespace
+
+size_t gs2m_scan_temp_bytes(size_t n) { return gs2m_align_up(((n + 4095) / 4096 + 64) * 4) + 2 * GS2M_ALIGN; }
+
+// num_rendered must stay below 2^30 (30-bit look-back payload)
+hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
+                                   const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
+                                   uint32_t* counters, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int tiles = (int)((n + 4095) / 4096);
+    if (temp_bytes < gs2m_scan_temp_bytes(n)) return hipErrorInvalidValue;
+    uint32_t* base = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
+    hipError_t e = hipMemsetAsync(base, 0, (size_t)(tiles + 64) * 4, s);
+    if (e != hipSuccess) return e;
+    scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64);
+    return hipGetLastError();
+}
