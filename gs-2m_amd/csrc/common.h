@@ -99,6 +99,9 @@ int gs2m_row_floats(int fc);
 void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, const float* grad_color,
                            const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
+void gs2m_launch_blend_bwd_hyb(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                               const BinningState& b, const ImageState& im, const float* grad_color,
+                               const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
 int gs2m_row_floats_mfma(int fc);
 void gs2m_launch_blend_bwd_mfma(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                                 const BinningState& b, const ImageState& im, const float* grad_color,

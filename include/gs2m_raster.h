@@ -173,7 +173,9 @@ int gs2m_set_reference_binning(int on);
 
 /* Backward blend implementation: 0 (default) = pixel-per-lane with permlane/DPP reductions
  * (csrc/blend_bwd.hip); 1 = survivor-per-lane layout with fp32 MFMA reductions
- * (csrc/blend_bwd_mfma.hip, experimental: fewer vector instructions, currently slower end to end).
+ * (csrc/blend_bwd_mfma.hip); 2 = pixel-per-lane evaluation with MFMA reductions through an LDS
+ * transpose (csrc/blend_bwd_hyb.hip).  1 and 2 are experimental: fewer vector instructions, currently
+ * slower end to end.
  * Same results within fp32 rounding; both are covered by the parity tests. */
 int gs2m_set_bwd_impl(int impl);
 

@@ -11,7 +11,7 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1], ids=["bwd_permlane", "bwd_mfma"])
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["bwd_permlane", "bwd_mfma", "bwd_hybrid"])
 def bwd_impl(request):
     """every test runs against both backward blend implementations"""
     import gs2m_native
