@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
         bool hit = false;
         if (lane < cnt) {
             const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
-            hit = (a.x + c.z >= bx0) && (a.x - c.z <= bx1) && (a.y + c.w >= by0) && (a.y - c.w <= by1);
+            hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, c.z, c.w, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
         }
         const unsigned long long mask = __ballot(hit);
         // back to front: the hit with the highest list position gets rank 0

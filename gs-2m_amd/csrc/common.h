@@ -12,7 +12,8 @@
 // ---- blend record: 8 x float4 = 128 B per Gaussian (one aligned HBM line) -------------
 // q0: x, y, A, B          pixel-space mean, conic (A = conic.x, B = conic.y)
 // q1: C, opacity, hx, hy  conic.z, opacity, half extents of the alpha >= 1/255 ellipse
-// q2: off, rmin, rwh, z   u32 emission offset, tile rect min (x | y << 16), rect (w | h << 16), depth
+// q2: off, rmin, rwh, t2  u32 emission offset, tile rect min (x | y << 16), rect (w | h << 16),
+//                        t2 = upper bound of A dx^2 + 2B dx dy + C dy^2 where alpha can reach 1/255
 // q3: r, g, b, -          colour (SH-evaluated or precomputed)
 // q4..q6: features[0..9], 2 pad floats
 // q7: unused
@@ -188,6 +189,32 @@ __device__ __forceinline__ float gs2m_power(float dx, float dy, float A, float B
     const float t3 = (B * dx) * dy;
     return (-0.5f * (t1 + t2)) - t3;
 }
+// Does the region {A dx^2 + 2B dx dy + C dy^2 <= t2} around (gx, gy) reach the pixel rectangle
+// [x0, x1] x [y0, y1]?  Conservative (t2 and the box carry margins, preprocess.hip): bounding-box test
+// first, then the exact minimum of the quadratic form over the rectangle (centre inside, or the best
+// point of the four edges).  Instances that fail cannot contribute to any pixel of the rectangle.
+__device__ __forceinline__ bool gs2m_reaches_rect(float gx, float gy, float A, float B, float C, float hx, float hy,
+                                                  float t2, float x0, float x1, float y0, float y1) {
+    if (!((gx + hx >= x0) && (gx - hx <= x1) && (gy + hy >= y0) && (gy - hy <= y1))) return false;
+    if (!(t2 < 3.0e38f)) return true;  // culling disabled for this Gaussian (ill-conditioned conic)
+    const float lx = x0 - gx, ux = x1 - gx, ly = y0 - gy, uy = y1 - gy;  // rectangle relative to the centre
+    if (lx <= 0.f && ux >= 0.f && ly <= 0.f && uy >= 0.f) return true;
+    float qmin = 3.0e38f;
+    {   // vertical edges dx = lx, ux: minimise over dy in [ly, uy]
+        const float rC = 1.0f / C;
+        const float dyl = fminf(uy, fmaxf(ly, -B * lx * rC)), dyu = fminf(uy, fmaxf(ly, -B * ux * rC));
+        qmin = fminf(qmin, A * lx * lx + 2.f * B * lx * dyl + C * dyl * dyl);
+        qmin = fminf(qmin, A * ux * ux + 2.f * B * ux * dyu + C * dyu * dyu);
+    }
+    {   // horizontal edges dy = ly, uy: minimise over dx in [lx, ux]
+        const float rA = 1.0f / A;
+        const float dxl = fminf(ux, fmaxf(lx, -B * ly * rA)), dxu = fminf(ux, fmaxf(lx, -B * uy * rA));
+        qmin = fminf(qmin, A * dxl * dxl + 2.f * B * dxl * ly + C * ly * ly);
+        qmin = fminf(qmin, A * dxu * dxu + 2.f * B * dxu * uy + C * uy * uy);
+    }
+    return qmin <= t2 + 1.0e-3f * fabsf(qmin);
+}
+
 // exp(x) for x <= 0 through v_exp_f32
 __device__ __forceinline__ float gs2m_exp(float x) { return __builtin_amdgcn_exp2f(x * GS2M_LOG2E); }
 #endif

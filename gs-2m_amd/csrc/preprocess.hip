@@ -197,8 +197,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 // switched off (infinite) for ill-conditioned or indefinite conics.
                 const float op = opacities[idx];
                 float ex, ey;
+                float tau2f = __builtin_inff();  // bound on A dx^2 + 2B dx dy + C dy^2 inside the ellipse
                 if (op < 1.0f / 255.0f) {
                     ex = ey = -1.0f;  // alpha <= opacity < 1/255 everywhere: never contributes
+                    tau2f = -1.0f;
                 } else {
                     const double dA = cA, dB = cB, dC = cC;
                     const double ddet = dA * dC - dB * dB;
@@ -208,6 +210,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                         const double tau2 = 2.0 * fmax(0.0, log(255.0 * (double)op) + 1.0e-3);
                         ex = (float)(sqrt(tau2 * dC / ddet) * 1.001 + 0.01);
                         ey = (float)(sqrt(tau2 * dA / ddet) * 1.001 + 0.01);
+                        tau2f = (float)(tau2 * 1.002 + 1.0e-3);
                     }
                 }
                 // Tile rectangle actually emitted: the reference's radius rectangle intersected with
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 float4* r4 = rec + (size_t)idx * REC_Q;
                 r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
                 r4[REC_GEO1] = make_float4(cC, op, ex, ey);
-                r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), vz);
+                r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), tau2f);
                 r4[REC_RGB] = make_float4(cr, cg, cb, 0.f);
                 if (features != nullptr) {
                     const float2* f2 = reinterpret_cast<const float2*>(features + (size_t)idx * GS2M_NUM_FEATURES);
