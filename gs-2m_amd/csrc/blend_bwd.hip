@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     __shared__ __align__(16) float s_acc[4][BB][ROWF];
     __shared__ unsigned long long s_mask[4];
     __shared__ uint32_t s_max;
+    __shared__ float s_dummy[256];  // sink for the lanes that own no value after the reduction
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.x;
@@ -242,7 +243,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             float outv = r[0];
 #pragma unroll
             for (int q = 1; q < RQ; q++) outv = (c16 == q) ? r[q] : outv;
-            if (c16 < RQ) s_acc[wave][jj][c16 + RQ * row] = outv;
+            // every lane stores (owners into the row, the others into a sink): keeping the store out of a
+            // divergent branch lets the last DPP add of the reduction stay a single v_add_f32_dpp
+            float* dst = (c16 < RQ) ? &s_acc[wave][jj][c16 + RQ * row] : &s_dummy[tid];
+            *dst = outv;
             wrote |= (1ull << jj);
         }
         if (lane == 0) s_mask[wave] = wrote;
