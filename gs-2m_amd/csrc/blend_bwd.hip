@@ -221,20 +221,23 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 }
                 const float dL_dalpha = T * gc - Sg * inv1ma;
                 Sg = __builtin_fmaf(gc, w, Sg);
-                const float dL_dG = c.y * dL_dalpha;  // a = x, y, A, B;  c = C, opacity, hx, hy
-                const float gdx = Gm * dx, gdy = Gm * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * c.x - gdx * a.w;
-                const float mx = dL_dG * dG_ddelx * ddelx_dx;
-                const float my = dL_dG * dG_ddely * ddely_dy;
+                // a = x, y, A, B;  c = C, opacity, hx, hy.  With s = opacity * dL/dalpha * G (backward.cu:569-595):
+                //   d mean2D = -s * (A dx + B dy, C dy + B dx) * (W/2, H/2),  d conic = -0.5 s (dx^2, dx dy, dy^2)
+                const float GdA = Gm * dL_dalpha;
+                const float s_ = c.y * GdA;
+                const float t1 = __builtin_fmaf(a.w, dy, a.z * dx), t2 = __builtin_fmaf(a.w, dx, c.x * dy);
+                const float mx = (s_ * t1) * -ddelx_dx;
+                const float my = (s_ * t2) * -ddely_dy;
+                const float hs = -0.5f * s_;
+                const float hsdx = hs * dx;
                 v[0] = mx;
                 v[1] = my;
                 v[2] = fabsf(mx);
                 v[3] = fabsf(my);
-                v[4] = -0.5f * gdx * dx * dL_dG;
-                v[5] = -0.5f * gdx * dy * dL_dG;
-                v[6] = -0.5f * gdy * dy * dL_dG;
-                v[7] = Gm * dL_dalpha;
+                v[4] = hsdx * dx;
+                v[5] = hsdx * dy;
+                v[6] = (hs * dy) * dy;
+                v[7] = GdA;
             }
             // transposed 64-lane sums: lane (row, c) with c < RQ ends up owning value c + RQ*row
             float r[RQ];
