@@ -46,7 +46,7 @@ struct Prof {
 };
 Prof g_prof;
 int g_reference_binning = 0;
-int g_bwd_impl = 0;  // 0: pixel-per-lane + permlane reduction (blend_bwd.hip), 1: survivor-per-lane + MFMA
+int g_bwd_impl = 1;  // 1: survivor-per-lane + MFMA (blend_bwd_mfma.hip), 0: pixel-per-lane + permlane reduction, 2: hybrid
 
 struct StageTimer {
     hipStream_t s;

@@ -26,7 +26,7 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int BB = 64;
+constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the occupancy here)
 
 __device__ __forceinline__ float row_scan_mul(float x) {  // inclusive prefix product over the 16 lanes of a row
     x *= __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(x), DPP_ROW_SHR(1), 0xF, 0xF, false));
@@ -61,7 +61,6 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     __shared__ uint32_t s_slot[BB];
     __shared__ uint32_t s_list[BB];
     __shared__ __align__(16) float s_g[64][16];    // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
-    __shared__ __align__(16) float s_phi[64][8];   // per pixel: 1, cx, cy, cx^2, cx*cy, cy^2, 0, 0
     __shared__ float4 s_px[64];                    // per pixel: running T, running Sg, n_contrib (bits), -
     __shared__ __align__(16) float s_d[16][16];    // geometry moments of the current group
     __shared__ uint32_t s_slotg[16];               // emission slot of each survivor of the current group
@@ -96,9 +95,6 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++)
             *reinterpret_cast<float4*>(&s_g[lane][4 * q]) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-        const float cx = (float)(lane & 7) - 3.5f, cy = (float)(lane >> 3) - 3.5f;
-        *reinterpret_cast<float4*>(&s_phi[lane][0]) = make_float4(1.f, cx, cy, cx * cx);
-        *reinterpret_cast<float4*>(&s_phi[lane][4]) = make_float4(cx * cy, cy * cy, 0.f, 0.f);
         // suffix sum seeded with the background term (backward.cu:562-566)
         s_px[lane] = make_float4(Tf, Tf * (bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2]), u2f(lastp), 0.f);
     }
@@ -115,6 +111,8 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     // of the pixel's row each step, written back by its last lane.  LDS operations of one wave execute
     // in order, so the next group's read sees this group's write.
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
+    const float ph0 = j == 0 ? 1.f : 0.f, ph1 = j == 1 ? 1.f : 0.f, ph2 = j == 2 ? 1.f : 0.f, ph3 = j == 3 ? 1.f : 0.f,
+                ph4 = j == 4 ? 1.f : 0.f, ph5 = j == 5 ? 1.f : 0.f;  // one-hot selector of this lane's moment column
     const float halfW = 0.5f * W, halfH = 0.5f * H;
     const float xq = (float)qx0 + 3.5f, yq = (float)qy0 + 3.5f;
 
@@ -130,7 +128,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     auto process_group = [&](int nvalid) {
         v4f acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
         float U1 = 0.f, U2 = 0.f;  // per-lane partial |.| sums over this lane's 16 pixels
-#pragma unroll
+#pragma unroll 4
         for (int t = 0; t < 16; t++) {
             const int p = 4 * t + r;
             const float pxf = qxr + ((t & 1) ? 4.0f : 0.0f), pyf = qyf + (float)(t >> 1);
@@ -165,7 +163,10 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             U1 += fabsf(s * t1);
             U2 += fabsf(s * t2);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, s_g[p][j], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, j < 8 ? s_phi[p][j & 7] : 0.f, acc2, 0, 0, 0);
+            // B operand of the moment product: Phi[p][j] = 1, cx, cy, cx^2, cx*cy, cy^2 (j = 0..5), else 0
+            const float cx = (float)(p & 7) - 3.5f, cy = (float)(p >> 3) - 3.5f;
+            const float phi = __builtin_fmaf(cx, __builtin_fmaf(ph3, cx, __builtin_fmaf(ph4, cy, ph1)), __builtin_fmaf(cy, __builtin_fmaf(ph5, cy, ph2), ph0));
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, phi, acc2, 0, 0, 0);
         }
         // |.| sums: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48)
         {

@@ -126,8 +126,14 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             }
         } else {  // one row per (instance, quadrant): the 4 valid bytes of an instance form one word
             const uint32_t* valid4 = reinterpret_cast<const uint32_t*>(row_valid);
+            // the valid words of the next two instances are fetched while the rows of the current one are in
+            // flight (the row loads depend on the valid word: without this every instance costs two serial
+            // memory latencies)
+            uint32_t vm_a = n > 0 ? valid4[off] : 0u, vm_b = n > 1 ? valid4[off + 1] : 0u;
             for (uint32_t t = 0; t < n; t++) {
-                const uint32_t vm4 = valid4[off + t];
+                const uint32_t vm4 = vm_a;
+                vm_a = vm_b;
+                vm_b = t + 2 < n ? valid4[off + t + 2] : 0u;
                 float4 rv[4][6];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {

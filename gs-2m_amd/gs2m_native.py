@@ -110,6 +110,6 @@ def set_reference_binning(on):
 
 
 def set_bwd_impl(impl):
-    """0 (default): pixel-per-lane backward blend with permlane/DPP reductions; 1: survivor-per-lane + fp32 MFMA;
-    2: pixel-per-lane evaluation + MFMA reductions through an LDS transpose (both experimental, slower)."""
+    """1 (default): survivor-per-lane backward blend, DPP row scans + fp32 MFMA reductions; 0: pixel-per-lane
+    with permlane/DPP reductions; 2: pixel-per-lane evaluation + MFMA reductions through an LDS transpose."""
     check(lib().gs2m_set_bwd_impl(int(impl)), "gs2m_set_bwd_impl")

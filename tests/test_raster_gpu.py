@@ -11,7 +11,7 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["bwd_permlane", "bwd_mfma", "bwd_hybrid"])
+@pytest.fixture(autouse=True, params=[1, 0, 2], ids=["bwd_mfma", "bwd_permlane", "bwd_hybrid"])
 def bwd_impl(request):
     """every test runs against both backward blend implementations"""
     import gs2m_native
@@ -19,7 +19,7 @@ def bwd_impl(request):
         gs2m_native.set_bwd_impl(request.param)
     yield request.param
     if torch.cuda.is_available():
-        gs2m_native.set_bwd_impl(0)
+        gs2m_native.set_bwd_impl(1)
 
 
 def _require_gpu():

@@ -4,7 +4,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 ROUNDS=${3:-2}
 for i in $(seq $ROUNDS); do
   for v in "$1" "$2"; do
-    eval "$v python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline" 2>/dev/null | python3 -c "
+    if [[ "$v" == --* ]]; then pre=""; post="$v"; else pre="$v"; post=""; fi
+    eval "$pre python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline $post" 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 s = d['stages_ms']
