@@ -28,11 +28,15 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the occupancy here)
 
-__device__ __forceinline__ float row_scan_mul(float x) {  // inclusive prefix product over the 16 lanes of a row
-    x *= __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(x), DPP_ROW_SHR(1), 0xF, 0xF, false));
-    x *= __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(x), DPP_ROW_SHR(2), 0xF, 0xF, false));
-    x *= __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(x), DPP_ROW_SHR(4), 0xF, 0xF, false));
-    x *= __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(x), DPP_ROW_SHR(8), 0xF, 0xF, false));
+// Inclusive prefix product over the 16 lanes of a row.  One v_mul_f32_dpp per level: lanes whose source
+// falls outside the row are disabled by the DPP (bound_ctrl:0) and keep x, i.e. multiply by 1.  hipcc does
+// not fold mov_dpp + mul for a float identity, hence the asm; `s_nop 1` covers the VALU-write -> DPP-read
+// hazard, which the compiler does not track through inline asm.
+__device__ __forceinline__ float row_scan_mul(float x) {
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
     return x;
 }
 __device__ __forceinline__ float row_scan_add(float x) {  // inclusive prefix sum over the 16 lanes of a row

@@ -19,12 +19,13 @@ namespace {
 
 constexpr int BATCH = 128;
 
-template <int FQ>  // number of float4 feature quads staged (1..3)
+template <int FC>  // feature channels blended (compile time); runtime fc <= FC
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, int W,
     int H, int tiles_x, const float* __restrict__ bg, int fc, float* __restrict__ out_color,
     float* __restrict__ out_buffer, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ inst_obs) {
+    constexpr int FQ = (FC + 3) / 4;
     constexpr int NQ = 4 + FQ;  // record quads staged: geo0, geo1, bin, rgb, feat...
     __shared__ float4 s_v[NQ][BATCH];
     __shared__ uint32_t s_gid[BATCH];
@@ -118,10 +119,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 #pragma unroll
                         for (int q = 0; q < FQ; q++) {
                             const float4 f = s_v[REC_FEAT + q][jj];
-                            F[q].x = __builtin_fmaf(f.x, w, F[q].x);
-                            F[q].y = __builtin_fmaf(f.y, w, F[q].y);
-                            F[q].z = __builtin_fmaf(f.z, w, F[q].z);
-                            F[q].w = __builtin_fmaf(f.w, w, F[q].w);
+                            if (4 * q + 0 < FC) F[q].x = __builtin_fmaf(f.x, w, F[q].x);
+                            if (4 * q + 1 < FC) F[q].y = __builtin_fmaf(f.y, w, F[q].y);
+                            if (4 * q + 2 < FC) F[q].z = __builtin_fmaf(f.z, w, F[q].z);
+                            if (4 * q + 3 < FC) F[q].w = __builtin_fmaf(f.w, w, F[q].w);
                         }
                         last_contributor = (uint32_t)(base + jj + 1);
                     }
@@ -170,12 +171,15 @@ void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const
                            const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
                            hipStream_t s) {
     const int tiles = tiles_x * tiles_y;
-    const int fq = fc <= 4 ? 1 : (fc <= 8 ? 2 : 3);
-#define GS2M_FWD(FQ)                                                                                              \
-    blend_fwd_kernel<FQ><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, out_color, \
+    const int fct = fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10));
+#define GS2M_FWD(FC)                                                                                              \
+    blend_fwd_kernel<FC><<<tiles, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, bg, fc, out_color, \
                                                out_buffer, im.final_T, im.n_contrib, b.inst_obs)
-    if (fq == 1) GS2M_FWD(1);
-    else if (fq == 2) GS2M_FWD(2);
-    else GS2M_FWD(3);
+    switch (fct) {
+        case 1: GS2M_FWD(1); break;
+        case 5: GS2M_FWD(5); break;
+        case 9: GS2M_FWD(9); break;
+        default: GS2M_FWD(10); break;
+    }
 #undef GS2M_FWD
 }
