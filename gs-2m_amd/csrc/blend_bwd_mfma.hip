@@ -27,6 +27,9 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the occupancy here)
+#ifndef GS2M_BWDM_UNROLL_B
+#define GS2M_BWDM_UNROLL_B 1
+#endif
 
 // Inclusive prefix product over the 16 lanes of a row.  One v_mul_f32_dpp per level: lanes whose source
 // falls outside the row are disabled by the DPP (bound_ctrl:0) and keep x, i.e. multiply by 1.  hipcc does
@@ -58,6 +61,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     constexpr int NV = ROW_FEAT + FC;
     constexpr int ROWF = ((NV + 3) / 4) * 4;
     constexpr int NC = 3 + FC;  // colour + feature columns of the W x Ggrad product
+    constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each)
     // +1 quad of padding per array: the 8 lanes that stage one record write quads q = 0..6 of the same
     // row; without the pad their addresses differ by a multiple of 128 B (7-way bank conflict)
     __shared__ float4 s_v[NQ][BB + 1];
@@ -121,56 +125,78 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     const float xq = (float)qx0 + 3.5f, yq = (float)qy0 + 3.5f;
 
     float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f;
-    float sc[NC];
+    // colour . gradient dot products gc[survivor][pixel] come from the matrix pipe as well:
+    //   D[i][n] = sum_k A[i][k] B[k][n],  i = pixel slot of a 16-pixel block, n = survivor, k = channel.
+    // Lane (j, r) receives D[4r + rr][j] in accumulator element rr, so with pixel slot 4r + rr := the pixel
+    // this lane evaluates in step 4b + rr (p = 16b + 4rr + r) the four elements are exactly the four
+    // steps' gc -- no transposition.  A[i][k] = s_g[16b + 4(i & 3) + (i >> 2)][4kk + k] (lane i = j, k = r),
+    // B[k][n] = channel 4kk + r of survivor j: KK registers per lane instead of 3 + FC.
+    float scB[KK];
 #pragma unroll
-    for (int k = 0; k < NC; k++) sc[k] = 0.f;
-    uint32_t spos = 0;
-    bool svalid = false;
+    for (int k = 0; k < KK; k++) scB[k] = 0.f;
+    int coff[KK];  // float offset of channel 4kk + r inside s_v (record quads REC_RGB.xyz, REC_FEAT...)
+#pragma unroll
+    for (int k = 0; k < KK; k++) {
+        const int c = 4 * k + r;
+        const int q = c < 3 ? REC_RGB : REC_FEAT + ((c - 3) >> 2), e = c < 3 ? c : ((c - 3) & 3);
+        coff[k] = c < NC ? (q * (BB + 1)) * 4 + e : -1;
+    }
+    const float* gA = &s_g[4 * (j & 3) + (j >> 2)][r];  // + 16 b rows, + 4 kk columns
+    uint32_t spos = 0xFFFFFFFFu;  // empty slot: behind every pixel's last contributor
     int nfill = 0;
+    const float pxf0 = qxr, pxf1 = qxr + 4.0f;
+    // Phi[p][j] = 1, cx, cy, cx^2, cx*cy, cy^2 (j = 0..5) as phA + cy * (phB + ph5 * cy); cx takes two values per lane
+    const float cx0 = (float)r - 3.5f, cx1 = (float)r + 0.5f;
+    const float phA0 = __builtin_fmaf(cx0, __builtin_fmaf(ph3, cx0, ph1), ph0), phA1 = __builtin_fmaf(cx1, __builtin_fmaf(ph3, cx1, ph1), ph0);
+    const float phB0 = __builtin_fmaf(ph4, cx0, ph2), phB1 = __builtin_fmaf(ph4, cx1, ph2);
 
     // one group = up to 16 survivors: 16 steps of (16 survivors x 4 pixels), then the epilogue
     auto process_group = [&](int nvalid) {
         v4f acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
         float U1 = 0.f, U2 = 0.f;  // per-lane partial |.| sums over this lane's 16 pixels
-#pragma unroll 4
-        for (int t = 0; t < 16; t++) {
-            const int p = 4 * t + r;
-            const float pxf = qxr + ((t & 1) ? 4.0f : 0.0f), pyf = qyf + (float)(t >> 1);
-            const float dx = sx - pxf, dy = sy - pyf;
-            const float power = gs2m_power(dx, dy, sA, sB, sC);
-            const float G = gs2m_exp(power);
-            const float alpha = fminf(0.99f, so * G);
-            const float4 pst = s_px[p];  // running T, running Sg, n_contrib
-            const bool contrib = svalid && (spos <= f2u(pst.z)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-            const float am = contrib ? alpha : 0.f;
-            const float Gm = contrib ? G : 0.f;
-            const float inv = __builtin_amdgcn_rcpf(1.f - am);
-            const float Pinc = row_scan_mul(inv);
-            const float Ti = pst.x * Pinc;  // transmittance in front of survivor j at this pixel
-            const float w = am * Ti;
-            const float4 ga = *reinterpret_cast<const float4*>(&s_g[p][0]);
-            const float4 gb = *reinterpret_cast<const float4*>(&s_g[p][4]);
-            const float4 gc4 = *reinterpret_cast<const float4*>(&s_g[p][8]);
-            const float gv[12] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w, gc4.x, gc4.y, gc4.z, gc4.w};
-            float gc = sc[0] * gv[0];
+        auto gc_block = [&](int b) {
+            v4f a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 1; k < NC; k++)
-                if (k < 12) gc = __builtin_fmaf(sc[k], gv[k], gc);
-            if (NC > 12) gc = __builtin_fmaf(sc[12], s_g[p][12], gc);
-            const float qv = gc * w;
-            const float Sinc = row_scan_add(qv);
-            const float Sprev = pst.y + (Sinc - qv);  // contributions of everything behind survivor j
-            const float da = Ti * gc - Sprev * inv;   // dL/dalpha (header of blend_bwd.hip)
-            if (j == 15) *reinterpret_cast<float2*>(&s_px[p]) = make_float2(Ti, pst.y + Sinc);
-            const float s = so * da * Gm;
-            const float t1 = dx * sA + dy * sB, t2 = dy * sC + dx * sB;
-            U1 += fabsf(s * t1);
-            U2 += fabsf(s * t2);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, s_g[p][j], acc1, 0, 0, 0);
-            // B operand of the moment product: Phi[p][j] = 1, cx, cy, cx^2, cx*cy, cy^2 (j = 0..5), else 0
-            const float cx = (float)(p & 7) - 3.5f, cy = (float)(p >> 3) - 3.5f;
-            const float phi = __builtin_fmaf(cx, __builtin_fmaf(ph3, cx, __builtin_fmaf(ph4, cy, ph1)), __builtin_fmaf(cy, __builtin_fmaf(ph5, cy, ph2), ph0));
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, phi, acc2, 0, 0, 0);
+            for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * 16 + 4 * k], scB[k], a, 0, 0, 0);
+            return a;
+        };
+        v4f gnext = gc_block(0);
+#pragma unroll GS2M_BWDM_UNROLL_B
+        for (int b = 0; b < 4; b++) {
+            const v4f gcur = gnext;
+            if (b < 3) gnext = gc_block(b + 1);  // one block ahead: the matrix pipe's latency stays hidden
+            const float pyb = qyf + (float)(2 * b), cyb = (float)(2 * b) - 3.5f;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int p = 16 * b + 4 * rr + r;
+                const float pxf = (rr & 1) ? pxf1 : pxf0, pyf = (rr & 2) ? pyb + 1.0f : pyb;
+                const float dx = sx - pxf, dy = sy - pyf;
+                const float power = gs2m_power(dx, dy, sA, sB, sC);
+                const float G = gs2m_exp(power);
+                const float alpha = fminf(0.99f, so * G);
+                const float4 pst = s_px[p];  // running T, running Sg, n_contrib
+                const bool contrib = (spos <= f2u(pst.z)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                const float am = contrib ? alpha : 0.f;
+                const float Gm = contrib ? G : 0.f;
+                const float inv = __builtin_amdgcn_rcpf(1.f - am);
+                const float Pinc = row_scan_mul(inv);
+                const float Ti = pst.x * Pinc;  // transmittance in front of survivor j at this pixel
+                const float w = am * Ti;
+                const float gc = gcur[rr];
+                const float qv = gc * w;
+                const float Sinc = row_scan_add(qv);
+                const float Sprev = pst.y + (Sinc - qv);  // contributions of everything behind survivor j
+                const float da = Ti * gc - Sprev * inv;   // dL/dalpha (header of blend_bwd.hip)
+                if (j == 15) *reinterpret_cast<float2*>(&s_px[p]) = make_float2(Ti, pst.y + Sinc);
+                const float s = so * da * Gm;
+                const float t1 = dx * sA + dy * sB, t2 = dy * sC + dx * sB;
+                U1 += fabsf(s * t1);
+                U2 += fabsf(s * t2);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, s_g[p][j], acc1, 0, 0, 0);
+                const float cy = (rr & 2) ? cyb + 1.0f : cyb;
+                const float phi = __builtin_fmaf(cy, __builtin_fmaf(ph5, cy, (rr & 1) ? phB1 : phB0), (rr & 1) ? phA1 : phA0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, phi, acc2, 0, 0, 0);
+            }
         }
         // |.| sums: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48)
         {
@@ -252,19 +278,12 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             const int want = j - nfill;
             if (want >= 0 && want < n) {
                 const int jj = (int)s_list[taken + want];
-                const float4 a = s_v[REC_GEO0][jj], c = s_v[REC_GEO1][jj], col = s_v[REC_RGB][jj];
+                const float4 a = s_v[REC_GEO0][jj], c = s_v[REC_GEO1][jj];
                 sx = a.x; sy = a.y; sA = a.z; sB = a.w; sC = c.x; so = c.y;
-                sc[0] = col.x; sc[1] = col.y; sc[2] = col.z;
 #pragma unroll
-                for (int q = 0; q < FQ; q++) {
-                    const float4 f = s_v[REC_FEAT + q][jj];
-                    const float fa[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (4 * q + e < FC) sc[3 + 4 * q + e] = fa[e];
-                }
+                for (int k = 0; k < KK; k++)
+                    scB[k] = coff[k] >= 0 ? reinterpret_cast<const float*>(&s_v[0][0])[coff[k] + 4 * jj] : 0.f;
                 spos = (uint32_t)(base + jj + 1);
-                svalid = true;
                 if (r == 0) s_slotg[j] = s_slot[jj];
             }
             nfill += n;
@@ -272,7 +291,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             if (nfill == 16) {
                 process_group(16);
                 nfill = 0;
-                svalid = false;
+                spos = 0xFFFFFFFFu;
             }
         }
     }
