@@ -36,10 +36,10 @@ constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the 
 // not fold mov_dpp + mul for a float identity, hence the asm; `s_nop 1` covers the VALU-write -> DPP-read
 // hazard, which the compiler does not track through inline asm.
 __device__ __forceinline__ float row_scan_mul(float x) {
-    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
     return x;
 }
 __device__ __forceinline__ float row_scan_add(float x) {  // inclusive prefix sum over the 16 lanes of a row
@@ -164,8 +164,20 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
 #pragma unroll GS2M_BWDM_UNROLL_B
         for (int b = 0; b < 4; b++) {
             const v4f gcur = gnext;
-            if (b < 3) gnext = gc_block(b + 1);  // one block ahead: the matrix pipe's latency stays hidden
             const float pyb = qyf + (float)(2 * b), cyb = (float)(2 * b) - 3.5f;
+            // the block's LDS operands up front: the compiler cannot move these reads above the s_px writes of
+            // earlier steps on its own (it cannot see that the four pixels differ), and every step would wait
+            // out a full LDS latency twice
+            float4 pstv[4];
+            float gBv[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                pstv[rr] = s_px[16 * b + 4 * rr + r];
+                gBv[rr] = s_g[16 * b + 4 * rr + r][j];
+            }
+            float gAn[KK];  // A operand of the NEXT block's colour . gradient product
+#pragma unroll
+            for (int k = 0; k < KK; k++) gAn[k] = gA[(16 * ((b + 1) & 3)) * 16 + 4 * k];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int p = 16 * b + 4 * rr + r;
@@ -174,7 +186,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 const float power = gs2m_power(dx, dy, sA, sB, sC);
                 const float G = gs2m_exp(power);
                 const float alpha = fminf(0.99f, so * G);
-                const float4 pst = s_px[p];  // running T, running Sg, n_contrib
+                const float4 pst = pstv[rr];  // running T, running Sg, n_contrib
                 const bool contrib = (spos <= f2u(pst.z)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
                 const float am = contrib ? alpha : 0.f;
                 const float Gm = contrib ? G : 0.f;
@@ -192,10 +204,16 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 const float t1 = dx * sA + dy * sB, t2 = dy * sC + dx * sB;
                 U1 += fabsf(s * t1);
                 U2 += fabsf(s * t2);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, s_g[p][j], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, gBv[rr], acc1, 0, 0, 0);
                 const float cy = (rr & 2) ? cyb + 1.0f : cyb;
                 const float phi = __builtin_fmaf(cy, __builtin_fmaf(ph5, cy, (rr & 1) ? phB1 : phB0), (rr & 1) ? phA1 : phA0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, phi, acc2, 0, 0, 0);
+                if (rr == 1) {  // one block ahead, operands long since loaded: the matrix pipe's latency stays hidden
+                    v4f a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
+                    gnext = a;
+                }
             }
         }
         // |.| sums: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48)
@@ -238,11 +256,19 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
         }
     };
 
+    // Staging is two dependent memory accesses (list entry -> record) that nothing inside the wave overlaps.
+    // The list entries are therefore fetched one batch ahead into a register, and the next batch's record
+    // lines are touched (one dword each, result unused) before this batch's groups are processed: when the
+    // real staging loads come they hit L2.  Costs 2 VGPRs instead of a second staging buffer.
+    uint32_t gid_next = 0, touch = 0;
+    if (nb > 0 && lane < min(BB, maxc - (nb - 1) * BB)) gid_next = point_list[range.x + (nb - 1) * BB + lane];
     for (int bi = nb - 1; bi >= 0; bi--) {
         const int base = bi * BB;
         const int cnt = min(BB, maxc - base);
+        asm volatile("" ::"v"(touch));  // the touch loads of the previous iteration retire here at the latest
         gs2m_sync();
-        if (lane < cnt) s_gid[lane] = point_list[range.x + base + lane];
+        if (lane < cnt) s_gid[lane] = gid_next;
+        if (bi > 0 && lane < BB) gid_next = point_list[range.x + base - BB + lane];
         gs2m_sync();
         {
             const int q = lane & 7;
@@ -271,6 +297,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
         // back to front: the hit with the highest list position gets rank 0
         if (hit) s_list[lane == 63 ? 0 : (int)__popcll(mask >> (lane + 1))] = (uint32_t)lane;
         const int nh = (int)__popcll(mask);
+        if (bi > 0 && lane < BB) touch = *reinterpret_cast<const volatile uint32_t*>(rec + (size_t)gid_next * REC_Q);
         gs2m_sync();
         int taken = 0;
         while (taken < nh) {

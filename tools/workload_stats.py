@@ -70,5 +70,10 @@ for impl in (1, 0):
     a0 = (-t.data_ptr()) % 256
     rb = (R * rpi * rowf * 4 + 255) // 256 * 256
     v = t[a0 + rb: a0 + rb + R * rpi].cpu().numpy()
+    if impl == 1:
+        rws = t[a0: a0 + R * rpi * rowf * 4].view(torch.float32).view(R * rpi, rowf)
+        vm = torch.from_numpy(v != 0).to(dev)
+        nz = (rws != 0).any(1) & vm
+        print("impl 1: valid rows that are entirely zero:", int((vm & ~nz).sum().item()), "of", int(vm.sum().item()))
     print(f"impl {impl}: valid rows {int((v != 0).sum())} of {R * rpi}; instances with any valid row",
           int((v.reshape(R, rpi) != 0).any(1).sum()))
