@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
-    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1, 2],
+    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1],
                     help="backward blend implementation (default: the library's default)")
     a = ap.parse_args()
 

@@ -46,7 +46,7 @@ struct Prof {
 };
 Prof g_prof;
 int g_reference_binning = 0;
-int g_bwd_impl = 1;  // 1: survivor-per-lane + MFMA (blend_bwd_mfma.hip), 0: pixel-per-lane + permlane reduction, 2: hybrid
+int g_bwd_impl = 1;  // 1: survivor-per-lane + MFMA (blend_bwd_mfma.hip), 0: pixel-per-lane + permlane reduction
 
 struct StageTimer {
     hipStream_t s;
@@ -210,10 +210,7 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     HIP_TRY(hipMemsetAsync(row_valid, 0, Rn * rpi, s));
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s);
-        if (g_bwd_impl == 2)
-            gs2m_launch_blend_bwd_hyb(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
-                                      grad_buffer, rows, row_valid, s);
-        else if (g_bwd_impl == 1)
+        if (g_bwd_impl == 1)
             gs2m_launch_blend_bwd_mfma(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
                                        grad_buffer, rows, row_valid, s);
         else
@@ -246,7 +243,7 @@ int gs2m_set_reference_binning(int on) {
 }
 
 int gs2m_set_bwd_impl(int impl) {
-    if (impl < 0 || impl > 2) return GS2M_ERR_INVALID_ARG;
+    if (impl < 0 || impl > 1) return GS2M_ERR_INVALID_ARG;
     g_bwd_impl = impl;
     return GS2M_OK;
 }

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
     const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
     constexpr int FQ = (FC + 3) / 4;
-    constexpr int NQ = 4 + FQ;
+    constexpr int NQ = 3 + (3 + FC + 3) / 4;  // geo0, geo1, bin + channel quads
     constexpr int NV = ROW_FEAT + FC;  // values reduced per instance
     constexpr int RQ = (NV + 3) / 4;
     constexpr int ROWF = RQ * 4;       // row length in floats (zero padded)
@@ -199,7 +199,13 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 const float inv1ma = __builtin_amdgcn_rcpf(1.f - am);
                 T = T * inv1ma;
                 const float w = am * T;
-                const float4 col = s_v[REC_RGB][jj];
+                float chv[4 * (NQ - 3)];  // r, g, b, feature 0.. (record quads REC_CH..)
+#pragma unroll
+                for (int q = 0; q < NQ - 3; q++) {
+                    const float4 t = s_v[REC_CH + q][jj];
+                    chv[4 * q] = t.x; chv[4 * q + 1] = t.y; chv[4 * q + 2] = t.z; chv[4 * q + 3] = t.w;
+                }
+                const float4 col = make_float4(chv[0], chv[1], chv[2], 0.f);
                 float gc = col.x * g0;
                 gc = __builtin_fmaf(col.y, g1, gc);
                 gc = __builtin_fmaf(col.z, g2, gc);
@@ -208,8 +214,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 v[ROW_COL + 2] = w * g2;
 #pragma unroll
                 for (int q = 0; q < FQ; q++) {
-                    const float4 f = s_v[REC_FEAT + q][jj];
-                    const float fa[4] = {f.x, f.y, f.z, f.w};
+                    float fa[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) fa[e] = 4 * q + e < FC ? chv[3 + 4 * q + e] : 0.f;
                     const float ga[4] = {gf[q].x, gf[q].y, gf[q].z, gf[q].w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) {

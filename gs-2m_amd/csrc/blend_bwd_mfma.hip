@@ -56,12 +56,11 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
     const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
-    constexpr int FQ = (FC + 3) / 4;
-    constexpr int NQ = 4 + FQ;
     constexpr int NV = ROW_FEAT + FC;
     constexpr int ROWF = ((NV + 3) / 4) * 4;
     constexpr int NC = 3 + FC;  // colour + feature columns of the W x Ggrad product
-    constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each)
+    constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each) = channel quads
+    constexpr int NQ = 3 + KK;        // record quads staged: geo0, geo1, bin, channels
     // +1 quad of padding per array: the 8 lanes that stage one record write quads q = 0..6 of the same
     // row; without the pad their addresses differ by a multiple of 128 B (7-way bank conflict)
     __shared__ float4 s_v[NQ][BB + 1];
@@ -134,13 +133,8 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     float scB[KK];
 #pragma unroll
     for (int k = 0; k < KK; k++) scB[k] = 0.f;
-    int coff[KK];  // float offset of channel 4kk + r inside s_v (record quads REC_RGB.xyz, REC_FEAT...)
-#pragma unroll
-    for (int k = 0; k < KK; k++) {
-        const int c = 4 * k + r;
-        const int q = c < 3 ? REC_RGB : REC_FEAT + ((c - 3) >> 2), e = c < 3 ? c : ((c - 3) & 3);
-        coff[k] = c < NC ? (q * (BB + 1)) * 4 + e : -1;
-    }
+    // channel 4kk + r is element r of record quad REC_CH + kk (pad channels are 0 in the record and in s_g)
+    const float* chB = reinterpret_cast<const float*>(&s_v[REC_CH][0]) + r;
     const float* gA = &s_g[4 * (j & 3) + (j >> 2)][r];  // + 16 b rows, + 4 kk columns
     uint32_t spos = 0xFFFFFFFFu;  // empty slot: behind every pixel's last contributor
     int nfill = 0;
@@ -309,7 +303,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 sx = a.x; sy = a.y; sA = a.z; sB = a.w; sC = c.x; so = c.y;
 #pragma unroll
                 for (int k = 0; k < KK; k++)
-                    scB[k] = coff[k] >= 0 ? reinterpret_cast<const float*>(&s_v[0][0])[coff[k] + 4 * jj] : 0.f;
+                    scB[k] = chB[(k * (BB + 1) + jj) * 4];
                 spos = (uint32_t)(base + jj + 1);
                 if (r == 0) s_slotg[j] = s_slot[jj];
             }

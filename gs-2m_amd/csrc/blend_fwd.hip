@@ -10,6 +10,9 @@
 // ballot, and walks only the set bits; the per-instance data is then read from LDS with a
 // wave-uniform address (broadcast).  Skipped instances cannot contribute (alpha < 1/255
 // over the whole quadrant, see preprocess.hip), so results are unchanged.
+// The colour/feature accumulation runs as packed fp32 (v_pk_fma_f32: two channels per instruction, the
+// weight broadcast) -- measured on gfx950 a packed FMA issues at the rate of a scalar one, and the matrix
+// pipe is no alternative here: MFMA and VALU instructions do not overlap on a SIMD (tools/micro/).
 // `observe` is accumulated per instance in LDS (one popcount of a ballot per wave) and stored
 // once per instance in emission order -- no global atomics (forward.cu:348-350 uses one
 // atomicAdd per pixel); binning.hip:observe_kernel reduces them per Gaussian.
@@ -17,6 +20,7 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BATCH = 128;
 
 template <int FC>  // feature channels blended (compile time); runtime fc <= FC
@@ -25,8 +29,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     int H, int tiles_x, const float* __restrict__ bg, int fc, float* __restrict__ out_color,
     float* __restrict__ out_buffer, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ inst_obs) {
-    constexpr int FQ = (FC + 3) / 4;
-    constexpr int NQ = 4 + FQ;  // record quads staged: geo0, geo1, bin, rgb, feat...
+    constexpr int NC = 3 + FC;            // blended channels: r, g, b, features
+    constexpr int KQ = (NC + 3) / 4;      // channel quads of the record
+    constexpr int NP = (NC + 1) / 2;      // channel pairs accumulated
+    constexpr int NQ = 3 + KQ;            // record quads staged: geo0, geo1, bin, channels
     __shared__ float4 s_v[NQ][BATCH];
     __shared__ uint32_t s_gid[BATCH];
     __shared__ uint32_t s_slot[BATCH];
@@ -47,10 +53,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    float4 F[FQ];
+    v2f acc[NP];  // acc[k] = channels 2k, 2k + 1
 #pragma unroll
-    for (int q = 0; q < FQ; q++) F[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NP; k++) acc[k] = v2f{0.f, 0.f};
     bool done = !inside;
     int prev_cnt = 0;
 
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         gs2m_sync();  // (S3) batch staged
         prev_cnt = cnt;
 
-        if (__ballot(!done) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
             for (int sub = 0; sub < cnt; sub += GS2M_WAVE) {
                 const int j = sub + lane;
                 bool hit = false;
@@ -95,12 +100,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                     const float4 a = s_v[REC_GEO0][j], b = s_v[REC_GEO1][j];
                     hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, b.x, b.z, b.w, s_v[REC_BIN][j].w, bx0, bx1, by0, by1);
                 }
-                unsigned long long mask = __ballot(hit);
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                int myobs = 0;  // observe count of instance sub + lane in this quadrant
                 while (mask) {
                     const int bit = __builtin_ctzll(mask);
                     mask &= mask - 1;
                     const int jj = sub + bit;  // wave-uniform
                     const float4 a = s_v[REC_GEO0][jj], b = s_v[REC_GEO1][jj];
+                    float4 c[KQ];  // requested before the evaluation: their LDS latency hides behind it
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) c[q] = s_v[REC_CH + q][jj];
                     const float dx = a.x - pxf, dy = a.y - pyf;
                     const float p2 = gs2m_power(dx, dy, a.z, a.w, b.x);
                     const float alpha = fminf(0.99f, b.y * gs2m_exp(p2));
@@ -110,30 +119,23 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                         done = true;
                         contrib = false;
                     }
-                    if (contrib) {
-                        const float w = alpha * T;
-                        const float4 c = s_v[REC_RGB][jj];
-                        C0 = __builtin_fmaf(c.x, w, C0);
-                        C1 = __builtin_fmaf(c.y, w, C1);
-                        C2 = __builtin_fmaf(c.z, w, C2);
+                    const float tw = contrib ? T : 0.f;  // branch-free: non-contributing lanes add 0
+                    const float w = alpha * tw;
+                    const v2f ww = {w, w};
 #pragma unroll
-                        for (int q = 0; q < FQ; q++) {
-                            const float4 f = s_v[REC_FEAT + q][jj];
-                            if (4 * q + 0 < FC) F[q].x = __builtin_fmaf(f.x, w, F[q].x);
-                            if (4 * q + 1 < FC) F[q].y = __builtin_fmaf(f.y, w, F[q].y);
-                            if (4 * q + 2 < FC) F[q].z = __builtin_fmaf(f.z, w, F[q].z);
-                            if (4 * q + 3 < FC) F[q].w = __builtin_fmaf(f.w, w, F[q].w);
-                        }
-                        last_contributor = (uint32_t)(base + jj + 1);
+                    for (int q = 0; q < KQ; q++) {
+                        if (4 * q < NC) acc[2 * q] = __builtin_elementwise_fma(v2f{c[q].x, c[q].y}, ww, acc[2 * q]);
+                        if (4 * q + 2 < NC) acc[2 * q + 1] = __builtin_elementwise_fma(v2f{c[q].z, c[q].w}, ww, acc[2 * q + 1]);
                     }
-                    const unsigned long long seen = __ballot(contrib && T > 0.5f);
-                    if (seen != 0ull && lane == 0) atomicAdd(&s_obs[jj], (int)__popcll(seen));
+                    if (contrib) last_contributor = (uint32_t)(base + jj + 1);
+                    const int seen = (int)__popcll(__builtin_amdgcn_ballot_w64(tw > 0.5f));  // wave-uniform
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myobs) : "s"(seen), "s"(bit) : "m0");  // myobs[lane == bit] = seen
                     if (contrib) T = test_T;
-                    if (__ballot(!done) == 0ull) {
-                        mask = 0ull;
-                        sub = cnt;  // leave both loops
-                    }
                 }
+                if (myobs != 0) atomicAdd(&s_obs[j], myobs);  // one LDS atomic per lane and 64 instances, 4 waves
+                // every pixel of the quadrant finished: skip the rest of the batch (the reference votes once per
+                // 256-instance batch, forward.cu:300-302; finished pixels ignore later instances either way)
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
             }
         }
     }
@@ -148,20 +150,14 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = T;
         n_contrib[pix] = last_contributor;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
-        float f[12];
+        out_color[pix] = acc[0][0] + T * bg[0];
+        out_color[HW + pix] = acc[0][1] + T * bg[1];
+        out_color[2 * HW + pix] = acc[1][0] + T * bg[2];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (q < FQ) {
-                f[4 * q] = F[q].x; f[4 * q + 1] = F[q].y; f[4 * q + 2] = F[q].z; f[4 * q + 3] = F[q].w;
-            } else {
-                f[4 * q] = f[4 * q + 1] = f[4 * q + 2] = f[4 * q + 3] = 0.f;
-            }
+        for (int ch = 0; ch < GS2M_NUM_FEATURES; ch++) {
+            const int c = 3 + ch;
+            out_buffer[ch * HW + pix] = (ch < FC && ch < fc) ? acc[(c >> 1) < NP ? (c >> 1) : 0][c & 1] : 0.0f;
         }
-#pragma unroll
-        for (int ch = 0; ch < GS2M_NUM_FEATURES; ch++) out_buffer[ch * HW + pix] = ch < fc ? f[ch] : 0.0f;
     }
 }
 

@@ -14,15 +14,15 @@
 // q1: C, opacity, hx, hy  conic.z, opacity, half extents of the alpha >= 1/255 ellipse
 // q2: off, rmin, rwh, t2  u32 emission offset, tile rect min (x | y << 16), rect (w | h << 16),
 //                        t2 = upper bound of A dx^2 + 2B dx dy + C dy^2 where alpha can reach 1/255
-// q3: r, g, b, -          colour (SH-evaluated or precomputed)
-// q4..q6: features[0..9], 2 pad floats
+// q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
+//         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
+//         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
 // q7: unused
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
 #define REC_BIN 2
-#define REC_RGB 3
-#define REC_FEAT 4
+#define REC_CH 3
 
 // per tile-instance partial-gradient row produced by the blend backward (floats):
 // 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature
@@ -100,9 +100,6 @@ int gs2m_row_floats(int fc);
 void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, const float* grad_color,
                            const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
-void gs2m_launch_blend_bwd_hyb(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
-                               const BinningState& b, const ImageState& im, const float* grad_color,
-                               const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
 int gs2m_row_floats_mfma(int fc);
 void gs2m_launch_blend_bwd_mfma(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                                 const BinningState& b, const ImageState& im, const float* grad_color,
@@ -129,6 +126,7 @@ __device__ __forceinline__ float dpp_mov0(float v) {
 }
 #define DPP_QUAD_XOR1 0xB1     // quad_perm [1,0,3,2]
 #define DPP_QUAD_XOR2 0x4E     // quad_perm [2,3,0,1]
+#define DPP_QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define DPP_ROW_HALF_MIRROR 0x141
 #define DPP_ROW_MIRROR 0x140
 #define DPP_ROW_BCAST15 0x142

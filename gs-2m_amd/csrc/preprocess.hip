@@ -238,18 +238,21 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
                 r4[REC_GEO1] = make_float4(cC, op, ex, ey);
                 r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), tau2f);
-                r4[REC_RGB] = make_float4(cr, cg, cb, 0.f);
+                float f[GS2M_NUM_FEATURES];
+#pragma unroll
+                for (int k = 0; k < GS2M_NUM_FEATURES; k++) f[k] = 0.f;
                 if (features != nullptr) {
                     const float2* f2 = reinterpret_cast<const float2*>(features + (size_t)idx * GS2M_NUM_FEATURES);
-                    const float2 a = f2[0], b = f2[1], c = f2[2], d = f2[3], e = f2[4];
-                    r4[REC_FEAT + 0] = make_float4(a.x, a.y, b.x, b.y);
-                    r4[REC_FEAT + 1] = make_float4(c.x, c.y, d.x, d.y);
-                    r4[REC_FEAT + 2] = make_float4(e.x, e.y, 0.f, 0.f);
-                } else {
-                    r4[REC_FEAT + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    r4[REC_FEAT + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    r4[REC_FEAT + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < GS2M_NUM_FEATURES / 2; k++) {
+                        const float2 t = f2[k];
+                        f[2 * k] = t.x; f[2 * k + 1] = t.y;
+                    }
                 }
+                r4[REC_CH + 0] = make_float4(cr, cg, cb, f[0]);
+                r4[REC_CH + 1] = make_float4(f[1], f[2], f[3], f[4]);
+                r4[REC_CH + 2] = make_float4(f[5], f[6], f[7], f[8]);
+                r4[REC_CH + 3] = make_float4(f[9], 0.f, 0.f, 0.f);
                 out_radius = mr;
                 out_tt = ew * eh;  // 0 is possible: visible (radii > 0) but nothing to emit
                 out_key = f2u(vz);

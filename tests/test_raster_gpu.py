@@ -11,7 +11,7 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[1, 0, 2], ids=["bwd_mfma", "bwd_permlane", "bwd_hybrid"])
+@pytest.fixture(autouse=True, params=[1, 0], ids=["bwd_mfma", "bwd_permlane"])
 def bwd_impl(request):
     """every test runs against both backward blend implementations"""
     import gs2m_native
