@@ -18,7 +18,12 @@
 //     constants):  dL/dcolour,feature = W x Ggrad;  geometry = S x Phi with
 //     Phi = [1, cx, cy, cx^2, cx*cy, cy^2] (quadrant-centred pixel coordinates), from which
 //     sum(s*dx), sum(s*dx^2), ... follow per Gaussian;  |.| sums = U x e_k.
-//     The matrix pipe runs beside the VALU, so the reductions cost no vector issue slots.
+// Measured on gfx950 (tools/micro/mfma_overlap.hip): MFMA and VALU instructions do NOT overlap on a SIMD,
+// a 16x16x4 fp32 MFMA costs 8 VALU issue slots (it does 16 MACs per lane: the rate of v_pk_fma_f32).
+// Hence: the two wide products (W x Ggrad with 12-13 useful columns, colour . gradient) stay on the matrix
+// pipe, the 6-column moment product does not -- the moments are accumulated per lane with packed FMAs
+// and reduced across the 4 pixel rows of a survivor once per group; and a lane evaluates its two pixels
+// of one image row (x, x + 4) as one packed fp32 pair (v_pk_mul/add/fma_f32 issue at the scalar rate).
 // One wave per quadrant (64-thread workgroups, no cross-wave barriers), XCD-aware block ids, one
 // partial-gradient row per (instance, quadrant) -- gaussian_bwd.hip sums the 4 quadrant rows.
 #include "common.h"
@@ -26,6 +31,7 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the occupancy here)
 #ifndef GS2M_BWDM_UNROLL_B
 #define GS2M_BWDM_UNROLL_B 1
@@ -68,8 +74,11 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     __shared__ uint32_t s_slot[BB];
     __shared__ uint32_t s_list[BB];
     __shared__ __align__(16) float s_g[64][16];    // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
-    __shared__ float4 s_px[64];                    // per pixel: running T, running Sg, n_contrib (bits), -
-    __shared__ __align__(16) float s_d[16][16];    // geometry moments of the current group
+    // per pixel pair {(x, y), (x + 4, y)}, index 4 y + (x & 3): running T, running suffix sum Sg, n_contrib
+    __shared__ float2 s_T2[32];
+    __shared__ float2 s_S2[32];
+    __shared__ uint2 s_N2[32];
+    __shared__ __align__(16) float s_d[16][8];     // per survivor of the current group: 6 moments, 2 |.| sums
     __shared__ uint32_t s_slotg[16];               // emission slot of each survivor of the current group
 
     const int b = blockIdx.x;
@@ -103,7 +112,10 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
         for (int q = 0; q < 4; q++)
             *reinterpret_cast<float4*>(&s_g[lane][4 * q]) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
         // suffix sum seeded with the background term (backward.cu:562-566)
-        s_px[lane] = make_float4(Tf, Tf * (bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2]), u2f(lastp), 0.f);
+        const int pe = ((lane >> 3) * 4 + (lane & 3)) * 2 + ((lane >> 2) & 1);  // pair index * 2 + element
+        reinterpret_cast<float*>(s_T2)[pe] = Tf;
+        reinterpret_cast<float*>(s_S2)[pe] = Tf * (bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2]);
+        reinterpret_cast<uint32_t*>(s_N2)[pe] = lastp;
     }
     uint32_t m = lastp;
 #pragma unroll
@@ -114,12 +126,10 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
 
     // ---- survivor-per-lane state ----
     const int j = lane & 15, r = lane >> 4;
-    // The running per-pixel transmittance / suffix sum live in LDS (s_px): read by the 16 survivor lanes
+    // The running per-pixel transmittance / suffix sum live in LDS (s_T2, s_S2): read by the 16 survivor lanes
     // of the pixel's row each step, written back by its last lane.  LDS operations of one wave execute
     // in order, so the next group's read sees this group's write.
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
-    const float ph0 = j == 0 ? 1.f : 0.f, ph1 = j == 1 ? 1.f : 0.f, ph2 = j == 2 ? 1.f : 0.f, ph3 = j == 3 ? 1.f : 0.f,
-                ph4 = j == 4 ? 1.f : 0.f, ph5 = j == 5 ? 1.f : 0.f;  // one-hot selector of this lane's moment column
     const float halfW = 0.5f * W, halfH = 0.5f * H;
     const float xq = (float)qx0 + 3.5f, yq = (float)qy0 + 3.5f;
 
@@ -138,16 +148,15 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     const float* gA = &s_g[4 * (j & 3) + (j >> 2)][r];  // + 16 b rows, + 4 kk columns
     uint32_t spos = 0xFFFFFFFFu;  // empty slot: behind every pixel's last contributor
     int nfill = 0;
-    const float pxf0 = qxr, pxf1 = qxr + 4.0f;
-    // Phi[p][j] = 1, cx, cy, cx^2, cx*cy, cy^2 (j = 0..5) as phA + cy * (phB + ph5 * cy); cx takes two values per lane
-    const float cx0 = (float)r - 3.5f, cx1 = (float)r + 0.5f;
-    const float phA0 = __builtin_fmaf(cx0, __builtin_fmaf(ph3, cx0, ph1), ph0), phA1 = __builtin_fmaf(cx1, __builtin_fmaf(ph3, cx1, ph1), ph0);
-    const float phB0 = __builtin_fmaf(ph4, cx0, ph2), phB1 = __builtin_fmaf(ph4, cx1, ph2);
+    const v2f pxf2 = {qxr, qxr + 4.0f};                      // this lane's two pixel columns
+    const float cx0 = (float)r - 3.5f, cx1 = (float)r + 0.5f;  // ... relative to the quadrant centre
 
     // one group = up to 16 survivors: 16 steps of (16 survivors x 4 pixels), then the epilogue
     auto process_group = [&](int nvalid) {
-        v4f acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        v4f acc1 = {0.f, 0.f, 0.f, 0.f};
         float U1 = 0.f, U2 = 0.f;  // per-lane partial |.| sums over this lane's 16 pixels
+        // per-lane moments of s over its 16 pixels, per pixel column (.x: cx0, .y: cx1): sum s, sum s cy, sum s cy^2
+        v2f m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
         auto gc_block = [&](int b) {
             v4f a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -155,54 +164,75 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             return a;
         };
         v4f gnext = gc_block(0);
+        const v2f sx2 = {sx, sx}, sA2 = {sA, sA}, sB2 = {sB, sB}, so2 = {so, so};
 #pragma unroll GS2M_BWDM_UNROLL_B
         for (int b = 0; b < 4; b++) {
             const v4f gcur = gnext;
             const float pyb = qyf + (float)(2 * b), cyb = (float)(2 * b) - 3.5f;
-            // the block's LDS operands up front: the compiler cannot move these reads above the s_px writes of
-            // earlier steps on its own (it cannot see that the four pixels differ), and every step would wait
-            // out a full LDS latency twice
-            float4 pstv[4];
+            // the block's LDS operands up front: the compiler cannot move these reads above the s_T2/s_S2 writes
+            // of earlier steps on its own (it cannot see that the pixels differ), and every step would wait out
+            // a full LDS latency twice
+            v2f T2[2], S2[2];
+            uint2 N2[2];
             float gBv[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                pstv[rr] = s_px[16 * b + 4 * rr + r];
-                gBv[rr] = s_g[16 * b + 4 * rr + r][j];
+            for (int h = 0; h < 2; h++) {
+                const int pi = (2 * b + h) * 4 + r;
+                const float2 t = s_T2[pi], q = s_S2[pi];
+                T2[h] = v2f{t.x, t.y};
+                S2[h] = v2f{q.x, q.y};
+                N2[h] = s_N2[pi];
             }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
             float gAn[KK];  // A operand of the NEXT block's colour . gradient product
 #pragma unroll
             for (int k = 0; k < KK; k++) gAn[k] = gA[(16 * ((b + 1) & 3)) * 16 + 4 * k];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int p = 16 * b + 4 * rr + r;
-                const float pxf = (rr & 1) ? pxf1 : pxf0, pyf = (rr & 2) ? pyb + 1.0f : pyb;
-                const float dx = sx - pxf, dy = sy - pyf;
-                const float power = gs2m_power(dx, dy, sA, sB, sC);
-                const float G = gs2m_exp(power);
-                const float alpha = fminf(0.99f, so * G);
-                const float4 pst = pstv[rr];  // running T, running Sg, n_contrib
-                const bool contrib = (spos <= f2u(pst.z)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-                const float am = contrib ? alpha : 0.f;
-                const float Gm = contrib ? G : 0.f;
-                const float inv = __builtin_amdgcn_rcpf(1.f - am);
-                const float Pinc = row_scan_mul(inv);
-                const float Ti = pst.x * Pinc;  // transmittance in front of survivor j at this pixel
-                const float w = am * Ti;
-                const float gc = gcur[rr];
-                const float qv = gc * w;
-                const float Sinc = row_scan_add(qv);
-                const float Sprev = pst.y + (Sinc - qv);  // contributions of everything behind survivor j
-                const float da = Ti * gc - Sprev * inv;   // dL/dalpha (header of blend_bwd.hip)
-                if (j == 15) *reinterpret_cast<float2*>(&s_px[p]) = make_float2(Ti, pst.y + Sinc);
-                const float s = so * da * Gm;
-                const float t1 = dx * sA + dy * sB, t2 = dy * sC + dx * sB;
-                U1 += fabsf(s * t1);
-                U2 += fabsf(s * t2);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, gBv[rr], acc1, 0, 0, 0);
-                const float cy = (rr & 2) ? cyb + 1.0f : cyb;
-                const float phi = __builtin_fmaf(cy, __builtin_fmaf(ph5, cy, (rr & 1) ? phB1 : phB0), (rr & 1) ? phA1 : phA0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, phi, acc2, 0, 0, 0);
-                if (rr == 1) {  // one block ahead, operands long since loaded: the matrix pipe's latency stays hidden
+            for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
+                const int pi = (2 * b + h) * 4 + r;
+                const float pyf = h ? pyb + 1.0f : pyb, cy = h ? cyb + 1.0f : cyb;
+                const float dy = sy - pyf;
+                const v2f dx = sx2 - pxf2;
+                // gs2m_power's operation order (the forward's alpha must be reproduced bit for bit)
+                const float cdy = sC * dy;
+                const float t2 = cdy * dy;
+                const v2f t1 = (sA2 * dx) * dx;
+                const v2f t3 = (sB2 * dx) * dy;
+                const v2f power = (-0.5f * (t1 + t2)) - t3;
+                const v2f e = power * GS2M_LOG2E;
+                const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
+                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
+                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
+                const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
+                const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
+                const v2f om = 1.0f - am;
+                const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const v2f Pinc = {row_scan_mul(inv.x), row_scan_mul(inv.y)};
+                const v2f Ti = T2[h] * Pinc;  // transmittance in front of survivor j at the two pixels
+                const v2f w = am * Ti;
+                const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
+                const v2f qv = gc * w;
+                const v2f Sinc = {row_scan_add(qv.x), row_scan_add(qv.y)};
+                const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
+                const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of blend_bwd.hip)
+                if (j == 15) {
+                    const v2f Sn = S2[h] + Sinc;
+                    s_T2[pi] = make_float2(Ti.x, Ti.y);
+                    s_S2[pi] = make_float2(Sn.x, Sn.y);
+                }
+                const v2f sv = da * sg;  // s = opacity * dL/dalpha * G
+                const v2f u1 = dx * sA2 + dy * sB, u2 = cdy + dx * sB2;
+                const v2f a1 = sv * u1, a2 = sv * u2;
+                U1 += fabsf(a1.x); U1 += fabsf(a1.y);
+                U2 += fabsf(a2.x); U2 += fabsf(a2.y);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, gBv[2 * h], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, gBv[2 * h + 1], acc1, 0, 0, 0);
+                m0 += sv;
+                m1 = __builtin_elementwise_fma(sv, v2f{cy, cy}, m1);
+                m2 = __builtin_elementwise_fma(sv, v2f{cy * cy, cy * cy}, m2);
+                if (h == 0) {  // one block ahead, operands long since loaded: the result is there when the next block starts
                     v4f a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
@@ -210,22 +240,27 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 }
             }
         }
-        // |.| sums: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48)
-        {
-            const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(U1), __float_as_uint(U2), false, false);
-            float h = __uint_as_float(a[0]) + __uint_as_float(a[1]);  // lanes 0-31: U1 halves, lanes 32-63: U2 halves
-            const auto bsw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h), __float_as_uint(h), false, false);
-            h = __uint_as_float(bsw[0]) + __uint_as_float(bsw[1]);    // row 0 (and 1): total U1, row 2 (and 3): total U2
-            U1 = h;
-        }
-        // ---- epilogue: lane (j, r) holds D[4r + rr][j], rr = 0..3 ----
+        // ---- per-survivor totals: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48) ----
+        // two values at a time: permlane32_swap + add leaves value A's two half sums in lanes 0-31 and value B's in
+        // lanes 32-63; permlane16_swap + add on two such registers leaves the totals of (A, C, B, D) in rows 0..3
+        auto reduce4 = [&](float va, float vb, float vc, float vd) {
+            const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+            const float hab = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+            const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(vc), __float_as_uint(vd), false, false);
+            const float hcd = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+            const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(hab), __float_as_uint(hcd), false, false);
+            return __uint_as_float(z[0]) + __uint_as_float(z[1]);  // row 0: A, row 1: C, row 2: B, row 3: D
+        };
+        // moments about the quadrant centre: M0, Mx, My, Mxx, Mxy, Myy
+        const float M0 = m0.x + m0.y, Mx = cx0 * m0.x + cx1 * m0.y, My = m1.x + m1.y;
+        const float Mxx = cx0 * cx0 * m0.x + cx1 * cx1 * m0.y, Mxy = cx0 * m1.x + cx1 * m1.y, Myy = m2.x + m2.y;
+        const float R1 = reduce4(M0, My, Mx, Mxx);   // rows: M0, Mx, My, Mxx
+        const float R2 = reduce4(Mxy, U1, Myy, U2);  // rows: Mxy, Myy, U1, U2
         gs2m_sync();
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-            if (j < 6) s_d[4 * r + rr][j] = acc2[rr];
-        if (r == 0) s_d[j][6] = U1;
-        if (r == 2) s_d[j][7] = U1;
+        s_d[j][r] = R1;
+        s_d[j][4 + r] = R2;
         gs2m_sync();
+        // ---- epilogue: lane (j, r) holds the colour / feature sums D[4r + rr][j], rr = 0..3 ----
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
             const int i = 4 * r + rr;
