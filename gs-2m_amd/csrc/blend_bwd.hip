@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
             hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, c.z, c.w, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
         }
-        unsigned long long mask = __ballot(hit);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         unsigned long long wrote = 0ull;
         while (mask) {
             const int jj = 63 - __builtin_clzll(mask);  // back to front
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             const float G = gs2m_exp(p2);
             const float alpha = fminf(0.99f, c.y * G);
             const bool contrib = (pos <= last) && (p2 <= 0.0f) && (alpha >= 1.0f / 255.0f);
-            if (__ballot(contrib) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
 
             // Branch-free payload: non-contributing lanes run with alpha = 0 and G = 0, which makes every
             // reduced value exactly 0 and leaves T and Sg unchanged (rcp(1) = 1, fma(gc, 0, Sg) = Sg).

@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
             hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, c.z, c.w, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
         }
-        const unsigned long long mask = __ballot(hit);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         // back to front: the hit with the highest list position gets rank 0
         if (hit) s_list[lane == 63 ? 0 : (int)__popcll(mask >> (lane + 1))] = (uint32_t)lane;
         const int nh = (int)__popcll(mask);

@@ -107,11 +107,11 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     for (int k = 0; k < RS_ITEMS; k++) {
         const bool valid = segbase + k * 64 + lane < n;
         const uint32_t d = (key[k] >> shift) & (BINS - 1);
-        unsigned long long peers = __ballot(valid);
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(bit);
             peers &= bit ? bal : ~bal;
         }
         const uint32_t old = s_cnt[wave][d];  // every peer reads before the leader's write (in-order LDS)
