@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         bool hit = false;
         if (lane < cnt) {
             const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
-            hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, c.z, c.w, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
+            hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
         }
         unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         unsigned long long wrote = 0ull;

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     for (int bi = nb - 1; bi >= 0; bi--) {
         const int base = bi * BB;
         const int cnt = min(BB, maxc - base);
-        asm volatile("" ::"v"(touch));  // the touch loads of the previous iteration retire here at the latest
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(touch));  // the touch load of the previous iteration retires here at the latest
         gs2m_sync();
         if (lane < cnt) s_gid[lane] = gid_next;
         if (bi > 0 && lane < BB) gid_next = point_list[range.x + base - BB + lane];
@@ -317,16 +317,25 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             }
         }
         gs2m_sync();
-        bool hit = false;
-        if (lane < cnt) {
-            const float4 a = s_v[REC_GEO0][lane], c = s_v[REC_GEO1][lane];
-            hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, c.x, c.z, c.w, s_v[REC_BIN][lane].w, bx0, bx1, by0, by1);
+        bool hit;
+        {   // 32 staged instances on 64 lanes: lane and lane + 32 share instance (lane & 31), one pair of edges each
+            static_assert(BB == 32, "the split quadrant test assumes 32 instances per batch");
+            const int il = lane & 31;
+            const float4 a = s_v[REC_GEO0][il];
+            const float cC = s_v[REC_GEO1][il].x, t2 = s_v[REC_BIN][il].w;
+            hit = gs2m_reaches_rect_split(lane >= 32, a.x, a.y, a.z, a.w, cC, t2, bx0, bx1, by0, by1) && lane < cnt;
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         // back to front: the hit with the highest list position gets rank 0
         if (hit) s_list[lane == 63 ? 0 : (int)__popcll(mask >> (lane + 1))] = (uint32_t)lane;
         const int nh = (int)__popcll(mask);
-        if (bi > 0 && lane < BB) touch = *reinterpret_cast<const volatile uint32_t*>(rec + (size_t)gid_next * REC_Q);
+        if (bi > 0 && lane < BB) {
+            // plain asm: a volatile C++ load is waited for on the spot (sc0 sc1 + s_waitcnt vmcnt(0)), which would
+            // put the whole memory latency back on this wave; the result register stays reserved until the
+            // s_waitcnt at the top of the next iteration
+            const float4* tp = rec + (size_t)gid_next * REC_Q;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(tp));
+        }
         gs2m_sync();
         int taken = 0;
         while (taken < nh) {

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                 bool hit = false;
                 if (j < cnt) {
                     const float4 a = s_v[REC_GEO0][j], b = s_v[REC_GEO1][j];
-                    hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, b.x, b.z, b.w, s_v[REC_BIN][j].w, bx0, bx1, by0, by1);
+                    hit = gs2m_reaches_rect(a.x, a.y, a.z, a.w, b.x, s_v[REC_BIN][j].w, bx0, bx1, by0, by1);
                 }
                 unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                 int myobs = 0;  // observe count of instance sub + lane in this quadrant

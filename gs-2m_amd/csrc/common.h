@@ -187,30 +187,42 @@ __device__ __forceinline__ float gs2m_power(float dx, float dy, float A, float B
     const float t3 = (B * dx) * dy;
     return (-0.5f * (t1 + t2)) - t3;
 }
-// Does the region {A dx^2 + 2B dx dy + C dy^2 <= t2} around (gx, gy) reach the pixel rectangle
-// [x0, x1] x [y0, y1]?  Conservative (t2 and the box carry margins, preprocess.hip): bounding-box test
-// first, then the exact minimum of the quadratic form over the rectangle (centre inside, or the best
-// point of the four edges).  Instances that fail cannot contribute to any pixel of the rectangle.
-__device__ __forceinline__ bool gs2m_reaches_rect(float gx, float gy, float A, float B, float C, float hx, float hy,
-                                                  float t2, float x0, float x1, float y0, float y1) {
-    if (!((gx + hx >= x0) && (gx - hx <= x1) && (gy + hy >= y0) && (gy - hy <= y1))) return false;
-    if (!(t2 < 3.0e38f)) return true;  // culling disabled for this Gaussian (ill-conditioned conic)
+// Does the region {q(dx, dy) = A dx^2 + 2B dx dy + C dy^2 <= t2} around (gx, gy) reach the pixel rectangle
+// [x0, x1] x [y0, y1]?  Exact up to the margins t2 carries (preprocess.hip): the centre lies inside, or the
+// minimum of q over the four edges is within t2.  Instances that fail cannot contribute to any pixel of the
+// rectangle; t2 >= 3e38 marks Gaussians whose culling is disabled (indefinite / ill-conditioned conic).
+// The blend loops are issue bound and this test runs once per (instance, quadrant), so it is written for
+// instruction count: v_rcp_f32 (1 ulp, second-order effect on q at the clamped minimiser), v_med3 clamps.
+//
+// Minimum of q over the two edges dx = l, dx = u with the free coordinate clamped to [fl, fu]
+// (a, c = the conic entries of the fixed and the free coordinate, b2 = 2B).
+__device__ __forceinline__ float gs2m_edge_pair_qmin(float a, float b2, float c, float l, float u, float fl, float fu) {
+    const float nhr = -0.5f * __builtin_amdgcn_rcpf(c);
+    const float bl = b2 * l, bu = b2 * u;
+    const float fml = __builtin_amdgcn_fmed3f(bl * nhr, fl, fu), fmu = __builtin_amdgcn_fmed3f(bu * nhr, fl, fu);
+    const float ql = __builtin_fmaf(__builtin_fmaf(c, fml, bl), fml, (a * l) * l);
+    const float qu = __builtin_fmaf(__builtin_fmaf(c, fmu, bu), fmu, (a * u) * u);
+    return fminf(ql, qu);
+}
+__device__ __forceinline__ bool gs2m_reaches_rect(float gx, float gy, float A, float B, float C, float t2, float x0,
+                                                  float x1, float y0, float y1) {
     const float lx = x0 - gx, ux = x1 - gx, ly = y0 - gy, uy = y1 - gy;  // rectangle relative to the centre
-    if (lx <= 0.f && ux >= 0.f && ly <= 0.f && uy >= 0.f) return true;
-    float qmin = 3.0e38f;
-    {   // vertical edges dx = lx, ux: minimise over dy in [ly, uy]
-        const float rC = 1.0f / C;
-        const float dyl = fminf(uy, fmaxf(ly, -B * lx * rC)), dyu = fminf(uy, fmaxf(ly, -B * ux * rC));
-        qmin = fminf(qmin, A * lx * lx + 2.f * B * lx * dyl + C * dyl * dyl);
-        qmin = fminf(qmin, A * ux * ux + 2.f * B * ux * dyu + C * dyu * dyu);
-    }
-    {   // horizontal edges dy = ly, uy: minimise over dx in [lx, ux]
-        const float rA = 1.0f / A;
-        const float dxl = fminf(ux, fmaxf(lx, -B * ly * rA)), dxu = fminf(ux, fmaxf(lx, -B * uy * rA));
-        qmin = fminf(qmin, A * dxl * dxl + 2.f * B * dxl * ly + C * ly * ly);
-        qmin = fminf(qmin, A * dxu * dxu + 2.f * B * dxu * uy + C * uy * uy);
-    }
-    return qmin <= t2 + 1.0e-3f * fabsf(qmin);
+    const bool inside = lx <= 0.f && ux >= 0.f && ly <= 0.f && uy >= 0.f;
+    const float b2 = B + B;
+    const float qmin = fminf(gs2m_edge_pair_qmin(A, b2, C, lx, ux, ly, uy), gs2m_edge_pair_qmin(C, b2, A, ly, uy, lx, ux));
+    return !(t2 < 3.0e38f) || inside || qmin <= __builtin_fmaf(1.0e-3f, fabsf(qmin), t2);
+}
+// The same test with the work of one instance split over two lanes (lane and lane ^ 32): `swap` lanes take
+// the horizontal edges by exchanging the roles of x and y, then the halves are combined.
+__device__ __forceinline__ bool gs2m_reaches_rect_split(bool swap, float gx, float gy, float A, float B, float C,
+                                                        float t2, float x0, float x1, float y0, float y1) {
+    const float lx = x0 - gx, ux = x1 - gx, ly = y0 - gy, uy = y1 - gy;
+    const bool inside = lx <= 0.f && ux >= 0.f && ly <= 0.f && uy >= 0.f;
+    const float q = gs2m_edge_pair_qmin(swap ? C : A, B + B, swap ? A : C, swap ? ly : lx, swap ? uy : ux,
+                                        swap ? lx : ly, swap ? ux : uy);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q), __float_as_uint(q), false, false);
+    const float qmin = fminf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // own half and the partner's
+    return !(t2 < 3.0e38f) || inside || qmin <= __builtin_fmaf(1.0e-3f, fabsf(qmin), t2);
 }
 
 // exp(x) for x <= 0 through v_exp_f32
