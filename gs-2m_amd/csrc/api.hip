@@ -142,7 +142,7 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (!bbase) return GS2M_ERR_ALLOC;
     BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
 
-    HIP_TRY(hipMemsetAsync(im.ranges, 0, tiles * sizeof(uint2), s));
+    HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     if (R > 0) {
         {
             StageTimer t(ST_EMIT, s);
@@ -156,7 +156,7 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         {
             StageTimer t(ST_RANGES, s);
             gs2m_launch_ranges(R, b, im, s);
-            HIP_TRY(hipMemsetAsync(b.inst_obs, 0, (size_t)R * sizeof(uint32_t), s));
+            HIP_TRY(gs2m_zero_async(b.inst_obs, (size_t)R * sizeof(uint32_t), s));
         }
     }
     {
@@ -207,7 +207,7 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     float* rows = (float*)al;
     uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
 
-    HIP_TRY(hipMemsetAsync(row_valid, 0, Rn * rpi, s));
+    HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s);
         if (g_bwd_impl == 1)

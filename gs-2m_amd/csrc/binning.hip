@@ -171,6 +171,26 @@ void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
                                                 b.vals_unsorted);
 }
+// Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
+// leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them
+// per view were 3 % of the step.  `bytes` must be a multiple of 4, `p` 4-byte aligned.
+__global__ void zero_kernel(uint32_t* __restrict__ p, size_t words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t head = (4 - (((uintptr_t)p >> 2) & 3)) & 3;  // words up to the first 16-B boundary
+    const size_t quads = words > head ? (words - head) >> 2 : 0;
+    if (i < quads) reinterpret_cast<uint4*>(p + head)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < head && i < words) p[i] = 0u;
+    const size_t tail = head + 4 * quads;
+    if (i < words - min(words, tail)) p[tail + i] = 0u;
+}
+hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) return hipMemsetAsync(p, 0, bytes, s);
+    const size_t words = bytes >> 2, threads = (words >> 2) + 4;
+    zero_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((uint32_t*)p, words);
+    return hipGetLastError();
+}
+
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s) {
     if (R > 0) ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, b.tile_keys, im.ranges);
 }

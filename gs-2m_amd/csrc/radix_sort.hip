@@ -221,7 +221,7 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     uint32_t* tickets = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4));
     uint32_t* status = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN);
     const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
-    hipError_t e = hipMemsetAsync(base, 0, zero_bytes, s);
+    hipError_t e = gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     rs_hist_kernel<<<tiles, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
                                                 make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist);
@@ -331,7 +331,7 @@ hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, cons
     const int tiles = (int)((n + 4095) / 4096);
     if (temp_bytes < gs2m_scan_temp_bytes(n)) return hipErrorInvalidValue;
     uint32_t* base = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    hipError_t e = hipMemsetAsync(base, 0, (size_t)(tiles + 64) * 4, s);
+    hipError_t e = gs2m_zero_async(base, (size_t)(tiles + 64) * 4, s);
     if (e != hipSuccess) return e;
     scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64);
     return hipGetLastError();
