@@ -20,6 +20,9 @@
 #include "common.h"
 
 namespace {
+#ifndef LB_WIN
+#define LB_WIN 4
+#endif
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
@@ -149,17 +152,31 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
             __hip_atomic_store(my, FLAG_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __hip_atomic_store(my, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look-back, LB_WIN predecessors per round trip: the loads of one window are independent, so a chain
+            // of k not-yet-prefixed tiles costs k / LB_WIN memory latencies instead of k
             int p = (int)tile - 1;
-            while (true) {
-                const uint32_t w = __hip_atomic_load(status + (size_t)p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t f = w & ~VAL_MASK;
-                if (f == 0u) {
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool found = false;
+            while (!found) {
+                uint32_t w[LB_WIN];
+#pragma unroll
+                for (int k = 0; k < LB_WIN; k++)
+                    w[k] = p - k >= 0 ? __hip_atomic_load(status + (size_t)(p - k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : FLAG_PFX;  // in front of tile 0: prefix 0
+                bool stalled = false;
+#pragma unroll
+                for (int k = 0; k < LB_WIN; k++) {
+                    const uint32_t f = w[k] & ~VAL_MASK;
+                    if (!found && !stalled) {
+                        if (f == 0u) {
+                            stalled = true;  // not published yet: poll again from here
+                        } else {
+                            excl += w[k] & VAL_MASK;
+                            p--;
+                            found = f == FLAG_PFX;
+                        }
+                    }
                 }
-                excl += w & VAL_MASK;
-                if (f == FLAG_PFX) break;
-                p--;
+                if (stalled) __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(my, FLAG_PFX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -291,16 +308,27 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
         } else {
             __hip_atomic_store(status + tile, FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int p = (int)tile - 1;
-            while (true) {
-                const uint32_t w = __hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t f = w & ~VAL_MASK;
-                if (f == 0u) {
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool found = false;
+            while (!found) {  // windowed look-back as in rs_onesweep_kernel
+                uint32_t w[LB_WIN];
+#pragma unroll
+                for (int k = 0; k < LB_WIN; k++)
+                    w[k] = p - k >= 0 ? __hip_atomic_load(status + (p - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_PFX;
+                bool stalled = false;
+#pragma unroll
+                for (int k = 0; k < LB_WIN; k++) {
+                    const uint32_t f = w[k] & ~VAL_MASK;
+                    if (!found && !stalled) {
+                        if (f == 0u) {
+                            stalled = true;
+                        } else {
+                            excl += w[k] & VAL_MASK;
+                            p--;
+                            found = f == FLAG_PFX;
+                        }
+                    }
                 }
-                excl += w & VAL_MASK;
-                if (f == FLAG_PFX) break;
-                p--;
+                if (stalled) __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
