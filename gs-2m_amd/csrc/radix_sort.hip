@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
                                                       uint32_t* __restrict__ counters, uint32_t* ticket, uint32_t* status) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile, s_base;
-    __shared__ uint32_t s_t[256 * SC_ITEMS + 128];
+    __shared__ uint32_t s_t[256 * SC_ITEMS + 128], s_o[256 * SC_ITEMS + 128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     gs2m_sync();
@@ -284,7 +284,6 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
         s_t[e + (e >> 5)] = i < n ? tiles_touched[sorted_gid[i]] : 0u;
     }
     gs2m_sync();
-    const uint32_t i0 = tbase + tid * SC_ITEMS;
     uint32_t v[SC_ITEMS], sum = 0;
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; k++) {
@@ -336,15 +335,23 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
         if ((tile + 1) * (256 * SC_ITEMS) >= n) counters[0] = excl + total;  // last tile: num_rendered
     }
     gs2m_sync();
+    // results leave the way the inputs came: through LDS, so that every global store is a coalesced 256-B run
+    // (a thread owns 16 consecutive elements: storing them directly is a 64-B lane stride)
     uint32_t run = s_base + wbase + (incl - sum);
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; k++) {
-        const uint32_t i = i0 + k;
-        if (i < n) {
-            sorted_tt[i] = v[k];
-            sorted_off[i] = run;
-        }
+        const uint32_t e = tid * SC_ITEMS + k;
+        s_o[e + (e >> 5)] = run;
         run += v[k];
+    }
+    gs2m_sync();
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t e = k * 256 + tid, i = tbase + e;
+        if (i < n) {
+            sorted_tt[i] = s_t[e + (e >> 5)];
+            sorted_off[i] = s_o[e + (e >> 5)];
+        }
     }
 }
 }  // namespace
