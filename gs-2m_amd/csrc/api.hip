@@ -199,13 +199,16 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
 
     const int rpi = g_bwd_impl == 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
     const int rowf = g_bwd_impl == 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
-    const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rowf * sizeof(float));
+    const int rstride = rowf;
+    const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rstride * sizeof(float));
     const size_t valid_bytes = gs2m_align_up(Rn * rpi);
-    char* sbase = scratch_alloc(rows_bytes + valid_bytes + 2 * GS2M_ALIGN, scratch_user);
+    const size_t sums_bytes = gs2m_align_up((size_t)(P > 0 ? P : 1) * rowf * sizeof(float));  // one reduced row per Gaussian
+    char* sbase = scratch_alloc(rows_bytes + valid_bytes + sums_bytes + 2 * GS2M_ALIGN, scratch_user);
     if (!sbase) return GS2M_ERR_ALLOC;
     char* al = (char*)gs2m_align_up((size_t)(uintptr_t)sbase);
     float* rows = (float*)al;
     uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
+    float* sums = (float*)(al + rows_bytes + valid_bytes);
 
     HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
@@ -218,9 +221,10 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
                                   grad_buffer, rows, row_valid, s);
     }
     StageTimer tg(ST_GAUSSIAN_BWD, s);
+    if (P > 0) gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
     gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
-                             rows, row_valid, rowf, rpi, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
+                             sums, row_valid, rowf, 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
                              dL_dcov3D, dL_dshs, dL_dscales, dL_drots, dL_dfeatures, s);
     HIP_TRY(hipGetLastError());
     return GS2M_OK;

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
     const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
     constexpr int NV = ROW_FEAT + FC;
     constexpr int ROWF = ((NV + 3) / 4) * 4;
+    constexpr int RSTRIDE = ROWF;  // rows are packed (a 128-B stride was tried: random single lines read no faster)
     constexpr int NC = 3 + FC;  // colour + feature columns of the W x Ggrad product
     constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each) = channel quads
     constexpr int NQ = 3 + KK;        // record quads staged: geo0, geo1, bin, channels
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             const int i = 4 * r + rr;
             if (i < nvalid && j < ROWF - ROW_COL) {
                 const size_t rslot = (size_t)s_slotg[i] * 4 + quad;
-                rows[rslot * ROWF + ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
+                rows[rslot * RSTRIDE + ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
             }
         }
         if (r == 0 && j < nvalid) {  // geometry sums of survivor j from its moments
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
             const float Sdxy = xc * yc * m0.x - xc * m0.z - yc * m0.y + m1.x;
             const float Sdyy = yc * yc * m0.x - 2.f * yc * m0.z + m1.y;
             const size_t rslot = (size_t)s_slotg[j] * 4 + quad;
-            float4* o4 = reinterpret_cast<float4*>(rows + rslot * ROWF);
+            float4* o4 = reinterpret_cast<float4*>(rows + rslot * RSTRIDE);
             o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
             o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x / so : 0.f);
             row_valid[rslot] = 1;

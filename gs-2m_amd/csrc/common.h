@@ -91,6 +91,8 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, const GeomState& g, int shrink, hipStream_t s);
 void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s);
+void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
+                            int rstride, int rpi, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
