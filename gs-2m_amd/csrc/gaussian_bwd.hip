@@ -416,87 +416,112 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 }
 
 // Sum of the partial-gradient rows of every Gaussian, ahead of gaussian_bwd_kernel.
-// Threads run in DEPTH-SORTED order (the order the emission slots were assigned in), so the rows of the 64
-// Gaussians of a wave are ONE contiguous range of instance slots.  The wave walks that range 64 instances at
-// a time: (a) every lane loads the valid word and the <= RPI rows of ONE instance and adds them in quadrant
-// order -- balanced, all loads of a lane in flight together, consecutive lanes on consecutive slots; (b) the
-// per-instance sums go through LDS; (c) every lane, now acting for ITS Gaussian, adds its instances of this
-// window in slot order.  The only imbalance left is in (c), on LDS reads.  Fixed summation order: bitwise
-// reproducible.  The per-thread loop this replaces (a serial walk over the Gaussian's instances with
-// dependent valid -> row loads, 6.7 iterations per wave for a mean of 2.7) ran at 1.6 TB/s.
+// Threads run in DEPTH-SORTED order (the order the emission slots were assigned in), so the instances of the 64
+// Gaussians of a wave are ONE contiguous range of slots.  The wave walks that range 64 instances at a time:
+// (a) every lane loads the valid flags and the <= RPI rows of ONE instance (predicated, all in flight
+// together) and adds them in quadrant order; (b) the per-instance sums go through LDS; (c) the LDS phase runs
+// with rq lanes per Gaussian -- lane = (group, float4 chunk) -- one LDS read and one float4 add per step, every
+// group walking its own Gaussians in order.  Fixed summation order: bitwise reproducible.
+// What this replaces -- a per-thread walk over the Gaussian's instances with dependent valid -> row loads --
+// left most lanes idle (6.7 iterations per wave for a mean of 2.7 instances).
 template <int RPI>
 __global__ void __launch_bounds__(256) row_reduce_kernel(int P, const uint32_t* __restrict__ sorted_gid,
                                                          const uint32_t* __restrict__ sorted_tt,
                                                          const uint32_t* __restrict__ sorted_off,
                                                          const float* __restrict__ rows,
                                                          const uint8_t* __restrict__ row_valid, int rowf,
-                                                         int rstride, float* __restrict__ sums) {
+                                                         float* __restrict__ sums) {
     constexpr int MAXQ = 6;  // float4 per row at most (11 + 10 features, padded)
     __shared__ float4 s_inst[4][GS2M_WAVE][MAXQ];
+    __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t cnt = 0, off = 0, gid = 0;
+    uint32_t cnt = 0, off = 0, gid = 0xFFFFFFFFu;
     if (i < P) {
         cnt = sorted_tt[i];
         off = sorted_off[i];
         gid = sorted_gid[i];
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64), excl = incl - cnt;
-    const uint32_t base = __shfl(off, 0, 64);  // sorted_off is the exclusive scan in this very order
+    const uint32_t total = __shfl(incl, 63, 64);
+    // first slot of the wave: offsets are exclusive scans in this very order, so instance k of the wave is base + k
+    // (lanes beyond P carry off = 0: take the first lane's, which is in range whenever total > 0)
+    const uint32_t base = __shfl(off, 0, 64);
+    s_excl[wave][lane] = incl - cnt;
+    s_cnt[wave][lane] = cnt;
+    s_gidw[wave][lane] = gid;
     const int rq = rowf >> 2;
-    float4 racc[MAXQ];
+    // (c) runs with rq lanes per Gaussian -- lane = (group g, float4 chunk c) -- so that one step is ONE LDS read
+    // and one float4 add per lane with all groups busy; group g owns the Gaussians g, g + G, g + 2G, ... of the
+    // wave, in order, and keeps the running sum of its current one in registers across windows.
+    const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
+    const bool worker = g < G;
+    uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;  // this group's current Gaussian (index within the wave)
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The windows of a wave are a serial chain (valid byte -> row -> LDS -> sum) with few waves per CU to hide
+    // it, so the chain is cut: the valid bytes of the first 32 windows are fetched up front (independent loads),
+    // and the rows of window w + 1 are requested before window w is summed.
+    uint32_t vbits = 0;  // RPI valid flags per window, the first 32 / RPI windows
+    constexpr uint32_t PRE = 32 / RPI;
+    const uint32_t nwin = (total + GS2M_WAVE - 1) / GS2M_WAVE;
+    auto valid_flags = [&](uint32_t k) -> uint32_t {  // bit q: row q of instance k of the wave is valid
+        if (k >= total) return 0u;
+        const size_t slot = (size_t)base + k;
+        if (RPI == 4) {
+            const uint32_t w4 = reinterpret_cast<const uint32_t*>(row_valid)[slot];  // the instance's 4 valid bytes
+            return (w4 & 0xFFu ? 1u : 0u) | (w4 & 0xFF00u ? 2u : 0u) | (w4 & 0xFF0000u ? 4u : 0u) | (w4 & 0xFF000000u ? 8u : 0u);
+        }
+        return row_valid[slot] != 0 ? 1u : 0u;
+    };
+    for (uint32_t w = 0; w < min(nwin, PRE); w++) vbits |= valid_flags(w * GS2M_WAVE + lane) << (RPI * w);
+    auto load_window = [&](uint32_t w, float4* a) {
+        const uint32_t k = w * GS2M_WAVE + lane;
+        const size_t slot = (size_t)base + k;
+        uint32_t fl = 0;
+        if (w < nwin) fl = w < PRE ? (vbits >> (RPI * w)) & ((1u << RPI) - 1u) : valid_flags(k);
+        float4 rv[RPI][MAXQ];  // predicated loads, no branches: all rows of the instance are in flight together
 #pragma unroll
-    for (int c = 0; c < MAXQ; c++) racc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t k0 = 0; k0 < total; k0 += GS2M_WAVE) {
-        const uint32_t k = k0 + lane;
-        float4 a[MAXQ];
+        for (int q = 0; q < RPI; q++) {
+            const bool on = ((fl >> q) & 1u) != 0;
+            const float4* r4 = reinterpret_cast<const float4*>(rows + (slot * RPI + q) * rowf);
 #pragma unroll
-        for (int c = 0; c < MAXQ; c++) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < total) {
-            const size_t slot = (size_t)base + k;
-            if (RPI == 4) {
-                const uint32_t vm4 = reinterpret_cast<const uint32_t*>(row_valid)[slot];  // 4 valid bytes of the instance
-                float4 rv[4][MAXQ];  // predicated loads, no branches: all rows of the instance are in flight together
+            for (int e = 0; e < MAXQ; e++) rv[q][e] = (on && e < rq) ? r4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool on = ((vm4 >> (8 * q)) & 0xFFu) != 0;
-                    const float4* r4 = reinterpret_cast<const float4*>(rows + (slot * 4 + q) * rstride);
+        for (int e = 0; e < MAXQ; e++) a[e] = rv[0][e];
 #pragma unroll
-                    for (int c = 0; c < MAXQ; c++) rv[q][c] = (on && c < rq) ? r4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+        for (int q = 1; q < RPI; q++)
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int c = 0; c < MAXQ; c++) {
-                        a[c].x += rv[q][c].x; a[c].y += rv[q][c].y; a[c].z += rv[q][c].z; a[c].w += rv[q][c].w;
-                    }
-            } else {
-                const bool on = row_valid[slot] != 0;
-                const float4* r4 = reinterpret_cast<const float4*>(rows + slot * rstride);
-#pragma unroll
-                for (int c = 0; c < MAXQ; c++) a[c] = (on && c < rq) ? r4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < MAXQ; e++) {
+                a[e].x += rv[q][e].x; a[e].y += rv[q][e].y; a[e].z += rv[q][e].z; a[e].w += rv[q][e].w;
             }
-        }
+    };
+    float4 anext[MAXQ];
+    load_window(0, anext);
+    // one extra pass (w == nwin, empty window) lets every group finish and write its remaining Gaussians
+    for (uint32_t w = 0; w <= nwin; w++) {
+        const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
+        if (w < nwin) {
 #pragma unroll
-        for (int c = 0; c < MAXQ; c++)
-            if (c < rq) s_inst[wave][lane][c] = a[c];
+            for (int q = 0; q < MAXQ; q++)
+                if (q < rq) s_inst[wave][lane][q] = anext[q];
+            load_window(w + 1, anext);
+        }
         // LDS operations of one wave execute in order: the reads below see the writes above
-        const uint32_t lo = max(excl, k0), hi = min(excl + cnt, k0 + GS2M_WAVE);
-        for (uint32_t t = lo; t < hi; t++) {
-#pragma unroll
-            for (int c = 0; c < MAXQ; c++)
-                if (c < rq) {
-                    const float4 v = s_inst[wave][t - k0][c];
-                    racc[c].x += v.x; racc[c].y += v.y; racc[c].z += v.z; racc[c].w += v.w;
-                }
+        while (j < GS2M_WAVE) {
+            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
+            if (ex >= k1 && cn > 0) break;  // starts in a later window
+            const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
+            for (uint32_t t = t0; t < t1; t++) {
+                const float4 v = s_inst[wave][t - k0][c];
+                racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
+            }
+            if (ex + cn > k1) break;  // continues in the next window
+            const uint32_t gj = s_gidw[wave][j];
+            if (gj != 0xFFFFFFFFu) reinterpret_cast<float4*>(sums + (size_t)gj * rowf)[c] = racc;
+            racc = make_float4(0.f, 0.f, 0.f, 0.f);
+            j += (uint32_t)G;
         }
-    }
-    if (i < P) {
-        float4* o4 = reinterpret_cast<float4*>(sums + (size_t)gid * rowf);
-#pragma unroll
-        for (int c = 0; c < MAXQ; c++)
-            if (c < rq) o4[c] = racc[c];
     }
 }
 
@@ -504,10 +529,11 @@ __global__ void __launch_bounds__(256) row_reduce_kernel(int P, const uint32_t* 
 
 void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                             int rstride, int rpi, float* sums, hipStream_t s) {
+    (void)rstride;  // rows are packed at rowf floats
     if (rpi == 4)
-        row_reduce_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, rstride, sums);
+        row_reduce_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
     else
-        row_reduce_kernel<1><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, rstride, sums);
+        row_reduce_kernel<1><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
 }
 
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,

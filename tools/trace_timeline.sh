@@ -12,7 +12,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last occurrence of preprocess_kernel marks the start of the last forward
 idx = max(i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"])
 t0 = int(rows[idx]["Start_Timestamp"])
-for r in rows[idx:idx + 24]:
-    n = r["Kernel_Name"].split("(")[0][-40:]
-    print("%-42s q%-3s start %8.1f us  end %8.1f us" % (n, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3))
+for r in rows[idx:idx + 40]:
+    import re
+    n = r["Kernel_Name"]
+    m = re.search(r"(\w+_kernel|fillBuffer\w*|copyBuffer\w*|\w+Functor)", n)
+    n = m.group(1) if m else n[:40]
+    print("%-28s start %8.1f us  dur %7.1f us" % (n, (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 PY
