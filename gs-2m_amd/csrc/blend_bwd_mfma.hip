@@ -33,31 +33,52 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BB = 32;  // instances staged per batch (LDS per wave decides the occupancy here)
+#ifndef GS2M_BWDM_WAVES
+#define GS2M_BWDM_WAVES
+#endif
 #ifndef GS2M_BWDM_UNROLL_B
 #define GS2M_BWDM_UNROLL_B 1
 #endif
 
-// Inclusive prefix product over the 16 lanes of a row.  One v_mul_f32_dpp per level: lanes whose source
-// falls outside the row are disabled by the DPP (bound_ctrl:0) and keep x, i.e. multiply by 1.  hipcc does
-// not fold mov_dpp + mul for a float identity, hence the asm; `s_nop 1` covers the VALU-write -> DPP-read
-// hazard, which the compiler does not track through inline asm.
-__device__ __forceinline__ float row_scan_mul(float x) {
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    return x;
+// Inclusive prefix product / sum over the 16 lanes of a DPP row, for a PAIR of independent values with the two
+// chains interleaved.  One v_mul/add_f32_dpp per level and value: lanes whose source falls outside the row are
+// disabled by the DPP and keep x (product) or add 0 (sum, bound_ctrl:1); hipcc does not fold mov_dpp + mul for a
+// float identity, hence the asm.  A DPP read needs 2 wait states after the VALU write of its source, and the
+// other chain's instruction is one of them: one `s_nop 0` per level (the compiler does not track the hazard
+// through inline asm, so the nops are explicit).
+__device__ __forceinline__ void row_scan_mul2(float& x, float& y) {
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(x), "+v"(y));
 }
-__device__ __forceinline__ float row_scan_add(float x) {  // inclusive prefix sum over the 16 lanes of a row
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_ROW_SHR(1), 0xF, 0xF, false));
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_ROW_SHR(2), 0xF, 0xF, false));
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_ROW_SHR(4), 0xF, 0xF, false));
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_ROW_SHR(8), 0xF, 0xF, false));
-    return x;
+__device__ __forceinline__ void row_scan_add2(float& x, float& y) {  // bound_ctrl:1: lanes without a source add 0
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(x), "+v"(y));
 }
 
 template <int FC>
-__global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
+__global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, int W,
     int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
@@ -210,12 +231,16 @@ __global__ void __launch_bounds__(64) blend_bwd_mfma_kernel(
                 const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
                 const v2f om = 1.0f - am;
                 const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const v2f Pinc = {row_scan_mul(inv.x), row_scan_mul(inv.y)};
+                float Px = inv.x, Py = inv.y;
+                row_scan_mul2(Px, Py);
+                const v2f Pinc = {Px, Py};
                 const v2f Ti = T2[h] * Pinc;  // transmittance in front of survivor j at the two pixels
                 const v2f w = am * Ti;
                 const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
                 const v2f qv = gc * w;
-                const v2f Sinc = {row_scan_add(qv.x), row_scan_add(qv.y)};
+                float Sx = qv.x, Sy = qv.y;
+                row_scan_add2(Sx, Sy);
+                const v2f Sinc = {Sx, Sy};
                 const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
                 const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of blend_bwd.hip)
                 if (j == 15) {
