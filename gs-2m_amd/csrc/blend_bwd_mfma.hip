@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
             const size_t rslot = (size_t)s_slotg[j] * 4 + quad;
             float4* o4 = reinterpret_cast<float4*>(rows + rslot * RSTRIDE);
             o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
-            o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x / so : 0.f);
+            o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)
             row_valid[rslot] = 1;
         }
     };
