@@ -87,6 +87,16 @@ def test_large_and_thin_gaussians(oracle_lib):
     _check(oracle_lib, sc)
 
 
+def test_many_instances_per_gaussian(oracle_lib):
+    """screen-filling splats on a 20 x 16 tile image: hundreds of tile instances per Gaussian, i.e. Gaussians whose
+    partial rows span several 64-instance windows of the row reduction and waves with more windows than it prefetches
+    valid flags for (gaussian_bwd.hip: row_reduce_kernel), and tile lists many batches long."""
+    _require_gpu()
+    sc = Hh.make_scene(700, 320, 256, seed=11, fc=9, scale_lo=0.2, scale_hi=1.5, bg=(0.1, 0.0, 0.3))
+    f, out = _check(oracle_lib, sc)
+    assert f.tiles_touched.max() > 128 and f.num_rendered > 20000
+
+
 def test_dense_scene_terminates(oracle_lib):
     """many opaque layers: exercises T < 1e-4 termination, n_contrib < list length, block early-out."""
     _require_gpu()
