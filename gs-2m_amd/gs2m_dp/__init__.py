@@ -17,6 +17,28 @@ import torch
 import torch.distributed as dist
 
 
+class PendingReduce:
+    """Collectives in flight (GradReducer.reduce_*_async).  Holds the tensors alive until `wait()`."""
+
+    def __init__(self, result):
+        self.result = result
+        self.handles = []
+        self.restore = []
+        self.finish = None
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        for g, part in self.restore:
+            g[:, :part.shape[1]] = part
+        self.restore = []
+        if self.finish is not None:
+            self.result = self.finish()
+            self.finish = None
+        return self.result
+
+
 class GradReducer:
     """Sums per-Gaussian gradient tensors across ranks, in place.
 
@@ -45,42 +67,50 @@ class GradReducer:
         else:
             handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def reduce_grads(self, grads):
-        """grads: dict name -> contiguous tensor (summed in place across ranks). Returns the dict."""
+    def reduce_grads_async(self, grads):
+        """Starts the sum of `grads` (dict name -> contiguous tensor, summed in place across ranks) and returns a
+        PendingReduce; nothing waits yet.  The collectives run on the backend's own stream behind the work already
+        queued on the current stream, so whatever the caller launches next -- the NEXT view's forward and backward
+        -- overlaps them; `.wait()` then makes the current stream (gloo: the host) wait and returns the dict.
+        The tensors must not be touched before `.wait()`."""
+        pend = PendingReduce(grads)
         if self.world_size == 1:
-            return grads
-        handles = []
-        restore = []
+            return pend
         for name, g in grads.items():
             if g is None:
                 continue
             if name == "shs" and self.sh_active_coeffs is not None and self.sh_active_coeffs < g.shape[1]:
                 # bands above the active degree have exactly zero gradient on every rank
                 part = g[:, :self.sh_active_coeffs].contiguous()
-                self._sum(part, handles)
-                restore.append((g, part))
+                self._sum(part, pend.handles)
+                pend.restore.append((g, part))
             else:
                 assert g.is_contiguous(), name
-                self._sum(g, handles)
-        for h in handles:
-            h.wait()
-        for g, part in restore:
-            g[:, :part.shape[1]] = part
-        return grads
+                self._sum(g, pend.handles)
+        return pend
 
-    def reduce_densification_stats(self, viewspace_grad, radii, observe):
-        """Per-view statistics -> what a single process would have accumulated over all ranks' views.
-        Returns (grad_norm_sum (P,1), grad_abs_norm_sum (P,1), visible_count (P,1), max_radii (P), observe_sum (P))."""
+    def reduce_grads(self, grads):
+        """grads: dict name -> contiguous tensor (summed in place across ranks). Returns the dict."""
+        return self.reduce_grads_async(grads).wait()
+
+    def reduce_densification_stats_async(self, viewspace_grad, radii, observe):
+        """Per-view statistics -> what a single process would have accumulated over all ranks' views; returns a
+        PendingReduce whose `.wait()` gives (grad_norm_sum (P,1), grad_abs_norm_sum (P,1), visible_count (P,1),
+        max_radii (P), observe_sum (P))."""
         vis = (radii > 0)
         gn = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
         ga = torch.norm(viewspace_grad[:, 2:], dim=-1, keepdim=True) * vis[:, None]
         packed = torch.cat([gn, ga, vis[:, None].to(gn.dtype), observe[:, None].to(gn.dtype)], dim=1).contiguous()
         mr = radii.clone()
+        pend = PendingReduce(None)
         if self.world_size > 1:
-            h1 = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            h2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-            h1.wait(); h2.wait()
-        return packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr, packed[:, 3].round().to(observe.dtype)
+            pend.handles.append(dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            pend.handles.append(dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+        pend.finish = lambda: (packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr, packed[:, 3].round().to(observe.dtype))
+        return pend
+
+    def reduce_densification_stats(self, viewspace_grad, radii, observe):
+        return self.reduce_densification_stats_async(viewspace_grad, radii, observe).wait()
 
 
 def shard_views(num_views, rank, world_size):

@@ -38,8 +38,15 @@ def _worker(rank, world, port, mode, q):
     assert shard_views(4, rank, world) == [rank, rank + 2]
     g, m2d, radii, observe = _grads_for_view(rank)
     red = GradReducer(mode=mode, sh_active_coeffs=16)
-    red.reduce_grads(g)
-    stats = red.reduce_densification_stats(m2d, radii, observe)
+    if mode == "allreduce":  # blocking form
+        red.reduce_grads(g)
+        stats = red.reduce_densification_stats(m2d, radii, observe)
+    else:  # pipelined form (bench.py at N > 1): both reductions in flight, other work in between, then wait
+        p1 = red.reduce_grads_async(g)
+        p2 = red.reduce_densification_stats_async(m2d, radii, observe)
+        _ = torch.ones(1000).sum()  # stands for the next view's forward + backward
+        assert p1.wait() is g
+        stats = p2.wait()
     q.put((rank, {k: v.numpy() for k, v in g.items()}, [s.numpy() for s in stats]))
     dist.barrier()
     dist.destroy_process_group()
