@@ -71,11 +71,18 @@ def main():
         raise SystemExit(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("GS2M_DIST_BACKEND", "nccl")  # "gloo": functional check of the N > 1 path on one GPU
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} HIP devices visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import gs2m_native
     import gs2m_synth as S
