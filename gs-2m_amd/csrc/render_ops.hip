@@ -1,0 +1,283 @@
+// Fused pre- and post-processing of render() around the rasterizer, for gfx950.
+//
+// The reference does this work with ~25 small PyTorch ops per view (gaussian_renderer/__init__.py:83-96,
+// 126-141; scene/gaussian_model.py:146-160), among them three (N,3)x(3,3) matmuls and a bmm.  On ROCm those
+// K = 3 products go to the BLAS library and cost 22 ms per view at 1M Gaussians / 1080p -- ten times the
+// rasterizer.  Everything here is elementwise per Gaussian or per pixel and HBM bound:
+//   pack_features   xyz, scales, rotations, albedo, roughness, metallic -> the (P, 10) feature rows
+//                   [1, distance, normal(3), albedo(3), roughness, metallic]  (normal: min-scale axis of the
+//                   rotation, flipped to face the camera, GM:146-160; distance: |n_cam . p_cam| or z, GR:89)
+//   gbuffer_post    blended G-buffer -> normal mask, camera-space normals, plane-distance -> depth (GR:126-141)
+// plus their backward passes (the reference gets those from autograd).  Index/sign decisions (argmin of the
+// scales, the flip, abs) are evaluated exactly as the PyTorch ops do.
+#include "common.h"
+
+namespace {
+
+struct Mat3 {  // V[:3, :3] of the row-vector convention: out_j = sum_i in_i * m[i][j]
+    float m[3][3];
+    float t[3];  // V[3, :3]
+};
+
+// world_view_transform, row-major 4x4 in device memory (wave-uniform: scalar loads)
+__device__ __forceinline__ Mat3 load_view(const float* __restrict__ v) {
+    Mat3 V;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) V.m[i][j] = v[4 * i + j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) V.t[j] = v[12 + j];
+    return V;
+}
+
+__device__ __forceinline__ void quat_to_rot(const float q[4], float R[3][3]) {  // utils/general_utils.py:75-98
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// everything the forward and the backward share for one Gaussian
+struct NormalEval {
+    int k;           // min-scale axis
+    float qn;        // |rot|
+    float q[4];      // rot / |rot|
+    float sgn;       // +-1: flip to face the camera
+    float mlen;      // |column k of R|
+    float n[3];      // unit normal, world space
+};
+__device__ __forceinline__ NormalEval eval_normal(const float* __restrict__ xyz, const float* __restrict__ scales,
+                                                  const float* __restrict__ rot, const float* __restrict__ campos, int i) {
+    NormalEval e;
+    const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    e.k = 0;  // torch.argmin: the first index of the minimum
+    float sm = s0;
+    if (s1 < sm) { sm = s1; e.k = 1; }
+    if (s2 < sm) { e.k = 2; }
+    const float4 rq = reinterpret_cast<const float4*>(rot)[i];
+    e.qn = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+    e.q[0] = rq.x / e.qn; e.q[1] = rq.y / e.qn; e.q[2] = rq.z / e.qn; e.q[3] = rq.w / e.qn;
+    float R[3][3];
+    quat_to_rot(e.q, R);
+    float m[3] = {R[0][e.k], R[1][e.k], R[2][e.k]};
+    const float vx = campos[0] - xyz[3 * i], vy = campos[1] - xyz[3 * i + 1], vz = campos[2] - xyz[3 * i + 2];
+    e.sgn = (m[0] * vx + m[1] * vy + m[2] * vz) < 0.0f ? -1.f : 1.f;
+    m[0] *= e.sgn; m[1] *= e.sgn; m[2] *= e.sgn;
+    e.mlen = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    e.n[0] = m[0] / e.mlen; e.n[1] = m[1] / e.mlen; e.n[2] = m[2] / e.mlen;
+    return e;
+}
+
+__global__ void __launch_bounds__(256) pack_features_kernel(int P, const float* __restrict__ xyz,
+                                                            const float* __restrict__ scales,
+                                                            const float* __restrict__ rot,
+                                                            const float* __restrict__ albedo,
+                                                            const float* __restrict__ roughness,
+                                                            const float* __restrict__ metallic,
+                                                            const float* __restrict__ campos, const float* __restrict__ view,
+                                                            int z_depth, int blend_metallic,
+                                                            float* __restrict__ features) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const Mat3 V = load_view(view);
+    const NormalEval e = eval_normal(xyz, scales, rot, campos, i);
+    const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+    float cn[3], cp[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        cn[j] = e.n[0] * V.m[0][j] + e.n[1] * V.m[1][j] + e.n[2] * V.m[2][j];
+        cp[j] = px * V.m[0][j] + py * V.m[1][j] + pz * V.m[2][j] + V.t[j];
+    }
+    const float dist = z_depth ? cp[2] : fabsf(cn[0] * cp[0] + cn[1] * cp[1] + cn[2] * cp[2]);
+    float2* f2 = reinterpret_cast<float2*>(features + (size_t)i * GS2M_NUM_FEATURES);
+    f2[0] = make_float2(1.0f, dist);
+    f2[1] = make_float2(e.n[0], e.n[1]);
+    f2[2] = make_float2(e.n[2], albedo[3 * i]);
+    f2[3] = make_float2(albedo[3 * i + 1], albedo[3 * i + 2]);
+    f2[4] = make_float2(roughness[i], blend_metallic ? metallic[i] : 0.0f);
+}
+
+__global__ void __launch_bounds__(256) pack_features_bwd_kernel(
+    int P, const float* __restrict__ xyz, const float* __restrict__ scales, const float* __restrict__ rot,
+    const float* __restrict__ campos, const float* __restrict__ view, int z_depth, int blend_metallic,
+    const float* __restrict__ dF,
+    float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_albedo,
+    float* __restrict__ d_roughness, float* __restrict__ d_metallic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const Mat3 V = load_view(view);
+    const NormalEval e = eval_normal(xyz, scales, rot, campos, i);
+    const float2* g2 = reinterpret_cast<const float2*>(dF + (size_t)i * GS2M_NUM_FEATURES);
+    const float2 g0 = g2[0], g1 = g2[1], g2_ = g2[2], g3 = g2[3], g4 = g2[4];
+    d_albedo[3 * i] = g2_.y; d_albedo[3 * i + 1] = g3.x; d_albedo[3 * i + 2] = g3.y;
+    d_roughness[i] = g4.x;
+    d_metallic[i] = blend_metallic ? g4.y : 0.0f;
+    float dn[3] = {g1.x, g1.y, g2_.x};
+    float dp[3] = {0.f, 0.f, 0.f};
+    const float ddist = g0.y;
+    if (z_depth) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) dp[a] = ddist * V.m[a][2];
+    } else {
+        const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        float cn[3], cp[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cn[j] = e.n[0] * V.m[0][j] + e.n[1] * V.m[1][j] + e.n[2] * V.m[2][j];
+            cp[j] = px * V.m[0][j] + py * V.m[1][j] + pz * V.m[2][j] + V.t[j];
+        }
+        const float s = cn[0] * cp[0] + cn[1] * cp[1] + cn[2] * cp[2];
+        const float ds = ddist * (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f));  // abs backward: sign, 0 at 0
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            dn[a] += ds * (cp[0] * V.m[a][0] + cp[1] * V.m[a][1] + cp[2] * V.m[a][2]);
+            dp[a] = ds * (cn[0] * V.m[a][0] + cn[1] * V.m[a][1] + cn[2] * V.m[a][2]);
+        }
+    }
+    d_xyz[3 * i] = dp[0]; d_xyz[3 * i + 1] = dp[1]; d_xyz[3 * i + 2] = dp[2];
+    // n = m / |m|,  m = sgn * R[:, k]
+    const float ndn = e.n[0] * dn[0] + e.n[1] * dn[1] + e.n[2] * dn[2];
+    float dc[3];  // gradient of column k of R
+#pragma unroll
+    for (int a = 0; a < 3; a++) dc[a] = e.sgn * (dn[a] - e.n[a] * ndn) / e.mlen;
+    // column k of R as a function of q = (r, x, y, z)
+    const float r = e.q[0], x = e.q[1], y = e.q[2], z = e.q[3];
+    float dq[4];
+    if (e.k == 0) {  // (1 - 2(y^2 + z^2), 2(xy + rz), 2(xz - ry))
+        dq[0] = 2.f * (z * dc[1] - y * dc[2]);
+        dq[1] = 2.f * (y * dc[1] + z * dc[2]);
+        dq[2] = -4.f * y * dc[0] + 2.f * x * dc[1] - 2.f * r * dc[2];
+        dq[3] = -4.f * z * dc[0] + 2.f * r * dc[1] + 2.f * x * dc[2];
+    } else if (e.k == 1) {  // (2(xy - rz), 1 - 2(x^2 + z^2), 2(yz + rx))
+        dq[0] = 2.f * (-z * dc[0] + x * dc[2]);
+        dq[1] = 2.f * y * dc[0] - 4.f * x * dc[1] + 2.f * r * dc[2];
+        dq[2] = 2.f * (x * dc[0] + z * dc[2]);
+        dq[3] = -2.f * r * dc[0] - 4.f * z * dc[1] + 2.f * y * dc[2];
+    } else {  // (2(xz + ry), 2(yz - rx), 1 - 2(x^2 + y^2))
+        dq[0] = 2.f * (y * dc[0] - x * dc[1]);
+        dq[1] = 2.f * z * dc[0] - 2.f * r * dc[1] - 4.f * x * dc[2];
+        dq[2] = 2.f * r * dc[0] + 2.f * z * dc[1] - 4.f * y * dc[2];
+        dq[3] = 2.f * (x * dc[0] + y * dc[1]);
+    }
+    // q = rot / |rot|
+    const float qdq = e.q[0] * dq[0] + e.q[1] * dq[1] + e.q[2] * dq[2] + e.q[3] * dq[3];
+    reinterpret_cast<float4*>(d_rot)[i] = make_float4((dq[0] - e.q[0] * qdq) / e.qn, (dq[1] - e.q[1] * qdq) / e.qn,
+                                                      (dq[2] - e.q[2] * qdq) / e.qn, (dq[3] - e.q[3] * qdq) / e.qn);
+}
+
+__global__ void __launch_bounds__(256) gbuffer_post_kernel(int N, const float* __restrict__ buffer,
+                                                           const float* __restrict__ rays, const float* __restrict__ view,
+                                                           int z_depth, uint8_t* __restrict__ normal_mask,
+                                                           float* __restrict__ local_normal,
+                                                           float* __restrict__ depth) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const Mat3 V = load_view(view);
+    const size_t n = (size_t)N;
+    const float dist = buffer[n + p], a = buffer[2 * n + p], b = buffer[3 * n + p], c = buffer[4 * n + p];
+    normal_mask[p] = (a != 0.f && b != 0.f && c != 0.f) ? 1 : 0;
+    float ln[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        ln[j] = a * V.m[0][j] + b * V.m[1][j] + c * V.m[2][j];
+        local_normal[j * n + p] = ln[j];
+    }
+    if (z_depth) {
+        depth[p] = dist;
+    } else {
+        const float denom = ln[0] * rays[3 * (size_t)p] + ln[1] * rays[3 * (size_t)p + 1] + ln[2] * rays[3 * (size_t)p + 2];
+        depth[p] = dist / -(denom + 1e-8f);
+    }
+}
+
+// gradient with respect to buffer channels 1..4 (written into a (10, H, W) tensor whose other channels the caller
+// zero-fills or already holds)
+__global__ void __launch_bounds__(256) gbuffer_post_bwd_kernel(int N, const float* __restrict__ buffer,
+                                                               const float* __restrict__ rays, const float* __restrict__ view,
+                                                               int z_depth, const float* __restrict__ d_local_normal,
+                                                               const float* __restrict__ d_depth,
+                                                               float* __restrict__ d_buffer) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const Mat3 V = load_view(view);
+    const size_t n = (size_t)N;
+    float dl[3] = {0.f, 0.f, 0.f};
+    if (d_local_normal != nullptr) { dl[0] = d_local_normal[p]; dl[1] = d_local_normal[n + p]; dl[2] = d_local_normal[2 * n + p]; }
+    const float dd = d_depth != nullptr ? d_depth[p] : 0.f;
+    float ddist;
+    if (z_depth) {
+        ddist = dd;
+    } else {
+        const float dist = buffer[n + p], a = buffer[2 * n + p], b = buffer[3 * n + p], c = buffer[4 * n + p];
+        const float r0 = rays[3 * (size_t)p], r1 = rays[3 * (size_t)p + 1], r2 = rays[3 * (size_t)p + 2];
+        float denom = 0.f;
+        const float rr[3] = {r0, r1, r2};
+#pragma unroll
+        for (int j = 0; j < 3; j++) denom += (a * V.m[0][j] + b * V.m[1][j] + c * V.m[2][j]) * rr[j];
+        const float e = denom + 1e-8f;
+        ddist = -dd / e;             // depth = -dist / e
+        const float de = dd * dist / (e * e);
+#pragma unroll
+        for (int j = 0; j < 3; j++) dl[j] += de * rr[j];
+    }
+    d_buffer[n + p] = ddist;
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++) d_buffer[(2 + a_) * n + p] = dl[0] * V.m[a_][0] + dl[1] * V.m[a_][1] + dl[2] * V.m[a_][2];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs2m_pack_features_forward(int P, const float* xyz, const float* scales, const float* rotations, const float* albedo,
+                               const float* roughness, const float* metallic, const float* campos,
+                               const float* view, int z_depth, int blend_metallic, float* features, void* stream) {
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if (P == 0) return GS2M_OK;
+    if (!xyz || !scales || !rotations || !albedo || !roughness || !metallic || !campos || !view || !features)
+        return GS2M_ERR_INVALID_ARG;
+    pack_features_kernel<<<(P + 255) / 256, 256, 0, (hipStream_t)stream>>>(P, xyz, scales, rotations, albedo, roughness,
+                                                                          metallic, campos, view, z_depth,
+                                                                          blend_metallic, features);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_pack_features_backward(int P, const float* xyz, const float* scales, const float* rotations, const float* campos,
+                                const float* view, int z_depth, int blend_metallic, const float* dL_dfeatures,
+                                float* dL_dxyz, float* dL_drotations, float* dL_dalbedo, float* dL_droughness,
+                                float* dL_dmetallic, void* stream) {
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if (P == 0) return GS2M_OK;
+    if (!xyz || !scales || !rotations || !campos || !view || !dL_dfeatures || !dL_dxyz || !dL_drotations || !dL_dalbedo ||
+        !dL_droughness || !dL_dmetallic)
+        return GS2M_ERR_INVALID_ARG;
+    pack_features_bwd_kernel<<<(P + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+        P, xyz, scales, rotations, campos, view, z_depth, blend_metallic, dL_dfeatures, dL_dxyz, dL_drotations,
+        dL_dalbedo, dL_droughness, dL_dmetallic);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_gbuffer_post_forward(int width, int height, const float* buffer, const float* rays, const float* view,
+                              int z_depth, uint8_t* normal_mask, float* local_normal_map, float* depth_map, void* stream) {
+    if (width <= 0 || height <= 0 || !buffer || !view || !normal_mask || !local_normal_map || !depth_map)
+        return GS2M_ERR_INVALID_ARG;
+    if (!z_depth && !rays) return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    gbuffer_post_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, buffer, rays, view, z_depth,
+                                                                         normal_mask, local_normal_map, depth_map);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const float* rays, const float* view,
+                               int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, float* dL_dbuffer,
+                               void* stream) {
+    if (width <= 0 || height <= 0 || !buffer || !view || !dL_dbuffer) return GS2M_ERR_INVALID_ARG;
+    if (!z_depth && !rays) return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    gbuffer_post_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, buffer, rays, view, z_depth,
+                                                                             dL_dlocal_normal, dL_ddepth, dL_dbuffer);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@ import math
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+import gs2m_render_ops
 from gs2m_scene import eval_sh, normal_from_depth_image
 
 
@@ -61,20 +62,31 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
     else:
         shs = pc.get_features
 
-    normals = pc.get_normals(viewpoint_camera.camera_center)  # world space
-    cam_normals = normals @ viewpoint_camera.world_view_transform[:3, :3]
-    cam_points = means3D @ viewpoint_camera.world_view_transform[:3, :3] + viewpoint_camera.world_view_transform[3, :3]
-
     feature_count = 9 if material_stage else 5 if geometry_stage else 1
-    features = torch.zeros((means3D.shape[0], 10), dtype=torch.float32, device=device)
-    features[:, 0] = 1.0  # alpha
-    features[:, 1] = cam_points[:, 2] if pipe.z_depth else (cam_normals * cam_points).sum(dim=-1).abs()  # distance
-    features[:, 2:5] = normals
-    features[:, 5:8] = albedo
-    features[:, 8:9] = roughness
     if blend_metallic:
         feature_count += 1
-        features[:, 9:10] = metallic
+    # pipe.fused_render_ops (default on): the normals, the camera-space products, the feature packing and the
+    # G-buffer post-processing below run as fused HIP kernels (gs2m_render_ops) -- same values and gradients as
+    # the PyTorch formulation of the reference, which stays here as the alternative (and is what the fused ops
+    # are tested against).  On ROCm the K = 3 matmuls of that formulation cost ten times the rasterizer.
+    fused = bool(getattr(pipe, "fused_render_ops", True)) and means3D.is_cuda
+    if fused:
+        features = gs2m_render_ops.pack_features(
+            means3D, scales if scales is not None else pc.get_scaling,
+            rotations if rotations is not None else pc.get_rotation, albedo, roughness, metallic, viewpoint_camera.camera_center,
+            viewpoint_camera.world_view_transform, z_depth=pipe.z_depth, blend_metallic=blend_metallic)
+    else:
+        normals = pc.get_normals(viewpoint_camera.camera_center)  # world space
+        cam_normals = normals @ viewpoint_camera.world_view_transform[:3, :3]
+        cam_points = means3D @ viewpoint_camera.world_view_transform[:3, :3] + viewpoint_camera.world_view_transform[3, :3]
+        features = torch.zeros((means3D.shape[0], 10), dtype=torch.float32, device=device)
+        features[:, 0] = 1.0  # alpha
+        features[:, 1] = cam_points[:, 2] if pipe.z_depth else (cam_normals * cam_points).sum(dim=-1).abs()  # distance
+        features[:, 2:5] = normals
+        features[:, 5:8] = albedo
+        features[:, 8:9] = roughness
+        if blend_metallic:
+            features[:, 9:10] = metallic
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
@@ -96,20 +108,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, features=features)
 
     normal_map = buffer[2:5, ...]  # (3, H, W)
-    normal_mask = (normal_map != 0).all(0, keepdim=True).detach()
-
-    local_normals = normal_map.permute(1, 2, 0).view(-1, 3)  # (H*W, 3)
-    local_normals = local_normals @ viewpoint_camera.world_view_transform[:3, :3]
     H, W = viewpoint_camera.image_height, viewpoint_camera.image_width
-    local_normal_map = local_normals.reshape(H, W, 3).permute(2, 0, 1)
-
-    depth_map = buffer[1:2, ...]
-    distance_map = None
-    if not pipe.z_depth:
-        distance_map = buffer[1:2, ...]
-        rays = viewpoint_camera.get_rays().view(-1, 3)
-        denoms = torch.sum(local_normals * rays, dim=-1).view(1, H, W)
-        depth_map = distance_map / -(denoms + 1e-8)
+    distance_map = None if pipe.z_depth else buffer[1:2, ...]
+    if fused:
+        rays = None if pipe.z_depth else viewpoint_camera.get_rays().view(-1, 3)
+        normal_mask, local_normal_map, depth_map = gs2m_render_ops.gbuffer_post(
+            buffer, rays, viewpoint_camera.world_view_transform, z_depth=pipe.z_depth)
+    else:
+        normal_mask = (normal_map != 0).all(0, keepdim=True).detach()
+        local_normals = normal_map.permute(1, 2, 0).view(-1, 3)  # (H*W, 3)
+        local_normals = local_normals @ viewpoint_camera.world_view_transform[:3, :3]
+        local_normal_map = local_normals.reshape(H, W, 3).permute(2, 0, 1)
+        depth_map = buffer[1:2, ...]
+        if not pipe.z_depth:
+            rays = viewpoint_camera.get_rays().view(-1, 3)
+            denoms = torch.sum(local_normals * rays, dim=-1).view(1, H, W)
+            depth_map = distance_map / -(denoms + 1e-8)
 
     out = {
         "render": rendered_image,

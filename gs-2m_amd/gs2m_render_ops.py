@@ -1,0 +1,101 @@
+"""Autograd wrappers of the fused render() pre/post-processing kernels (csrc/render_ops.hip).
+
+`pack_features` replaces pc.get_normals + the camera-space products + the feature-row packing of the reference's
+render() (gaussian_renderer/__init__.py:83-96, scene/gaussian_model.py:146-160); `gbuffer_post` replaces its G-buffer
+post-processing (:126-141).  Same values, same gradients as the PyTorch ops they stand for (tests/test_render_ops_gpu.py);
+HIP tensors only -- there is no CPU path, the callers keep the reference's PyTorch formulation for that."""
+import torch
+
+import gs2m_native as _native
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"gs2m render ops: `{name}` must be on a HIP (cuda) device; there is no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"gs2m render ops: `{name}` must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _PackFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, scales, rotations, albedo, roughness, metallic, campos, view, z_depth, blend_metallic):
+        xyz, scales, rotations = _f32c(xyz, "xyz"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
+        albedo, roughness, metallic = _f32c(albedo, "albedo"), _f32c(roughness, "roughness"), _f32c(metallic, "metallic")
+        campos, view = _f32c(campos, "camera_center"), _f32c(view, "world_view_transform")
+        P = xyz.shape[0]
+        features = torch.empty((P, 10), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _native.check(_native.lib().gs2m_pack_features_forward(
+                P, _ptr(xyz), _ptr(scales), _ptr(rotations), _ptr(albedo), _ptr(roughness), _ptr(metallic), _ptr(campos),
+                _ptr(view), int(bool(z_depth)), int(bool(blend_metallic)), _ptr(features), _stream()), "gs2m_pack_features_forward")
+        ctx.save_for_backward(xyz, scales, rotations, campos, view)
+        ctx.flags = (int(bool(z_depth)), int(bool(blend_metallic)))
+        return features
+
+    @staticmethod
+    def backward(ctx, dF):
+        xyz, scales, rotations, campos, view = ctx.saved_tensors
+        dF = _f32c(dF, "grad_features")
+        P = xyz.shape[0]
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=xyz.device)
+        d_xyz, d_rot, d_alb, d_rgh, d_met = e(P, 3), e(P, 4), e(P, 3), e(P, 1), e(P, 1)
+        with torch.cuda.device(xyz.device):
+            _native.check(_native.lib().gs2m_pack_features_backward(
+                P, _ptr(xyz), _ptr(scales), _ptr(rotations), _ptr(campos), _ptr(view), ctx.flags[0], ctx.flags[1], _ptr(dF),
+                _ptr(d_xyz), _ptr(d_rot), _ptr(d_alb), _ptr(d_rgh), _ptr(d_met), _stream()), "gs2m_pack_features_backward")
+        # metallic is not read unless blend_metallic: no gradient then (None, as with the PyTorch formulation)
+        return d_xyz, None, d_rot, d_alb, d_rgh, (d_met if ctx.flags[1] else None), None, None, None, None
+
+
+def pack_features(xyz, scales, rotations, albedo, roughness, metallic, camera_center, world_view_transform,
+                  z_depth=False, blend_metallic=False):
+    """-> features (P, 10) = [1, distance, normal(3), albedo(3), roughness, metallic | 0] (GR:83-96, GM:146-160)."""
+    return _PackFeatures.apply(xyz, scales, rotations, albedo, roughness, metallic, camera_center, world_view_transform,
+                               z_depth, blend_metallic)
+
+
+class _GBufferPost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buffer, rays, view, z_depth):
+        buffer, view = _f32c(buffer, "buffer"), _f32c(view, "world_view_transform")
+        rays = None if rays is None else _f32c(rays, "rays")
+        _, H, W = buffer.shape
+        mask = torch.empty((1, H, W), dtype=torch.uint8, device=buffer.device)
+        local_normal = torch.empty((3, H, W), dtype=torch.float32, device=buffer.device)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=buffer.device)
+        with torch.cuda.device(buffer.device):
+            _native.check(_native.lib().gs2m_gbuffer_post_forward(
+                W, H, _ptr(buffer), _ptr(rays), _ptr(view), int(bool(z_depth)), _ptr(mask), _ptr(local_normal), _ptr(depth),
+                _stream()), "gs2m_gbuffer_post_forward")
+        ctx.save_for_backward(buffer, rays, view)
+        ctx.z_depth = int(bool(z_depth))
+        mask = mask.bool()
+        ctx.mark_non_differentiable(mask)
+        return mask, local_normal, depth
+
+    @staticmethod
+    def backward(ctx, _dmask, d_local_normal, d_depth):
+        buffer, rays, view = ctx.saved_tensors
+        _, H, W = buffer.shape
+        d_buffer = torch.zeros_like(buffer)  # channels 0, 5..9 get no gradient from here
+        dl = None if d_local_normal is None else _f32c(d_local_normal, "grad_local_normal_map")
+        dd = None if d_depth is None else _f32c(d_depth, "grad_depth_map")
+        with torch.cuda.device(buffer.device):
+            _native.check(_native.lib().gs2m_gbuffer_post_backward(
+                W, H, _ptr(buffer), _ptr(rays), _ptr(view), ctx.z_depth, _ptr(dl), _ptr(dd), _ptr(d_buffer), _stream()),
+                "gs2m_gbuffer_post_backward")
+        return d_buffer, None, None, None
+
+
+def gbuffer_post(buffer, rays, world_view_transform, z_depth=False):
+    """buffer (10,H,W) -> (normal_mask (1,H,W) bool, local_normal_map (3,H,W), depth_map (1,H,W)) (GR:126-141)."""
+    return _GBufferPost.apply(buffer, rays, world_view_transform, z_depth)

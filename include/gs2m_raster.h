@@ -171,6 +171,35 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
  * used by the parity tests of the integer artefacts. */
 int gs2m_set_reference_binning(int on);
 
+/* ---- render() pre/post-processing around the rasterizer ------------------------------
+ * Replace ~25 small PyTorch ops per view of the reference's render() (three (N,3)x(3,3) matmuls and a bmm among
+ * them) by four elementwise kernels.  All pointers are device pointers; `view` is world_view_transform, row-major
+ * 4x4 with the reference's row-vector convention (p_cam = p @ view[:3,:3] + view[3,:3]).
+ *
+ * gs2m_pack_features_*: gaussian_renderer/__init__.py:83-96 + scene/gaussian_model.py:146-160
+ *   (pc.get_normals(camera_center): min-scale axis of build_rotation(rotations), flipped to face the camera,
+ *   normalised) -> features (P,10) = [1, distance, normal(3), albedo(3), roughness, metallic | 0], distance =
+ *   |n_cam . p_cam| or p_cam.z when z_depth.  `scales`, `rotations`, `albedo`, ... are the ACTIVATED values
+ *   (pc.get_scaling, pc.get_rotation, ...).  The backward returns the gradients autograd would: xyz, rotations,
+ *   albedo, roughness, metallic (scales only select the axis: no gradient). */
+int gs2m_pack_features_forward(int P, const float* xyz, const float* scales, const float* rotations, const float* albedo,
+                               const float* roughness, const float* metallic, const float* campos, const float* view,
+                               int z_depth, int blend_metallic, float* features, void* stream);
+int gs2m_pack_features_backward(int P, const float* xyz, const float* scales, const float* rotations, const float* campos,
+                                const float* view, int z_depth, int blend_metallic, const float* dL_dfeatures,
+                                float* dL_dxyz, float* dL_drotations, float* dL_dalbedo, float* dL_droughness,
+                                float* dL_dmetallic, void* stream);
+/* gs2m_gbuffer_post_*: gaussian_renderer/__init__.py:126-141.  buffer (10,H,W) -> normal_mask (H*W bytes: all three
+ * normal channels != 0), local_normal_map (3,H,W) = normal_map rotated into the camera frame, depth_map (1,H,W) =
+ * distance / -(local_normal . ray + 1e-8) (or the distance channel itself when z_depth); rays (H*W,3) =
+ * viewpoint_camera.get_rays(), unused when z_depth.  The backward writes channels 1..4 of dL_dbuffer (10,H,W);
+ * either upstream gradient may be NULL (= zero). */
+int gs2m_gbuffer_post_forward(int width, int height, const float* buffer, const float* rays, const float* view, int z_depth,
+                              uint8_t* normal_mask, float* local_normal_map, float* depth_map, void* stream);
+int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const float* rays, const float* view,
+                               int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, float* dL_dbuffer,
+                               void* stream);
+
 /* Backward blend implementation (same results within fp32 rounding, all covered by the parity tests):
  *   1 (default) survivor-per-lane layout: DPP row scans for the per-pixel recurrences, fp32 MFMA for the
  *     per-Gaussian sums, one row per (instance, quadrant)                     csrc/blend_bwd_mfma.hip
