@@ -226,6 +226,134 @@ __global__ void __launch_bounds__(256) gbuffer_post_bwd_kernel(int N, const floa
     for (int a_ = 0; a_ < 3; a_++) d_buffer[(2 + a_) * n + p] = dl[0] * V.m[a_][0] + dl[1] * V.m[a_][1] + dl[2] * V.m[a_][2];
 }
 
+// ---- normal from the depth map (GR:167-175 render_normal_from_depth_map; utils/normal_utils.py:3-72) --------------
+// World point of pixel (u, v):  X = d * ray(u, v) + c,  ray = R_c2w K^-1 (u, v, 1),  c = camera centre;  normal =
+// normalize((X_right - X_left) x (X_top - X_bottom)) at interior pixels, 0 on the border;  output = normal * alpha +
+// background * (1 - alpha).  The reference builds this from ~40 PyTorch ops with two GEMMs over H*W rows and two
+// torch.inverse calls; here the inverse of the 3x3 rotation is the adjugate (wave-uniform), K^-1 is closed form.
+struct CamInv {
+    float R[3][3];  // camera -> world rotation, column-vector convention: x_w = R x_c + c
+    float fx, fy, cx, cy;
+};
+__device__ __forceinline__ CamInv load_cam_inv(const float* __restrict__ v, float fx, float fy, float cx, float cy) {
+    // world_view_transform v (row-major 4x4, row-vector convention): W2C rotation A[r][c] = v[4c + r]
+    float A[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[r][c] = v[4 * c + r];
+    const float c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2],
+                c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const float det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02, id = 1.0f / det;
+    CamInv C;
+    C.R[0][0] = c00 * id; C.R[1][0] = c01 * id; C.R[2][0] = c02 * id;
+    C.R[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id;
+    C.R[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id;
+    C.R[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+    C.R[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
+    C.R[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
+    C.R[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+    C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy;
+    return C;
+}
+__device__ __forceinline__ void world_ray(const CamInv& C, int u, int v, float r[3]) {
+    const float x = ((float)u - C.cx) / C.fx, y = ((float)v - C.cy) / C.fy;
+#pragma unroll
+    for (int a = 0; a < 3; a++) r[a] = C.R[a][0] * x + C.R[a][1] * y + C.R[a][2];
+}
+struct Stencil {
+    float a[3], b[3], n[3], len;  // a = X_right - X_left, b = X_top - X_bottom, n = normalize(a x b), len = |a x b|
+};
+__device__ __forceinline__ Stencil eval_stencil(const CamInv& C, const float* __restrict__ depth, int W, int u, int v) {
+    float rr[3], rl[3], rt[3], rb[3];
+    world_ray(C, u + 1, v, rr); world_ray(C, u - 1, v, rl); world_ray(C, u, v - 1, rt); world_ray(C, u, v + 1, rb);
+    const float dr = depth[(size_t)v * W + u + 1], dl = depth[(size_t)v * W + u - 1];
+    const float dt = depth[(size_t)(v - 1) * W + u], db = depth[(size_t)(v + 1) * W + u];
+    Stencil s;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        s.a[k] = dr * rr[k] - dl * rl[k];  // the camera centre cancels in the differences
+        s.b[k] = dt * rt[k] - db * rb[k];
+    }
+    const float m0 = s.a[1] * s.b[2] - s.a[2] * s.b[1], m1 = s.a[2] * s.b[0] - s.a[0] * s.b[2], m2 = s.a[0] * s.b[1] - s.a[1] * s.b[0];
+    s.len = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+    const float dn = fmaxf(s.len, 1e-12f);  // F.normalize(eps = 1e-12)
+    s.n[0] = m0 / dn; s.n[1] = m1 / dn; s.n[2] = m2 / dn;
+    return s;
+}
+
+__global__ void __launch_bounds__(256) sobel_normal_kernel(int W, int H, const float* __restrict__ depth,
+                                                           const float* __restrict__ alpha, const float* __restrict__ bg,
+                                                           const float* __restrict__ view, float fx, float fy, float cx,
+                                                           float cy, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    const int u = p % W, v = p / W;
+    float n[3] = {0.f, 0.f, 0.f};
+    if (u > 0 && u < W - 1 && v > 0 && v < H - 1) {
+        const CamInv C = load_cam_inv(view, fx, fy, cx, cy);
+        const Stencil s = eval_stencil(C, depth, W, u, v);
+        n[0] = s.n[0]; n[1] = s.n[1]; n[2] = s.n[2];
+    }
+    const float al = alpha[p];
+    const size_t N = (size_t)W * H;
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[c * N + p] = n[c] * al + bg[c] * (1.f - al);
+}
+
+// gradients of the stencil at (u, v) with respect to a and b, given the upstream gradient of its normal
+__device__ __forceinline__ void stencil_grads(const CamInv& C, const float* __restrict__ depth,
+                                              const float* __restrict__ alpha, const float* __restrict__ g, int W, int H,
+                                              int u, int v, float da[3], float db[3]) {
+    da[0] = da[1] = da[2] = db[0] = db[1] = db[2] = 0.f;
+    if (!(u > 0 && u < W - 1 && v > 0 && v < H - 1)) return;
+    const size_t N = (size_t)W * H, q = (size_t)v * W + u;
+    const Stencil s = eval_stencil(C, depth, W, u, v);
+    const float al = alpha[q];
+    const float dn[3] = {g[q] * al, g[N + q] * al, g[2 * N + q] * al};
+    float dm[3];
+    if (s.len >= 1e-12f) {
+        const float ndn = s.n[0] * dn[0] + s.n[1] * dn[1] + s.n[2] * dn[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) dm[k] = (dn[k] - s.n[k] * ndn) / s.len;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dm[k] = dn[k] / 1e-12f;
+    }
+    // m = a x b:  dL/da = b x dm,  dL/db = dm x a
+    da[0] = s.b[1] * dm[2] - s.b[2] * dm[1]; da[1] = s.b[2] * dm[0] - s.b[0] * dm[2]; da[2] = s.b[0] * dm[1] - s.b[1] * dm[0];
+    db[0] = dm[1] * s.a[2] - dm[2] * s.a[1]; db[1] = dm[2] * s.a[0] - dm[0] * s.a[2]; db[2] = dm[0] * s.a[1] - dm[1] * s.a[0];
+}
+
+// gather form: pixel p is the right neighbour of (u-1, v), the left of (u+1, v), the top of (u, v+1), the bottom of
+// (u, v-1); no atomics, bitwise reproducible
+__global__ void __launch_bounds__(256) sobel_normal_bwd_kernel(int W, int H, const float* __restrict__ depth,
+                                                               const float* __restrict__ alpha,
+                                                               const float* __restrict__ bg, const float* __restrict__ view,
+                                                               float fx, float fy, float cx, float cy,
+                                                               const float* __restrict__ g, float* __restrict__ d_depth,
+                                                               float* __restrict__ d_alpha) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    const int u = p % W, v = p / W;
+    const size_t N = (size_t)W * H;
+    const CamInv C = load_cam_inv(view, fx, fy, cx, cy);
+    float n[3] = {0.f, 0.f, 0.f};
+    if (u > 0 && u < W - 1 && v > 0 && v < H - 1) {
+        const Stencil s = eval_stencil(C, depth, W, u, v);
+        n[0] = s.n[0]; n[1] = s.n[1]; n[2] = s.n[2];
+    }
+    d_alpha[p] = g[p] * (n[0] - bg[0]) + g[N + p] * (n[1] - bg[1]) + g[2 * N + p] * (n[2] - bg[2]);
+    float acc[3] = {0.f, 0.f, 0.f}, da[3], db[3];
+    if (u > 0) { stencil_grads(C, depth, alpha, g, W, H, u - 1, v, da, db); acc[0] += da[0]; acc[1] += da[1]; acc[2] += da[2]; }
+    if (u < W - 1) { stencil_grads(C, depth, alpha, g, W, H, u + 1, v, da, db); acc[0] -= da[0]; acc[1] -= da[1]; acc[2] -= da[2]; }
+    if (v < H - 1) { stencil_grads(C, depth, alpha, g, W, H, u, v + 1, da, db); acc[0] += db[0]; acc[1] += db[1]; acc[2] += db[2]; }
+    if (v > 0) { stencil_grads(C, depth, alpha, g, W, H, u, v - 1, da, db); acc[0] -= db[0]; acc[1] -= db[1]; acc[2] -= db[2]; }
+    float r[3];
+    world_ray(C, u, v, r);
+    d_depth[p] = r[0] * acc[0] + r[1] * acc[1] + r[2] * acc[2];
+}
+
 }  // namespace
 
 extern "C" {
@@ -277,6 +405,28 @@ int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const
     const int N = width * height;
     gbuffer_post_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, buffer, rays, view, z_depth,
                                                                              dL_dlocal_normal, dL_ddepth, dL_dbuffer);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_sobel_normal_forward(int width, int height, const float* depth, const float* alpha, const float* bg,
+                              const float* view, float fx, float fy, float cx, float cy, float* sobel_map, void* stream) {
+    if (width <= 0 || height <= 0 || !depth || !alpha || !bg || !view || !sobel_map || fx == 0.f || fy == 0.f)
+        return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    sobel_normal_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx, cy,
+                                                                         sobel_map);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_sobel_normal_backward(int width, int height, const float* depth, const float* alpha, const float* bg,
+                               const float* view, float fx, float fy, float cx, float cy, const float* dL_dsobel,
+                               float* dL_ddepth, float* dL_dalpha, void* stream) {
+    if (width <= 0 || height <= 0 || !depth || !alpha || !bg || !view || !dL_dsobel || !dL_ddepth || !dL_dalpha || fx == 0.f ||
+        fy == 0.f)
+        return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    sobel_normal_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx,
+                                                                             cy, dL_dsobel, dL_ddepth, dL_dalpha);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

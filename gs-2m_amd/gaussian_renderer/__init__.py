@@ -143,13 +143,18 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
     }
     if sobel_normal:
         depth = out["depth_map"].squeeze(0)
-        out["sobel_map"] = render_normal_from_depth_map(viewpoint_camera, depth, bg_color, out["alpha_map"][0])
+        out["sobel_map"] = render_normal_from_depth_map(viewpoint_camera, depth, bg_color, out["alpha_map"][0], fused=fused)
     return out
 
 
-def render_normal_from_depth_map(viewpoint_cam, depth, bg_color, alpha_map):
+def render_normal_from_depth_map(viewpoint_cam, depth, bg_color, alpha_map, fused=True):
     """depth (H,W), bg_color (3), alpha (H,W) -> (3,H,W); GR:167-175."""
     intrinsic, extrinsic = viewpoint_cam.get_calib_matrix_nerf()
+    if fused and depth.is_cuda and not intrinsic.is_cuda:
+        K = intrinsic.tolist()  # host tensor in the reference (scene/cameras.py:83-90): no device sync
+        if K[0][1] == 0.0 and K[1][0] == 0.0 and K[2] == [0.0, 0.0, 1.0]:
+            return gs2m_render_ops.sobel_normal(depth, alpha_map, bg_color, viewpoint_cam.world_view_transform,
+                                                K[0][0], K[1][1], K[0][2], K[1][2])
     normal_ref = normal_from_depth_image(depth, intrinsic.to(depth.device), extrinsic.to(depth.device), view_space=False)
     background = bg_color[None, None, ...]
     normal_ref = normal_ref * alpha_map[..., None] + background * (1. - alpha_map[..., None])

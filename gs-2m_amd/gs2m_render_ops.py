@@ -99,3 +99,35 @@ class _GBufferPost(torch.autograd.Function):
 def gbuffer_post(buffer, rays, world_view_transform, z_depth=False):
     """buffer (10,H,W) -> (normal_mask (1,H,W) bool, local_normal_map (3,H,W), depth_map (1,H,W)) (GR:126-141)."""
     return _GBufferPost.apply(buffer, rays, world_view_transform, z_depth)
+
+
+class _SobelNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, alpha, bg, view, fx, fy, cx, cy):
+        depth, alpha, bg, view = _f32c(depth, "depth"), _f32c(alpha, "alpha_map"), _f32c(bg, "bg_color"), _f32c(view, "world_view_transform")
+        H, W = depth.shape
+        out = torch.empty((3, H, W), dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            _native.check(_native.lib().gs2m_sobel_normal_forward(W, H, _ptr(depth), _ptr(alpha), _ptr(bg), _ptr(view), fx, fy, cx, cy,
+                                                                  _ptr(out), _stream()), "gs2m_sobel_normal_forward")
+        ctx.save_for_backward(depth, alpha, bg, view)
+        ctx.k = (fx, fy, cx, cy)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, alpha, bg, view = ctx.saved_tensors
+        g = _f32c(g, "grad_sobel_map")
+        H, W = depth.shape
+        d_depth, d_alpha = torch.empty_like(depth), torch.empty_like(alpha)
+        with torch.cuda.device(depth.device):
+            _native.check(_native.lib().gs2m_sobel_normal_backward(W, H, _ptr(depth), _ptr(alpha), _ptr(bg), _ptr(view), *ctx.k,
+                                                                   _ptr(g), _ptr(d_depth), _ptr(d_alpha), _stream()),
+                          "gs2m_sobel_normal_backward")
+        return d_depth, d_alpha, None, None, None, None, None, None
+
+
+def sobel_normal(depth, alpha_map, bg_color, world_view_transform, fx, fy, cx, cy):
+    """depth (H,W), alpha (H,W), bg (3) -> (3,H,W): render_normal_from_depth_map (GR:167-175, utils/normal_utils.py:3-72)
+    for a zero-skew pinhole camera (intrinsic [[fx,0,cx],[0,fy,cy],[0,0,1]] as get_calib_matrix_nerf() builds it)."""
+    return _SobelNormal.apply(depth, alpha_map, bg_color, world_view_transform, float(fx), float(fy), float(cx), float(cy))

@@ -200,6 +200,17 @@ int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const
                                int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, float* dL_dbuffer,
                                void* stream);
 
+/* gs2m_sobel_normal_*: render_normal_from_depth_map, gaussian_renderer/__init__.py:167-175 with
+ * utils/normal_utils.py:3-72 (depth -> world points -> cross product of the central differences -> normalize, 0 on the
+ * border; blended with the background by alpha).  depth, alpha: (H,W); bg: 3 floats; view: world_view_transform;
+ * fx, fy, cx, cy: the zero-skew intrinsics of get_calib_matrix_nerf(); sobel_map: (3,H,W).  The backward returns
+ * dL/ddepth and dL/dalpha (gather form, no atomics). */
+int gs2m_sobel_normal_forward(int width, int height, const float* depth, const float* alpha, const float* bg,
+                              const float* view, float fx, float fy, float cx, float cy, float* sobel_map, void* stream);
+int gs2m_sobel_normal_backward(int width, int height, const float* depth, const float* alpha, const float* bg,
+                               const float* view, float fx, float fy, float cx, float cy, const float* dL_dsobel,
+                               float* dL_ddepth, float* dL_dalpha, void* stream);
+
 /* Backward blend implementation (same results within fp32 rounding, all covered by the parity tests):
  *   1 (default) survivor-per-lane layout: DPP row scans for the per-pixel recurrences, fp32 MFMA for the
  *     per-Gaussian sums, one row per (instance, quadrant)                     csrc/blend_bwd_mfma.hip

@@ -133,14 +133,15 @@ def test_render_fused_equals_unfused(material_stage, blend_metallic):
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
     gen = torch.Generator().manual_seed(2)
     H, W = cam.image_height, cam.image_width
-    keys = ["render", "alpha_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "metallic_map", "local_normal_map"]
+    keys = ["render", "alpha_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "metallic_map", "local_normal_map", "sobel_map"]
     res = {}
     for fused in (False, True):
         pipe = PipelineParams()
         pipe.fused_render_ops = fused
         for t in pc.parameters():
             t.grad = None
-        out = render(cam, pc, pipe, bg, geometry_stage=not material_stage, material_stage=material_stage, blend_metallic=blend_metallic)
+        out = render(cam, pc, pipe, bg, geometry_stage=not material_stage, material_stage=material_stage, blend_metallic=blend_metallic,
+                     sobel_normal=True)
         g2 = torch.Generator().manual_seed(4)
         loss = sum((out[k] * torch.rand(out[k].shape, generator=g2).to(dev)).sum() for k in keys)
         loss.backward()
@@ -154,3 +155,32 @@ def test_render_fused_equals_unfused(material_stage, blend_metallic):
         assert (a is None) == (b is None), n
         if a is not None:
             _close("grad " + n, a, b, 1e-3)  # the depth division amplifies fp32 rounding; 1e-3 is the gradient bar of the path
+
+
+def test_sobel_normal_matches_torch():
+    """depth -> world points -> cross product normals -> alpha blend with the background: fused kernel (forward and the
+    gather-form backward) against utils/normal_utils.py as restated in gs2m_scene.normal_from_depth_image."""
+    assert torch.cuda.is_available()
+    import gs2m_render_ops as R
+    import gs2m_synth as S
+    from gs2m_scene import Camera
+    from gaussian_renderer import render_normal_from_depth_map
+    dev = "cuda"
+    H, W = 45, 61
+    cam = Camera(S.look_at_camera(W, H, (1.0, -0.7, 0.5), (0.2, 0.1, 6.0)), dev)
+    gen = torch.Generator().manual_seed(8)
+    depth = (torch.rand(H, W, generator=gen) * 3.0 + 2.0).to(dev).requires_grad_(True)
+    alpha = torch.rand(H, W, generator=gen).to(dev).requires_grad_(True)
+    bg = torch.tensor([0.3, 0.1, 0.7], device=dev)
+    G = torch.randn(3, H, W, generator=gen).to(dev)
+    ref = render_normal_from_depth_map(cam, depth, bg, alpha, fused=False)
+    (ref * G).sum().backward()
+    gd, ga = depth.grad.clone(), alpha.grad.clone()
+    depth.grad = None; alpha.grad = None
+    out = render_normal_from_depth_map(cam, depth, bg, alpha, fused=True)
+    _close("sobel_map", out, ref, 2e-5)
+    (out * G).sum().backward()
+    _close("grad depth", depth.grad, gd, 1e-4)
+    _close("grad alpha", alpha.grad, ga, 2e-5)
+    # the border carries no normal: output = background * (1 - alpha)
+    assert torch.allclose(out[:, 0, :], bg[:, None] * (1 - alpha[0, :])[None], atol=1e-7)

@@ -10,6 +10,8 @@ from gs2m_scene import GaussianParams, PipelineParams, Camera
 from gaussian_renderer import render
 
 P, W, H = 1_000_000, 1920, 1080
+SOBEL = "--sobel" in sys.argv
+FUSED = "--unfused" not in sys.argv
 dev = "cuda"
 cam0 = S.make_camera(W, H)
 g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=0).items()}
@@ -21,6 +23,7 @@ for t in pc.parameters():
     t.requires_grad_(True)
 cam = Camera(cam0, dev)
 pipe = PipelineParams()
+pipe.fused_render_ops = FUSED
 bg = torch.zeros(3, device=dev)
 wts = {k: torch.rand(s, device=dev) for k, s in (("render", (3, H, W)), ("depth_map", (1, H, W)), ("normal_map", (3, H, W)),
                                                  ("albedo_map", (3, H, W)), ("roughness_map", (1, H, W)), ("local_normal_map", (3, H, W)))}
@@ -28,8 +31,10 @@ wts = {k: torch.rand(s, device=dev) for k, s in (("render", (3, H, W)), ("depth_
 def step():
     for t in pc.parameters():
         t.grad = None
-    out = render(cam, pc, pipe, bg, material_stage=True)
+    out = render(cam, pc, pipe, bg, material_stage=True, sobel_normal=SOBEL)
     loss = sum((out[k] * w).sum() for k, w in wts.items())
+    if SOBEL:
+        loss = loss + (out["sobel_map"] * wts["normal_map"]).sum()
     loss.backward()
 
 for _ in range(10):
@@ -40,7 +45,7 @@ n = 50
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print("render() fwd+bwd incl. a weighted-sum loss: %.3f ms per view" % ((time.perf_counter() - t0) / n * 1e3))
+print(("render(sobel_normal=%s, fused=%s) fwd+bwd incl. a weighted-sum loss: " % (SOBEL, FUSED)) + "%.3f ms per view" % ((time.perf_counter() - t0) / n * 1e3))
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(3):
