@@ -60,3 +60,17 @@ def test_op_fails_loudly_without_a_device():
     with pytest.raises(RuntimeError, match="no CPU path"):
         r(g["means3D"], torch.zeros(8, 4), g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
           features=g["features"])
+
+
+def test_render_ops_refuse_cpu_tensors():
+    """the fused render() pre/post-processing has no CPU path either: CPU tensors raise instead of silently computing"""
+    import torch
+    import gs2m_render_ops as R
+    P = 4
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R.pack_features(torch.zeros(P, 3), torch.ones(P, 3), torch.ones(P, 4), torch.zeros(P, 3), torch.zeros(P, 1),
+                        torch.zeros(P, 1), torch.zeros(3), torch.eye(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R.gbuffer_post(torch.zeros(10, 4, 4), torch.zeros(16, 3), torch.eye(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R.sobel_normal(torch.ones(4, 4), torch.ones(4, 4), torch.zeros(3), torch.eye(4), 1.0, 1.0, 2.0, 2.0)
