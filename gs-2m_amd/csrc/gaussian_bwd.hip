@@ -87,10 +87,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     if (!SH_LDS && !in_range) return;
     if (in_range) {
 
-    // independent loads first, so that their latency overlaps the dependent row-summing chain
+    // the per-Gaussian inputs (the reduced gradient row follows)
     const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-    const uint32_t off = f2u(rec[(size_t)idx * REC_Q + REC_BIN].x);  // garbage for culled Gaussians: unused
-    const uint32_t n = visible ? tiles_touched[idx] : 0u;
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float s_in[3] = {0.f, 0.f, 0.f};
     if (scales != nullptr) {
@@ -103,60 +101,12 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     for (int k = 0; k < 24; k++) acc[k] = 0.f;
     {
         const int rq = rowf >> 2;
-        if (rpi == 0) {  // `rows` holds one reduced row per Gaussian (row_reduce_kernel): P x rowf floats
+        {   // `rows` holds one reduced row per Gaussian (row_reduce_kernel below): P x rowf floats
             const float4* s4 = reinterpret_cast<const float4*>(rows + (size_t)idx * rowf);
 #pragma unroll
             for (int q = 0; q < 6; q++) {
                 const float4 v = q < rq ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
                 acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
-            }
-        } else if (rpi == 1) {
-            for (uint32_t t = 0; t < n; t += 4) {  // up to 4 rows in flight
-                uint8_t vld[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) vld[u] = (t + u < n) ? row_valid[off + t + u] : (uint8_t)0;
-                float4 rv[4][6];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float4* r4 = reinterpret_cast<const float4*>(rows + (size_t)(off + t + u) * rowf);
-#pragma unroll
-                    for (int q = 0; q < 6; q++)
-                        rv[u][q] = (vld[u] && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {  // fixed summation order: bitwise reproducible
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
-                    }
-                }
-            }
-        } else {  // one row per (instance, quadrant): the 4 valid bytes of an instance form one word
-            const uint32_t* valid4 = reinterpret_cast<const uint32_t*>(row_valid);
-            // the valid words of the next two instances are fetched while the rows of the current one are in
-            // flight (the row loads depend on the valid word: without this every instance costs two serial
-            // memory latencies)
-            uint32_t vm_a = n > 0 ? valid4[off] : 0u, vm_b = n > 1 ? valid4[off + 1] : 0u;
-            for (uint32_t t = 0; t < n; t++) {
-                const uint32_t vm4 = vm_a;
-                vm_a = vm_b;
-                vm_b = t + 2 < n ? valid4[off + t + 2] : 0u;
-                float4 rv[4][6];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool on = ((vm4 >> (8 * u)) & 0xFFu) != 0;
-                    const float4* r4 = reinterpret_cast<const float4*>(rows + ((size_t)(off + t) * 4 + u) * rowf);
-#pragma unroll
-                    for (int q = 0; q < 6; q++)
-                        rv[u][q] = (on && q < rq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        acc[4 * q] += rv[u][q].x; acc[4 * q + 1] += rv[u][q].y; acc[4 * q + 2] += rv[u][q].z; acc[4 * q + 3] += rv[u][q].w;
-                    }
-                }
             }
         }
     }
