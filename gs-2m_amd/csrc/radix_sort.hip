@@ -28,6 +28,7 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_MAXPASS = 4;
+constexpr int RS_RESIDENT_TILES = 768;  // 3 workgroups per CU x 256 CUs fit for certain (LDS 34 KB, 256 threads each)
 constexpr uint32_t FLAG_AGG = 1u << 30, FLAG_PFX = 2u << 30, VAL_MASK = (1u << 30) - 1;
 
 struct SortPlan {
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_key[RS_TILE], s_val[RS_TILE];  // tile reordered by digit: coalesced runs on the way out
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    if (tid == 0) s_tile = ticket != nullptr ? atomicAdd(ticket, 1u) : blockIdx.x;
     for (int i = tid; i < 4 * BINS; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
     gs2m_sync();
     const uint32_t tile = s_tile;
@@ -212,7 +213,10 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
 template <int BITS>
 void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
                  const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s) {
-    rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist, ticket, status);
+    // Tile ids: blockIdx when every workgroup of the pass is resident at once (then no tile can wait for one that
+    // cannot start, whatever the dispatch order); beyond that an atomic ticket hands them out in start order.  The
+    // ticket serialises the starts on one address: 0.088 -> 0.074 ms for the 661-tile instance sort without it.
+    rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist, tiles <= RS_RESIDENT_TILES ? nullptr : ticket, status);
 }
 
 }  // namespace
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
     __shared__ uint32_t s_tile, s_base;
     __shared__ uint32_t s_t[256 * SC_ITEMS + 128], s_o[256 * SC_ITEMS + 128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    if (tid == 0) s_tile = ticket != nullptr ? atomicAdd(ticket, 1u) : blockIdx.x;
     gs2m_sync();
     const uint32_t tile = s_tile;
     // coalesced gather (element k*256 + tid), transposed through LDS so that each thread then owns 16

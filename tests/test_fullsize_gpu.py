@@ -73,9 +73,13 @@ def test_backward_linear_in_upstream_gradients(big):
         assert np.array_equal(g1[k], g1b[k]), f"{k} not bitwise reproducible"
 
 
-def test_tile_list_invariants(big):
+@pytest.mark.parametrize("reference_binning", [False, True])
+def test_tile_list_invariants(big, reference_binning):
+    """reference binning emits 3.8 M instances here: more sort tiles than are resident at once, i.e. the ticketed tile
+    ids of the radix sort (radix_sort.hip); the default 2.7 M take the blockIdx path."""
     import gs2m_native
     import diff_gaussian_rasterization as dgr
+    gs2m_native.set_reference_binning(reference_binning)
     g = {k: v.cuda() for k, v in big["g"].items()}
     st = Hh.settings_for(big, "cuda")
     e = torch.Tensor([])
@@ -83,6 +87,8 @@ def test_tile_list_invariants(big):
         st.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
         st.projmatrix, st.tanfovx, st.tanfovy, H, W, g["shs"], 3, st.campos, False, FC)
     torch.cuda.synchronize()
+    gs2m_native.set_reference_binning(False)
+    assert (R > 768 * 4096) == reference_binning, "the two modes are meant to sit on either side of the ticket threshold"
     lay = gs2m_native.debug_layout(P, R, W, H)
     al = lambda t: (-t.data_ptr()) % 256
     view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
