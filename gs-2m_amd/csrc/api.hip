@@ -112,21 +112,29 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
 
     int R = 0;
     if (P > 0) {
+        // scratch of the depth sort and of the scan, side by side in g.temp; zeroed by the preprocess kernel
+        char* sort_temp = g.temp;
+        const size_t sort_temp_bytes = gs2m_align_up(gs2m_radix_temp_bytes((size_t)P, 32));
+        char* scan_temp = g.temp + sort_temp_bytes;
+        const size_t scan_temp_bytes = g.temp_bytes - sort_temp_bytes;
+        ZeroJobs zj = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
+        gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
+        gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
         {
             StageTimer t(ST_PREPROCESS, s);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, g_reference_binning ? 0 : 1, s);
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, g_reference_binning ? 0 : 1, zj, s);
         }
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s);
-            HIP_TRY(gs2m_radix_sort_pairs(g.temp, g.temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
-                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, s));
+            HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
+                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s));
         }
         {   // 2. emission offsets in that order
             StageTimer t(ST_SCAN, s);
-            HIP_TRY(gs2m_scan_tiles_touched(g.temp, g.temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
-                                            g.sorted_off, g.counters, s));
+            HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
+                                            g.sorted_off, g.counters, true, s));
         }
         if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
         HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -142,22 +150,24 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (!bbase) return GS2M_ERR_ALLOC;
     BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
 
-    HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     if (R > 0) {
-        {
+        {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the per-instance observe counts
             StageTimer t(ST_EMIT, s);
-            gs2m_launch_emit(P, tiles_x, g, b, s);
+            ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
+            gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
+            gs2m_launch_emit(P, tiles_x, g, b, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s);
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
-                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, s));
+                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s));
         }
         {
             StageTimer t(ST_RANGES, s);
             gs2m_launch_ranges(R, b, im, s);
-            HIP_TRY(gs2m_zero_async(b.inst_obs, (size_t)R * sizeof(uint32_t), s));
         }
+    } else {
+        HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     }
     {
         StageTimer t(ST_BLEND_FWD, s);

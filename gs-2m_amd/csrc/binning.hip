@@ -75,8 +75,8 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
 }
 
 size_t gs2m_geom_temp_bytes(size_t P) {
-    const size_t a = gs2m_radix_temp_bytes(P, 32), b = gs2m_scan_temp_bytes(P);
-    return gs2m_align_up(a > b ? a : b) + GS2M_ALIGN;
+    // the depth sort's and the scan's scratch side by side: the preprocess kernel zeroes both ahead of time
+    return gs2m_align_up(gs2m_radix_temp_bytes(P, 32)) + gs2m_align_up(gs2m_scan_temp_bytes(P)) + GS2M_ALIGN;
 }
 
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) { return gs2m_align_up(gs2m_radix_temp_bytes(R, tile_bits)) + GS2M_ALIGN; }
@@ -90,13 +90,15 @@ namespace {
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uint32_t* __restrict__ sorted_gid,
                                                    const uint32_t* __restrict__ sorted_tt,
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
-                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                   uint32_t* __restrict__ inst_obs, ZeroJobs zero) {
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
     uint32_t cnt = 0, gid = 0, off = 0, rmin = 0, rw = 1;
     if (i < P) {
         gid = sorted_gid[i];
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
             const uint32_t rm = s_rmin[wave][lo];
             keys_out[base + j] = ((rm >> 16) + ry) * (uint32_t)tiles_x + (rm & 0xFFFFu) + rx;
             vals_out[base + j] = s_gid[wave][lo];
+            inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
         }
     }
 }
@@ -167,9 +170,9 @@ __global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, c
 
 }  // namespace
 
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s) {
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted);
+                                                b.vals_unsorted, b.inst_obs, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

@@ -67,6 +67,20 @@ struct ImageState {
     size_t total_bytes;
 };
 
+// Up to three word ranges a kernel zeroes on the side (grid-stride over all its threads): saves the separate zero-fill
+// launches in front of the kernels that consume them.
+struct ZeroJobs {
+    uint32_t* p[3];
+    size_t words[3];
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void gs2m_zero_jobs(const ZeroJobs& z, size_t thread, size_t threads) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (size_t i = thread; i < z.words[k]; i += threads) z.p[k][i] = 0u;
+}
+#endif
+
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
 GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes);
 BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
@@ -77,11 +91,13 @@ size_t gs2m_geom_temp_bytes(size_t P);
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
-                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, hipStream_t s);
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s);
+void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
                                    const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, hipStream_t s);
+                                   uint32_t* counters, bool prezeroed, hipStream_t s);
+void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words);
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -89,11 +105,12 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, int shrink, hipStream_t s);
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, hipStream_t s);
+                            int* radii, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
 void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                             int rstride, int rpi, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
+
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,

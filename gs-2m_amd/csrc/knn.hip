@@ -208,7 +208,7 @@ extern "C" int gs2m_knn_dist2(int P, const float* points, float* mean_dists, gs2
     aabb_kernel<<<1, 256, 0, s>>>(nblk, reinterpret_cast<const float*>(part), 0, 1, aabb);
     morton_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, aabb, codes);
     // 30-bit Morton codes; values implicit (index); iota doubles as the ping value buffer
-    if (gs2m_radix_sort_pairs(base + o_temp, sort_bytes, codes, nullptr, (uint32_t*)(base + o_kA), iota, codes_s, order, n, 32, s) != hipSuccess) return GS2M_ERR_HIP;
+    if (gs2m_radix_sort_pairs(base + o_temp, sort_bytes, codes, nullptr, (uint32_t*)(base + o_kA), iota, codes_s, order, n, 32, false, s) != hipSuccess) return GS2M_ERR_HIP;
     gather_points_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, order, sorted);
     box_kernel<<<num_boxes, 256, 0, s>>>(P, sorted, boxes);
     knn_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, sorted, order, boxes, num_boxes, mean_dists);

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, float4* __restrict__ rec,
     uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped) {
+    uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, ZeroJobs zero) {
     // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian read has a 192-B lane
     // stride.  The block instead streams its 256 rows (48 KiB, contiguous) with coalesced float4
     // loads into LDS (row stride 49 floats: conflict-free column reads) and each thread then reads
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         }
         gs2m_sync();
     }
+    gs2m_zero_jobs(zero, (size_t)idx, (size_t)gridDim.x * blockDim.x);  // the sort / scan scratch of the stages that follow
     if (idx >= P) return;
 
     int out_radius = 0;
@@ -281,13 +282,13 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, int shrink, hipStream_t s) {
+                            int* radii, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s) {
 #define GS2M_PRE(LDS)                                                                                                  \
     preprocess_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, \
                                                            shs, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, g.rec,             \
-                                                           g.tiles_touched, g.depth_key, g.clamped)
+                                                           g.tiles_touched, g.depth_key, g.clamped, zero)
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;
     if (lds) GS2M_PRE(true);
     else GS2M_PRE(false);

@@ -231,8 +231,17 @@ size_t gs2m_radix_temp_bytes(size_t n, int total_bits) {
 // Sorts n pairs by key bits [0, total_bits), stable.  The input (kin, vin) is only read (vin may be
 // nullptr: values are then the indices 0..n-1); passes alternate between (kA, vA) and (kB, vB) and the
 // number of passes is even, so the result is in (kB, vB).
+// The part of `temp` a sort of n keys needs zeroed beforehand (histograms, tickets, look-back status).  A caller that
+// zeroes it itself -- e.g. inside the kernel that produces the keys -- passes prezeroed = true and saves a launch.
+void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words) {
+    const SortPlan p = make_plan(total_bits);
+    const size_t tiles = (n + RS_TILE - 1) / RS_TILE;
+    *ptr = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
+    *words = (gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4) / 4;
+}
+
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
-                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, hipStream_t s) {
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -242,7 +251,7 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     uint32_t* tickets = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4));
     uint32_t* status = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN);
     const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
-    hipError_t e = gs2m_zero_async(base, zero_bytes, s);
+    hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     rs_hist_kernel<<<tiles, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
                                                 make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist);
@@ -363,14 +372,19 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
 size_t gs2m_scan_temp_bytes(size_t n) { return gs2m_align_up(((n + 4095) / 4096 + 64) * 4) + 2 * GS2M_ALIGN; }
 
 // num_rendered must stay below 2^30 (30-bit look-back payload)
+void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words) {
+    *ptr = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
+    *words = (n + 4095) / 4096 + 64;
+}
+
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
                                    const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, hipStream_t s) {
+                                   uint32_t* counters, bool prezeroed, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const int tiles = (int)((n + 4095) / 4096);
     if (temp_bytes < gs2m_scan_temp_bytes(n)) return hipErrorInvalidValue;
     uint32_t* base = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    hipError_t e = gs2m_zero_async(base, (size_t)(tiles + 64) * 4, s);
+    hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, (size_t)(tiles + 64) * 4, s);
     if (e != hipSuccess) return e;
     scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64);
     return hipGetLastError();
