@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
             for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
             float gAn[KK];  // A operand of the NEXT block's colour . gradient product
 #pragma unroll
-            for (int k = 0; k < KK; k++) gAn[k] = gA[(16 * ((b + 1) & 3)) * 16 + 4 * k];
+            for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * 16 + 4 * k] : 0.f;  // the last block has no successor
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
                 const int pi = (2 * b + h) * 4 + r;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
                 m0 += sv;
                 m1 = __builtin_elementwise_fma(sv, v2f{cy, cy}, m1);
                 m2 = __builtin_elementwise_fma(sv, v2f{cy * cy, cy * cy}, m2);
-                if (h == 0) {  // one block ahead, operands long since loaded: the result is there when the next block starts
+                if (h == 0 && b < 3) {  // one block ahead, operands long since loaded: the result is there when the next block starts
                     v4f a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
