@@ -3,6 +3,7 @@
 // CudaRasterizer::Rasterizer::forward/backward (cuda_rasterizer/rasterizer_impl.cu:185-438)
 // with the pipeline described in binning.hip.
 #include "common.h"
+#include <chrono>
 
 #define HIP_TRY(expr)                          \
     do {                                       \
@@ -46,6 +47,7 @@ struct Prof {
 };
 Prof g_prof;
 int g_reference_binning = 0;
+int g_spin_wait = 1;  // forward: poll the pinned num_rendered instead of hipStreamSynchronize
 int g_bwd_impl = 1;  // 1: survivor-per-lane + MFMA (blend_bwd_mfma.hip), 0: pixel-per-lane + permlane reduction
 
 struct StageTimer {
@@ -137,9 +139,23 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                                             g.sorted_off, g.counters, true, s));
         }
         if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
+        // The reference has a sync at the same point (rasterizer_impl.cu:269-270).  The GPU idles from here until the
+        // host has seen num_rendered, sized the binning buffer and launched the next kernel, so the wake-up matters:
+        // the host polls the pinned landing zone for the value (a sentinel no count can take: R < 2^30) instead of
+        // sleeping in hipStreamSynchronize, whose wake-up costs tens of microseconds and far more on a loaded host.
+        volatile uint32_t* land = t_pinned.p;
+        land[0] = 0xFFFFFFFFu;
         HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));  // the reference has the same sync point (rasterizer_impl.cu:269-270)
-        R = (int)t_pinned.p[0];
+        if (g_spin_wait) {
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (land[0] == 0xFFFFFFFFu) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            }
+        }
+        if (land[0] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
+        R = (int)land[0];
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -253,6 +269,11 @@ int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatri
 
 int gs2m_set_reference_binning(int on) {
     g_reference_binning = on ? 1 : 0;
+    return GS2M_OK;
+}
+
+int gs2m_set_spin_wait(int on) {
+    g_spin_wait = on ? 1 : 0;
     return GS2M_OK;
 }
 

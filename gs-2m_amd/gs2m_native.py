@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
+           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
@@ -66,6 +66,8 @@ def lib():
     L.gs2m_set_reference_binning.argtypes = [i]
     L.gs2m_set_bwd_impl.restype = i
     L.gs2m_set_bwd_impl.argtypes = [i]
+    L.gs2m_set_spin_wait.restype = i
+    L.gs2m_set_spin_wait.argtypes = [i]
     L.gs2m_pack_features_forward.restype = i
     L.gs2m_pack_features_forward.argtypes = [i, p, p, p, p, p, p, p, p, i, i, p, p]
     L.gs2m_pack_features_backward.restype = i
@@ -100,6 +102,11 @@ def debug_layout(P, R, W, H):
     lay = Layout()
     check(lib().gs2m_debug_layout(P, R, W, H, C.byref(lay)), "gs2m_debug_layout")
     return lay
+
+
+def set_spin_wait(on):
+    """Forward: poll the pinned num_rendered (default) or sleep in hipStreamSynchronize."""
+    check(lib().gs2m_set_spin_wait(int(bool(on))), "gs2m_set_spin_wait")
 
 
 def profile_mode(mode):

@@ -211,6 +211,10 @@ int gs2m_sobel_normal_backward(int width, int height, const float* depth, const 
                                const float* view, float fx, float fy, float cx, float cy, const float* dL_dsobel,
                                float* dL_ddepth, float* dL_dalpha, void* stream);
 
+/* Forward: how the host waits for num_rendered.  1 (default): it polls the pinned landing zone of the 4-byte copy
+ * (falls back to a stream synchronize after 2 s); 0: hipStreamSynchronize.  Same results. */
+int gs2m_set_spin_wait(int on);
+
 /* Backward blend implementation (same results within fp32 rounding, all covered by the parity tests):
  *   1 (default) survivor-per-lane layout: DPP row scans for the per-pixel recurrences, fp32 MFMA for the
  *     per-Gaussian sums, one row per (instance, quadrant)                     csrc/blend_bwd_mfma.hip

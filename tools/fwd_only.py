@@ -20,7 +20,8 @@ for _ in range(50):
     dgr._C.rasterize_gaussians(*args)
 res = {0: [], 1: []}
 for rep in range(12):
-    for on in (1, 0):  # two interleaved series of the same configuration: their spread is the noise floor
+    for on in (1, 0):  # series 1: host polls num_rendered; series 0: hipStreamSynchronize
+        gs2m_native.set_spin_wait(on)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(100):
