@@ -60,6 +60,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _ScratchCache(_Alloc):
+    """Backward scratch (partial-gradient rows: ~1 GB at 1M Gaussians / 1080p), kept per (device, stream) and only
+    ever grown.  The scratch is dead once the backward's kernels have run, and calls on one stream are ordered, so
+    the next backward may reuse it; handing a block of that size back to the caching allocator every step only
+    invites it to split the block for smaller requests and to hipMalloc a new one the step after."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device, stream):
+        key = (torch.device(device).index, stream)
+        a = cls._cache.get(key)
+        if a is None:
+            a = cls._cache[key] = cls(device)
+        return a
+
+    def _alloc(self, nbytes, _user):
+        if self.tensor.numel() >= int(nbytes):
+            return self.tensor.data_ptr()
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=self.device)  # drop the old block before growing
+        return super()._alloc(nbytes, _user)
+
+
 class _CModule:
     """Function-for-function mirror of the reference's `_C` extension module."""
 
@@ -113,7 +135,7 @@ class _CModule:
         dL_dfeatures = mk(P, NUM_FEATURES); dL_dopacities = mk(P, 1); dL_dcov3D = mk(P, 6)
         dL_dshs = mk(P, M, 3); dL_dscales = mk(P, 3); dL_drotations = mk(P, 4)
         dL_dconics = mk(P, 2, 2) if return_conics else None
-        scratch = _Alloc(device)
+        scratch = _ScratchCache.get(device, _stream())
         with torch.cuda.device(device):
             rc = L.gs2m_raster_backward(
                 P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
