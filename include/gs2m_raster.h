@@ -219,7 +219,7 @@ int gs2m_set_spin_wait(int on);
  *   1 (default) survivor-per-lane layout: DPP row scans for the per-pixel recurrences, fp32 MFMA for the
  *     per-Gaussian sums, one row per (instance, quadrant)                     csrc/blend_bwd_mfma.hip
  *   0 pixel-per-lane, permlane/DPP reductions, one row per instance           csrc/blend_bwd.hip
- * Measured at 1M Gaussians / 1080p: 0.70 / 1.13 ms for the blend kernel; variant 1 costs 0.10 ms more in
+ * Measured at 1M Gaussians / 1080p: 0.66 / 1.13 ms for the blend kernel; variant 1 costs 0.08 ms more in
  * the per-Gaussian pass (4 rows per instance) and 4x the row scratch. */
 int gs2m_set_bwd_impl(int impl);
 
