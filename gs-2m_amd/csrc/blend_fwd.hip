@@ -13,9 +13,10 @@
 // The colour/feature accumulation runs as packed fp32 (v_pk_fma_f32: two channels per instruction, the
 // weight broadcast) -- measured on gfx950 a packed FMA issues at the rate of a scalar one, and the matrix
 // pipe is no alternative here: MFMA and VALU instructions do not overlap on a SIMD (tools/micro/).
-// `observe` is accumulated per instance in LDS (one popcount of a ballot per wave) and stored
-// once per instance in emission order -- no global atomics (forward.cu:348-350 uses one
-// atomicAdd per pixel); binning.hip:observe_kernel reduces them per Gaussian.
+// `observe` (pixels an instance contributes to with T > 0.5) is one ballot popcount per survivor, written into a
+// per-lane register with v_writelane, added to the instance's LDS counter once per lane and 64 instances, and stored
+// once per instance in emission order -- no global atomics (forward.cu:348-350 uses one atomicAdd per pixel);
+// binning.hip:observe_kernel reduces the per-instance counts per Gaussian.
 #include "common.h"
 
 namespace {
