@@ -76,9 +76,9 @@ extern "C" {
 
 const char* gs2m_version(void) { return "gs2m_raster 0.1 (gfx950, round 1)"; }
 
-int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
+static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
                         void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
-                        const float* background, int width, int height, const float* means3D, const float* shs,
+                        const float* background, int width, int height, const float* means3D, const float* shs, const float* shs_rest,
                         const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                         const float* rotations, const float* cov3D_precomp, const float* features,
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -92,6 +92,7 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (P > 0 && ((shs == nullptr) == (colors_precomp == nullptr))) return GS2M_ERR_INVALID_ARG;
     if (P > 0 && (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))) return GS2M_ERR_INVALID_ARG;
     if (P > 0 && shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1) || !cam_pos)) return GS2M_ERR_INVALID_ARG;
+    if (shs_rest && (!shs || M != 16 || (((uintptr_t)shs_rest) & 15))) return GS2M_ERR_UNSUPPORTED;  // split SH: M = 16 only
     if (P > 0 && feature_count > 0 && !features) return GS2M_ERR_INVALID_ARG;
     if (width > 16 * 65535 || height > 16 * 65535) return GS2M_ERR_UNSUPPORTED;
 
@@ -124,7 +125,7 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
         {
             StageTimer t(ST_PREPROCESS, s);
-            gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+            gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                                    tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, g_reference_binning ? 0 : 1, zj, s);
         }
@@ -197,14 +198,14 @@ int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     return R;
 }
 
-int gs2m_raster_backward(int P, int D, int M, int R, const float* background, int width, int height,
-                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp,
                          const float* features, const float* viewmatrix, const float* projmatrix, const float* campos,
                          float tan_fovx, float tan_fovy, const int* radii, const float* buffer, char* geom_buffer,
                          char* binning_buffer, char* image_buffer, int feature_count, const float* grad_colors,
                          const float* grad_buffer, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities,
-                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                          float* dL_drots, float* dL_dfeatures, gs2m_alloc_fn scratch_alloc, void* scratch_user,
                          void* stream_) {
     (void)buffer; (void)features;
@@ -215,6 +216,7 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     if (feature_count > 0 && !grad_buffer) return GS2M_ERR_INVALID_ARG;
     if (!dL_dmeans2D || !dL_dopacities || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drots || !dL_dfeatures) return GS2M_ERR_INVALID_ARG;
     if (shs && M > 0 && !dL_dshs) return GS2M_ERR_INVALID_ARG;
+    if (shs_rest && (M != 16 || !dL_dshs_rest || ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15))) return GS2M_ERR_UNSUPPORTED;
 
     const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
@@ -248,12 +250,62 @@ int gs2m_raster_backward(int P, int D, int M, int R, const float* background, in
     }
     StageTimer tg(ST_GAUSSIAN_BWD, s);
     if (P > 0) gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
-    gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+    gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
                              sums, row_valid, rowf, 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
-                             dL_dcov3D, dL_dshs, dL_dscales, dL_drots, dL_dfeatures, s);
+                             dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures, s);
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
+}
+
+int gs2m_raster_forward(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
+                        void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* features,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, int feature_count, float* out_color, int* out_radii,
+                        int* out_observe, float* out_buffer, void* stream_) {
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, features, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, feature_count, out_color, out_radii, out_observe, out_buffer, stream_);
+}
+
+int gs2m_raster_forward_split_sh(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
+                        void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* sh_dc, const float* sh_rest,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* features,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, int feature_count, float* out_color, int* out_radii,
+                        int* out_observe, float* out_buffer, void* stream_) {
+    if (!sh_dc || !sh_rest) return GS2M_ERR_INVALID_ARG;
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height, means3D, sh_dc, sh_rest, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, features, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, feature_count, out_color, out_radii, out_observe, out_buffer, stream_);
+}
+
+int gs2m_raster_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* features, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         float tan_fovx, float tan_fovy, const int* radii, const float* buffer, char* geom_buffer,
+                         char* binning_buffer, char* image_buffer, int feature_count, const float* grad_colors,
+                         const float* grad_buffer, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                         float* dL_drots, float* dL_dfeatures, gs2m_alloc_fn scratch_alloc, void* scratch_user,
+                         void* stream_) {
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, features, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, buffer, geom_buffer, binning_buffer, image_buffer, feature_count, grad_colors, grad_buffer, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, nullptr, dL_dscales, dL_drots, dL_dfeatures, scratch_alloc, scratch_user, stream_);
+}
+
+int gs2m_raster_backward_split_sh(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* sh_dc, const float* sh_rest, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* features, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         float tan_fovx, float tan_fovy, const int* radii, const float* buffer, char* geom_buffer,
+                         char* binning_buffer, char* image_buffer, int feature_count, const float* grad_colors,
+                         const float* grad_buffer, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscales,
+                         float* dL_drots, float* dL_dfeatures, gs2m_alloc_fn scratch_alloc, void* scratch_user,
+                         void* stream_) {
+    if (!sh_dc || !sh_rest) return GS2M_ERR_INVALID_ARG;
+    return backward_impl(P, D, M, R, background, width, height, means3D, sh_dc, sh_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, features, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, buffer, geom_buffer, binning_buffer, image_buffer, feature_count, grad_colors, grad_buffer, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh_dc, dL_dsh_rest, dL_dscales, dL_drots, dL_dfeatures, scratch_alloc, scratch_user, stream_);
 }
 
 int gs2m_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -81,6 +81,119 @@ __device__ __forceinline__ void gs2m_zero_jobs(const ZeroJobs& z, size_t thread,
 }
 #endif
 
+#ifdef __HIPCC__
+// ---- SH rows of a 256-Gaussian block <-> LDS (row stride 49 floats: conflict-free column reads) -------------------
+// SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian access has a 192-B lane stride, so the block
+// streams its rows with coalesced float4 accesses and every thread then works on its own LDS row.  Two source
+// layouts: one (P,16,3) tensor, or -- as the reference model stores its parameters (scene/gaussian_model.py:
+// _features_dc (P,1,3), _features_rest (P,15,3)) -- the DC and the rest separately (rest != nullptr), which saves
+// the caller a 192-B-per-Gaussian concatenation per view and its backward.
+__device__ __forceinline__ void gs2m_stage_sh(const float* __restrict__ shs, const float* __restrict__ rest, int P,
+                                              float* __restrict__ s_sh) {
+    const int tid = threadIdx.x;
+    if (rest == nullptr) {
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;  // float4 index of the block's first row
+        const float4* g4 = reinterpret_cast<const float4*>(shs);
+        float4 t[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + tid + 256 * i;
+            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e = 4 * (tid + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            float* d = s_sh + row * 49 + col;
+            d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
+        }
+    } else {
+        // DC: 3 floats per row, 768 per block, scalar loads; rest: 45 floats per row, 2880 float4 per block
+        const size_t dbase = (size_t)blockIdx.x * 768, dlim = (size_t)P * 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int e = tid + 256 * i;
+            const float v = dbase + e < dlim ? shs[dbase + e] : 0.f;
+            s_sh[(e / 3) * 49 + (e % 3)] = v;
+        }
+        const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
+        float4 t[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int k4 = tid + 256 * i;
+            const size_t ge = rbase + 4 * (size_t)k4;
+            t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k4 < 2880) {
+                if (ge + 3 < rlim) {
+                    t[i] = *reinterpret_cast<const float4*>(rest + ge);
+                } else {  // the tensor ends inside this float4
+                    if (ge < rlim) t[i].x = rest[ge];
+                    if (ge + 1 < rlim) t[i].y = rest[ge + 1];
+                    if (ge + 2 < rlim) t[i].z = rest[ge + 2];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int k4 = tid + 256 * i;
+            if (k4 < 2880) {
+                const float v[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int e = 4 * k4 + c;
+                    s_sh[(e / 45) * 49 + 3 + (e % 45)] = v[c];
+                }
+            }
+        }
+    }
+}
+// the reverse: every thread has replaced its LDS row by its dL/dSH row
+__device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float* __restrict__ drest, int P,
+                                                const float* __restrict__ s_sh) {
+    const int tid = threadIdx.x;
+    if (drest == nullptr) {
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
+        float4* o4 = reinterpret_cast<float4*>(dshs);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + tid + 256 * i;
+            const int e = 4 * (tid + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            const float* d = s_sh + row * 49 + col;
+            if (k < lim4) o4[k] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    } else {
+        const size_t dbase = (size_t)blockIdx.x * 768, dlim = (size_t)P * 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int e = tid + 256 * i;
+            if (dbase + e < dlim) dshs[dbase + e] = s_sh[(e / 3) * 49 + (e % 3)];
+        }
+        const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int k4 = tid + 256 * i;
+            if (k4 < 2880) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int e = 4 * k4 + c;
+                    v[c] = s_sh[(e / 45) * 49 + 3 + (e % 45)];
+                }
+                const size_t ge = rbase + 4 * (size_t)k4;
+                if (ge + 3 < rlim) {
+                    *reinterpret_cast<float4*>(drest + ge) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    if (ge < rlim) drest[ge] = v[0];
+                    if (ge + 1 < rlim) drest[ge + 1] = v[1];
+                    if (ge + 2 < rlim) drest[ge + 2] = v[2];
+                }
+            }
+        }
+    }
+}
+#endif
+
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
 GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes);
 BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
@@ -101,7 +214,7 @@ void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words);
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
-                            const float* rotations, const float* opacities, const float* shs,
+                            const float* rotations, const float* opacities, const float* shs, const float* shs_rest,
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
@@ -124,13 +237,14 @@ int gs2m_row_floats_mfma(int fc);
 void gs2m_launch_blend_bwd_mfma(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                                 const BinningState& b, const ImageState& im, const float* grad_color,
                                 const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
-void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
+                              const float* colors_precomp,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
                               int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                               int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
-                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s);
 void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 

@@ -51,35 +51,21 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 template <bool SH_LDS>
 __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-    const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ vm,
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
     const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ rows,
     const uint8_t* __restrict__ row_valid, int rowf, int rpi, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
     // SH rows in and dL/dSH rows out go through LDS so that every global access of the two
     // (P,16,3) tensors is a coalesced stream (see preprocess.hip); row stride 49 floats.
     __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (SH_LDS) {
-        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
-        const float4* g4 = reinterpret_cast<const float4*>(shs);
-        float4 t[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const size_t k = base4 + threadIdx.x + 256 * i;
-            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int e = 4 * (threadIdx.x + 256 * i);
-            const int row = e / 48, col = e - row * 48;
-            float* d = s_sh + row * 49 + col;
-            d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
-        }
+        gs2m_stage_sh(shs, shs_rest, P, s_sh);
         gs2m_sync();
     }
     const bool in_range = idx < P;
@@ -352,16 +338,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     }  // in_range
     if (SH_LDS) {
         gs2m_sync();  // every thread has replaced its LDS row by its dL/dSH row
-        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
-        float4* o4 = reinterpret_cast<float4*>(dL_dshs);
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const size_t k = base4 + threadIdx.x + 256 * i;
-            const int e = 4 * (threadIdx.x + 256 * i);
-            const int row = e / 48, col = e - row * 48;
-            const float* d = s_sh + row * 49 + col;
-            if (k < lim4) o4[k] = make_float4(d[0], d[1], d[2], d[3]);
-        }
+        gs2m_unstage_sh(dL_dshs, dL_dshs_rest, P, s_sh);
     }
 }
 
@@ -486,23 +463,28 @@ void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const 
         row_reduce_kernel<1><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
 }
 
-void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
+                              const float* colors_precomp,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
                               int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                               int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
-                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales,
+                              float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
 #define GS2M_GB(LDS)                                                                                                    \
     gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
-        P, D, M, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, \
+        P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
+        projmatrix,                                                                                                     \
         campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,      \
         rows_per_inst,                                                                                                  \
-        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drots,      \
+        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales,  \
+        dL_drots,                                                                                                       \
         dL_dfeatures)
-    const bool lds = shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0 && (((uintptr_t)dL_dshs) & 15) == 0;
+    const bool lds = shs != nullptr && M == 16 &&
+                     (shs_rest ? ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15) == 0
+                               : ((((uintptr_t)shs) | ((uintptr_t)dL_dshs)) & 15) == 0);
     if (lds) GS2M_GB(true);
     else GS2M_GB(false);
 #undef GS2M_GB

@@ -54,35 +54,17 @@ template <bool SH_LDS>
 __global__ void __launch_bounds__(256) preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
-    const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs_rest, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, float4* __restrict__ rec,
     uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, ZeroJobs zero) {
-    // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian read has a 192-B lane
-    // stride.  The block instead streams its 256 rows (48 KiB, contiguous) with coalesced float4
-    // loads into LDS (row stride 49 floats: conflict-free column reads) and each thread then reads
-    // its own row from LDS.  Other M fall back to direct loads.
+    // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (SH_LDS) {
-        const size_t base4 = (size_t)blockIdx.x * 256 * 12;                 // float4 index of the block's first row
-        const size_t lim4 = (size_t)P * 12;
-        const float4* g4 = reinterpret_cast<const float4*>(shs);
-        float4 t[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const size_t k = base4 + threadIdx.x + 256 * i;
-            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int e = 4 * (threadIdx.x + 256 * i);
-            const int row = e / 48, col = e - row * 48;
-            float* d = s_sh + row * 49 + col;
-            d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
-        }
+        gs2m_stage_sh(shs, shs_rest, P, s_sh);
         gs2m_sync();
     }
     gs2m_zero_jobs(zero, (size_t)idx, (size_t)gridDim.x * blockDim.x);  // the sort / scan scratch of the stages that follow
@@ -278,18 +260,20 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
-                            const float* rotations, const float* opacities, const float* shs,
+                            const float* rotations, const float* opacities, const float* shs, const float* shs_rest,
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s) {
 #define GS2M_PRE(LDS)                                                                                                  \
     preprocess_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, \
-                                                           shs, cov3D_precomp, colors_precomp, features, viewmatrix,      \
+                                                           shs, shs_rest, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, g.rec,             \
                                                            g.tiles_touched, g.depth_key, g.clamped, zero)
-    const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;
+    // split SH (shs = DC, shs_rest = the other 15 coefficients) exists in the LDS-staged form only: api.hip checks
+    const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 &&
+                     (shs_rest ? (((uintptr_t)shs_rest) & 15) == 0 : (((uintptr_t)shs) & 15) == 0);
     if (lds) GS2M_PRE(true);
     else GS2M_PRE(false);
 #undef GS2M_PRE

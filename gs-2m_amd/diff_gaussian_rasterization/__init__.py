@@ -88,7 +88,9 @@ class _CModule:
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                             features, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, featureCount):
+                            campos, prefiltered, featureCount, sh_rest=None):
+        """`sh_rest` (this repository's extension): when given, `sh` is the DC part (P,1,3) and `sh_rest` the other
+        coefficients (P,M-1,3), as the reference model stores them -- no concatenation needed (M = 16 only)."""
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:52-54
         L = _native.lib()
@@ -101,6 +103,12 @@ class _CModule:
         projmatrix = _f32c(projmatrix, "projmatrix"); sh = _f32c(sh, "shs"); campos = _f32c(campos, "campos")
         P, H, W = means3D.size(0), int(image_height), int(image_width)
         M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        split = sh_rest is not None and sh_rest.numel() != 0
+        if split:
+            sh_rest = _f32c(sh_rest, "shs_rest")
+            if sh_rest.data_ptr() % 16:  # e.g. a view into a larger tensor: the kernels stream it as float4
+                sh_rest = sh_rest.clone()
+            M = 1 + sh_rest.size(1)
         # outputs need no zero fill: the kernels write every element
         out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
         out_buffer = torch.empty((NUM_FEATURES, H, W), dtype=torch.float32, device=device)
@@ -108,9 +116,11 @@ class _CModule:
         observe = torch.empty((P,), dtype=torch.int32, device=device)
         geom, binning, img = _Alloc(device), _Alloc(device), _Alloc(device)
         with torch.cuda.device(device):
-            rendered = L.gs2m_raster_forward(
+            fwd = L.gs2m_raster_forward_split_sh if split else L.gs2m_raster_forward
+            sh_args = (_ptr(sh), _ptr(sh_rest)) if split else (_ptr(sh),)
+            rendered = fwd(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
-                _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacities), _ptr(scales), float(scale_modifier),
+                _ptr(means3D), *sh_args, _ptr(colors), _ptr(opacities), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(features), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), int(featureCount), _ptr(out_color),
                 _ptr(radii), _ptr(observe), _ptr(out_buffer), _stream())
@@ -121,33 +131,45 @@ class _CModule:
     def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, features, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_colors,
                                      grad_buffer, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                     featureCount, return_conics=False):
+                                     featureCount, return_conics=False, sh_rest=None):
         L = _native.lib()
         device = means3D.device
         means3D = _f32c(means3D, "means3D")
         P = means3D.size(0)
         H, W = grad_colors.size(1), grad_colors.size(2)
         M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        split = sh_rest is not None and sh_rest.numel() != 0
+        if split:
+            sh_rest = _f32c(sh_rest, "shs_rest")
+            if sh_rest.data_ptr() % 16:
+                sh_rest = sh_rest.clone()
+            M = 1 + sh_rest.size(1)
         grad_colors = _f32c(grad_colors, "grad_colors"); grad_buffer = _f32c(grad_buffer, "grad_buffer")
         mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=device)) if P == 0 else \
              (lambda *s: torch.empty(s, dtype=torch.float32, device=device))
         dL_dmeans3D = mk(P, 3); dL_dmeans2D = mk(P, 4); dL_dcolors = mk(P, NUM_CHANNELS)
         dL_dfeatures = mk(P, NUM_FEATURES); dL_dopacities = mk(P, 1); dL_dcov3D = mk(P, 6)
-        dL_dshs = mk(P, M, 3); dL_dscales = mk(P, 3); dL_drotations = mk(P, 4)
+        dL_dshs = mk(P, 1 if split else M, 3); dL_dscales = mk(P, 3); dL_drotations = mk(P, 4)
+        dL_dshs_rest = mk(P, M - 1, 3) if split else None
         dL_dconics = mk(P, 2, 2) if return_conics else None
         scratch = _ScratchCache.get(device, _stream())
         with torch.cuda.device(device):
-            rc = L.gs2m_raster_backward(
-                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+            bwd = L.gs2m_raster_backward_split_sh if split else L.gs2m_raster_backward
+            sh_args = (_ptr(sh), _ptr(sh_rest)) if split else (_ptr(sh),)
+            dsh_args = (_ptr(dL_dshs), _ptr(dL_dshs_rest)) if split else (_ptr(dL_dshs),)
+            rc = bwd(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), *sh_args, _ptr(colors),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(features),
                 _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii),
                 _ptr(buffer), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), int(featureCount),
                 _ptr(grad_colors), _ptr(grad_buffer), _ptr(dL_dmeans2D), _ptr(dL_dconics), _ptr(dL_dopacities),
-                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dshs), _ptr(dL_dscales),
+                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), *dsh_args, _ptr(dL_dscales),
                 _ptr(dL_drotations), _ptr(dL_dfeatures), scratch.cb, None, _stream())
         _native.check(rc, "gs2m_raster_backward")
         out = (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drotations,
                dL_dfeatures)
+        if split:
+            out = out + (dL_dshs_rest,)
         return out + (dL_dconics,) if return_conics else out
 
     @staticmethod
@@ -168,25 +190,28 @@ _C = _CModule()
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
-                        raster_settings):
+                        raster_settings, shs_rest=None):
+    if shs_rest is None:
+        shs_rest = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, features, raster_settings)
+                                     cov3Ds_precomp, features, raster_settings, shs_rest)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
-                raster_settings):
+                raster_settings, shs_rest):
         args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
                 raster_settings.scale_modifier, cov3Ds_precomp, features, raster_settings.viewmatrix,
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
                 raster_settings.image_height, raster_settings.image_width, shs, raster_settings.sh_degree,
                 raster_settings.campos, raster_settings.prefiltered, raster_settings.feature_count)
-        num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
+            *args, sh_rest=shs_rest)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
-                              geomBuffer, binningBuffer, imgBuffer)
+                              geomBuffer, binningBuffer, imgBuffer, shs_rest)
         ctx.mark_non_differentiable(radii, observe)
         return color, radii, observe, buffer
 
@@ -195,7 +220,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         (buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs, geomBuffer,
-         binningBuffer, imgBuffer) = ctx.saved_tensors
+         binningBuffer, imgBuffer, shs_rest) = ctx.saved_tensors
         if grad_out_color is None:
             grad_out_color = torch.zeros_like(buffer[:NUM_CHANNELS])
         if grad_out_buffer is None:
@@ -205,15 +230,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
                 grad_out_buffer, shs, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
                 binningBuffer, imgBuffer, raster_settings.feature_count)
+        res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_features) = _C.rasterize_gaussians_backward(*args)
+         grad_rotations, grad_features) = res[:9]
+        grad_sh_rest = res[9] if len(res) > 9 else None
 
         def opt(g, x):  # gradients for absent optionals (empty placeholder tensors) are dropped
             return g if (x is not None and x.numel() != 0) else None
 
         return (grad_means3D, grad_means2D, opt(grad_sh, shs), opt(grad_colors_precomp, colors_precomp), grad_opacities,
                 opt(grad_scales, scales), opt(grad_rotations, rotations), opt(grad_cov3Ds_precomp, cov3Ds_precomp),
-                opt(grad_features, features), None)
+                opt(grad_features, features), None, grad_sh_rest)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -244,7 +271,9 @@ class GaussianRasterizer(nn.Module):
         return visible
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, features=None):
+                cov3D_precomp=None, features=None, shs_rest=None):
+        """`shs_rest` is this repository's extension: with it, `shs` is the DC coefficient (P,1,3) and `shs_rest` the
+        others (P,15,3) -- the two tensors the reference model keeps -- and no concatenated copy is needed."""
         raster_settings = self.raster_settings
 
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -268,4 +297,4 @@ class GaussianRasterizer(nn.Module):
             features = torch.Tensor([])
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   features, raster_settings)
+                                   features, raster_settings, shs_rest=shs_rest)

@@ -52,6 +52,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
         rotations = pc.get_rotation
 
     shs = None
+    shs_rest = None
     colors_precomp = None
     if pipe.convert_SHs_python:
         shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
@@ -60,7 +61,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
         sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
         colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
     else:
-        shs = pc.get_features
+        # the reference model keeps the SH coefficients as two parameters and concatenates them for every view
+        # (get_features: 192 B per Gaussian, and the split again in the backward); this rasterizer takes the two
+        # parts directly (GaussianRasterizer.forward(..., shs_rest=...), degree-3 layout only)
+        dc, rest = getattr(pc, "_features_dc", None), getattr(pc, "_features_rest", None)
+        if (bool(getattr(pipe, "split_sh", True)) and torch.is_tensor(dc) and torch.is_tensor(rest) and dc.is_cuda
+                and dc.dim() == 3 and rest.dim() == 3 and dc.shape[1] == 1 and rest.shape[1] == 15):
+            shs, shs_rest = dc, rest
+        else:
+            shs = pc.get_features
 
     feature_count = 9 if material_stage else 5 if geometry_stage else 1
     if blend_metallic:
@@ -105,7 +114,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
 
     rendered_image, radii, observe, buffer = rasterizer(
         means3D=means3D, means2D=means2D, opacities=opacity, shs=shs, colors_precomp=colors_precomp,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, features=features)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, features=features, **({} if shs_rest is None else {"shs_rest": shs_rest}))
 
     normal_map = buffer[2:5, ...]  # (3, H, W)
     H, W = viewpoint_camera.image_height, viewpoint_camera.image_width

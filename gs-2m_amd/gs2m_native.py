@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
-EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_knn_dist2",
+EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_raster_forward_split_sh", "gs2m_raster_backward_split_sh", "gs2m_knn_dist2",
            "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
@@ -56,6 +56,12 @@ def lib():
     L.gs2m_raster_backward.restype = i
     L.gs2m_raster_backward.argtypes = [i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, p, f, f, p, p, p, p, p, i,
                                        p, p, p, p, p, p, p, p, p, p, p, p, ALLOC_FN, p, p]
+    L.gs2m_raster_forward_split_sh.restype = i
+    L.gs2m_raster_forward_split_sh.argtypes = [ALLOC_FN, p, ALLOC_FN, p, ALLOC_FN, p, i, i, i, p, i, i, p, p, p, p, p, p, f, p, p,
+                                               p, p, p, p, f, f, i, i, p, p, p, p, p]
+    L.gs2m_raster_backward_split_sh.restype = i
+    L.gs2m_raster_backward_split_sh.argtypes = [i, i, i, i, p, i, i, p, p, p, p, p, f, p, p, p, p, p, p, f, f, p, p, p, p, p, i,
+                                                p, p, p, p, p, p, p, p, p, p, p, p, p, ALLOC_FN, p, p]
     L.gs2m_raster_mark_visible.restype = i
     L.gs2m_raster_mark_visible.argtypes = [i, p, p, p, p, p]
     L.gs2m_knn_dist2.restype = i

@@ -139,6 +139,7 @@ class PipelineParams:
     compute_cov3D_python = False
     debug = False
     z_depth = False
+    split_sh = True          # this repository's addition: hand _features_dc / _features_rest to the rasterizer unconcatenated
     fused_render_ops = True  # this repository's addition: fused HIP pre/post-processing in render() (gs2m_render_ops)
 
 

@@ -171,6 +171,31 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
  * used by the parity tests of the integer artefacts. */
 int gs2m_set_reference_binning(int on);
 
+/* ---- SH coefficients in two tensors ------------------------------------------------------------------------------
+ * The reference model stores them that way (scene/gaussian_model.py: _features_dc (P,1,3), _features_rest (P,15,3))
+ * and concatenates them for every view (get_features, 192 B per Gaussian forward and again in the backward).  These
+ * two entry points take -- and in the backward return -- the two parts directly; everything else is
+ * gs2m_raster_forward / gs2m_raster_backward.  M must be 16 (sh_rest holds M - 1 = 15 coefficients), both pointers
+ * 16-byte aligned; otherwise GS2M_ERR_UNSUPPORTED (concatenate and use the plain entry points). */
+int gs2m_raster_forward_split_sh(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
+                        void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* sh_dc, const float* sh_rest,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* features,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, int feature_count, float* out_color, int* out_radii,
+                        int* out_observe, float* out_buffer, void* stream_);
+int gs2m_raster_backward_split_sh(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* sh_dc, const float* sh_rest, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* features, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         float tan_fovx, float tan_fovy, const int* radii, const float* buffer, char* geom_buffer,
+                         char* binning_buffer, char* image_buffer, int feature_count, const float* grad_colors,
+                         const float* grad_buffer, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscales,
+                         float* dL_drots, float* dL_dfeatures, gs2m_alloc_fn scratch_alloc, void* scratch_user,
+                         void* stream_);
+
 /* ---- render() pre/post-processing around the rasterizer ------------------------------
  * Replace ~25 small PyTorch ops per view of the reference's render() (three (N,3)x(3,3) matmuls and a bmm among
  * them) by four elementwise kernels.  All pointers are device pointers; `view` is world_view_transform, row-major

@@ -184,3 +184,35 @@ def test_sobel_normal_matches_torch():
     _close("grad alpha", alpha.grad, ga, 2e-5)
     # the border carries no normal: output = background * (1 - alpha)
     assert torch.allclose(out[:, 0, :], bg[:, None] * (1 - alpha[0, :])[None], atol=1e-7)
+
+
+@pytest.mark.parametrize("P", [1, 255, 256, 257, 3001])
+def test_split_sh_equals_concatenated(P):
+    """SH coefficients handed over as (DC, rest) -- the reference model's two parameters -- give bit-identical images and
+    the gradients of the concatenated call, sliced (block boundaries of the LDS staging: 256 Gaussians)."""
+    assert torch.cuda.is_available()
+    import helpers as Hh
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = "cuda"
+    sc = Hh.make_scene(P, 96, 64, seed=31 + P, fc=9, scale_hi=0.1)
+    g = {k: v.to(dev) for k, v in sc["g"].items()}
+    st = Hh.settings_for(sc, dev)
+    Gc, Gb = sc["Gc"].to(dev), sc["Gb"].to(dev)
+    res = []
+    for split in (False, True):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in g.items() if k != "shs"}
+        if split:
+            dc = g["shs"][:, :1].contiguous().requires_grad_(True)
+            rest = g["shs"][:, 1:].contiguous().requires_grad_(True)
+            kw = dict(shs=dc, shs_rest=rest)
+        else:
+            sh = g["shs"].clone().requires_grad_(True)
+            kw = dict(shs=sh)
+        m2 = torch.zeros(P, 4, device=dev, requires_grad=True)
+        color, radii, observe, buffer = GaussianRasterizer(st)(leaves["means3D"], m2, leaves["opacities"], scales=leaves["scales"],
+                                                               rotations=leaves["rotations"], features=leaves["features"], **kw)
+        ((color * Gc).sum() + (buffer * Gb).sum()).backward()
+        gsh = torch.cat((dc.grad, rest.grad), dim=1) if split else sh.grad
+        res.append((color.detach(), buffer.detach(), gsh, leaves["means3D"].grad, leaves["scales"].grad, m2.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
