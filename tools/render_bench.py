@@ -24,6 +24,7 @@ for t in pc.parameters():
 cam = Camera(cam0, dev)
 pipe = PipelineParams()
 pipe.fused_render_ops = FUSED
+pipe.split_sh = FUSED
 bg = torch.zeros(3, device=dev)
 wts = {k: torch.rand(s, device=dev) for k, s in (("render", (3, H, W)), ("depth_map", (1, H, W)), ("normal_map", (3, H, W)),
                                                  ("albedo_map", (3, H, W)), ("roughness_map", (1, H, W)), ("local_normal_map", (3, H, W)))}
