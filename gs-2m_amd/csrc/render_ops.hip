@@ -166,6 +166,13 @@ __global__ void __launch_bounds__(256) pack_features_bwd_kernel(
                                                       (dq[2] - e.q[2] * qdq) / e.qn, (dq[3] - e.q[3] * qdq) / e.qn);
 }
 
+// upstream gradients of the ten channels taken as plain slices of the buffer (NULL = none); all = 0: channels 1..4
+// only, the caller owns the rest of d_buffer
+struct GBufDirect {
+    const float* g[10];
+    int all;
+};
+
 __global__ void __launch_bounds__(256) gbuffer_post_kernel(int N, const float* __restrict__ buffer,
                                                            const float* __restrict__ rays, const float* __restrict__ view,
                                                            int z_depth, uint8_t* __restrict__ normal_mask,
@@ -196,7 +203,7 @@ __global__ void __launch_bounds__(256) gbuffer_post_kernel(int N, const float* _
 __global__ void __launch_bounds__(256) gbuffer_post_bwd_kernel(int N, const float* __restrict__ buffer,
                                                                const float* __restrict__ rays, const float* __restrict__ view,
                                                                int z_depth, const float* __restrict__ d_local_normal,
-                                                               const float* __restrict__ d_depth,
+                                                               const float* __restrict__ d_depth, GBufDirect dir,
                                                                float* __restrict__ d_buffer) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
@@ -221,9 +228,18 @@ __global__ void __launch_bounds__(256) gbuffer_post_bwd_kernel(int N, const floa
 #pragma unroll
         for (int j = 0; j < 3; j++) dl[j] += de * rr[j];
     }
-    d_buffer[n + p] = ddist;
+    // plus the gradients of the maps that are plain channel slices (alpha, distance, normal, albedo, roughness,
+    // metallic): every channel of d_buffer is written here, once
+    auto direct = [&](int c) -> float { return dir.g[c] != nullptr ? dir.g[c][p] : 0.f; };
+    if (dir.all) {
+        d_buffer[p] = direct(0);
 #pragma unroll
-    for (int a_ = 0; a_ < 3; a_++) d_buffer[(2 + a_) * n + p] = dl[0] * V.m[a_][0] + dl[1] * V.m[a_][1] + dl[2] * V.m[a_][2];
+        for (int c = 5; c < 10; c++) d_buffer[c * n + p] = direct(c);
+    }
+    d_buffer[n + p] = ddist + (dir.all ? direct(1) : 0.f);
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+        d_buffer[(2 + a_) * n + p] = dl[0] * V.m[a_][0] + dl[1] * V.m[a_][1] + dl[2] * V.m[a_][2] + (dir.all ? direct(2 + a_) : 0.f);
 }
 
 // ---- normal from the depth map (GR:167-175 render_normal_from_depth_map; utils/normal_utils.py:3-72) --------------
@@ -403,8 +419,30 @@ int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const
     if (width <= 0 || height <= 0 || !buffer || !view || !dL_dbuffer) return GS2M_ERR_INVALID_ARG;
     if (!z_depth && !rays) return GS2M_ERR_INVALID_ARG;
     const int N = width * height;
+    GBufDirect dir = {};
     gbuffer_post_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, buffer, rays, view, z_depth,
-                                                                             dL_dlocal_normal, dL_ddepth, dL_dbuffer);
+                                                                             dL_dlocal_normal, dL_ddepth, dir, dL_dbuffer);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_gbuffer_maps_backward(int width, int height, const float* buffer, const float* rays, const float* view,
+                               int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, const float* dL_dalpha,
+                               const float* dL_ddistance, const float* dL_dnormal, const float* dL_dalbedo,
+                               const float* dL_droughness, const float* dL_dmetallic, float* dL_dbuffer, void* stream) {
+    if (width <= 0 || height <= 0 || !buffer || !view || !dL_dbuffer) return GS2M_ERR_INVALID_ARG;
+    if (!z_depth && !rays) return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    const size_t n = (size_t)N;
+    GBufDirect dir = {};
+    dir.all = 1;
+    dir.g[0] = dL_dalpha;
+    dir.g[1] = dL_ddistance;
+    for (int c = 0; c < 3; c++) dir.g[2 + c] = dL_dnormal ? dL_dnormal + c * n : nullptr;
+    for (int c = 0; c < 3; c++) dir.g[5 + c] = dL_dalbedo ? dL_dalbedo + c * n : nullptr;
+    dir.g[8] = dL_droughness;
+    dir.g[9] = dL_dmetallic;
+    gbuffer_post_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, buffer, rays, view, z_depth,
+                                                                             dL_dlocal_normal, dL_ddepth, dir, dL_dbuffer);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

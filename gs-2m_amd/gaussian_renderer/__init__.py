@@ -121,9 +121,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
     distance_map = None if pipe.z_depth else buffer[1:2, ...]
     if fused:
         rays = None if pipe.z_depth else viewpoint_camera.get_rays().view(-1, 3)
-        normal_mask, local_normal_map, depth_map = gs2m_render_ops.gbuffer_post(
-            buffer, rays, viewpoint_camera.world_view_transform, z_depth=pipe.z_depth)
+        (alpha_map, dist_ch, normal_map, albedo_map, roughness_map, metallic_map, normal_mask, local_normal_map,
+         depth_map) = gs2m_render_ops.gbuffer_maps(buffer, rays, viewpoint_camera.world_view_transform, z_depth=pipe.z_depth)
+        distance_map = None if pipe.z_depth else dist_ch
     else:
+        alpha_map, albedo_map, roughness_map, metallic_map = buffer[0:1, ...], buffer[5:8, ...], buffer[8:9, ...], buffer[9:10, ...]
         normal_mask = (normal_map != 0).all(0, keepdim=True).detach()
         local_normals = normal_map.permute(1, 2, 0).view(-1, 3)  # (H*W, 3)
         local_normals = local_normals @ viewpoint_camera.world_view_transform[:3, :3]
@@ -140,13 +142,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
         "visibility_filter": radii > 0,
         "radii": radii,
         "observe": observe,
-        "alpha_map": buffer[0:1, ...],
+        "alpha_map": alpha_map,
         "distance_map": distance_map if not pipe.z_depth else None,
         "depth_map": depth_map,
         "normal_map": normal_map,
-        "albedo_map": buffer[5:8, ...],
-        "roughness_map": buffer[8:9, ...],
-        "metallic_map": buffer[9:10, ...],
+        "albedo_map": albedo_map,
+        "roughness_map": roughness_map,
+        "metallic_map": metallic_map,
         "normal_mask": normal_mask,
         "local_normal_map": local_normal_map,
     }

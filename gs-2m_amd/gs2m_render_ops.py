@@ -101,6 +101,37 @@ def gbuffer_post(buffer, rays, world_view_transform, z_depth=False):
     return _GBufferPost.apply(buffer, rays, world_view_transform, z_depth)
 
 
+class _GBufferMaps(torch.autograd.Function):
+    """gbuffer_post plus the maps render() hands out as channel slices of the buffer, as ONE autograd node: the slices
+    are returned as views (no copy) and their gradients are folded into the single kernel that writes dL/dbuffer."""
+
+    @staticmethod
+    def forward(ctx, buffer, rays, view, z_depth):
+        b = _f32c(buffer, "buffer")
+        mask, local_normal, depth = _GBufferPost.forward(ctx, b, rays, view, z_depth)
+        return b[0:1], b[1:2], b[2:5], b[5:8], b[8:9], b[9:10], mask, local_normal, depth
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_dist, d_normal, d_albedo, d_rough, d_metal, _dmask, d_local_normal, d_depth):
+        buffer, rays, view = ctx.saved_tensors
+        _, H, W = buffer.shape
+        d_buffer = torch.empty_like(buffer)  # the kernel writes all ten channels
+        c = lambda t, n: None if t is None else _f32c(t, n)
+        with torch.cuda.device(buffer.device):
+            _native.check(_native.lib().gs2m_gbuffer_maps_backward(
+                W, H, _ptr(buffer), _ptr(rays), _ptr(view), ctx.z_depth, _ptr(c(d_local_normal, "grad_local_normal_map")),
+                _ptr(c(d_depth, "grad_depth_map")), _ptr(c(d_alpha, "grad_alpha_map")), _ptr(c(d_dist, "grad_distance_map")),
+                _ptr(c(d_normal, "grad_normal_map")), _ptr(c(d_albedo, "grad_albedo_map")), _ptr(c(d_rough, "grad_roughness_map")),
+                _ptr(c(d_metal, "grad_metallic_map")), _ptr(d_buffer), _stream()), "gs2m_gbuffer_maps_backward")
+        return d_buffer, None, None, None
+
+
+def gbuffer_maps(buffer, rays, world_view_transform, z_depth=False):
+    """buffer (10,H,W) -> (alpha_map, distance_map, normal_map, albedo_map, roughness_map, metallic_map  [channel slices],
+    normal_mask, local_normal_map, depth_map): everything render() derives from the G-buffer (GR:126-163)."""
+    return _GBufferMaps.apply(buffer, rays, world_view_transform, z_depth)
+
+
 class _SobelNormal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, alpha, bg, view, fx, fy, cx, cy):

@@ -225,6 +225,14 @@ int gs2m_gbuffer_post_backward(int width, int height, const float* buffer, const
                                int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, float* dL_dbuffer,
                                void* stream);
 
+/* The same backward with the gradients of the maps render() hands out as channel slices of the buffer (alpha 0,
+ * distance 1, normal 2..4, albedo 5..7, roughness 8, metallic 9; each (k,H,W), NULL = none) folded in: writes ALL ten
+ * channels of dL_dbuffer once (PyTorch's slicing backward zero-fills and adds a full (10,H,W) tensor per slice). */
+int gs2m_gbuffer_maps_backward(int width, int height, const float* buffer, const float* rays, const float* view,
+                               int z_depth, const float* dL_dlocal_normal, const float* dL_ddepth, const float* dL_dalpha,
+                               const float* dL_ddistance, const float* dL_dnormal, const float* dL_dalbedo,
+                               const float* dL_droughness, const float* dL_dmetallic, float* dL_dbuffer, void* stream);
+
 /* gs2m_sobel_normal_*: render_normal_from_depth_map, gaussian_renderer/__init__.py:167-175 with
  * utils/normal_utils.py:3-72 (depth -> world points -> cross product of the central differences -> normalize, 0 on the
  * border; blended with the background by alpha).  depth, alpha: (H,W); bg: 3 floats; view: world_view_transform;

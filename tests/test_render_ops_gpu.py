@@ -121,6 +121,46 @@ def test_gbuffer_post_matches_torch(z_depth):
     _close("grad buffer", buf.grad, g0, 1e-5)
 
 
+@pytest.mark.parametrize("z_depth", [False, True])
+@pytest.mark.parametrize("used", ["all", "some", "post_only"])
+def test_gbuffer_maps_matches_slices(z_depth, used):
+    """gbuffer_maps = the channel slices + gbuffer_post as one autograd node: same maps, and the same dL/dbuffer
+    whichever subset of the maps the loss touches (the untouched ones arrive as NULL gradients)."""
+    assert torch.cuda.is_available()
+    import gs2m_render_ops as R
+    import gs2m_synth as S
+    from gs2m_scene import Camera
+    dev = "cuda"
+    H, W = 41, 67
+    cam = Camera(S.make_camera(W, H), dev)
+    gen = torch.Generator().manual_seed(11)
+    buf = torch.randn(10, H, W, generator=gen).to(dev)
+    buf[2:5, :4] = 0.0
+    buf[1] = buf[1].abs() + 0.5
+    buf.requires_grad_(True)
+    G = [torch.randn(c, H, W, generator=gen).to(dev) for c in (1, 1, 3, 3, 1, 1, 3, 1)]
+    rays = None if z_depth else cam.get_rays().view(-1, 3)
+    pick = {"all": range(8), "some": (0, 2, 4, 7), "post_only": (6, 7)}[used]
+
+    def loss(maps):
+        return sum((maps[k] * G[k]).sum() for k in pick)
+
+    m0, l0, d0 = R.gbuffer_post(buf, rays, cam.world_view_transform, z_depth=z_depth)
+    ref = [buf[0:1], buf[1:2], buf[2:5], buf[5:8], buf[8:9], buf[9:10], l0, d0]
+    loss(ref).backward()
+    g0 = buf.grad.clone()
+    buf.grad = None
+    out = R.gbuffer_maps(buf, rays, cam.world_view_transform, z_depth=z_depth)
+    got = list(out[:6]) + [out[7], out[8]]
+    assert torch.equal(out[6], m0)
+    for k in range(8):
+        assert torch.equal(got[k], ref[k])
+    for k in range(6):
+        assert got[k].data_ptr() == ref[k].data_ptr()  # slices stay views of the rasterizer's buffer
+    loss(got).backward()
+    _close("grad buffer", buf.grad, g0, 1e-6)
+
+
 @pytest.mark.parametrize("material_stage,blend_metallic", [(True, False), (True, True), (False, False)])
 def test_render_fused_equals_unfused(material_stage, blend_metallic):
     """render() end to end: fused pre/post-processing against the reference's PyTorch formulation around the same
