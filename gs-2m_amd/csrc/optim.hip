@@ -1,0 +1,135 @@
+// Fused multi-tensor Adam for the reference's nine parameter groups (the reference builds
+// torch.optim.Adam(l, lr=0.0, eps=1e-15) at scene/gaussian_model.py:245 and steps it at train.py:258).
+//
+// torch's default (foreach) Adam runs eight elementwise passes over every tensor -- lerp, mul, addcmul, sqrt, div,
+// add, addcdiv, plus the temporaries -- 100 B of HBM traffic per element.  One pass needs 28 B: read param, grad,
+// exp_avg, exp_avg_sq, write the three that change.  Everything here is that one pass, for up to GS2M_ADAM_MAX_TENSORS
+// tensors per launch (one launch for the whole model), in the arithmetic order of torch/optim/adam.py
+// `_multi_tensor_adam` (weight_decay = 0, amsgrad = False, maximize = False) with its scalar factors formed in
+// double precision on the host exactly as the Python code forms them:
+//     exp_avg     = lerp(exp_avg, grad, 1 - beta1)                         = fma(1 - beta1, grad - exp_avg, exp_avg)
+//     exp_avg_sq  = fma(1 - beta2, grad * grad, exp_avg_sq * beta2)
+//     denom       = sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps
+//     param       = fma(-(lr / (1 - beta1^step)), exp_avg / denom, param)
+// HBM bound: 28 B per element, nothing else.
+#include "common.h"
+#include "../../include/gs2m_optim.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int ADAM_THREADS = 256;
+constexpr int ADAM_VEC_PER_THREAD = 4;                                    // float4 per thread
+constexpr int ADAM_CHUNK = ADAM_THREADS * ADAM_VEC_PER_THREAD * 4;         // elements per workgroup
+
+struct AdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    unsigned long long n;
+    float neg_step_size;  // -(lr / bias_correction1)
+    float bc2_sqrt;       // sqrt(bias_correction2)
+    unsigned int first_block;
+    unsigned int vec_ok;  // all four pointers 16-byte aligned
+};
+
+struct AdamLaunch {
+    AdamTensor t[GS2M_ADAM_MAX_TENSORS];
+    int count;
+    float w1;     // 1 - beta1
+    float beta2;
+    float w2;     // 1 - beta2
+    float eps;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamLaunch& L, float nss, float bc2s) {
+    m = __builtin_fmaf(L.w1, g - m, m);
+    v = __builtin_fmaf(L.w2, g * g, v * L.beta2);
+    const float denom = sqrtf(v) / bc2s + L.eps;
+    p = __builtin_fmaf(nss, m / denom, p);
+}
+
+__global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(const AdamLaunch L) {
+    // which tensor: a scalar walk over <= 16 block offsets
+    int ti = 0;
+#pragma unroll 1
+    for (int k = 1; k < L.count; k++)
+        if (blockIdx.x >= L.t[k].first_block) ti = k;
+    const AdamTensor T = L.t[ti];
+    const unsigned long long base = (unsigned long long)(blockIdx.x - T.first_block) * ADAM_CHUNK;
+    const float nss = T.neg_step_size, bc2s = T.bc2_sqrt;
+    if (T.vec_ok && base + ADAM_CHUNK <= T.n) {
+        float4 p[ADAM_VEC_PER_THREAD], g[ADAM_VEC_PER_THREAD], m[ADAM_VEC_PER_THREAD], v[ADAM_VEC_PER_THREAD];
+        const size_t q0 = base / 4 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < ADAM_VEC_PER_THREAD; u++) {
+            const size_t q = q0 + (size_t)u * ADAM_THREADS;
+            g[u] = reinterpret_cast<const float4*>(T.g)[q];
+            p[u] = reinterpret_cast<const float4*>(T.p)[q];
+            m[u] = reinterpret_cast<const float4*>(T.m)[q];
+            v[u] = reinterpret_cast<const float4*>(T.v)[q];
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_VEC_PER_THREAD; u++) {
+            adam_one(p[u].x, g[u].x, m[u].x, v[u].x, L, nss, bc2s);
+            adam_one(p[u].y, g[u].y, m[u].y, v[u].y, L, nss, bc2s);
+            adam_one(p[u].z, g[u].z, m[u].z, v[u].z, L, nss, bc2s);
+            adam_one(p[u].w, g[u].w, m[u].w, v[u].w, L, nss, bc2s);
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_VEC_PER_THREAD; u++) {
+            const size_t q = q0 + (size_t)u * ADAM_THREADS;
+            reinterpret_cast<float4*>(T.p)[q] = p[u];
+            reinterpret_cast<float4*>(T.m)[q] = m[u];
+            reinterpret_cast<float4*>(T.v)[q] = v[u];
+        }
+    } else {  // ragged tail or an unaligned tensor
+        for (unsigned long long e = base + threadIdx.x; e < base + ADAM_CHUNK && e < T.n; e += ADAM_THREADS) {
+            float p = T.p[e], m = T.m[e], v = T.v[e];
+            adam_one(p, T.g[e], m, v, L, nss, bc2s);
+            T.p[e] = p; T.m[e] = m; T.v[e] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs2m_adam_step(int n_tensors, const gs2m_adam_tensor* tensors, double beta1, double beta2, double eps,
+                              void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && !tensors)) return GS2M_ERR_INVALID_ARG;
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return GS2M_ERR_INVALID_ARG;
+    for (int i = 0; i < n_tensors; i++) {
+        const gs2m_adam_tensor& t = tensors[i];
+        if (t.step < 1 || (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq))) return GS2M_ERR_INVALID_ARG;
+    }
+    for (int i0 = 0; i0 < n_tensors; i0 += GS2M_ADAM_MAX_TENSORS) {
+        AdamLaunch L;
+        L.count = 0;
+        // the scalar factors, in double as torch/optim/adam.py forms them, then rounded once to fp32
+        L.w1 = (float)(1.0 - beta1);
+        L.beta2 = (float)beta2;
+        L.w2 = (float)(1.0 - beta2);
+        L.eps = (float)eps;
+        unsigned long long blocks = 0;
+        for (int i = i0; i < n_tensors && i < i0 + GS2M_ADAM_MAX_TENSORS; i++) {
+            const gs2m_adam_tensor& t = tensors[i];
+            if (t.numel == 0) continue;
+            AdamTensor& T = L.t[L.count++];
+            T.p = t.param; T.g = t.grad; T.m = t.exp_avg; T.v = t.exp_avg_sq; T.n = t.numel;
+            const double bc1 = 1.0 - std::pow(beta1, (double)t.step);
+            const double bc2 = 1.0 - std::pow(beta2, (double)t.step);
+            T.neg_step_size = (float)((t.lr / bc1) * -1.0);
+            T.bc2_sqrt = (float)std::sqrt(bc2);
+            T.first_block = (unsigned int)blocks;
+            T.vec_ok = (((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0;
+            blocks += (t.numel + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            if (blocks > 0x7fffffffull) return GS2M_ERR_UNSUPPORTED;
+        }
+        if (L.count == 0) continue;
+        adam_kernel<<<(unsigned int)blocks, ADAM_THREADS, 0, (hipStream_t)stream>>>(L);
+        if (hipGetLastError() != hipSuccess) return GS2M_ERR_HIP;
+    }
+    return GS2M_OK;
+}

@@ -74,3 +74,18 @@ def test_render_ops_refuse_cpu_tensors():
         R.gbuffer_post(torch.zeros(10, 4, 4), torch.zeros(16, 3), torch.eye(4))
     with pytest.raises(RuntimeError, match="no CPU path"):
         R.sobel_normal(torch.ones(4, 4), torch.ones(4, 4), torch.zeros(3), torch.eye(4), 1.0, 1.0, 2.0, 2.0)
+
+
+def test_fused_adam_refuses_cpu_tensors_and_unsupported_modes():
+    import torch
+    import gs2m_optim
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = gs2m_optim.Adam([p], lr=0.1)
+    assert set(opt.param_groups[0].keys()) == set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]).param_groups[0].keys())
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        opt.step()
+    with pytest.raises(NotImplementedError):
+        gs2m_optim.Adam([p], weight_decay=0.1)
+    with pytest.raises(NotImplementedError):
+        gs2m_optim.Adam([p], amsgrad=True)
