@@ -1,0 +1,231 @@
+// Fused SSIM map (11x11 separable Gaussian window, sigma 1.5, zero "same" padding), forward and backward, for gfx950
+// (the ROCm replacement of submodules/fused-ssim, the D-SSIM term of train.py:103 and :136).
+//
+// Same operator as utils/loss_utils.py:30-70 `ssim` (five depthwise 11x11 conv2d + ~15 elementwise ops), same op
+// boundary as the reference's extension (fused_ssim/__init__.py:8-41): forward returns the map plus the three
+// partial derivatives the backward needs, backward turns dL/dmap into dL/dimg1.
+//
+// Layout for wave64: ONE WAVE walks down a 64-column strip.  Per image row it stages the 74 halo columns of both
+// images in LDS, every lane forms the five horizontal sums (a, a^2, b, b^2, ab) for its column, and feeds them into
+// a ring of 11 vertical accumulators per quantity that lives in registers (scatter form: row t adds w[k]*h into the
+// output that started k rows ago) -- so the vertical pass costs no LDS traffic at all and each input row is read
+// from HBM once per strip (+10 halo rows per SSIM_ROWS).  The epilogue (SSIM value and derivatives) runs on the
+// row that completes.  HBM: 8 B read + 16 B written per element forward, 24 + 4 B backward; the kernels are VALU
+// bound (~200 lane-ops per element), not HBM bound.
+#include "common.h"
+#include "../../include/gs2m_ssim.h"
+
+namespace {
+
+// torch.Tensor([exp(-(x - 5)^2 / (2 * 1.5^2)) for x in range(11)]) / sum, in fp32 (utils/loss_utils.py:41-43)
+__device__ __constant__ const float SSIM_W[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
+                                                  0.10936068743467331f,  0.21300552785396576f,   0.26601171493530273f,
+                                                  0.21300552785396576f,  0.10936068743467331f,   0.036000773310661316f,
+                                                  0.0075987582094967365f, 0.001028380123898387f};
+
+constexpr int SSIM_ROWS = 45;   // output rows per strip (1080 = 24 * 45); +10 halo rows of input
+constexpr int SSIM_LDSW = 80;   // 64 + 10 halo columns, padded
+
+template <int NQ>
+struct Ring {  // NQ quantities x 11 vertical accumulators
+    float a[NQ][11];
+};
+
+// ---------------------------------------------------------------- forward
+__global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
+                                                      const float* __restrict__ img2, float* __restrict__ ssim_map,
+                                                      float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                                                      float* __restrict__ dm_dsigma12) {
+    __shared__ float s_a[2][SSIM_LDSW], s_b[2][SSIM_LDSW];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * SSIM_ROWS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const float* __restrict__ A = img1 + plane;
+    const float* __restrict__ Bm = img2 + plane;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = SSIM_W[k];
+
+    const int xa = x0 - 5 + lane, xb = x0 + 59 + lane;  // main column and (lanes 0..9) the right halo column
+    const bool ina = xa >= 0 && xa < W, inb = lane < 10 && xb < W;
+    auto fetch = [&](int y, float& a0, float& b0, float& a1, float& b1) {
+        const bool row = y >= 0 && y < H;
+        const size_t o = (size_t)(row ? y : 0) * W;
+        a0 = (row && ina) ? A[o + xa] : 0.f;
+        b0 = (row && ina) ? Bm[o + xa] : 0.f;
+        a1 = (row && inb) ? A[o + xb] : 0.f;
+        b1 = (row && inb) ? Bm[o + xb] : 0.f;
+    };
+
+    Ring<5> R;
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
+
+    const int nrows = min(SSIM_ROWS, H - y0) + 10;  // input rows y0-5 .. y0+rows+4
+    float pa0, pb0, pa1, pb1;
+    fetch(y0 - 5, pa0, pb0, pa1, pb1);
+    const int x = x0 + lane;
+    for (int t0 = 0; t0 < nrows; t0 += 11) {
+#pragma unroll
+        for (int u = 0; u < 11; u++) {
+            const int t = t0 + u;
+            if (t < nrows) {  // wave-uniform
+                const int buf = u & 1;
+                s_a[buf][lane] = pa0; s_b[buf][lane] = pb0;
+                if (lane < 10) { s_a[buf][64 + lane] = pa1; s_b[buf][64 + lane] = pb1; }
+                fetch(y0 - 5 + t + 1 < y0 + nrows - 5 ? y0 - 5 + t + 1 : -1, pa0, pb0, pa1, pb1);  // next row in flight
+                __syncthreads();
+                float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const float a = s_a[buf][lane + k], b = s_b[buf][lane + k];
+                    const float wa = w[k] * a, wb = w[k] * b;
+                    h[0] += wa; h[1] = __builtin_fmaf(wa, a, h[1]);
+                    h[2] += wb; h[3] = __builtin_fmaf(wb, b, h[3]);
+                    h[4] = __builtin_fmaf(wa, b, h[4]);
+                }
+                // input row t is tap k of the output row t - k: ring slot (u - k) mod 11
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const int j = (u - k + 11) % 11;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) R.a[q][j] = __builtin_fmaf(w[k], h[q], R.a[q][j]);
+                }
+                const int jo = (u + 1) % 11;  // output row t - 10 is complete
+                const int yo = y0 + t - 10;
+                if (t >= 10) {
+                    const float mu1 = R.a[0][jo], mu2 = R.a[2][jo];
+                    const float sigma1_sq = R.a[1][jo] - mu1 * mu1;
+                    const float sigma2_sq = R.a[3][jo] - mu2 * mu2;
+                    const float sigma12 = R.a[4][jo] - mu1 * mu2;
+                    const float Cc = 2.f * (mu1 * mu2) + C1;
+                    const float Dd = 2.f * sigma12 + C2;
+                    const float Aa = mu1 * mu1 + mu2 * mu2 + C1;
+                    const float Bb = sigma1_sq + sigma2_sq + C2;
+                    const float rAB = 1.f / (Aa * Bb);
+                    if (x < W) {
+                        const size_t o = plane + (size_t)yo * W + x;
+                        ssim_map[o] = (Cc * Dd) * rAB;
+                        if (dm_dmu1 != nullptr) {
+                            // d/dmu1 of (C D)/(A B) with sigma1_sq, sigma12 depending on mu1 through -mu1^2, -mu1 mu2
+                            dm_dmu1[o] = (mu2 * 2.f * Dd) * rAB - (mu2 * 2.f * Cc) * rAB - (mu1 * 2.f * Cc * Dd) * rAB / Aa +
+                                         (mu1 * 2.f * Cc * Dd) * rAB / Bb;
+                            dm_dsigma1_sq[o] = (-Cc * Dd) * rAB / Bb;
+                            dm_dsigma12[o] = (2.f * Cc) * rAB;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 5; q++) R.a[q][jo] = 0.f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward
+// dL/dimg1 = conv(dL dm/dmu1) + 2 img1 conv(dL dm/dsigma1_sq) + img2 conv(dL dm/dsigma12)   (the window is symmetric)
+__global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
+                                                      const float* __restrict__ img2, const float* __restrict__ dL_dmap,
+                                                      const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
+                                                      const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+    __shared__ float s_x[2][3][SSIM_LDSW];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * SSIM_ROWS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = SSIM_W[k];
+    const int xa = x0 - 5 + lane, xb = x0 + 59 + lane;
+    const bool ina = xa >= 0 && xa < W, inb = lane < 10 && xb < W;
+    auto fetch = [&](int y, float (&v0)[3], float (&v1)[3]) {
+        const bool row = y >= 0 && y < H;
+        const size_t o = plane + (size_t)(row ? y : 0) * W;
+        const float d0 = (row && ina) ? dL_dmap[o + xa] : 0.f;
+        const float d1 = (row && inb) ? dL_dmap[o + xb] : 0.f;
+        v0[0] = (row && ina) ? d0 * dm_dmu1[o + xa] : 0.f;
+        v0[1] = (row && ina) ? d0 * dm_dsigma1_sq[o + xa] : 0.f;
+        v0[2] = (row && ina) ? d0 * dm_dsigma12[o + xa] : 0.f;
+        v1[0] = (row && inb) ? d1 * dm_dmu1[o + xb] : 0.f;
+        v1[1] = (row && inb) ? d1 * dm_dsigma1_sq[o + xb] : 0.f;
+        v1[2] = (row && inb) ? d1 * dm_dsigma12[o + xb] : 0.f;
+    };
+    Ring<3> R;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
+    const int nrows = min(SSIM_ROWS, H - y0) + 10;
+    float p0[3], p1[3];
+    fetch(y0 - 5, p0, p1);
+    const int x = x0 + lane;
+    for (int t0 = 0; t0 < nrows; t0 += 11) {
+#pragma unroll
+        for (int u = 0; u < 11; u++) {
+            const int t = t0 + u;
+            if (t < nrows) {
+                const int buf = u & 1;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    s_x[buf][q][lane] = p0[q];
+                    if (lane < 10) s_x[buf][q][64 + lane] = p1[q];
+                }
+                fetch(y0 - 5 + t + 1 < y0 + nrows - 5 ? y0 - 5 + t + 1 : -1, p0, p1);
+                __syncthreads();
+                float h[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) h[q] = __builtin_fmaf(w[k], s_x[buf][q][lane + k], h[q]);
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const int j = (u - k + 11) % 11;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) R.a[q][j] = __builtin_fmaf(w[k], h[q], R.a[q][j]);
+                }
+                const int jo = (u + 1) % 11;
+                const int yo = y0 + t - 10;
+                if (t >= 10 && x < W) {
+                    const size_t o = plane + (size_t)yo * W + x;
+                    const float a = img1[o], b = img2[o];
+                    dL_dimg1[o] = R.a[0][jo] + 2.f * a * R.a[1][jo] + b * R.a[2][jo];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) R.a[q][jo] = 0.f;
+            }
+        }
+    }
+}
+
+inline bool ssim_dims_ok(int B, int CH, int H, int W) {
+    return B > 0 && CH > 0 && H > 0 && W > 0 && (long long)B * CH <= 65535 && (H + SSIM_ROWS - 1) / SSIM_ROWS <= 65535;
+}
+
+}  // namespace
+
+extern "C" int gs2m_ssim_forward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                                 float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+    if (B == 0 || CH == 0 || H == 0 || W == 0) return GS2M_OK;
+    if (B < 0 || CH < 0 || H < 0 || W < 0 || !img1 || !img2 || !ssim_map) return GS2M_ERR_INVALID_ARG;
+    const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
+    if (train && !(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12)) return GS2M_ERR_INVALID_ARG;
+    if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
+    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
+    ssim_fwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq,
+                                                         dm_dsigma12);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+extern "C" int gs2m_ssim_backward(int B, int CH, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                                  const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                                  float* dL_dimg1, void* stream) {
+    if (B == 0 || CH == 0 || H == 0 || W == 0) return GS2M_OK;
+    if (B < 0 || CH < 0 || H < 0 || W < 0 || !img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
+        return GS2M_ERR_INVALID_ARG;
+    if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
+    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
+    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                                                         dL_dimg1);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}

@@ -89,3 +89,10 @@ def test_fused_adam_refuses_cpu_tensors_and_unsupported_modes():
         gs2m_optim.Adam([p], weight_decay=0.1)
     with pytest.raises(NotImplementedError):
         gs2m_optim.Adam([p], amsgrad=True)
+
+
+def test_fused_ssim_refuses_cpu_tensors():
+    import torch
+    from fused_ssim import fused_ssim
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
