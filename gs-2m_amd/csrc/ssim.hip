@@ -25,6 +25,8 @@ __device__ __constant__ const float SSIM_W[11] = {0.001028380123898387f, 0.00759
 
 constexpr int SSIM_ROWS = 45;   // output rows per strip (1080 = 24 * 45); +10 halo rows of input
 constexpr int SSIM_LDSW = 80;   // 64 + 10 halo columns, padded
+constexpr int SSIM_PF_FWD = 3;  // input rows in flight ahead of the row being consumed: the strip walk is a chain of
+constexpr int SSIM_PF_BWD = 5;  // dependent HBM round trips (~1 us each) with only ~2 waves per SIMD to hide them
 
 template <int NQ>
 struct Ring {  // NQ quantities x 11 vertical accumulators
@@ -64,8 +66,9 @@ __global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, fl
         for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
 
     const int nrows = min(SSIM_ROWS, H - y0) + 10;  // input rows y0-5 .. y0+rows+4
-    float pa0, pb0, pa1, pb1;
-    fetch(y0 - 5, pa0, pb0, pa1, pb1);
+    float pf[SSIM_PF_FWD][4];  // queue of fetched rows: pf[0] is the next one to consume
+#pragma unroll
+    for (int d = 0; d < SSIM_PF_FWD; d++) fetch(d < nrows ? y0 - 5 + d : -1, pf[d][0], pf[d][1], pf[d][2], pf[d][3]);
     const int x = x0 + lane;
     for (int t0 = 0; t0 < nrows; t0 += 11) {
 #pragma unroll
@@ -73,9 +76,16 @@ __global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, fl
             const int t = t0 + u;
             if (t < nrows) {  // wave-uniform
                 const int buf = u & 1;
-                s_a[buf][lane] = pa0; s_b[buf][lane] = pb0;
-                if (lane < 10) { s_a[buf][64 + lane] = pa1; s_b[buf][64 + lane] = pb1; }
-                fetch(y0 - 5 + t + 1 < y0 + nrows - 5 ? y0 - 5 + t + 1 : -1, pa0, pb0, pa1, pb1);  // next row in flight
+                s_a[buf][lane] = pf[0][0]; s_b[buf][lane] = pf[0][1];
+                if (lane < 10) { s_a[buf][64 + lane] = pf[0][2]; s_b[buf][64 + lane] = pf[0][3]; }
+#pragma unroll
+                for (int d = 0; d + 1 < SSIM_PF_FWD; d++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pf[d][c] = pf[d + 1][c];
+                {
+                    constexpr int D = SSIM_PF_FWD - 1;
+                    fetch(t + SSIM_PF_FWD < nrows ? y0 - 5 + t + SSIM_PF_FWD : -1, pf[D][0], pf[D][1], pf[D][2], pf[D][3]);
+                }
                 __syncthreads();
                 float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -139,17 +149,18 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
     for (int k = 0; k < 11; k++) w[k] = SSIM_W[k];
     const int xa = x0 - 5 + lane, xb = x0 + 59 + lane;
     const bool ina = xa >= 0 && xa < W, inb = lane < 10 && xb < W;
-    auto fetch = [&](int y, float (&v0)[3], float (&v1)[3]) {
+    auto fetch = [&](int y, float (&v)[8]) {  // dL and the three derivative maps, main and halo column
         const bool row = y >= 0 && y < H;
         const size_t o = plane + (size_t)(row ? y : 0) * W;
-        const float d0 = (row && ina) ? dL_dmap[o + xa] : 0.f;
-        const float d1 = (row && inb) ? dL_dmap[o + xb] : 0.f;
-        v0[0] = (row && ina) ? d0 * dm_dmu1[o + xa] : 0.f;
-        v0[1] = (row && ina) ? d0 * dm_dsigma1_sq[o + xa] : 0.f;
-        v0[2] = (row && ina) ? d0 * dm_dsigma12[o + xa] : 0.f;
-        v1[0] = (row && inb) ? d1 * dm_dmu1[o + xb] : 0.f;
-        v1[1] = (row && inb) ? d1 * dm_dsigma1_sq[o + xb] : 0.f;
-        v1[2] = (row && inb) ? d1 * dm_dsigma12[o + xb] : 0.f;
+        const bool m0 = row && ina, m1 = row && inb;
+        v[0] = m0 ? dL_dmap[o + xa] : 0.f;
+        v[1] = m0 ? dm_dmu1[o + xa] : 0.f;
+        v[2] = m0 ? dm_dsigma1_sq[o + xa] : 0.f;
+        v[3] = m0 ? dm_dsigma12[o + xa] : 0.f;
+        v[4] = m1 ? dL_dmap[o + xb] : 0.f;
+        v[5] = m1 ? dm_dmu1[o + xb] : 0.f;
+        v[6] = m1 ? dm_dsigma1_sq[o + xb] : 0.f;
+        v[7] = m1 ? dm_dsigma12[o + xb] : 0.f;
     };
     Ring<3> R;
 #pragma unroll
@@ -157,8 +168,9 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
 #pragma unroll
         for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
     const int nrows = min(SSIM_ROWS, H - y0) + 10;
-    float p0[3], p1[3];
-    fetch(y0 - 5, p0, p1);
+    float pf[SSIM_PF_BWD][8];
+#pragma unroll
+    for (int d = 0; d < SSIM_PF_BWD; d++) fetch(d < nrows ? y0 - 5 + d : -1, pf[d]);
     const int x = x0 + lane;
     for (int t0 = 0; t0 < nrows; t0 += 11) {
 #pragma unroll
@@ -168,10 +180,14 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
                 const int buf = u & 1;
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
-                    s_x[buf][q][lane] = p0[q];
-                    if (lane < 10) s_x[buf][q][64 + lane] = p1[q];
+                    s_x[buf][q][lane] = pf[0][0] * pf[0][1 + q];
+                    if (lane < 10) s_x[buf][q][64 + lane] = pf[0][4] * pf[0][5 + q];
                 }
-                fetch(y0 - 5 + t + 1 < y0 + nrows - 5 ? y0 - 5 + t + 1 : -1, p0, p1);
+#pragma unroll
+                for (int d = 0; d + 1 < SSIM_PF_BWD; d++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) pf[d][c] = pf[d + 1][c];
+                fetch(t + SSIM_PF_BWD < nrows ? y0 - 5 + t + SSIM_PF_BWD : -1, pf[SSIM_PF_BWD - 1]);
                 __syncthreads();
                 float h[3] = {0.f, 0.f, 0.f};
 #pragma unroll

@@ -136,3 +136,31 @@ def algo_bytes(P, V, R, N, Tn, fc, M=16):
     bwd = blend_b + gauss_b
     return dict(preprocess=pre_f, scan=scan, keygen=keygen, sort=sort, ranges=ranges, blend_fwd=blend_f,
                 blend_bwd=blend_b, gaussian_bwd=gauss_b, forward=fwd, backward=bwd, total=fwd + bwd)
+
+
+def make_surface_scene(n, seed=0, centre=(0.0, 0.0, 6.0), sh_degree=3):
+    """A compact synthetic object for the train.py-level configuration (SURVEY.md 8(d) C4 substitute: no dataset on the
+    GPU box): n flat Gaussians on a unit-and-a-half sphere plus a ground disc, smoothly varying colours, normals
+    known.  -> dict(points, normals, colors [0,1], scales, rotations (w,x,y,z), opacities, shs (n,16,3))."""
+    g = torch.Generator().manual_seed(seed)
+    ns = int(n * 0.7)
+    d = torch.nn.functional.normalize(torch.randn(ns, 3, generator=g), dim=1)
+    sphere = 1.5 * d
+    r = 3.0 * torch.sqrt(torch.rand(n - ns, generator=g))
+    a = 2 * math.pi * torch.rand(n - ns, generator=g)
+    disc = torch.stack([r * torch.cos(a), torch.full_like(r, 1.5), r * torch.sin(a)], dim=1)  # +y is down
+    pts = torch.cat([sphere, disc], dim=0)
+    normals = torch.cat([d, torch.tensor([0.0, -1.0, 0.0]).expand(n - ns, 3)], dim=0)
+    colors = 0.5 + 0.45 * torch.stack([torch.sin(2.1 * pts[:, 0] + 0.3), torch.sin(1.7 * pts[:, 1] + 1.1) * torch.cos(1.3 * pts[:, 2]),
+                                       torch.cos(2.3 * pts[:, 2] - 0.4)], dim=1)
+    # rotation taking +z to the normal: q = normalize(1 + n_z, z x n)
+    w = 1.0 + normals[:, 2]
+    q = torch.stack([w, -normals[:, 1], normals[:, 0], torch.zeros(n)], dim=1)
+    q[w < 1e-6] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    q = torch.nn.functional.normalize(q, dim=1)
+    scales = torch.tensor([0.05, 0.05, 0.005]).expand(n, 3) * (0.7 + 0.6 * torch.rand(n, 1, generator=g))
+    shs = torch.zeros(n, (sh_degree + 1) ** 2, 3)
+    shs[:, 0] = (colors - 0.5) / 0.28209479177387814
+    c = torch.tensor(centre)
+    return dict(points=(pts + c).float(), normals=normals.float(), colors=colors.float().clamp(0, 1), scales=scales.float().contiguous(),
+                rotations=q.float(), opacities=torch.full((n, 1), 0.95), shs=shs.float())

@@ -1,0 +1,125 @@
+"""The reference's training iteration (train.py:76-262) on MI355X, for the stages this repository covers: the RGB
+stage and the geometry stage without the multi-view term (no PBR shading): render -> clamp -> (1 - l) L1 + l (1 - SSIM)
++ plane loss (+ depth-normal loss from `geometry_from_iter`) -> backward -> densification statistics -> densify / prune /
+opacity reset on the reference's schedule -> fused Adam step.  Every device-side piece is this repository's: the
+rasterizer, the fused render() pre/post-processing, fused_ssim, gs2m_optim.Adam, distCUDA2.
+
+There is no dataset on the GPU box, so the scene is synthetic (SURVEY.md 8(d) C4 says to substitute and say so):
+`synthetic_scene()` renders ground-truth views of a known surface-aligned Gaussian object with this rasterizer and
+initialises the model from a noisy subsample of its points, the way COLMAP points initialise the reference.
+
+    python gs-2m_amd/gs2m_train.py --iterations 1000 --width 960 --height 540
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import torch
+
+import gs2m_synth as S
+from fused_ssim import fused_ssim
+from gaussian_renderer import render
+from gs2m_losses import depth_normal_loss, l1_loss, plane_loss
+from gs2m_model import GaussianModel, OptimizationParams
+from gs2m_scene import Camera, GaussianParams, PipelineParams, inverse_sigmoid
+
+
+def psnr(a, b):
+    return (-10.0 * torch.log10(((a - b) ** 2).mean().clamp_min(1e-12))).item()
+
+
+def synthetic_scene(n_true=60_000, n_views=12, W=640, H=360, init_frac=0.15, seed=0, device="cuda"):
+    """-> (cameras, gt_images, init_points, init_colors, cameras_extent)."""
+    sc = S.make_surface_scene(n_true, seed=seed)
+    t = {k: v.to(device) for k, v in sc.items()}
+    truth = GaussianParams(t["points"], t["shs"][:, :1].contiguous(), t["shs"][:, 1:].contiguous(), torch.log(t["scales"]),
+                           t["rotations"], inverse_sigmoid(t["opacities"]), *(inverse_sigmoid(torch.full((n_true, c), 0.5, device=device)) for c in (3, 1, 1)))
+    cams = [Camera(c, device) for c in S.orbit_cameras(n_views, W, H, radius=6.0, centre=(0.0, -0.8, 6.0), fx=1.1 * W)]
+    pipe, bg = PipelineParams(), torch.zeros(3, device=device)
+    with torch.no_grad():
+        gts = [render(c, truth, pipe, bg)["render"].clamp(0, 1) for c in cams]
+    g = torch.Generator().manual_seed(seed + 1)
+    pick = torch.randperm(n_true, generator=g)[: max(1, int(init_frac * n_true))]
+    pts = sc["points"][pick] + 0.02 * torch.randn(len(pick), 3, generator=g)
+    cols = (sc["colors"][pick] + 0.05 * torch.randn(len(pick), 3, generator=g)).clamp(0, 1)
+    centers = torch.stack([c.camera_center for c in cams])
+    extent = 1.1 * (centers - centers.mean(0)).norm(dim=1).max().item()  # scene/dataset_readers.py getNerfppNorm
+    return cams, gts, pts.numpy(), cols.numpy(), extent
+
+
+def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
+          device="cuda", scene=None):
+    opt = opt or OptimizationParams()
+    geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
+    cams, gts, pts, cols, extent = scene or synthetic_scene(n_true, n_views, W, H, seed=seed, device=device)
+    torch.manual_seed(seed)
+    gaussians = GaussianModel(3, device)
+    gaussians.create_from_pcd(pts, cols, extent)
+    gaussians.training_setup(opt)
+    pipe, bg = PipelineParams(), torch.zeros(3, device=device)
+
+    def evaluate():
+        with torch.no_grad():
+            return sum(psnr(render(c, gaussians, pipe, bg)["render"].clamp(0, 1), gt) for c, gt in zip(cams, gts)) / len(cams)
+
+    stats = dict(psnr_start=evaluate(), points_start=gaussians.get_xyz.shape[0])
+    order = torch.Generator().manual_seed(seed)
+    stack = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, iterations + 1):
+        gaussians.update_learning_rate(it)
+        if it % 1000 == 0:
+            gaussians.oneupSHdegree()
+        if not stack:
+            stack = torch.randperm(len(cams), generator=order).tolist()
+        k = stack.pop()
+        cam, gt = cams[k], gts[k]
+        geometry_stage = it > geometry_from_iter
+        out = render(cam, gaussians, pipe, bg, geometry_stage, False, sobel_normal=geometry_stage)
+        vis, radii = out["visibility_filter"], out["radii"]
+        rgb = out["render"].clamp(0, 1)
+        Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
+        loss = (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim + opt.lambda_plane * plane_loss(vis, gaussians)
+        if geometry_stage:
+            loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], gt_image=gt)
+        loss.backward()
+        with torch.no_grad():
+            if it <= opt.densify_until_iter:
+                gaussians.update_max_radii(out["observe"], vis, radii)
+                gaussians.add_densification_stats(out["viewspace_points"], vis)
+                if it > opt.densify_from_iter and it % opt.densification_interval == 0:
+                    thr = opt.radii2D_threshold if it > opt.opacity_reset_interval else None
+                    gaussians.densify_and_prune(opt.densify_grad_threshold, opt.densify_grad_abs_threshold, opt.opacity_prune_threshold, extent, thr)
+                if it % opt.opacity_reset_interval == 0:
+                    gaussians.reset_opacity()
+            if it < iterations:
+                gaussians.optimizer.step()
+                gaussians.optimizer.zero_grad(set_to_none=True)
+        if log and it % log == 0:
+            print(f"[{it:6d}] loss {loss.item():.5f}  points {gaussians.get_xyz.shape[0]}", flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats.update(psnr_end=evaluate(), points_end=gaussians.get_xyz.shape[0], seconds=dt, it_per_s=iterations / dt, loss_end=loss.item())
+    return gaussians, stats
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=1000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--views", type=int, default=12)
+    ap.add_argument("--true-gaussians", type=int, default=60_000)
+    ap.add_argument("--save-ply", default=None)
+    a = ap.parse_args()
+    model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10))
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
+    if a.save_ply:
+        model.save_ply(a.save_ply)

@@ -1,0 +1,91 @@
+"""One training iteration of the reference's geometry stage without the multi-view term (train.py:94-130, 223-227,
+258-259) at the bench workload: render(sobel_normal=True) -> clamp -> (1-l)L1 + l(1-SSIM) + plane + depth-normal ->
+backward -> densification statistics -> Adam step.  `--reference-formulation` swaps every fused piece for what the
+reference itself runs on top of the drop-in rasterizer: PyTorch pre/post-processing in render(), the conv2d `ssim`,
+torch.optim.Adam (foreach)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gs-2m_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import gs2m_synth as S
+import gs2m_optim
+from gs2m_scene import GaussianParams, PipelineParams, Camera
+from gs2m_losses import l1_loss, plane_loss, depth_normal_loss
+from gaussian_renderer import render
+from fused_ssim import fused_ssim
+
+REF = "--reference-formulation" in sys.argv
+P, W, H = 1_000_000, 1920, 1080
+dev = "cuda"
+cam0 = S.make_camera(W, H)
+g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=0).items()}
+albedo = torch.rand(P, 3, device=dev) * 0.8 + 0.1
+rough = torch.rand(P, 1, device=dev) * 0.8 + 0.1
+metal = torch.rand(P, 1, device=dev) * 0.8 + 0.1
+pc = GaussianParams.from_activated(g["means3D"], g["shs"], g["scales"], g["rotations"], g["opacities"].clamp(0.01, 0.99), albedo, rough, metal)
+params = [torch.nn.Parameter(t) for t in pc.parameters()]
+(pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, pc._albedo, pc._roughness, pc._metallic) = params
+names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")
+lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, albedo=0.05, roughness=0.05, metallic=0.05)
+groups = [{"params": [p], "lr": lrs[n], "name": n} for p, n in zip(params, names)]
+opt = (torch.optim.Adam if REF else gs2m_optim.Adam)(groups, lr=0.0, eps=1e-15)
+cam = Camera(cam0, dev)
+pipe = PipelineParams()
+pipe.fused_render_ops = not REF
+pipe.split_sh = not REF
+bg = torch.zeros(3, device=dev)
+gt = torch.rand(3, H, W, device=dev)
+accum, accum_abs, denom = (torch.zeros(P, 1, device=dev) for _ in range(3))
+max_radii = torch.zeros(P, device=dev)
+if REF:
+    from test_ssim_gpu import _window
+    import torch.nn.functional as F
+    win = _window(3, dev)
+
+    def ssim_fn(a, b):
+        mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+        s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1.pow(2)
+        s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2.pow(2)
+        s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1.pow(2) + mu2.pow(2) + 1e-4) * (s1 + s2 + 9e-4))).mean()
+else:
+    ssim_fn = fused_ssim
+
+
+def step():
+    global max_radii
+    out = render(cam, pc, pipe, bg, material_stage=False, sobel_normal=True)
+    image, vis, radii = out["render"], out["visibility_filter"], out["radii"]
+    rgb = image.clamp(0, 1)
+    Lssim = 1.0 - ssim_fn(rgb.unsqueeze(0), gt.unsqueeze(0))
+    loss = 0.8 * l1_loss(rgb, gt) + 0.2 * Lssim + 0.01 * plane_loss(vis, pc)
+    loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+    loss.backward()
+    with torch.no_grad():  # train.py:223-227, GM:569-573
+        mask = (out["observe"] > 0) & vis
+        max_radii = torch.where(mask, torch.max(max_radii, radii), max_radii)
+        vg = out["viewspace_points"].grad
+        accum[vis] += torch.norm(vg[vis, :2], dim=-1, keepdim=True)
+        accum_abs[vis] += torch.norm(vg[vis, 2:], dim=-1, keepdim=True)
+        denom[vis] += 1
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+n = 30
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+print("training iteration (%s): %.3f ms" % ("reference formulation on the drop-in rasterizer" if REF else "fused", (time.perf_counter() - t0) / n * 1e3))
+if "--profile" in sys.argv:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
