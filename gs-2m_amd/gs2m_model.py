@@ -115,6 +115,8 @@ class GaussianModel(GaussianParams):
     def training_setup(self, args=OptimizationParams, optimizer_cls=None):  # GM:224-249
         self.percent_dense = args.percent_dense
         self._reset_stats()
+        if self.max_radii2D.shape[0] != self._xyz.shape[0]:  # a model that came from parameterize() / load_ply()
+            self.max_radii2D = torch.zeros(self._xyz.shape[0], device=self.device)
         lr = dict(xyz=args.position_lr_init * self.spatial_lr_scale, f_dc=args.feature_lr, f_rest=args.feature_lr / 20.0,
                   opacity=args.opacity_lr, scaling=args.scaling_lr, rotation=args.rotation_lr, albedo=args.opacity_lr,
                   roughness=args.opacity_lr, metallic=args.opacity_lr)

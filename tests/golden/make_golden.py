@@ -64,6 +64,28 @@ def ref_helpers():
     print("wrote ref_helpers.npz")
 
 
+def ref_model_helpers():
+    """(3) ref_model.npz -- the reference's host-side helpers behind GaussianModel (importable here: pure Python):
+    utils/general_utils.py:get_expon_lr_func (:36-66), inverse_sigmoid (:20-21); utils/sh_utils.py:RGB2SH (:114-115)."""
+    sys.path.insert(0, "/root/reference")
+    from utils.general_utils import get_expon_lr_func, inverse_sigmoid
+    from utils.sh_utils import RGB2SH
+    out = {}
+    steps = np.array([0, 1, 7, 100, 999, 1000, 5000, 15000, 29999, 30000, 40000])
+    out["lr_steps"] = steps
+    cfgs = [(0.00016 * 6.6, 0.0000016 * 6.6, 0, 0.01, 30000), (1e-2, 1e-4, 1000, 0.01, 20000), (3e-3, 3e-3, 0, 1.0, 100)]
+    out["lr_cfgs"] = np.array(cfgs, dtype=np.float64)
+    out["lr_values"] = np.array([[get_expon_lr_func(lr_init=a, lr_final=b, lr_delay_steps=int(c), lr_delay_mult=d, max_steps=int(e))(int(s))
+                                  for s in steps] for a, b, c, d, e in cfgs], dtype=np.float64)
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(64, 3, generator=g) * 0.98 + 0.01
+    out["unit_x"] = x.numpy()
+    out["inverse_sigmoid"] = inverse_sigmoid(x).numpy()
+    out["rgb2sh"] = RGB2SH(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_model.npz"), **out)
+    print("wrote ref_model.npz")
+
+
 def raster_small():
     import helpers as Hh
     from oracle import oracle
@@ -84,5 +106,9 @@ def raster_small():
 
 
 if __name__ == "__main__":
+    if "--model-only" in sys.argv:
+        ref_model_helpers()
+        sys.exit(0)
     ref_helpers()
+    ref_model_helpers()
     raster_small()

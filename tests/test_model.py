@@ -1,0 +1,98 @@
+"""Host-side model logic on the CPU: the schedule / conversions against vectors generated from the
+reference's own helpers (tests/golden/make_golden.py), the PLY layout, the optimizer surgery bookkeeping."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_model.npz")
+
+
+def test_lr_schedule_and_conversions_match_reference_vectors():
+    from gs2m_model import expon_lr, rgb_to_sh
+    from gs2m_scene import inverse_sigmoid
+    d = np.load(GOLD)
+    for (a, b, c, dm, e), want in zip(d["lr_cfgs"], d["lr_values"]):
+        f = expon_lr(a, b, lr_delay_steps=int(c), lr_delay_mult=dm, max_steps=int(e))
+        got = np.array([f(int(s)) for s in d["lr_steps"]])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    x = torch.tensor(d["unit_x"])
+    assert np.array_equal(inverse_sigmoid(x).numpy(), d["inverse_sigmoid"])
+    assert np.array_equal(rgb_to_sh(x).numpy(), d["rgb2sh"])
+
+
+def _random_model(n, seed=0):
+    from gs2m_model import GaussianModel
+    g = torch.Generator().manual_seed(seed)
+    m = GaussianModel(3, device="cpu")
+    r = lambda *s: torch.randn(*s, generator=g)
+    m.parameterize((r(n, 3), r(n, 1, 3), r(n, 15, 3), r(n, 3), r(n, 4), r(n, 1), r(n, 3), r(n, 1), r(n, 1)))
+    return m
+
+
+def test_ply_layout_and_round_trip(tmp_path):
+    from gs2m_model import GaussianModel
+    m = _random_model(37)
+    path = str(tmp_path / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    raw = open(path, "rb").read()
+    header, body = raw.split(b"end_header\n", 1)
+    lines = header.decode().strip().split("\n")
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    names = [l.split()[2] for l in lines[3:]]
+    assert all(l.startswith("property float ") for l in lines[3:])
+    assert names == m.construct_list_of_attributes() and len(names) == 6 + 3 + 45 + 1 + 3 + 4 + 3 + 2   # GM:260-278
+    assert len(body) == 37 * len(names) * 4
+    table = np.frombuffer(body, dtype="<f4").reshape(37, len(names))
+    assert np.array_equal(table[:, 0:3], m._xyz.detach().numpy()) and not table[:, 3:6].any()
+    # SH tensors are stored channel-major: f_rest_{c*15+k} = features_rest[:, k, c]   (GM:283-284)
+    assert np.array_equal(table[:, 9 + 1 * 15 + 4], m._features_rest.detach().numpy()[:, 4, 1])
+    assert np.array_equal(table[:, 6 + 2], m._features_dc.detach().numpy()[:, 0, 2])
+    again = GaussianModel(3, device="cpu")
+    again.load_ply(path)
+    for a, b in zip(m.parameters(), again.parameters()):
+        assert a.shape == b.shape and torch.equal(a.detach(), b.detach())
+    assert again.active_sh_degree == 3
+    # ascii files and extra elements after the vertex element are read too
+    v = GaussianModel.read_ply_vertices(path)
+    apath = str(tmp_path / "ascii.ply")
+    with open(apath, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment test\nelement vertex 37\n" + "".join(f"property float {n}\n" for n in names)
+                + "element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+        for i in range(37):
+            f.write(" ".join(repr(float(v[n][i])) for n in names) + "\n")
+    third = GaussianModel(3, device="cpu")
+    third.load_ply(apath)
+    for a, b in zip(m.parameters(), third.parameters()):
+        assert torch.equal(a.detach(), b.detach())
+
+
+def test_prune_and_cat_keep_parameters_and_adam_state_aligned():
+    """_prune_optimizer / cat_tensors_to_optimizer (GM:388-455) with torch.optim.Adam standing in for the fused
+    optimizer (same state layout; the fused step itself needs the GPU)."""
+    from gs2m_model import OptimizationParams
+    m = _random_model(50)
+    m.spatial_lr_scale = 1.0
+    m.training_setup(OptimizationParams, optimizer_cls=torch.optim.Adam)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    m.optimizer.step()
+    before = {g["name"]: (g["params"][0].detach().clone(), m.optimizer.state[g["params"][0]]["exp_avg"].clone()) for g in m.optimizer.param_groups}
+    mask = torch.arange(50) % 5 == 0
+    m.prune_points(mask)
+    assert m.get_xyz.shape[0] == 40 and m.denom.shape == (40, 1) and m.max_radii2D.shape == (40,)
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        st = m.optimizer.state[p]
+        assert torch.equal(p.detach(), before[g["name"]][0][~mask]) and torch.equal(st["exp_avg"], before[g["name"]][1][~mask])
+        assert float(st["step"]) == 1.0
+    m.densification_postfix(**{g["name"]: torch.full((7,) + tuple(g["params"][0].shape[1:]), 2.0) for g in m.optimizer.param_groups})
+    assert m.get_xyz.shape[0] == 47 and m._opacity is [g for g in m.optimizer.param_groups if g["name"] == "opacity"][0]["params"][0]
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        st = m.optimizer.state[p]
+        assert torch.equal(p.detach()[40:], torch.full_like(p.detach()[40:], 2.0)) and not st["exp_avg"][40:].any() and not st["exp_avg_sq"][40:].any()
+        assert torch.equal(st["exp_avg"][:40], before[g["name"]][1][~mask])
+    m.reset_opacity()
+    assert (m.get_opacity <= 0.01 + 1e-6).all() and not m.optimizer.state[m._opacity]["exp_avg"].any()
