@@ -12,6 +12,7 @@ import gs2m_synth as S
 import gs2m_optim
 from gs2m_scene import GaussianParams, PipelineParams, Camera
 from gs2m_losses import l1_loss, plane_loss, depth_normal_loss
+import gs2m_losses
 from gaussian_renderer import render
 from fused_ssim import fused_ssim
 
@@ -39,6 +40,10 @@ gt = torch.rand(3, H, W, device=dev)
 accum, accum_abs, denom = (torch.zeros(P, 1, device=dev) for _ in range(3))
 max_radii = torch.zeros(P, device=dev)
 if REF:
+    def plane_loss(visibility_filter, gaussians):  # utils/loss_utils.py:72-79 as written there (boolean-mask gather)
+        if visibility_filter.sum() == 0:
+            return 0.0
+        return torch.sort(gaussians.get_scaling[visibility_filter], dim=-1)[0][..., 0].mean()
     from test_ssim_gpu import _window
     import torch.nn.functional as F
     win = _window(3, dev)
@@ -63,12 +68,21 @@ def step():
     loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
     loss.backward()
     with torch.no_grad():  # train.py:223-227, GM:569-573
-        mask = (out["observe"] > 0) & vis
-        max_radii = torch.where(mask, torch.max(max_radii, radii), max_radii)
-        vg = out["viewspace_points"].grad
-        accum[vis] += torch.norm(vg[vis, :2], dim=-1, keepdim=True)
-        accum_abs[vis] += torch.norm(vg[vis, 2:], dim=-1, keepdim=True)
-        denom[vis] += 1
+        if REF:
+            mask = (out["observe"] > 0) & vis
+            max_radii = torch.where(mask, torch.max(max_radii, radii), max_radii)
+            vg = out["viewspace_points"].grad
+            accum[vis] += torch.norm(vg[vis, :2], dim=-1, keepdim=True)
+            accum_abs[vis] += torch.norm(vg[vis, 2:], dim=-1, keepdim=True)
+            denom[vis] += 1
+        else:  # gs2m_model.GaussianModel's masked forms
+            mask = (out["observe"] > 0) & vis
+            max_radii = torch.where(mask, torch.max(max_radii, radii), max_radii)
+            vg = out["viewspace_points"].grad
+            f = vis[:, None]
+            accum.add_(torch.where(f, torch.norm(vg[:, :2], dim=-1, keepdim=True), 0.0))
+            accum_abs.add_(torch.where(f, torch.norm(vg[:, 2:], dim=-1, keepdim=True), 0.0))
+            denom.add_(f)
         opt.step()
         opt.zero_grad(set_to_none=True)
 
