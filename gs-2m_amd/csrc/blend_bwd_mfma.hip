@@ -95,7 +95,11 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
     __shared__ uint32_t s_gid[BB];
     __shared__ uint32_t s_slot[BB];
     __shared__ uint32_t s_list[BB];
-    __shared__ __align__(16) float s_g[64][16];    // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
+#ifndef GS2M_BWDM_GSTRIDE
+#define GS2M_BWDM_GSTRIDE 20  // 16 + 4: with a 16-float stride the A-operand reads (16 pixel rows x 4 columns) fall on 16 banks
+#endif
+    constexpr int GST = GS2M_BWDM_GSTRIDE;
+    __shared__ __align__(16) float s_g[64][GST];   // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
     // per pixel pair {(x, y), (x + 4, y)}, index 4 y + (x & 3): running T, running suffix sum Sg, n_contrib
     __shared__ float2 s_T2[32];
     __shared__ float2 s_S2[32];
@@ -182,7 +186,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
         auto gc_block = [&](int b) {
             v4f a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * 16 + 4 * k], scB[k], a, 0, 0, 0);
+            for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * GST + 4 * k], scB[k], a, 0, 0, 0);
             return a;
         };
         v4f gnext = gc_block(0);
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDM_WAVES blend_bwd_mfma_kernel(
             for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
             float gAn[KK];  // A operand of the NEXT block's colour . gradient product
 #pragma unroll
-            for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * 16 + 4 * k] : 0.f;  // the last block has no successor
+            for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * GST + 4 * k] : 0.f;  // the last block has no successor
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
                 const int pi = (2 * b + h) * 4 + r;
