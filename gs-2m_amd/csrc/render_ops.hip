@@ -370,6 +370,70 @@ __global__ void __launch_bounds__(256) sobel_normal_bwd_kernel(int W, int H, con
     d_depth[p] = r[0] * acc[0] + r[1] * acc[1] + r[2] * acc[2];
 }
 
+// ---------------------------------------------------------------- parameter activations (GM:113-144 getters)
+// scales = exp(_scaling), rotations = _rotation / max(|_rotation|, 1e-12), opacity / albedo / roughness / metallic =
+// sigmoid(raw): six getters, ~9 PyTorch launches forward and ~14 backward per view; one launch each way here.
+struct ActPtrs {
+    const float* scaling; const float* rotation; const float* opacity; const float* albedo; const float* roughness; const float* metallic;
+    float* scales; float* rotations; float* opacities; float* albedo_a; float* roughness_a; float* metallic_a;
+};
+struct ActGradPtrs {
+    const float* rotation;  // raw quaternion
+    const float* scales; const float* opacities; const float* albedo_a; const float* roughness_a; const float* metallic_a;  // activated (saved outputs)
+    const float* d_scales; const float* d_rotations; const float* d_opacities; const float* d_albedo_a; const float* d_roughness_a; const float* d_metallic_a;
+    float* d_scaling; float* d_rotation; float* d_opacity; float* d_albedo; float* d_roughness; float* d_metallic;
+};
+
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }  // at::sigmoid: 1 / (1 + exp(-x))
+__device__ __forceinline__ float act_sigmoid_bwd(float g, float y) { return g * (1.f - y) * y; }
+
+__global__ void __launch_bounds__(256) activate_kernel(int P, ActPtrs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (a.scaling != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.scales[3 * i + c] = expf(a.scaling[3 * i + c]);
+    }
+    if (a.rotation != nullptr) {  // F.normalize(p=2, dim=1, eps=1e-12)
+        const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
+        const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        reinterpret_cast<float4*>(a.rotations)[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    }
+    if (a.opacity != nullptr) a.opacities[i] = act_sigmoid(a.opacity[i]);
+    if (a.albedo != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.albedo_a[3 * i + c] = act_sigmoid(a.albedo[3 * i + c]);
+    }
+    if (a.roughness != nullptr) a.roughness_a[i] = act_sigmoid(a.roughness[i]);
+    if (a.metallic != nullptr) a.metallic_a[i] = act_sigmoid(a.metallic[i]);
+}
+
+__global__ void __launch_bounds__(256) activate_bwd_kernel(int P, ActGradPtrs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (a.d_scaling != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.d_scaling[3 * i + c] = a.d_scales[3 * i + c] * a.scales[3 * i + c];
+    }
+    if (a.d_rotation != nullptr) {
+        const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.d_rotations)[i];
+        const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        const float n = fmaxf(nn, 1e-12f);
+        // y = q / n: dq = g / n - q (g . q) / (n^2 |q|); below the eps clamp the denominator is a constant
+        const float dot = g.x * q.x + g.y * q.y + g.z * q.z + g.w * q.w;
+        const float k = nn >= 1e-12f ? dot / (n * n * nn) : 0.f;
+        reinterpret_cast<float4*>(a.d_rotation)[i] = make_float4(g.x / n - q.x * k, g.y / n - q.y * k, g.z / n - q.z * k, g.w / n - q.w * k);
+    }
+    if (a.d_opacity != nullptr) a.d_opacity[i] = act_sigmoid_bwd(a.d_opacities[i], a.opacities[i]);
+    if (a.d_albedo != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.d_albedo[3 * i + c] = act_sigmoid_bwd(a.d_albedo_a[3 * i + c], a.albedo_a[3 * i + c]);
+    }
+    if (a.d_roughness != nullptr) a.d_roughness[i] = act_sigmoid_bwd(a.d_roughness_a[i], a.roughness_a[i]);
+    if (a.d_metallic != nullptr) a.d_metallic[i] = act_sigmoid_bwd(a.d_metallic_a[i], a.metallic_a[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -465,6 +529,39 @@ int gs2m_sobel_normal_backward(int width, int height, const float* depth, const 
     const int N = width * height;
     sobel_normal_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx,
                                                                              cy, dL_dsobel, dL_ddepth, dL_dalpha);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_activate_forward(int P, const float* scaling, const float* rotation, const float* opacity, const float* albedo,
+                          const float* roughness, const float* metallic, float* scales, float* rotations, float* opacities,
+                          float* albedo_a, float* roughness_a, float* metallic_a, void* stream) {
+    if (P == 0) return GS2M_OK;
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if ((scaling && !scales) || (rotation && !rotations) || (opacity && !opacities) || (albedo && !albedo_a) ||
+        (roughness && !roughness_a) || (metallic && !metallic_a))
+        return GS2M_ERR_INVALID_ARG;
+    if (rotation && ((((uintptr_t)rotation) | ((uintptr_t)rotations)) & 15)) return GS2M_ERR_UNSUPPORTED;
+    ActPtrs a = {scaling, rotation, opacity, albedo, roughness, metallic, scales, rotations, opacities, albedo_a, roughness_a, metallic_a};
+    activate_kernel<<<(P + 255) / 256, 256, 0, (hipStream_t)stream>>>(P, a);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_activate_backward(int P, const float* rotation, const float* scales, const float* opacities, const float* albedo_a,
+                           const float* roughness_a, const float* metallic_a, const float* dL_dscales,
+                           const float* dL_drotations, const float* dL_dopacities, const float* dL_dalbedo_a,
+                           const float* dL_droughness_a, const float* dL_dmetallic_a, float* dL_dscaling, float* dL_drotation,
+                           float* dL_dopacity, float* dL_dalbedo, float* dL_droughness, float* dL_dmetallic, void* stream) {
+    if (P == 0) return GS2M_OK;
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if ((dL_dscaling && !(dL_dscales && scales)) || (dL_drotation && !(dL_drotations && rotation)) ||
+        (dL_dopacity && !(dL_dopacities && opacities)) || (dL_dalbedo && !(dL_dalbedo_a && albedo_a)) ||
+        (dL_droughness && !(dL_droughness_a && roughness_a)) || (dL_dmetallic && !(dL_dmetallic_a && metallic_a)))
+        return GS2M_ERR_INVALID_ARG;
+    if (dL_drotation && ((((uintptr_t)rotation) | ((uintptr_t)dL_drotations) | ((uintptr_t)dL_drotation)) & 15)) return GS2M_ERR_UNSUPPORTED;
+    ActGradPtrs a = {rotation, scales, opacities, albedo_a, roughness_a, metallic_a, dL_dscales, dL_drotations, dL_dopacities,
+                     dL_dalbedo_a, dL_droughness_a, dL_dmetallic_a, dL_dscaling, dL_drotation, dL_dopacity, dL_dalbedo,
+                     dL_droughness, dL_dmetallic};
+    activate_bwd_kernel<<<(P + 255) / 256, 256, 0, (hipStream_t)stream>>>(P, a);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

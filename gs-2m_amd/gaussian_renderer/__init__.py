@@ -37,19 +37,25 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
 
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    albedo = pc.get_albedo
-    roughness = pc.get_roughness
-    metallic = pc.get_metallic
-
     scales = None
     rotations = None
     cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance()
+    # pipe.fused_render_ops: the six parameter activations (the model's getters: exp, normalize, sigmoid x4) as one
+    # launch each way, when the model exposes the reference's raw parameter names
+    raw = [getattr(pc, n, None) for n in ("_scaling", "_rotation", "_opacity", "_albedo", "_roughness", "_metallic")]
+    if (bool(getattr(pipe, "fused_render_ops", True)) and bool(getattr(pipe, "fused_activations", True)) and not pipe.compute_cov3D_python
+            and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in raw)):
+        scales, rotations, opacity, albedo, roughness, metallic = gs2m_render_ops.activate(*raw)
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
+        opacity = pc.get_opacity
+        albedo = pc.get_albedo
+        roughness = pc.get_roughness
+        metallic = pc.get_metallic
+        if pipe.compute_cov3D_python:
+            cov3D_precomp = pc.get_covariance()
+        else:
+            scales = pc.get_scaling
+            rotations = pc.get_rotation
 
     shs = None
     shs_rest = None

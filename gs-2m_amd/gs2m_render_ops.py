@@ -132,6 +132,41 @@ def gbuffer_maps(buffer, rays, world_view_transform, z_depth=False):
     return _GBufferMaps.apply(buffer, rays, world_view_transform, z_depth)
 
 
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity, albedo, roughness, metallic):
+        raw = [_f32c(t, n) for t, n in zip((scaling, rotation, opacity, albedo, roughness, metallic),
+                                           ("_scaling", "_rotation", "_opacity", "_albedo", "_roughness", "_metallic"))]
+        P = raw[0].shape[0]
+        out = [torch.empty_like(t) for t in raw]
+        with torch.cuda.device(raw[0].device):
+            _native.check(_native.lib().gs2m_activate_forward(P, *[_ptr(t) for t in raw], *[_ptr(t) for t in out], _stream()),
+                          "gs2m_activate_forward")
+        ctx.save_for_backward(raw[1], out[0], *out[2:])
+        ctx.set_materialize_grads(False)  # an activation the loss never reaches gets no gradient (None), as with the getters
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rotation, scales, opac, alb, rgh, met = ctx.saved_tensors
+        P = rotation.shape[0]
+        need = [g is not None and ctx.needs_input_grad[k] for k, g in enumerate(grads)]
+        g = [_f32c(t, "grad") if n else None for t, n in zip(grads, need)]
+        like = (scales, rotation, opac, alb, rgh, met)
+        d = [torch.empty_like(t) if n else None for t, n in zip(like, need)]
+        with torch.cuda.device(rotation.device):
+            _native.check(_native.lib().gs2m_activate_backward(
+                P, _ptr(rotation), _ptr(scales), _ptr(opac), _ptr(alb), _ptr(rgh), _ptr(met), *[_ptr(t) for t in g],
+                *[_ptr(t) for t in d], _stream()), "gs2m_activate_backward")
+        return tuple(d)
+
+
+def activate(scaling, rotation, opacity, albedo, roughness, metallic):
+    """raw parameters -> (scales, rotations, opacity, albedo, roughness, metallic) as the GaussianModel getters compute
+    them (exp, F.normalize, sigmoid x4; scene/gaussian_model.py:113-144), one launch forward and one backward."""
+    return _Activate.apply(scaling, rotation, opacity, albedo, roughness, metallic)
+
+
 class _SobelNormal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, alpha, bg, view, fx, fy, cx, cy):

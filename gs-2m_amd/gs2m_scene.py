@@ -141,6 +141,7 @@ class PipelineParams:
     z_depth = False
     split_sh = True          # this repository's addition: hand _features_dc / _features_rest to the rasterizer unconcatenated
     fused_render_ops = True  # this repository's addition: fused HIP pre/post-processing in render() (gs2m_render_ops)
+    fused_activations = True  # ... and the model's activation getters as one launch (needs fused_render_ops)
 
 
 class Camera:

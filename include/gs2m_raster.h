@@ -244,6 +244,21 @@ int gs2m_sobel_normal_backward(int width, int height, const float* depth, const 
                                const float* view, float fx, float fy, float cx, float cy, const float* dL_dsobel,
                                float* dL_ddepth, float* dL_dalpha, void* stream);
 
+/* The GaussianModel getters render() calls for every view (scene/gaussian_model.py:113-144): scales = exp(_scaling),
+ * rotations = normalize(_rotation) (torch.nn.functional.normalize: x / max(|x|, 1e-12)), opacity / albedo / roughness /
+ * metallic = sigmoid(raw), as ONE launch forward and ONE backward instead of ~9 + ~14 PyTorch launches.  Any input
+ * pointer may be NULL (that activation is skipped; its output pointer is ignored).  Backward: a NULL dL_d<raw> output
+ * skips that group (used when the loss does not reach it, e.g. metallic without blend_metallic); the activated values
+ * are the forward's outputs, `rotation` is the raw quaternion.  (P,4) arrays must be 16-byte aligned. */
+int gs2m_activate_forward(int P, const float* scaling, const float* rotation, const float* opacity, const float* albedo,
+                          const float* roughness, const float* metallic, float* scales, float* rotations, float* opacities,
+                          float* albedo_a, float* roughness_a, float* metallic_a, void* stream);
+int gs2m_activate_backward(int P, const float* rotation, const float* scales, const float* opacities, const float* albedo_a,
+                           const float* roughness_a, const float* metallic_a, const float* dL_dscales,
+                           const float* dL_drotations, const float* dL_dopacities, const float* dL_dalbedo_a,
+                           const float* dL_droughness_a, const float* dL_dmetallic_a, float* dL_dscaling, float* dL_drotation,
+                           float* dL_dopacity, float* dL_dalbedo, float* dL_droughness, float* dL_dmetallic, void* stream);
+
 /* Forward: how the host waits for num_rendered.  1 (default): it polls the pinned landing zone of the 4-byte copy
  * (falls back to a stream synchronize after 2 s); 0: hipStreamSynchronize.  Same results. */
 int gs2m_set_spin_wait(int on);

@@ -161,6 +161,34 @@ def test_gbuffer_maps_matches_slices(z_depth, used):
     _close("grad buffer", buf.grad, g0, 1e-6)
 
 
+@pytest.mark.parametrize("P", [1, 255, 4099])
+def test_activate_matches_model_getters(P):
+    """The six GaussianModel getters (exp, F.normalize, sigmoid x4; GM:113-144) as one launch: values and gradients."""
+    assert torch.cuda.is_available()
+    import torch.nn.functional as F
+    import gs2m_render_ops as R
+    gen = torch.Generator().manual_seed(P)
+    shapes = [(P, 3), (P, 4), (P, 1), (P, 3), (P, 1), (P, 1)]
+    raw = [(torch.randn(s, generator=gen) * 2.0).cuda().requires_grad_(True) for s in shapes]
+    with torch.no_grad():
+        raw[1][0] = 0.0      # a zero quaternion: below F.normalize's eps clamp
+    G = [torch.randn(s, generator=gen).cuda() for s in shapes]
+    fns = [torch.exp, F.normalize, torch.sigmoid, torch.sigmoid, torch.sigmoid, torch.sigmoid]
+    ref = [f(t) for f, t in zip(fns, raw)]
+    sum((a * g).sum() for a, g in zip(ref[:5], G)).backward()      # metallic gets no gradient
+    g_ref = [None if t.grad is None else t.grad.clone() for t in raw]
+    for t in raw:
+        t.grad = None
+    got = R.activate(*raw)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b) if k != 1 else (a - b).abs().max().item() <= 1.2e-7, k   # exp / sigmoid bit-equal, normalize 1 ulp
+    sum((a * g).sum() for a, g in zip(got[:5], G)).backward()
+    for k, (t, g) in enumerate(zip(raw, g_ref)):
+        assert (t.grad is None) == (g is None), k
+        if g is not None:
+            assert (t.grad - g).abs().max().item() <= 2e-6 * max(1.0, g.abs().max().item()), k
+
+
 @pytest.mark.parametrize("material_stage,blend_metallic", [(True, False), (True, True), (False, False)])
 def test_render_fused_equals_unfused(material_stage, blend_metallic):
     """render() end to end: fused pre/post-processing against the reference's PyTorch formulation around the same
