@@ -17,8 +17,9 @@
 // V spans longitudes psi_V +- asin(sin(theta) / |V_xz|).
 //
 // 1, 16 or 64 lanes per output texel by the size of the cone (a 512^2 level with a sub-texel lobe has 1.5M outputs of
-// ~9 pairs, a 32^2 level with a 40-degree lobe 6k outputs of ~700); texel directions and areas come from a per-level
-// table the caller caches, so a pair is a 16-byte load, a dot product and, inside the cone, ~10 more operations.
+// ~11 pairs, a 128^2 level with a 15-degree lobe 98k outputs of ~1600).  A pair costs ~5 operations for the cone test
+// (directions are recomputed, not loaded: loading a 16-byte table row per pair made the kernel L2-bandwidth bound)
+// and, inside the cone, a 12-byte colour load and ~12 more operations.
 #include "common.h"
 #include "../../include/gs2m_cubemap.h"
 
@@ -30,6 +31,17 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 safe_normalize(V3 v) {  // render-utils c_src/vec3f.h:90-94
     const float l = sqrtf(dot3(v, v));
     return l > 0.f ? v3(v.x / l, v.y / l, v.z / l) : v3(0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ V3 face_point(int side, float fx, float fy) {  // unnormalised texel direction
+    switch (side) {
+        case 0: return v3(1.f, -fy, -fx);
+        case 1: return v3(-1.f, -fy, fx);
+        case 2: return v3(fx, 1.f, fy);
+        case 3: return v3(fx, -1.f, -fy);
+        case 4: return v3(fx, -fy, 1.f);
+        default: return v3(-fx, -fy, -1.f);
+    }
 }
 
 __device__ __forceinline__ V3 texel_dir(int x, int y, int side, int N) {  // cubemap.cu:32-46
@@ -83,12 +95,6 @@ __device__ __forceinline__ void cone_range(float u, float cz, float sin_t, int N
     hi = min((int)floorf((fminf(a1, 1.f) + 1.f) * (0.5f * (float)N)) + 1, N - 1);
 }
 
-__device__ __forceinline__ float ndf_ggx(float alpha_sqr, float cos_theta) {  // cubemap.cu:193-198
-    const float c = fminf(fmaxf(cos_theta, 0.f), 1.f);
-    const float d = (c * alpha_sqr - c) * c + 1.0f;
-    return alpha_sqr / (d * d * 3.14159265358979323846f);
-}
-
 // ---------------------------------------------------------------- diffuse
 template <bool BWD>
 __global__ void __launch_bounds__(64) diffuse_kernel(int N, const float* __restrict__ in, float* __restrict__ out) {
@@ -117,44 +123,54 @@ __global__ void __launch_bounds__(64) diffuse_kernel(int N, const float* __restr
 }
 
 // ---------------------------------------------------------------- specular
-// per-texel table: (direction, area), so a pair costs a 16-byte load, a dot product and -- inside the cone -- the lobe:
-// for unit vectors V . H = sqrt((1 + L . V) / 2), no half vector needed
-__global__ void __launch_bounds__(256) texel_table_kernel(int N, float4* __restrict__ tab) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 6 * N * N) return;
-    const int s = t / (N * N), y = (t / N) % N, x = t % N;
-    const V3 L = texel_dir(x, y, s, N);
-    tab[t] = make_float4(L.x, L.y, L.z, texel_area(x, y, N));
+// The texel directions need no table: in the frame of face s (face = plane z = 1) the texel centre is (fx, fy, 1) and
+//   L . V = (P_o . P_t) / (|P_o| |P_t|),   P = (+-1, +-fx, +-fy) permuted by the face,
+// three multiplies, two adds, a reciprocal square root and two multiplies per pair.  The area proxy is separable,
+// area(x, y) = ax[x] * ax[y]; ax is the one table (res floats), and for unit vectors V . H = sqrt((1 + L . V) / 2).
+__global__ void __launch_bounds__(256) axis_area_kernel(int N, float* __restrict__ ax) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N) return;
+    if (N <= 1) { ax[x] = 1.f; return; }
+    const int H = N / 2, k = abs(x - H);
+    ax[x] = atanf((float)(k + 1) / (float)H) - atanf((float)k / (float)H);
 }
 
 // forward: o = output texel, gathers inputs (3 channels in, 4 out); backward: o = input texel, gathers output gradients
 // (4 channels in, of which the 4th -- d/d wsum -- does not reach the cubemap; 3 out).  TPO lanes share one output texel
 // and stride over the box of every face (wide lobes on small levels would otherwise leave the chip empty).
 template <bool BWD, int TPO>
-__global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, float cos_cut, const float4* __restrict__ tab,
+__global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, float cos_cut, const float* __restrict__ ax,
                                                        const float* __restrict__ in, float* __restrict__ out) {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = 6 * N * N;
     const int o_raw = gt / TPO, sub = gt % TPO;
     const bool live = o_raw < total;
     const int o = live ? o_raw : total - 1;  // keep whole groups converged for the reduction
-    const float4 T = tab[o];
-    const V3 Vo = v3(T.x, T.y, T.z);
+    const int os = o / (N * N), oy = (o / N) % N, ox = o % N;
+    const V3 Vo = texel_dir(ox, oy, os, N);
     const float alpha = roughness * roughness, alpha_sqr = alpha * alpha;
     const float sin_t = sqrtf(fmaxf(1.f - cos_cut * cos_cut, 0.f));
     constexpr int IC = BWD ? 4 : 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
-    auto pair = [&](int t) {
-        const float4 L = tab[t];
-        const float d = L.x * Vo.x + L.y * Vo.y + L.z * Vo.z;
+    // D_ggx at cos^2(theta_h) = V.H^2 = (1 + L.V) / 2 for unit vectors: no half vector, no square root; the clamp of
+    // ndfGGX (cubemap.cu:193-198) cannot bind for L.V in [cutoff, 1]
+    const float pi_inv_a2 = alpha_sqr / 3.14159265358979323846f, a2m1h = 0.5f * (alpha_sqr - 1.f);
+    auto accumulate = [&](float d, float area, const float c0, const float c1, const float c2) {
         if (d >= cos_cut) {
-            const float k = fmaxf(d, 0.f) * ndf_ggx(alpha_sqr, sqrtf(fmaxf(0.5f + 0.5f * d, 0.f)));
-            const float w = BWD ? k : k * L.w * 0.25f;
-            const float* p = in + (size_t)t * IC;
-            a0 += w * p[0]; a1 += w * p[1]; a2 += w * p[2];
+            const float den = (1.f + d) * a2m1h + 1.f;                      // cos^2 (alpha^2 - 1) + 1
+            const float k = fmaxf(d, 0.f) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
+            const float w = BWD ? k : k * area * 0.25f;
+            a0 += w * c0; a1 += w * c1; a2 += w * c2;
             ws += w;
         }
     };
+    const float step = 2.0f / (float)N, org = 1.0f / (float)N - 1.0f;  // fx = org + step * x
+    // L . V must come out bit-identical whichever of the two texels plays the output (the backward applies the same
+    // cone test with the roles swapped; a pair accepted one way and rejected the other breaks the adjoint): products of
+    // the UNNORMALISED face points summed in world-axis order, times the product of the two reciprocal lengths
+    const float fxo = org + step * (float)ox, fyo = org + step * (float)oy;
+    const V3 Po = face_point(os, fxo, fyo);
+    const float ro = __builtin_amdgcn_rsqf((fxo * fxo + fyo * fyo) + 1.f);
     for (int s = 0; s < 6; s++) {
         const V3 c = to_face_frame(s, Vo);
         int x0, x1, y0, y1;
@@ -165,16 +181,23 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
             cone_range(c.y, c.z, sin_t, N, y0, y1);
             if (x0 > x1 || y0 > y1) continue;
         }
-        const int base = N * N * s;
-        if (TPO == 1) {
-            for (int y = y0; y <= y1; y++)
-                for (int x = x0; x <= x1; x++) pair(base + x + N * y);
-        } else {
-            const int wdt = x1 - x0 + 1, cnt = wdt * (y1 - y0 + 1);
-            const float inv = 1.0f / (float)wdt;
-            for (int idx = sub; idx < cnt; idx += TPO) {
-                const int row = (int)(((float)idx + 0.5f) * inv);  // exact for idx < 2^22
-                pair(base + x0 + (idx - row * wdt) + N * (y0 + row));
+        // the group's lanes stride along x; two rows per step so that two colour loads are in flight
+        for (int y = y0; y <= y1; y += 2) {
+            const bool two = y + 1 <= y1;
+            const int r0 = N * N * s + N * y, r1 = two ? r0 + N : r0;
+            const float fya = org + step * (float)y, fyb = fya + step;
+            const float aya = BWD ? 0.f : ax[y], ayb = BWD ? 0.f : ax[two ? y + 1 : y];
+            for (int x = x0 + sub; x <= x1; x += TPO) {
+                const float fx = org + step * (float)x;
+                const V3 Pa = face_point(s, fx, fya), Pb = face_point(s, fx, fyb);
+                const float da = ((Po.x * Pa.x + Po.y * Pa.y) + Po.z * Pa.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fya * fya) + 1.f));
+                const float db = ((Po.x * Pb.x + Po.y * Pb.y) + Po.z * Pb.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fyb * fyb) + 1.f));
+                const float* pa = in + (size_t)(r0 + x) * IC;
+                const float* pb = in + (size_t)(r1 + x) * IC;
+                const float ca0 = pa[0], ca1 = pa[1], ca2 = pa[2], cb0 = pb[0], cb1 = pb[1], cb2 = pb[2];
+                const float axx = BWD ? 0.f : ax[x];
+                accumulate(da, axx * aya, ca0, ca1, ca2);
+                if (two) accumulate(db, axx * ayb, cb0, cb1, cb2);
             }
         }
     }
@@ -186,7 +209,7 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
     }
     if (!live || sub != 0) return;
     if (BWD) {
-        const float k = T.w * 0.25f;
+        const float k = ax[ox] * ax[oy] * 0.25f;
         out[3 * (size_t)o] = a0 * k; out[3 * (size_t)o + 1] = a1 * k; out[3 * (size_t)o + 2] = a2 * k;
     } else {
         out[4 * (size_t)o] = a0; out[4 * (size_t)o + 1] = a1; out[4 * (size_t)o + 2] = a2; out[4 * (size_t)o + 3] = ws;
@@ -194,7 +217,7 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
 }
 
 template <bool BWD>
-int launch_specular(int res, float roughness, float cos_cut, const float4* tab, const float* in, float* out, hipStream_t s) {
+int launch_specular(int res, float roughness, float cos_cut, const float* tab, const float* in, float* out, hipStream_t s) {
     const long long total = 6LL * res * res;
     // expected texel pairs per output: the cone's share of the sphere
     const double pairs = 0.5 * (1.0 - (double)cos_cut) * (double)total;
@@ -221,22 +244,22 @@ int gs2m_diffuse_cubemap_backward(int res, const float* dL_dout, float* dL_dcube
 }
 
 int gs2m_cubemap_texel_table(int res, float* table, void* stream) {
-    if (res < 1 || res > 4096 || !table || ((uintptr_t)table & 15)) return GS2M_ERR_INVALID_ARG;
-    texel_table_kernel<<<(6 * res * res + 255) / 256, 256, 0, (hipStream_t)stream>>>(res, reinterpret_cast<float4*>(table));
+    if (res < 1 || res > 4096 || !table) return GS2M_ERR_INVALID_ARG;
+    axis_area_kernel<<<(res + 255) / 256, 256, 0, (hipStream_t)stream>>>(res, table);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 
 int gs2m_specular_cubemap_forward(int res, float roughness, float costheta_cutoff, const float* texel_table, const float* cubemap,
                                   float* out, void* stream) {
-    if (res < 1 || res > 4096 || !texel_table || ((uintptr_t)texel_table & 15) || !cubemap || !out) return GS2M_ERR_INVALID_ARG;
-    return launch_specular<false>(res, roughness, costheta_cutoff, reinterpret_cast<const float4*>(texel_table), cubemap, out,
+    if (res < 1 || res > 4096 || !texel_table || !cubemap || !out) return GS2M_ERR_INVALID_ARG;
+    return launch_specular<false>(res, roughness, costheta_cutoff, texel_table, cubemap, out,
                                   (hipStream_t)stream);
 }
 
 int gs2m_specular_cubemap_backward(int res, float roughness, float costheta_cutoff, const float* texel_table, const float* dL_dout,
                                    float* dL_dcubemap, void* stream) {
-    if (res < 1 || res > 4096 || !texel_table || ((uintptr_t)texel_table & 15) || !dL_dout || !dL_dcubemap) return GS2M_ERR_INVALID_ARG;
-    return launch_specular<true>(res, roughness, costheta_cutoff, reinterpret_cast<const float4*>(texel_table), dL_dout, dL_dcubemap,
+    if (res < 1 || res > 4096 || !texel_table || !dL_dout || !dL_dcubemap) return GS2M_ERR_INVALID_ARG;
+    return launch_specular<true>(res, roughness, costheta_cutoff, texel_table, dL_dout, dL_dcubemap,
                                  (hipStream_t)stream);
 }
 

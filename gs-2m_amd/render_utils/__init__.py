@@ -52,10 +52,10 @@ _tables = {}
 
 
 def _texel_table(res, device):
-    """(6, res, res, 4) texel directions + areas of one cube-map level, cached per (device, res)."""
+    """(res,) separable texel-area factors of one cube-map level, cached per (device, res)."""
     key = (str(device), int(res))
     if key not in _tables:
-        t = torch.empty((6, res, res, 4), dtype=torch.float32, device=device)
+        t = torch.empty((res,), dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             _native.check(_native.lib().gs2m_cubemap_texel_table(res, t.data_ptr(), _stream(device)), "gs2m_cubemap_texel_table")
         _tables[key] = t

@@ -19,8 +19,8 @@ extern "C" {
 int gs2m_diffuse_cubemap_forward(int res, const float* cubemap, float* out, void* stream);
 int gs2m_diffuse_cubemap_backward(int res, const float* dL_dout, float* dL_dcubemap, void* stream);
 
-/* Per-level table of texel directions and areas, (6, res, res, 4) floats, 16-byte aligned: fill once per resolution and
- * keep (it depends on nothing else).  Needed by the specular operator. */
+/* Per-level table of the separable texel-area factors, `res` floats (area(x, y) = table[x] * table[y]): fill once per
+ * resolution and keep (it depends on nothing else).  Needed by the specular operator. */
 int gs2m_cubemap_texel_table(int res, float* table, void* stream);
 
 /* cubemap, dL_dcubemap: (6, res, res, 3); out, dL_dout: (6, res, res, 4) = (weighted colour sum, weight sum) -- the
