@@ -15,8 +15,17 @@ def pbr_render(scene, viewpoint_cam, canonical_rays, render_pkg, metallic, gamma
     the reference (:25-43)."""
     scene.cubemap.build_mips()
     H, W = viewpoint_cam.image_height, viewpoint_cam.image_width
-    c2w = viewpoint_cam.world_view_transform[:3, :3]
-    view_dirs = F.normalize(-canonical_rays @ c2w.T, p=2, dim=-1).reshape(H, W, 3)
+    # view directions: constant per camera, kept on it (an (H W, 3) x (3, 3) product is a BLAS call on ROCm, 0.13 ms at 1080p)
+    cache = getattr(viewpoint_cam, "_pbr_view_dirs", None)
+    if cache is None or cache[0] != (canonical_rays.data_ptr(), canonical_rays._version, H, W):
+        c2w = viewpoint_cam.world_view_transform[:3, :3]
+        view_dirs = F.normalize(-canonical_rays @ c2w.T, p=2, dim=-1).reshape(H, W, 3)
+        try:
+            viewpoint_cam._pbr_view_dirs = ((canonical_rays.data_ptr(), canonical_rays._version, H, W), view_dirs)
+        except AttributeError:
+            pass
+    else:
+        view_dirs = cache[1]
 
     normal_map = render_pkg["normal_map"].detach()
     normal_map = torch.where(torch.norm(normal_map, dim=0, keepdim=True) > 0, F.normalize(normal_map, dim=0, p=2), normal_map)

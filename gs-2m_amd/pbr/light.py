@@ -19,8 +19,19 @@ def cube_to_dir(s: int, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return torch.stack(table[s], dim=-1)
 
 
+_dirs_cache = {}
+
+
 def _texel_center_dirs(res, device):
-    """(6, res, res, 3) unit directions of the texel centres."""
+    """(6, res, res, 3) unit directions of the texel centres (constant per resolution: cached; the reference rebuilds
+    them in every backward call, ~25 small launches per level)."""
+    key = (str(device), int(res))
+    if key not in _dirs_cache:
+        _dirs_cache[key] = _build_texel_center_dirs(res, device)
+    return _dirs_cache[key]
+
+
+def _build_texel_center_dirs(res, device):
     c = torch.linspace(-1.0 + 1.0 / res, 1.0 - 1.0 / res, res, device=device)
     gy, gx = torch.meshgrid(c, c, indexing="ij")
     return torch.stack([F.normalize(cube_to_dir(s, gx, gy), p=2, dim=-1) for s in range(6)], dim=0)
