@@ -86,6 +86,59 @@ def ref_model_helpers():
     print("wrote ref_model.npz")
 
 
+def colmap_small():
+    """(4) colmap_small/ -- a small synthetic COLMAP binary model (written by gs2m_colmap.write_model: the files are test
+    DATA) and colmap_small.npz -- what the REFERENCE's reader (scene/colmap_loader.py:123-240, loaded as a standalone
+    module: scene/__init__ needs plyfile) and camera conventions (qvec2rotmat :41-51, getNerfppNorm's arithmetic via
+    utils/graphics_utils.getWorld2View2) return for them."""
+    import importlib.util
+    import gs2m_colmap as C
+    rng = np.random.default_rng(7)
+    folder = os.path.join(HERE, "colmap_small")
+    cams = [C.Camera(1, "PINHOLE", 640, 360, np.array([700.5, 701.25, 320.0, 180.0])),
+            C.Camera(2, "SIMPLE_PINHOLE", 800, 600, np.array([910.0, 400.0, 300.0]))]
+    images = []
+    for k in range(5):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        if q[0] < 0: q = -q
+        m = int(rng.integers(0, 6))
+        images.append(C.Image(10 + k, q, rng.normal(size=3) * 3, 1 + k % 2, f"rect_{k:03d}_3_r5000.png",
+                              rng.uniform(0, 600, size=(m, 2)), rng.integers(-1, 40, size=m)))
+    xyz = rng.normal(size=(23, 3)) * 2
+    rgb = rng.integers(0, 256, size=(23, 3))
+    err = rng.uniform(0, 2, size=23)
+    C.write_model(folder, cams, images, xyz, rgb, err)
+    spec = importlib.util.spec_from_file_location("ref_colmap_loader", "/root/reference/scene/colmap_loader.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    sys.path.insert(0, "/root/reference")
+    from utils.graphics_utils import getWorld2View2
+    out = {}
+    rc = ref.read_intrinsics_binary(os.path.join(folder, "cameras.bin"))
+    out["cam_ids"] = np.array(sorted(rc))
+    for cid in rc:
+        out[f"cam{cid}_model"] = np.array(rc[cid].model)
+        out[f"cam{cid}_wh"] = np.array([rc[cid].width, rc[cid].height])
+        out[f"cam{cid}_params"] = rc[cid].params
+    ri = ref.read_extrinsics_binary(os.path.join(folder, "images.bin"))
+    out["img_ids"] = np.array(list(ri))          # file order
+    centres = []
+    for iid, im in ri.items():
+        out[f"img{iid}_qvec"], out[f"img{iid}_tvec"], out[f"img{iid}_cam"] = im.qvec, im.tvec, np.array(im.camera_id)
+        out[f"img{iid}_name"], out[f"img{iid}_xys"], out[f"img{iid}_p3d"] = np.array(im.name), im.xys.reshape(-1, 2), im.point3D_ids
+        R = np.transpose(ref.qvec2rotmat(im.qvec))
+        out[f"img{iid}_R"] = R
+        centres.append(np.linalg.inv(getWorld2View2(R, np.array(im.tvec)))[:3, 3:4])
+    cc = np.hstack(centres)
+    centre = np.mean(cc, axis=1, keepdims=True)
+    out["norm_translate"] = -centre.flatten()
+    out["norm_radius"] = np.array(np.max(np.linalg.norm(cc - centre, axis=0, keepdims=True)) * 1.1)
+    x, c, e = ref.read_points3D_binary(os.path.join(folder, "points3D.bin"))
+    out["pts_xyz"], out["pts_rgb"], out["pts_err"] = x, c, e
+    np.savez_compressed(os.path.join(HERE, "colmap_small.npz"), **out)
+    print("wrote colmap_small/ and colmap_small.npz")
+
+
 def raster_small():
     import helpers as Hh
     from oracle import oracle
@@ -109,6 +162,10 @@ if __name__ == "__main__":
     if "--model-only" in sys.argv:
         ref_model_helpers()
         sys.exit(0)
+    if "--colmap-only" in sys.argv:
+        colmap_small()
+        sys.exit(0)
     ref_helpers()
     ref_model_helpers()
+    colmap_small()
     raster_small()

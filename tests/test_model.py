@@ -96,3 +96,37 @@ def test_prune_and_cat_keep_parameters_and_adam_state_aligned():
         assert torch.equal(st["exp_avg"][:40], before[g["name"]][1][~mask])
     m.reset_opacity()
     assert (m.get_opacity <= 0.01 + 1e-6).all() and not m.optimizer.state[m._opacity]["exp_avg"].any()
+
+
+def test_colmap_reader_matches_the_reference_reader(tmp_path):
+    """tests/golden/colmap_small/*.bin parsed by gs2m_colmap against what the reference's own reader returned for the
+    same files (tests/golden/colmap_small.npz, generated by make_golden.py), plus a write -> read round trip."""
+    import gs2m_colmap as C
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(here, "colmap_small.npz"))
+    folder = os.path.join(here, "colmap_small")
+    cams = C.read_intrinsics_binary(os.path.join(folder, "cameras.bin"))
+    assert sorted(cams) == list(d["cam_ids"])
+    for cid, c in cams.items():
+        assert c.model == str(d[f"cam{cid}_model"]) and [c.width, c.height] == list(d[f"cam{cid}_wh"])
+        assert np.array_equal(c.params, d[f"cam{cid}_params"])
+    imgs = C.read_extrinsics_binary(os.path.join(folder, "images.bin"))
+    assert list(imgs) == list(d["img_ids"])
+    for iid, im in imgs.items():
+        assert np.array_equal(im.qvec, d[f"img{iid}_qvec"]) and np.array_equal(im.tvec, d[f"img{iid}_tvec"])
+        assert im.camera_id == int(d[f"img{iid}_cam"]) and im.name == str(d[f"img{iid}_name"])
+        assert np.array_equal(im.xys.reshape(-1, 2), d[f"img{iid}_xys"]) and np.array_equal(im.point3D_ids, d[f"img{iid}_p3d"])
+        assert np.array_equal(np.transpose(C.qvec2rotmat(im.qvec)), d[f"img{iid}_R"])
+    infos = C.colmap_cameras(imgs, cams)
+    assert [i.Fx for i in infos][:2] == [700.5, 910.0] and [i.Fy for i in infos][:2] == [701.25, 910.0]   # PINHOLE fx, fy; SIMPLE_PINHOLE f, f
+    norm = C.nerf_normalization(infos)
+    np.testing.assert_allclose(norm["translate"], d["norm_translate"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(norm["radius"], float(d["norm_radius"]), rtol=1e-12)
+    xyz, rgb, err = C.read_points3D_binary(os.path.join(folder, "points3D.bin"))
+    assert np.array_equal(xyz, d["pts_xyz"]) and np.array_equal(rgb, d["pts_rgb"]) and np.array_equal(err, d["pts_err"])
+    # round trip through the writer, and quaternion <-> matrix
+    C.write_model(str(tmp_path), cams.values(), imgs.values(), xyz, rgb, err)
+    for name in ("cameras.bin", "images.bin", "points3D.bin"):
+        assert open(os.path.join(folder, name), "rb").read() == open(os.path.join(str(tmp_path), name), "rb").read()
+    for im in imgs.values():
+        np.testing.assert_allclose(C.rotmat2qvec(C.qvec2rotmat(im.qvec)), im.qvec, atol=1e-12)
