@@ -144,12 +144,7 @@ def colmap_cameras(extrinsics, intrinsics):
 def nerf_normalization(cam_infos):
     """getNerfppNorm (scene/dataset_readers.py:49-70): translate = -mean camera centre, radius = 1.1 x the largest
     distance of a camera centre from that mean (the `cameras_extent` densification thresholds are scaled by)."""
-    centres = []
-    for c in cam_infos:
-        Rt = np.eye(4)
-        Rt[:3, :3] = c.R.transpose()
-        Rt[:3, 3] = c.T
-        centres.append(np.linalg.inv(Rt)[:3, 3])
-    centres = np.stack(centres, axis=1)
+    from gs2m_synth import world2view   # getWorld2View2: returns float32, and the reference inverts THAT
+    centres = np.stack([np.linalg.inv(world2view(c.R, c.T))[:3, 3] for c in cam_infos], axis=1)
     centre = centres.mean(axis=1, keepdims=True)
     return {"translate": -centre.flatten(), "radius": float(np.linalg.norm(centres - centre, axis=0).max() * 1.1)}
