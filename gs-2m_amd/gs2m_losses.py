@@ -1,6 +1,6 @@
 """The per-iteration loss terms of the reference's training loop (train.py:101-130) that are plain PyTorch there and
 stay PyTorch here, restated from utils/loss_utils.py (l1_loss :27-28, plane_loss :72-79, depth_normal_loss :113-120,
-_get_img_grad_weight :122-135).  The D-SSIM term is the `fused_ssim` package (HIP)."""
+_get_img_grad_weight :122-135, tv_loss :536-557).  The D-SSIM term is the `fused_ssim` package (HIP)."""
 import torch
 import torch.nn.functional as F
 
@@ -33,3 +33,17 @@ def depth_normal_loss(normal_map, sobel_map, gt_image, weight_map=None):
     if weight_map is not None:
         weights = weights * weight_map.squeeze()
     return (weights * (sobel_map - normal_map).abs().sum(dim=0)).mean()
+
+
+def tv_loss(gt_image, pred, norm1=True, weight_map=None):
+    """Edge-aware total variation of `pred` (C,H,W): neighbour differences (L1, or squared with norm1=False) damped where the
+    reference image (3,H,W) has an edge, optionally weighted per pixel (1,H,W)."""
+    edge_h = torch.exp(-(gt_image[:, 1:, :] - gt_image[:, :-1, :]).abs().mean(dim=0, keepdim=True))
+    edge_w = torch.exp(-(gt_image[:, :, 1:] - gt_image[:, :, :-1]).abs().mean(dim=0, keepdim=True))
+    dh, dw = pred[:, 1:, :] - pred[:, :-1, :], pred[:, :, 1:] - pred[:, :, :-1]
+    loss_h = (dh.abs() if norm1 else dh * dh) * edge_h
+    loss_w = (dw.abs() if norm1 else dw * dw) * edge_w
+    if weight_map is not None:
+        loss_h = loss_h * ((weight_map[:, 1:, :] + weight_map[:, :-1, :]) / 2.0)
+        loss_w = loss_w * ((weight_map[:, :, 1:] + weight_map[:, :, :-1]) / 2.0)
+    return loss_h.mean() + loss_w.mean()

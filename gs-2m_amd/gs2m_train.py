@@ -1,8 +1,10 @@
-"""The reference's training iteration (train.py:76-262) on MI355X, for the stages this repository covers: the RGB
-stage and the geometry stage without the multi-view term (no PBR shading): render -> clamp -> (1 - l) L1 + l (1 - SSIM)
-+ plane loss (+ depth-normal loss from `geometry_from_iter`) -> backward -> densification statistics -> densify / prune /
-opacity reset on the reference's schedule -> fused Adam step.  Every device-side piece is this repository's: the
-rasterizer, the fused render() pre/post-processing, fused_ssim, gs2m_optim.Adam, distCUDA2.
+"""The reference's training iteration (train.py:76-262) on MI355X: the RGB stage, the geometry stage and the material
+stage, without the two multi-view terms (multi_view_loss, roughness_loss: SURVEY.md 8(f) row N4): render -> clamp ->
+(1 - l) L1 + l (1 - SSIM) + plane loss (+ depth-normal loss from `geometry_from_iter`; from `material_from_iter` the
+RGB term is replaced by the deferred PBR shading's L1 / D-SSIM plus the edge-aware smoothness terms, and the environment
+light gets its own Adam) -> backward -> densification statistics -> densify / prune / opacity reset on the reference's
+schedule -> fused Adam step(s).  Every device-side piece is this repository's: the rasterizer, the fused render()
+pre/post-processing, fused_ssim, the PBR stage (texture lookups, cubemap prefilters), gs2m_optim.Adam, distCUDA2.
 
 There is no dataset on the GPU box, so the scene is synthetic (SURVEY.md 8(d) C4 says to substitute and say so):
 `synthetic_scene()` renders ground-truth views of a known surface-aligned Gaussian object with this rasterizer and
@@ -25,7 +27,7 @@ import torch
 import gs2m_synth as S
 from fused_ssim import fused_ssim
 from gaussian_renderer import render
-from gs2m_losses import depth_normal_loss, l1_loss, plane_loss
+from gs2m_losses import depth_normal_loss, l1_loss, plane_loss, tv_loss
 from gs2m_model import GaussianModel, OptimizationParams
 from gs2m_scene import Camera, GaussianParams, PipelineParams, inverse_sigmoid
 
@@ -53,10 +55,22 @@ def synthetic_scene(n_true=60_000, n_views=12, W=640, H=360, init_frac=0.15, see
     return cams, gts, pts.numpy(), cols.numpy(), extent
 
 
+class _Lighting:
+    """What pbr_render needs of the reference's Scene (scene/__init__.py:44-46, 144-148)."""
+
+    def __init__(self, base_res, lr, device):
+        from pbr import CubemapLight, get_brdf_lut
+        import gs2m_optim
+        self.cubemap = CubemapLight(base_res=base_res, device=device)
+        self.brdf_lut = get_brdf_lut().to(device)
+        self.light_optimizer = gs2m_optim.Adam([{"name": "cubemap", "params": list(self.cubemap.parameters()), "lr": lr}], lr=lr)
+
+
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
-          device="cuda", scene=None):
+          device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1):
     opt = opt or OptimizationParams()
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
+    material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
     cams, gts, pts, cols, extent = scene or synthetic_scene(n_true, n_views, W, H, seed=seed, device=device)
     torch.manual_seed(seed)
     gaussians = GaussianModel(3, device)
@@ -68,7 +82,12 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         with torch.no_grad():
             return sum(psnr(render(c, gaussians, pipe, bg)["render"].clamp(0, 1), gt) for c, gt in zip(cams, gts)) / len(cams)
 
-    stats = dict(psnr_start=evaluate(), points_start=gaussians.get_xyz.shape[0])
+    lighting, rays = None, {}
+    if material_from_iter < iterations:
+        from pbr import pbr_render
+        import torch.nn.functional as F
+        lighting = _Lighting(light_res, opt.opacity_lr, device)
+    stats = dict(psnr_start=evaluate(), points_start=gaussians.get_xyz.shape[0], pbr_loss=[])
     order = torch.Generator().manual_seed(seed)
     stack = []
     torch.cuda.synchronize()
@@ -82,13 +101,26 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         k = stack.pop()
         cam, gt = cams[k], gts[k]
         geometry_stage = it > geometry_from_iter
-        out = render(cam, gaussians, pipe, bg, geometry_stage, False, sobel_normal=geometry_stage)
+        material_stage = it > material_from_iter
+        out = render(cam, gaussians, pipe, bg, geometry_stage, material_stage, sobel_normal=geometry_stage)
         vis, radii = out["visibility_filter"], out["radii"]
         rgb = out["render"].clamp(0, 1)
-        Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
-        loss = (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim + opt.lambda_plane * plane_loss(vis, gaussians)
+        loss = opt.lambda_plane * plane_loss(vis, gaussians)
+        if not material_stage:  # train.py:101-115
+            Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
+            loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
             loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], gt_image=gt)
+        if material_stage:  # train.py:132-196 without roughness_loss
+            if k not in rays:
+                rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
+            pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
+            pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
+            Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - fused_ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+            Lsm = lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
+            wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
+            loss = loss + Lpbr + Lsm + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn)
+            stats["pbr_loss"].append(Lpbr.item())
         loss.backward()
         with torch.no_grad():
             if it <= opt.densify_until_iter:
@@ -102,11 +134,16 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             if it < iterations:
                 gaussians.optimizer.step()
                 gaussians.optimizer.zero_grad(set_to_none=True)
+                if material_stage:  # train.py:260-263
+                    lighting.light_optimizer.step()
+                    lighting.light_optimizer.zero_grad(set_to_none=True)
+                    lighting.cubemap.clamp_(min=0.0)
         if log and it % log == 0:
             print(f"[{it:6d}] loss {loss.item():.5f}  points {gaussians.get_xyz.shape[0]}", flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stats.update(psnr_end=evaluate(), points_end=gaussians.get_xyz.shape[0], seconds=dt, it_per_s=iterations / dt, loss_end=loss.item())
+    stats["lighting"] = lighting
     return gaussians, stats
 
 
@@ -120,6 +157,6 @@ if __name__ == "__main__":
     ap.add_argument("--save-ply", default=None)
     a = ap.parse_args()
     model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10))
-    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items() if k not in ("pbr_loss", "lighting")})
     if a.save_ply:
         model.save_ply(a.save_ply)
