@@ -66,6 +66,47 @@ class _Lighting:
         self.light_optimizer = gs2m_optim.Adam([{"name": "cubemap", "params": list(self.cubemap.parameters()), "lr": lr}], lr=lr)
 
 
+def export_colmap_dataset(folder, scene):
+    """Write a scene (cameras, gt_images, points, colors, extent) as a COLMAP-format dataset the reference's loader
+    understands (scene/dataset_readers.py:141-197): `sparse/0/{cameras,images,points3D}.bin` and `images/*.png`."""
+    import numpy as np
+    from PIL import Image as PILImage
+    import gs2m_colmap as C
+    cams, gts, pts, cols, _ = scene
+    os.makedirs(os.path.join(folder, "images"), exist_ok=True)
+    cameras, images = [], []
+    for k, (cam, gt) in enumerate(zip(cams, gts)):
+        W2C = cam.world_view_transform.transpose(0, 1).double().cpu().numpy()   # rows of the 4x4 world-to-camera matrix
+        cameras.append(C.Camera(k + 1, "PINHOLE", cam.image_width, cam.image_height,
+                                np.array([cam.Fx, cam.Fy, 0.5 * cam.image_width, 0.5 * cam.image_height], dtype=np.float64)))
+        name = f"view_{k:03d}.png"
+        images.append(C.Image(k + 1, C.rotmat2qvec(W2C[:3, :3]), W2C[:3, 3], k + 1, name, None, None))
+        arr = (gt.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0 + 0.5).astype(np.uint8)
+        PILImage.fromarray(arr).save(os.path.join(folder, "images", name))
+    C.write_model(os.path.join(folder, "sparse", "0"), cameras, images, np.asarray(pts, dtype=np.float64),
+                  (np.asarray(cols) * 255.0 + 0.5).astype(np.uint8))
+
+
+def load_colmap_dataset(folder, images="images", device="cuda"):
+    """COLMAP-format dataset -> the `scene` tuple `train()` takes: cameras with the reference's matrices
+    (scene/cameras.py:58-67), ground-truth images, the sparse points and colours, and the scene radius
+    (readColmapSceneInfo, scene/dataset_readers.py:141-197; images sorted by name, PINHOLE / SIMPLE_PINHOLE only)."""
+    import numpy as np
+    from PIL import Image as PILImage
+    import gs2m_colmap as C
+    sparse = os.path.join(folder, "sparse", "0")
+    intr = C.read_intrinsics_binary(os.path.join(sparse, "cameras.bin"))
+    infos = sorted(C.colmap_cameras(C.read_extrinsics_binary(os.path.join(sparse, "images.bin")), intr), key=lambda c: c.image_name)
+    cams, gts = [], []
+    for info in infos:
+        img = PILImage.open(os.path.join(folder, images, info.image_name)).convert("RGB")
+        assert img.size == (info.width, info.height), "image size differs from the COLMAP camera (rescaling is not implemented)"
+        gts.append(torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous().to(device))
+        cams.append(Camera(S.make_camera(info.width, info.height, fx=info.Fx, fy=info.Fy, R=info.R, T=info.T), device))
+    xyz, rgb, _ = C.read_points3D_binary(os.path.join(sparse, "points3D.bin"))
+    return cams, gts, xyz.astype(np.float32), (rgb / 255.0).astype(np.float32), C.nerf_normalization(infos)["radius"]
+
+
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1):
     opt = opt or OptimizationParams()
@@ -155,8 +196,14 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=12)
     ap.add_argument("--true-gaussians", type=int, default=60_000)
     ap.add_argument("--save-ply", default=None)
+    ap.add_argument("--source-path", "-s", default=None, help="COLMAP-format dataset (sparse/0/*.bin + images/); default: synthetic scene")
+    ap.add_argument("--export-colmap", default=None, help="write the synthetic scene as a COLMAP-format dataset to this folder and exit")
     a = ap.parse_args()
-    model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10))
+    if a.export_colmap:
+        export_colmap_dataset(a.export_colmap, synthetic_scene(a.true_gaussians, a.views, a.width, a.height))
+        sys.exit(0)
+    scene = load_colmap_dataset(a.source_path) if a.source_path else None
+    model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10), scene=scene)
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items() if k not in ("pbr_loss", "lighting")})
     if a.save_ply:
         model.save_ply(a.save_ply)

@@ -90,3 +90,29 @@ def test_material_stage_runs_and_its_loss_falls():
     # the albedo is being trained now (the roughness only through roughness_loss, row N4: pbr_render detaches it)
     p = [g["params"][0] for g in model.optimizer.param_groups if g["name"] == "albedo"][0]
     assert model.optimizer.state[p]["exp_avg"].abs().sum().item() > 0
+
+
+def test_colmap_format_dataset_round_trip_and_training(tmp_path):
+    """SURVEY.md 8(d) C4 substitute: the synthetic scene written as a COLMAP-format dataset (sparse/0/*.bin + images/*.png),
+    read back through the COLMAP loader path -- same cameras (matrices to fp32 rounding), 8-bit images, points -- and
+    trained from."""
+    assert torch.cuda.is_available()
+    import gs2m_train
+    from gs2m_model import OptimizationParams
+    scene = gs2m_train.synthetic_scene(n_true=20_000, n_views=6, W=320, H=180)
+    gs2m_train.export_colmap_dataset(str(tmp_path), scene)
+    loaded = gs2m_train.load_colmap_dataset(str(tmp_path))
+    assert len(loaded[0]) == 6
+    for a, b in zip(scene[0], loaded[0]):
+        assert (a.image_width, a.image_height) == (b.image_width, b.image_height)
+        assert (a.world_view_transform - b.world_view_transform).abs().max().item() < 2e-6
+        assert (a.full_proj_transform - b.full_proj_transform).abs().max().item() < 1e-5
+        assert (a.camera_center - b.camera_center).abs().max().item() < 1e-5
+    for a, b in zip(scene[1], loaded[1]):
+        assert (a - b).abs().max().item() <= 0.5 / 255 + 1e-6
+    assert abs(scene[4] - loaded[4]) < 1e-4 * scene[4] and loaded[2].shape == scene[2].shape
+    assert abs(loaded[2] - scene[2]).max() < 1e-6 and abs(loaded[3] - scene[3]).max() <= 0.5 / 255 + 1e-6
+    opt = OptimizationParams()
+    opt.densify_from_iter, opt.densification_interval = 100, 50
+    _, st = gs2m_train.train(iterations=250, opt=opt, scene=loaded)
+    assert st["psnr_end"] > st["psnr_start"] + 4.0, st
