@@ -26,6 +26,7 @@
 // the atomic rate.
 #include "common.h"
 #include "../../include/gs2m_texture.h"
+#include "../../include/gs2m_pbr.h"
 
 namespace {
 
@@ -269,15 +270,11 @@ __global__ void __launch_bounds__(TEX_BWD_THREADS) texture_bwd_kernel(int n, Mip
             const int key = live ? (level << 24) | F.t[k] : -1;
             if (run_merge<C>(key, v)) {
                 if (loff >= 0) {
-#ifndef GS2M_TEX_NO_LDS_ATOMICS
 #pragma unroll
                     for (int c = 0; c < C; c++) atomicAdd(&s_acc[loff + F.t[k] * C + c], v[c]);  // ds_add_f32
-#endif
                 } else {
-#ifndef GS2M_TEX_NO_GLOBAL_ATOMICS
 #pragma unroll
                     for (int c = 0; c < C; c++) unsafeAtomicAdd(&M.grad[level][(size_t)F.t[k] * C + c], v[c]);
-#endif
                 }
             }
         }
@@ -373,6 +370,146 @@ int launch_bwd(int C, int n, MipStack& M, int height, const float* uv, const flo
     }
 }
 
+
+// ---------------------------------------------------------------- fused deferred shading (pbr/shade.py:130-213)
+// pbr_shading as ONE kernel each way: reflection vector, the three lookups (irradiance by the normal, environment BRDF by
+// (N.V, roughness), prefiltered radiance by the reflection vector at the roughness' level) and the split-sum combination
+//   rgb = clamp(E(n) albedo + L(r) (F0 A + B), 0, 1),   F0 = 0.04 (1 - m) + albedo m.
+// The PyTorch formulation is ~30 launches forward and ~50 backward over (H, W, 3) tensors with the lookups in between.
+struct ShadeIn {
+    const float* normals; const float* view_dirs; const float* albedo; const float* roughness; const float* metallic;  // metallic may be NULL
+    const float* lut; int lut_w, lut_h;
+    const float* diffuse; float* d_diffuse; int diffuse_w, diffuse_lds;  // lds: float offset of the private copy or -1
+    float min_r, max_r;
+};
+
+struct ShadePixel {  // everything both directions need for one pixel
+    float n[3], a[3], m, fgA, fgB, E[3], L[3], fl;
+    int l0, l1;
+    bool two;
+    Footprint Fd, F0, F1;
+};
+
+__device__ __forceinline__ ShadePixel shade_eval(const ShadeIn& P, const MipStack& M, size_t i) {
+    ShadePixel s;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { s.n[c] = P.normals[3 * i + c]; v[c] = P.view_dirs[3 * i + c]; s.a[c] = P.albedo[3 * i + c]; }
+    const float r = P.roughness[i];
+    s.m = P.metallic != nullptr ? P.metallic[i] : 0.f;
+    const float ndv = s.n[0] * v[0] + s.n[1] * v[1] + s.n[2] * v[2];
+    const float k = 2.0f * fmaxf(ndv, 0.f);
+    const float rx = k * s.n[0] - v[0], ry = k * s.n[1] - v[1], rz = k * s.n[2] - v[2];
+    // CubemapLight.get_mip (pbr/light.py:72-84), then the clamp of the lookup (textureCUDA.cu:575-589)
+    const int nl = M.levels;
+    float fl = r < P.max_r ? (fminf(fmaxf(r, P.min_r), P.max_r) - P.min_r) / (P.max_r - P.min_r) * (float)(nl - 2)
+                           : (fminf(fmaxf(r, P.max_r), 1.0f) - P.max_r) / (1.0f - P.max_r) + (float)(nl - 2);
+    fl = fminf(fmaxf(fl, 0.f), (float)(nl - 1));
+    s.l0 = (int)floorf(fl); s.l1 = s.l0; s.two = fl > 0.f;
+    if (s.two) { s.l1 = min(s.l0 + 1, nl - 1); fl -= (float)s.l0; }
+    s.fl = fl;
+    s.Fd = cube_footprint(s.n[0], s.n[1], s.n[2], P.diffuse_w);
+    sample<3>(P.diffuse, s.Fd, s.E);
+    float fg[2];
+    sample<2>(P.lut, clamp2d_footprint(fminf(fmaxf(ndv, 1e-4f), 1.0f), r, P.lut_w, P.lut_h), fg);
+    s.fgA = fg[0]; s.fgB = fg[1];
+    s.F0 = cube_footprint(rx, ry, rz, M.width[s.l0]);
+    sample<3>(M.tex[s.l0], s.F0, s.L);
+    if (s.two) {
+        s.F1 = cube_footprint(rx, ry, rz, M.width[s.l1]);
+        float L1[3];
+        sample<3>(M.tex[s.l1], s.F1, L1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) s.L[c] = lerpf(s.L[c], L1[c], fl);
+    } else {
+        s.F1 = s.F0;
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(256) shade_fwd_kernel(int n, ShadeIn P, MipStack M, float* __restrict__ rgb, float* __restrict__ diffuse_rgb,
+                                                        float* __restrict__ specular_rgb, float* __restrict__ diffuse_light) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ShadePixel s = shade_eval(P, M, (size_t)i);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float F0 = P.metallic != nullptr ? (1.0f - s.m) * 0.04f + s.a[c] * s.m : 0.04f;
+        const float d = s.E[c] * s.a[c], sp = s.L[c] * (F0 * s.fgA + s.fgB);
+        rgb[3 * (size_t)i + c] = fminf(fmaxf(d + sp, 0.f), 1.f);
+        if (diffuse_rgb != nullptr) diffuse_rgb[3 * (size_t)i + c] = d;
+        if (specular_rgb != nullptr) specular_rgb[3 * (size_t)i + c] = sp;
+        if (diffuse_light != nullptr) diffuse_light[3 * (size_t)i + c] = s.E[c];
+    }
+}
+
+__global__ void __launch_bounds__(TEX_BWD_THREADS) shade_bwd_kernel(int n, ShadeIn P, MipStack M, const float* __restrict__ d_rgb,
+                                                                    float* __restrict__ d_albedo, float* __restrict__ d_metallic) {
+    extern __shared__ float s_acc[];
+    const int lds_total = M.lds_floats + (P.diffuse_lds >= 0 ? 6 * P.diffuse_w * P.diffuse_w * 3 : 0);
+    for (int k = threadIdx.x; k < lds_total; k += TEX_BWD_THREADS) s_acc[k] = 0.f;
+    __syncthreads();
+    auto add = [&](bool on, int key_hi, int loff, float* gptr, const Footprint& F, const float (&g)[3], float scale) {
+        float wt[4];
+        footprint_weights(F, wt);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool live = on && F.t[k] >= 0;
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = live ? wt[k] * scale * g[c] : 0.f;
+            if (run_merge<3>(live ? (key_hi << 24) | F.t[k] : -1, v)) {
+                if (loff >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) atomicAdd(&s_acc[loff + F.t[k] * 3 + c], v[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) unsafeAtomicAdd(&gptr[(size_t)F.t[k] * 3 + c], v[c]);
+                }
+            }
+        }
+    };
+    const int per_pass = gridDim.x * TEX_BWD_THREADS;
+    for (int base = blockIdx.x * TEX_BWD_THREADS; base < n; base += per_pass) {
+        const int i = base + threadIdx.x;
+        const bool valid = i < n;
+        const size_t ii = valid ? (size_t)i : 0;
+        const ShadePixel s = shade_eval(P, M, ii);
+        float g[3], gE[3], gL[3], dm = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float F0 = P.metallic != nullptr ? (1.0f - s.m) * 0.04f + s.a[c] * s.m : 0.04f;
+            const float refl = F0 * s.fgA + s.fgB;
+            const float raw = s.E[c] * s.a[c] + s.L[c] * refl;
+            g[c] = (valid && raw >= 0.f && raw <= 1.f) ? d_rgb[3 * ii + c] : 0.f;  // clamp passes the gradient on [0, 1]
+            any |= g[c] != 0.f;
+            gE[c] = g[c] * s.a[c];
+            gL[c] = g[c] * refl;
+            const float dF0 = g[c] * s.L[c] * s.fgA;                                   // d/dF0
+            if (valid) d_albedo[3 * ii + c] = g[c] * s.E[c] + (P.metallic != nullptr ? dF0 * s.m : 0.f);
+            dm += dF0 * (s.a[c] - 0.04f);
+        }
+        if (valid && d_metallic != nullptr) d_metallic[ii] = dm;
+        add(any, 15, P.diffuse_lds, P.d_diffuse, s.Fd, gE, 1.f);
+        add(any, s.l0, M.lds_off[any ? s.l0 : 0], M.grad[any ? s.l0 : 0], s.F0, gL, s.two ? 1.f - s.fl : 1.f);
+        add(any && s.two, s.l1, M.lds_off[any ? s.l1 : 0], M.grad[any ? s.l1 : 0], s.F1, gL, s.fl);
+    }
+    __syncthreads();
+    auto flush = [&](int loff, float* gptr, int cnt) {
+        const int start = (int)(((long long)blockIdx.x * cnt) / gridDim.x);
+        for (int k0 = threadIdx.x; k0 < cnt; k0 += TEX_BWD_THREADS) {
+            int k = k0 + start;
+            if (k >= cnt) k -= cnt;
+            const float v = s_acc[loff + k];
+            if (v != 0.f) unsafeAtomicAdd(&gptr[k], v);
+        }
+    };
+    for (int l = 0; l < M.levels; l++)
+        if (M.lds_off[l] >= 0) flush(M.lds_off[l], M.grad[l], 6 * M.width[l] * M.width[l] * 3);
+    if (P.diffuse_lds >= 0) flush(P.diffuse_lds, P.d_diffuse, 6 * P.diffuse_w * P.diffuse_w * 3);
+}
+
 int fill_stack(MipStack& M, int levels, const float* const* tex, float* const* grad, const int* width, bool bwd) {
     if (levels < 1 || levels > GS2M_TEX_MAX_LEVELS || !width || (bwd ? !grad : !tex)) return GS2M_ERR_INVALID_ARG;
     M.levels = levels;
@@ -427,6 +564,62 @@ int gs2m_texture_2d_clamp_backward(int n, int channels, int width, int height, f
     MipStack M;
     M.levels = 1; M.tex[0] = nullptr; M.grad[0] = grad_tex; M.width[0] = width;
     return launch_bwd<2>(channels, n, M, height, uv, nullptr, dL_dout, (hipStream_t)stream);
+}
+
+int gs2m_pbr_shade_forward(int n, const float* normals, const float* view_dirs, const float* albedo, const float* roughness,
+                           const float* metallic, const float* brdf_lut, int lut_width, int lut_height, const float* diffuse,
+                           int diffuse_width, int levels, const float* const* specular, const int* width, float min_roughness,
+                           float max_roughness, float* render_rgb, float* diffuse_rgb, float* specular_rgb, float* diffuse_light,
+                           void* stream) {
+    if (n == 0) return GS2M_OK;
+    if (n < 0 || !normals || !view_dirs || !albedo || !roughness || !brdf_lut || !diffuse || !render_rgb || lut_width < 1 ||
+        lut_height < 1 || diffuse_width < 1 || levels < 2)
+        return GS2M_ERR_INVALID_ARG;
+    MipStack M;
+    const int rc = fill_stack(M, levels, specular, nullptr, width, false);
+    if (rc != GS2M_OK) return rc;
+    ShadeIn P = {normals, view_dirs, albedo, roughness, metallic, brdf_lut, lut_width, lut_height, diffuse, nullptr, diffuse_width, -1,
+                 min_roughness, max_roughness};
+    shade_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, P, M, render_rgb, diffuse_rgb, specular_rgb, diffuse_light);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_pbr_shade_backward(int n, const float* normals, const float* view_dirs, const float* albedo, const float* roughness,
+                            const float* metallic, const float* brdf_lut, int lut_width, int lut_height, const float* diffuse,
+                            int diffuse_width, int levels, const float* const* specular, const int* width, float min_roughness,
+                            float max_roughness, const float* dL_drender_rgb, float* dL_dalbedo, float* dL_dmetallic,
+                            float* dL_ddiffuse, float* const* dL_dspecular, void* stream) {
+    if (n == 0) return GS2M_OK;
+    if (n < 0 || !normals || !view_dirs || !albedo || !roughness || !brdf_lut || !diffuse || !dL_drender_rgb || !dL_dalbedo ||
+        !dL_ddiffuse || !dL_dspecular || lut_width < 1 || lut_height < 1 || diffuse_width < 1 || levels < 2 || (dL_dmetallic && !metallic))
+        return GS2M_ERR_INVALID_ARG;
+    MipStack M;
+    int rc = fill_stack(M, levels, specular, nullptr, width, false);
+    if (rc != GS2M_OK) return rc;
+    M.lds_floats = 0;
+    for (int l = 0; l < levels; l++) {
+        if (!dL_dspecular[l]) return GS2M_ERR_INVALID_ARG;
+        M.grad[l] = dL_dspecular[l];
+        const bool small = width[l] <= TEX_LDS_MAX_WIDTH;
+        M.lds_off[l] = small ? M.lds_floats : -1;
+        if (small) M.lds_floats += 6 * width[l] * width[l] * 3;
+    }
+    ShadeIn P = {normals, view_dirs, albedo, roughness, metallic, brdf_lut, lut_width, lut_height, diffuse, dL_ddiffuse, diffuse_width, -1,
+                 min_roughness, max_roughness};
+    int lds_floats = M.lds_floats;
+    if (diffuse_width <= TEX_LDS_MAX_WIDTH) { P.diffuse_lds = lds_floats; lds_floats += 6 * diffuse_width * diffuse_width * 3; }
+    if ((size_t)lds_floats * sizeof(float) > 159 * 1024) return GS2M_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&shade_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+            return GS2M_ERR_HIP;
+        attr_set = true;
+    }
+    int blocks = (n + TEX_BWD_THREADS - 1) / TEX_BWD_THREADS;
+    if (blocks > 256) blocks = 256;
+    shade_bwd_kernel<<<blocks, TEX_BWD_THREADS, (size_t)lds_floats * sizeof(float), (hipStream_t)stream>>>(n, P, M, dL_drender_rgb, dL_dalbedo,
+                                                                                                        dL_dmetallic);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 
 }  // extern "C"

@@ -4,12 +4,12 @@ import torch
 import torch.nn.functional as F
 
 from .light import CubemapLight
-from .shade import get_brdf_lut, pbr_shading, saturate_dot, linear_to_srgb, srgb_to_linear
+from .shade import get_brdf_lut, pbr_shading, pbr_shading_fused, saturate_dot, linear_to_srgb, srgb_to_linear
 
-__all__ = ["CubemapLight", "get_brdf_lut", "pbr_shading", "saturate_dot", "linear_to_srgb", "srgb_to_linear", "pbr_render"]
+__all__ = ["CubemapLight", "get_brdf_lut", "pbr_shading", "pbr_shading_fused", "saturate_dot", "linear_to_srgb", "srgb_to_linear", "pbr_render"]
 
 
-def pbr_render(scene, viewpoint_cam, canonical_rays, render_pkg, metallic, gamma=False):
+def pbr_render(scene, viewpoint_cam, canonical_rays, render_pkg, metallic, gamma=False, fused=True):
     """scene: anything with `.cubemap` (CubemapLight) and `.brdf_lut`.  Gradients reach the environment light, the albedo
     map and -- when `metallic` -- the metallic map; normals, roughness and the estimated metallic are detached, as in
     the reference (:25-43)."""
@@ -37,6 +37,11 @@ def pbr_render(scene, viewpoint_cam, canonical_rays, render_pkg, metallic, gamma
     rmin, rmax = 0.04, 1.0
     roughness_map = (roughness_map * (rmax - rmin) + rmin).detach()
 
+    if fused:  # the same shading as one kernel each way (include/gs2m_pbr.h); `fused=False`: the reference's op-by-op form
+        pkg = pbr_shading_fused(scene.cubemap, normal_map.permute(1, 2, 0), view_dirs, albedo_map.permute(1, 2, 0),
+                                roughness_map.permute(1, 2, 0), metallic=metallic_map.permute(1, 2, 0), brdf_lut=scene.brdf_lut, gamma=gamma)
+        pkg.update({"roughness_map": roughness_map, "metallic_map": metallic_map})
+        return pkg
     pkg = pbr_shading(light=scene.cubemap, normals=normal_map.permute(1, 2, 0), view_dirs=view_dirs, albedo=albedo_map.permute(1, 2, 0),
                       roughness=roughness_map.permute(1, 2, 0), metallic=metallic_map.permute(1, 2, 0),
                       occlusion=torch.ones_like(roughness_map).permute(1, 2, 0), irradiance=torch.zeros_like(roughness_map).permute(1, 2, 0),

@@ -133,3 +133,45 @@ def test_environment_light_is_learnable_through_the_whole_stack():
         light.clamp_(min=0.0)
         losses.append(loss.item())
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize("with_metallic", [True, False])
+def test_fused_shading_equals_the_op_by_op_form(with_metallic):
+    """pbr_shading_fused (one kernel each way) against pbr_shading (PyTorch ops around dr.texture): every output, and the
+    gradients to albedo, metallic and the light's base map through build_mips."""
+    assert torch.cuda.is_available()
+    from pbr import get_brdf_lut, pbr_shading, pbr_shading_fused
+    H, W = 45, 70
+    g = torch.Generator().manual_seed(21)
+    n = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)
+    n[:3] = 0.0                                                # background rows: zero normals
+    n = n.cuda()
+    v = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).cuda()
+    rough = (0.04 + 0.96 * torch.rand(H, W, 1, generator=g)).cuda()
+    lut = get_brdf_lut().cuda()
+    Gw = torch.randn(H, W, 3, generator=g).cuda()
+    res = {}
+    for fused in (False, True):
+        light = _light(64, seed=22)
+        with torch.no_grad():
+            light.base.mul_(2.5)                               # push part of the image over 1: the clamp must gate the gradient
+        albedo = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(23)).cuda().requires_grad_(True)
+        metal = torch.rand(H, W, 1, generator=torch.Generator().manual_seed(24)).cuda().requires_grad_(True)
+        light.build_mips()
+        if fused:
+            pkg = pbr_shading_fused(light, n, v, albedo, rough, metallic=metal if with_metallic else None, brdf_lut=lut)
+        else:
+            pkg = pbr_shading(light, n, v, albedo, rough, metallic=metal if with_metallic else None, occlusion=torch.ones_like(rough),
+                              irradiance=torch.zeros_like(rough), brdf_lut=lut)
+        (pkg["render_rgb"] * Gw).sum().backward()
+        res[fused] = (pkg, albedo.grad, metal.grad, light.base.grad)
+    for k in ("render_rgb", "diffuse_rgb", "specular_rgb", "diffuse_light"):
+        assert (res[True][0][k].reshape(H, W, 3) - res[False][0][k].reshape(H, W, 3)).abs().max().item() < 2e-5, k
+    assert 0.02 < (res[False][0]["render_rgb"] >= 1.0).float().mean().item() < 0.98
+    assert (res[True][1] - res[False][1]).abs().max().item() < 1e-4 * max(1.0, res[False][1].abs().max().item())
+    if with_metallic:
+        assert (res[True][2] - res[False][2]).abs().max().item() < 1e-4 * max(1.0, res[False][2].abs().max().item())
+    else:
+        assert res[True][2] is None and res[False][2] is None
+    gb0, gb1 = res[False][3], res[True][3]
+    assert (gb1 - gb0).abs().max().item() < 2e-4 * max(1.0, gb0.abs().max().item())

@@ -64,7 +64,7 @@ def view():
         t.grad = None
     scene.cubemap.base.grad = None
     out = render(cam, pc, pipe, bg, material_stage=True)
-    pkg = pbr_render(scene, cam, rays, out, metallic=False)
+    pkg = pbr_render(scene, cam, rays, out, metallic=False, fused="--unfused-shade" not in sys.argv)
     img = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1), bg[:, None, None])
     ((img - gt).abs().mean()).backward()
 

@@ -21,7 +21,7 @@ for e in prof.key_averages():
     if re.search(r"blend_|preprocess_kernel|gaussian_bwd|row_reduce|rs_|emit_kernel|scan_tt|ranges_kernel|observe_kernel|zero_kernel", n): g = "rasterizer"
     elif re.search(r"pack_features|gbuffer_post|sobel_normal|activate", n): g = "render ops (fused pre/post)"
     elif re.search(r"specular_kernel|diffuse_kernel|axis_area", n): g = "specular/diffuse prefilter"
-    elif re.search(r"texture_", n): g = "texture lookups"
+    elif re.search(r"texture_|shade_", n): g = "texture lookups"
     elif re.search(r"Cijk|gemm", n): g = "BLAS"
     else: g = "torch elementwise / reduce / copy"
     groups[g][0] += t / N / 1e3
