@@ -1,0 +1,178 @@
+// Photometric term of the multi-view loss for gfx950: the plane-induced patch warp + NCC of
+// utils/loss_utils.py:303-349 (multi_view_loss) as one kernel each way.
+//
+// Per sampled pixel (up to 102,400 of them, `multi_view_sample_num`) the reference builds a 3x3 homography from the
+// rendered plane (camera-space normal n, distance d) and the relative pose,
+//     H = K_near (R_rn - t_rn n^T / d) K_ref^-1                                     (:322-327)
+// warps the (2P+1)^2 patch positions around the pixel (:309-311, _patch_warp :456-466), samples the reference and the
+// neighbour grey images bilinearly (F.grid_sample, align_corners=True, zero padding, :317, :333) and scores the two
+// patches with 1 - NCC^2 (_loss_ncc :468-509).  In PyTorch that is two batched 3x3 matmuls over N matrices (BLAS at
+// K = 3), an einsum, two grid_samples over 49 N points and five 7x7 "ones" conv2d that are just sums, plus their
+// backward -- here one thread per sample keeps the five running sums in registers:
+//     h = M p - b (n . r) / d,   M = K_near R_rn K_ref^-1,  b = K_near t_rn,  r = K_ref^-1 p      (p = (x, y, 1))
+// and the backward recomputes the samples, differentiates the bilinear lookups with respect to the warped position and
+// chains through h to n and d (the reference image, the pixel positions and the poses get no gradient, as there).
+#include "common.h"
+#include "../../include/gs2m_mvs.h"
+
+namespace {
+
+struct NccConst {
+    float M[9];     // K_near R_rn K_ref^-1, row major
+    float b[3];     // K_near t_rn
+    float Kinv[9];  // K_ref^-1 at the NCC scale, row major
+    float inv_scale;  // 1 / ncc_scale: full-resolution pixel -> grey-image pixel
+    int P;          // patch half size
+    int w, h;       // grey images
+};
+
+struct Bilinear {
+    float v, dx, dy;  // value and its derivative with respect to the sampling position
+};
+
+// F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True) at pixel position (x, y)
+__device__ __forceinline__ Bilinear sample_zero(const float* __restrict__ img, int w, int h, float x, float y) {
+    Bilinear r = {0.f, 0.f, 0.f};
+    if (!(x > -1.f && x < (float)w && y > -1.f && y < (float)h)) return r;  // also rejects NaN: all four texels outside
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float fx = x - xf, fy = y - yf;
+    auto at = [&](int xx, int yy) { return (xx >= 0 && xx < w && yy >= 0 && yy < h) ? img[(size_t)yy * w + xx] : 0.f; };
+    const float v00 = at(x0, y0), v10 = at(x0 + 1, y0), v01 = at(x0, y0 + 1), v11 = at(x0 + 1, y0 + 1);
+    r.v = v00 * (1.f - fx) * (1.f - fy) + v10 * fx * (1.f - fy) + v01 * (1.f - fx) * fy + v11 * fx * fy;
+    r.dx = (v10 - v00) * (1.f - fy) + (v11 - v01) * fy;
+    r.dy = (v01 - v00) * (1.f - fx) + (v11 - v10) * fx;
+    return r;
+}
+
+struct Warp {
+    float qx, qy;      // warped position in the neighbour image
+    float hx, hy, hz;  // homogeneous coordinates (hz includes the +1e-10 of _patch_warp)
+    float rx, ry, rz;  // K_ref^-1 p
+    float s;           // n . r
+};
+
+__device__ __forceinline__ Warp warp_point(const NccConst& C, float px, float py, const float (&n)[3], float inv_d) {
+    Warp W;
+    W.rx = C.Kinv[0] * px + C.Kinv[1] * py + C.Kinv[2];
+    W.ry = C.Kinv[3] * px + C.Kinv[4] * py + C.Kinv[5];
+    W.rz = C.Kinv[6] * px + C.Kinv[7] * py + C.Kinv[8];
+    W.s = n[0] * W.rx + n[1] * W.ry + n[2] * W.rz;
+    const float k = W.s * inv_d;
+    W.hx = C.M[0] * px + C.M[1] * py + C.M[2] - C.b[0] * k;
+    W.hy = C.M[3] * px + C.M[4] * py + C.M[5] - C.b[1] * k;
+    W.hz = C.M[6] * px + C.M[7] * py + C.M[8] - C.b[2] * k + 1e-10f;
+    W.qx = W.hx / W.hz;
+    W.qy = W.hy / W.hz;
+    return W;
+}
+
+struct Sums {
+    float r, n, rr, nn, rn;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const float* __restrict__ pixels,
+                                                        const float* __restrict__ normals, const float* __restrict__ dists,
+                                                        const float* __restrict__ ref_gray, const float* __restrict__ near_gray,
+                                                        float* __restrict__ ncc_out, const float* __restrict__ d_ncc,
+                                                        float* __restrict__ d_normals, float* __restrict__ d_dists) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float cx = pixels[2 * (size_t)i] * C.inv_scale, cy = pixels[2 * (size_t)i + 1] * C.inv_scale;
+    const float n[3] = {normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]};
+    const float d = dists[i], inv_d = 1.0f / d;
+    const float tps = (float)((2 * C.P + 1) * (2 * C.P + 1));
+    // The variances and the covariance are differences of nearly equal sums (grey values ~0.5, contrast ~0.05): summing
+    // the raw moments in fp32 costs three digits.  They are shift invariant, so both patches are accumulated relative to
+    // their centre samples.
+    const float r0 = sample_zero(ref_gray, C.w, C.h, cx, cy).v;
+    float v0;
+    {
+        const Warp W = warp_point(C, cx, cy, n, inv_d);
+        v0 = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v;
+    }
+    Sums S = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int oy = -C.P; oy <= C.P; oy++)
+        for (int ox = -C.P; ox <= C.P; ox++) {
+            const float px = cx + (float)ox, py = cy + (float)oy;
+            const float r = sample_zero(ref_gray, C.w, C.h, px, py).v - r0;
+            const Warp W = warp_point(C, px, py, n, inv_d);
+            const float v = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v - v0;
+            S.r += r; S.n += v; S.rr += r * r; S.nn += v * v; S.rn += r * v;
+        }
+    const float ref_avg = S.r / tps, nea_avg = S.n / tps;
+    const float cross = S.rn - nea_avg * S.r;
+    const float ref_var = S.rr - ref_avg * S.r;
+    const float nea_var = S.nn - nea_avg * S.n;
+    const float D = ref_var * nea_var + 1e-8f;
+    const float raw = 1.0f - cross * cross / D;
+    if (!BWD) {
+        ncc_out[i] = fminf(fmaxf(raw, 0.0f), 2.0f);
+        return;
+    }
+    // d ncc / d v_k for the neighbour samples v_k; the clamp passes the gradient on [0, 2]
+    const float g = (raw >= 0.0f && raw <= 2.0f) ? -d_ncc[i] : 0.0f;                // d / d cc
+    const float g_cross = g * 2.0f * cross / D, g_var = -g * cross * cross * ref_var / (D * D);
+    float dn[3] = {0.f, 0.f, 0.f}, dd = 0.f;
+    if (g != 0.0f) {
+        for (int oy = -C.P; oy <= C.P; oy++)
+            for (int ox = -C.P; ox <= C.P; ox++) {
+                const float px = cx + (float)ox, py = cy + (float)oy;
+                const float r = sample_zero(ref_gray, C.w, C.h, px, py).v - r0;
+                const Warp W = warp_point(C, px, py, n, inv_d);
+                const Bilinear B = sample_zero(near_gray, C.w, C.h, W.qx, W.qy);
+                const float gv = g_cross * (r - ref_avg) + g_var * (2.0f * (B.v - v0) - 2.0f * nea_avg);
+                const float gqx = gv * B.dx, gqy = gv * B.dy;
+                // q = (hx, hy) / hz
+                const float ghx = gqx / W.hz, ghy = gqy / W.hz, ghz = -(gqx * W.qx + gqy * W.qy) / W.hz;
+                const float gb = ghx * C.b[0] + ghy * C.b[1] + ghz * C.b[2];       // h = M p - b (n . r) / d
+                const float k = -gb * inv_d;
+                dn[0] += k * W.rx; dn[1] += k * W.ry; dn[2] += k * W.rz;
+                dd += gb * W.s * inv_d * inv_d;
+            }
+    }
+    d_normals[3 * (size_t)i] = dn[0]; d_normals[3 * (size_t)i + 1] = dn[1]; d_normals[3 * (size_t)i + 2] = dn[2];
+    d_dists[i] = dd;
+}
+
+int fill(NccConst& C, const float* M, const float* b, const float* Kinv, float ncc_scale, int patch, int w, int h) {
+    if (!M || !b || !Kinv || !(ncc_scale > 0.f) || patch < 0 || patch > 8 || w < 1 || h < 1) return GS2M_ERR_INVALID_ARG;
+    for (int k = 0; k < 9; k++) { C.M[k] = M[k]; C.Kinv[k] = Kinv[k]; }
+    for (int k = 0; k < 3; k++) C.b[k] = b[k];
+    C.inv_scale = 1.0f / ncc_scale; C.P = patch; C.w = w; C.h = h;
+    return GS2M_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs2m_patch_ncc_forward(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                           const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                           float ncc_scale, int patch, float* ncc, void* stream) {
+    if (N == 0) return GS2M_OK;
+    if (N < 0 || !pixels || !normals || !dists || !ref_gray || !near_gray || !ncc) return GS2M_ERR_INVALID_ARG;
+    NccConst C;
+    const int rc = fill(C, M, b, Kinv, ncc_scale, patch, width, height);
+    if (rc != GS2M_OK) return rc;
+    patch_ncc_kernel<false><<<(N + 127) / 128, 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, ncc,
+                                                                             nullptr, nullptr, nullptr);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_patch_ncc_backward(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                            const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                            float ncc_scale, int patch, const float* dL_dncc, float* dL_dnormals, float* dL_ddists, void* stream) {
+    if (N == 0) return GS2M_OK;
+    if (N < 0 || !pixels || !normals || !dists || !ref_gray || !near_gray || !dL_dncc || !dL_dnormals || !dL_ddists)
+        return GS2M_ERR_INVALID_ARG;
+    NccConst C;
+    const int rc = fill(C, M, b, Kinv, ncc_scale, patch, width, height);
+    if (rc != GS2M_OK) return rc;
+    patch_ncc_kernel<true><<<(N + 127) / 128, 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, nullptr,
+                                                                            dL_dncc, dL_dnormals, dL_ddists);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+"""Multi-view geometric + photometric consistency loss: `multi_view_loss` of
+utils/loss_utils.py:245-349 and what it needs of the reference's Scene (neighbour-camera tables, grey images, the pixel
+grid: scene/__init__.py:125-141, 150-204).
+
+Host-side Python as in the reference.  The photometric core -- plane-induced homography per sampled pixel, 7x7 patch
+warp, two bilinear image lookups per patch point, NCC, and the backward to the rendered plane normals / distances --
+is one fused HIP kernel each way (`patch_ncc`, include/gs2m_mvs.h); `patch_ncc_torch` is the same computation op by
+op as the reference writes it (batched 3x3 matmuls, einsum, grid_sample, "ones" conv2d) and is what the fused kernel
+is tested against.  The geometric part (reprojection error, normal agreement) stays PyTorch here.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import gs2m_native as _native
+
+
+class MultiViewParams:
+    """arguments/__init__.py:104-130 defaults read by this module."""
+    multi_view_num = 8
+    multi_view_ncc_weight = 0.15
+    multi_view_geo_weight = 2e-3
+    multi_view_ncc_scale = -1.0
+    multi_view_max_angle = 30
+    multi_view_min_dist = 0.01
+    multi_view_max_dist = 1.5
+    multi_view_sample_num = 102400
+    multi_view_patch_size = 3
+    mv_angle_threshold = 30
+    mv_angle_factor = 2.0
+    mv_occlusion_threshold = 5e-4
+    mv_geo_weight_decay = 3.0
+
+
+# ---------------------------------------------------------------- the fused photometric core
+class _PatchNCC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pixels, normals, dists, ref_gray, near_gray, M, b, Kinv, ncc_scale, patch):
+        f = lambda t: t.contiguous().float()
+        pixels, normals, dists, ref_gray, near_gray = f(pixels), f(normals), f(dists), f(ref_gray), f(near_gray)
+        if not pixels.is_cuda:
+            raise RuntimeError("patch_ncc: HIP kernel, there is no CPU path")
+        h, w = ref_gray.shape[-2:]
+        assert near_gray.shape[-2:] == (h, w), "both grey images must have the same size"
+        N = pixels.shape[0]
+        ncc = torch.empty((N, 1), dtype=torch.float32, device=pixels.device)
+        consts = tuple((C.c_float * len(v))(*[float(x) for x in v]) for v in (M.reshape(-1).tolist(), b.reshape(-1).tolist(), Kinv.reshape(-1).tolist()))
+        ctx.args = (N, w, h, consts, float(ncc_scale), int(patch))
+        with torch.cuda.device(pixels.device):
+            _native.check(_native.lib().gs2m_patch_ncc_forward(
+                N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), ref_gray.data_ptr(), near_gray.data_ptr(), w, h, *consts,
+                float(ncc_scale), int(patch), ncc.data_ptr(), C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)), "gs2m_patch_ncc_forward")
+        ctx.save_for_backward(pixels, normals, dists, ref_gray, near_gray)
+        return ncc
+
+    @staticmethod
+    def backward(ctx, d_ncc):
+        pixels, normals, dists, ref_gray, near_gray = ctx.saved_tensors
+        N, w, h, consts, ncc_scale, patch = ctx.args
+        d_ncc = d_ncc.contiguous().float()
+        dn, dd = torch.empty_like(normals), torch.empty_like(dists)
+        with torch.cuda.device(pixels.device):
+            _native.check(_native.lib().gs2m_patch_ncc_backward(
+                N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), ref_gray.data_ptr(), near_gray.data_ptr(), w, h, *consts,
+                ncc_scale, patch, d_ncc.data_ptr(), dn.data_ptr(), dd.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)), "gs2m_patch_ncc_backward")
+        return None, dn, dd, None, None, None, None, None, None, None
+
+
+def _homography_constants(ref_cam, near_cam, ncc_scale):
+    """M = K_near R_rn K_ref^-1, b = K_near t_rn, K_ref^-1 (utils/loss_utils.py:319-327), on the host in float64."""
+    Vr, Vn = ref_cam.world_view_transform.double().cpu(), near_cam.world_view_transform.double().cpu()
+    rn_R = Vn[:3, :3].transpose(-1, -2) @ Vr[:3, :3]
+    rn_t = -rn_R @ Vr[3, :3] + Vn[3, :3]
+    Kn, Kinv = near_cam.get_K(ncc_scale).double().cpu(), ref_cam.get_inv_K(ncc_scale).double().cpu()
+    return Kn @ rn_R @ Kinv, Kn @ rn_t, Kinv
+
+
+def patch_ncc(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch):
+    """pixels (N,2) full-resolution pixel coordinates, normals (N,3) camera-space plane normals, dists (N,) plane distances
+    -> ncc (N,1) in [0, 2] (0 = perfectly correlated), mask (N,1) = ncc < 0.9.  Gradients to normals and dists."""
+    M, b, Kinv = _homography_constants(ref_cam, near_cam, ncc_scale)
+    ncc = _PatchNCC.apply(pixels, normals, dists, ref_cam.gray_image, near_cam.gray_image, M, b, Kinv, ncc_scale, patch)
+    return ncc, ncc < 0.9
+
+
+# ---------------------------------------------------------------- the same, op by op (utils/loss_utils.py:303-349, 451-509)
+def _patch_offsets(h_patch_size, device):
+    o = torch.arange(-h_patch_size, h_patch_size + 1, device=device)
+    return torch.stack(torch.meshgrid(o, o, indexing="xy")[::-1], dim=-1).view(1, -1, 2)
+
+
+def _patch_warp(H, uv):
+    B, P = uv.shape[:2]
+    homo = torch.cat((uv, torch.ones((B, P, 1), device=uv.device, dtype=uv.dtype)), dim=-1)
+    g = torch.einsum("bik,bpk->bpi", H.view(B, 3, 3), homo).reshape(B, P, 3)
+    return g[..., :2] / (g[..., 2:] + 1e-10)
+
+
+def _loss_ncc(ref, nea):
+    bs, tps = nea.shape
+    ps = int(np.sqrt(tps))
+    filt = torch.ones(1, 1, ps, ps, device=ref.device, dtype=ref.dtype)
+    pad = ps // 2
+    v = lambda t: F.conv2d(t.view(bs, 1, ps, ps), filt, stride=1, padding=pad)[:, :, pad, pad]
+    ref_sum, nea_sum, ref2_sum, nea2_sum, rn_sum = v(ref), v(nea), v(ref.pow(2)), v(nea.pow(2)), v(ref * nea)
+    ref_avg, nea_avg = ref_sum / tps, nea_sum / tps
+    cross = rn_sum - nea_avg * ref_sum
+    ref_var = ref2_sum - ref_avg * ref_sum
+    nea_var = nea2_sum - nea_avg * nea_sum
+    ncc = torch.clamp(1 - cross * cross / (ref_var * nea_var + 1e-8), 0.0, 2.0)
+    ncc = torch.mean(ncc, dim=1, keepdim=True)
+    return ncc, ncc < 0.9
+
+
+def patch_ncc_torch(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch, dtype=torch.float32):
+    """`dtype=torch.float64` evaluates the same formulation in double precision (the arbiter in the tests: the variances
+    are differences of nearly equal sums, so two fp32 evaluations of a low-texture patch legitimately differ by ~1e-2)."""
+    dev = pixels.device
+    c = lambda t: t.to(dtype)
+    pixels, normals, dists = c(pixels), c(normals), c(dists)
+    ori = pixels.reshape(-1, 1, 2) / ncc_scale + c(_patch_offsets(patch, dev))
+    gray = c(ref_cam.gray_image)
+    h, w = gray.squeeze().shape
+    pp = ori.clone()
+    pp[:, :, 0] = 2 * pp[:, :, 0] / (w - 1) - 1.0
+    pp[:, :, 1] = 2 * pp[:, :, 1] / (h - 1) - 1.0
+    tps = (patch * 2 + 1) ** 2
+    ref_val = F.grid_sample(gray.unsqueeze(1), pp.view(1, -1, 1, 2), align_corners=True).reshape(-1, tps)
+    Vr, Vn = c(ref_cam.world_view_transform), c(near_cam.world_view_transform)
+    rn_R = Vn[:3, :3].transpose(-1, -2) @ Vr[:3, :3]
+    rn_t = -rn_R @ Vr[3, :3] + Vn[3, :3]
+    n = dists.shape[0]
+    H = rn_R[None] - torch.matmul(rn_t[None, :, None].expand(n, 3, 1), normals[:, :, None].expand(n, 3, 1).permute(0, 2, 1)) / dists[..., None, None]
+    H = torch.matmul(c(near_cam.get_K(ncc_scale))[None].expand(n, 3, 3), H)
+    H = H @ c(ref_cam.get_inv_K(ncc_scale))
+    grid = _patch_warp(H.reshape(-1, 3, 3), ori)
+    gx = 2 * grid[:, :, 0] / (w - 1) - 1.0
+    gy = 2 * grid[:, :, 1] / (h - 1) - 1.0
+    samp = F.grid_sample(c(near_cam.gray_image)[None], torch.stack((gx, gy), dim=-1).reshape(1, -1, 1, 2), align_corners=True).reshape(-1, tps)
+    return _loss_ncc(ref_val, samp)
+
+
+# ---------------------------------------------------------------- scene side (scene/__init__.py:125-141, 150-204)
+class MultiViewScene:
+    def __init__(self, cameras, gt_images, gaussians, opt=MultiViewParams, ncc_scale=1.0):
+        self.cameras, self.gaussians, self.ncc_scale = cameras, gaussians, float(ncc_scale)
+        cam = cameras[0]
+        ix, iy = torch.meshgrid(torch.arange(cam.image_width), torch.arange(cam.image_height), indexing="xy")
+        self.pixels = torch.stack([ix, iy], dim=-1).float().to(cam.device)
+        for c, img in zip(cameras, gt_images):
+            if self.ncc_scale != 1.0:
+                res = (int(c.image_height / self.ncc_scale), int(c.image_width / self.ncc_scale))
+                img = F.interpolate(img[None], size=res, mode="bilinear", align_corners=False, antialias=True)[0]
+            c.gray_image = (img[0:1] * 0.299 + img[1:2] * 0.587 + img[2:3] * 0.114).contiguous()
+        self.populate_neighbor_cameras(opt)
+
+    def getTrainCameras(self):
+        return self.cameras
+
+    def populate_neighbor_cameras(self, opt):
+        centres = torch.stack([c.camera_center for c in self.cameras], dim=0)
+        rays = F.normalize(torch.stack([torch.tensor(c.R, dtype=torch.float32)[:3, 2] for c in self.cameras], dim=0).to(centres.device), dim=-1)
+        dist = torch.norm(centres[:, None] - centres[None], dim=-1).cpu().numpy()
+        ang = (torch.arccos(torch.sum(rays[:, None] * rays[None], dim=-1)) * 180 / 3.14159).cpu().numpy()
+        for i, cam in enumerate(self.cameras):
+            order = np.lexsort((ang[i], dist[i]))
+            ok = (ang[i][order] <= opt.multi_view_max_angle) & (dist[i][order] > opt.multi_view_min_dist) & (dist[i][order] < opt.multi_view_max_dist)
+            cam.nearest_indices = [int(k) for k in order[ok][:opt.multi_view_num]]
+
+
+# ---------------------------------------------------------------- the loss (utils/loss_utils.py:245-349, 351-449)
+def _get_points_from_depth(camera, depth_map):
+    pts = (camera.get_rays() * depth_map.squeeze()[..., None]).reshape(-1, 3)
+    R = torch.tensor(camera.R, dtype=torch.float32, device=pts.device)
+    T = torch.tensor(camera.T, dtype=torch.float32, device=pts.device)
+    return (pts - T) @ R.transpose(-1, -2)
+
+
+def _sample_depth_normal(cam_points, camera, render_pkg):
+    W, H = int(camera.image_width), int(camera.image_height)
+    proj = torch.stack([cam_points[:, 0] * camera.Fx / cam_points[:, 2] + camera.Cx,
+                        cam_points[:, 1] * camera.Fy / cam_points[:, 2] + camera.Cy], dim=-1).float()
+    valid = (proj[:, 0] > 0) & (proj[:, 0] < W) & (proj[:, 1] > 0) & (proj[:, 1] < H) & (cam_points[:, 2] > 0.1)
+    grid = torch.stack([proj[:, 0] / ((W - 1) / 2) - 1, proj[:, 1] / ((H - 1) / 2) - 1], dim=-1).view(1, -1, 1, 2)
+    map_z = F.grid_sample(render_pkg["depth_map"][None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, 0, :, 0]
+    map_n = F.grid_sample(render_pkg["normal_map"][None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
+    return map_z, map_n / (map_n.norm(dim=1, keepdim=True) + 1e-8), valid
+
+
+def _reproject_points(from_camera, to_camera, points, sampled_depth):
+    pts = points / points[:, 2:3] * sampled_depth[..., None]
+    R = torch.tensor(from_camera.R, dtype=torch.float32, device=pts.device)
+    T = torch.tensor(from_camera.T, dtype=torch.float32, device=pts.device)
+    pts = (pts - T) @ R.transpose(-1, -2)
+    pts = pts @ to_camera.world_view_transform[:3, :3] + to_camera.world_view_transform[3, :3]
+    return torch.stack([pts[:, 0] * to_camera.Fx / pts[:, 2] + to_camera.Cx, pts[:, 1] * to_camera.Fy / pts[:, 2] + to_camera.Cy], dim=-1).float()
+
+
+def _sample_normal_map(pixels, normal_map):
+    H, W = pixels.shape[:2]
+    p = pixels.view(-1, 2)
+    grid = torch.stack([p[:, 0] / ((W - 1) / 2) - 1, p[:, 1] / ((H - 1) / 2) - 1], dim=-1).view(1, -1, 1, 2)
+    return F.grid_sample(normal_map.unsqueeze(0), grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
+
+
+def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, material_stage, render_fn, fused=True, rng=random):
+    cams = scene.getTrainCameras()
+    if len(viewpoint_cam.nearest_indices) == 0:
+        return 0.0
+    near = cams[rng.sample(viewpoint_cam.nearest_indices, 1)[0]]
+    near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
+    pts = _get_points_from_depth(viewpoint_cam, render_pkg["depth_map"])
+    pts_near = pts @ near.world_view_transform[:3, :3] + near.world_view_transform[3, :3]
+    map_z, map_n, valid = _sample_depth_normal(pts_near, near, near_pkg)
+    valid = valid & (pts_near[:, 2] - map_z <= opt.mv_occlusion_threshold)
+    reproj = _reproject_points(near, viewpoint_cam, pts_near, map_z)
+    pixel_noise = torch.norm(reproj - scene.pixels.reshape(*reproj.shape), dim=-1)
+    normals = _sample_normal_map(scene.pixels, render_pkg["normal_map"])
+    normals = normals / (normals.norm(dim=1, keepdim=True) + 1e-8)
+    angle = torch.acos(torch.sum(normals * map_n, dim=1).clamp(-1 + 1e-6, 1 - 1e-6))
+    angle_valid = valid & (angle < opt.mv_angle_threshold * torch.pi / 180.0)
+    pixel_valid = valid & (pixel_noise < 1.0)
+    geo_w = torch.where(pixel_valid, torch.exp(-pixel_noise * opt.mv_geo_weight_decay), 0.0).detach()
+    # masked means instead of boolean-mask gathers (same values up to the summation order; no nonzero / host sync)
+    pixel_loss = (geo_w * pixel_noise * pixel_valid).sum() / pixel_valid.sum().clamp(min=1)
+    angle_loss = (geo_w * (opt.mv_angle_factor * angle) * angle_valid).sum() / angle_valid.sum().clamp(min=1)
+    geo_loss = pixel_loss + angle_loss
+    if pipe.z_depth:
+        return opt.multi_view_geo_weight * geo_loss
+    with torch.no_grad():
+        idx = torch.nonzero(pixel_valid.reshape(-1)).squeeze(1)
+        if idx.numel() > opt.multi_view_sample_num:
+            idx = idx[torch.randperm(idx.numel(), device=idx.device)[:opt.multi_view_sample_num]]
+        if idx.numel() == 0:
+            return opt.multi_view_geo_weight * geo_loss
+        w_ncc = torch.where(pixel_valid, torch.exp(-pixel_noise), 0.0).reshape(-1)[idx]
+        if material_stage:
+            w_ncc = w_ncc * (render_pkg["roughness_map"].squeeze().clamp(0, 1) ** 2.0).reshape(-1)[idx]
+        pixels = scene.pixels.reshape(-1, 2)[idx]
+    local_n = render_pkg["local_normal_map"].permute(1, 2, 0).reshape(-1, 3)[idx]
+    local_d = render_pkg["distance_map"].reshape(-1)[idx]
+    ncc, mask = (patch_ncc if fused else patch_ncc_torch)(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size)
+    m = mask.reshape(-1)
+    ncc_loss = (ncc.reshape(-1) * w_ncc * m).sum() / m.sum().clamp(min=1)
+    return opt.multi_view_geo_weight * geo_loss + opt.multi_view_ncc_weight * ncc_loss

@@ -158,6 +158,15 @@ class Camera:
         self.full_proj_transform = cam["projmatrix"].to(device)
         self.camera_center = cam["campos"].to(device)
         self.device = device
+        self.R, self.T = cam.get("R"), cam.get("T")   # numpy, the reference's convention (R = transposed W2C rotation)
+        self.gray_image = None                         # (1, h, w) at the NCC scale, populated by the multi-view scene
+        self.nearest_indices, self.nearby_indices = [], []
+
+    def get_K(self, scale=1.0):  # scene/cameras.py:92-97
+        return torch.tensor([[self.Fx / scale, 0.0, self.Cx / scale], [0.0, self.Fy / scale, self.Cy / scale], [0.0, 0.0, 1.0]], device=self.device)
+
+    def get_inv_K(self, scale=1.0):  # scene/cameras.py:99-104
+        return torch.tensor([[scale / self.Fx, 0.0, -self.Cx / self.Fx], [0.0, scale / self.Fy, -self.Cy / self.Fy], [0.0, 0.0, 1.0]], device=self.device)
 
     def get_rays(self, scale=1.0):  # scene/cameras.py:72-81
         h, w = int(self.image_height / scale), int(self.image_width / scale)

@@ -58,7 +58,7 @@ def make_camera(W, H, fx=None, fy=None, R=None, T=None, znear=0.01, zfar=100.0):
     campos = view.inverse()[3, :3].contiguous()
     return dict(W=W, H=H, fx=fx, fy=fy, FoVx=fovx, FoVy=fovy, tanfovx=math.tan(fovx * 0.5),
                 tanfovy=math.tan(fovy * 0.5), viewmatrix=view, projmatrix=full, campos=campos,
-                znear=znear, zfar=zfar)
+                znear=znear, zfar=zfar, R=np.asarray(R, dtype=np.float64), T=np.asarray(T, dtype=np.float64))
 
 
 def look_at_camera(W, H, eye, target, up=(0.0, -1.0, 0.0), **kw):

@@ -1,0 +1,27 @@
+/* gs2m_mvs.h -- C ABI of the photometric multi-view term, part of libgs2m_raster.so.
+ *
+ * The plane-induced patch warp + normalised cross-correlation of multi_view_loss (utils/loss_utils.py:303-349, with
+ * _patch_offsets :451-454, _patch_warp :456-466, _loss_ncc :468-509) as one kernel each way, for N sampled pixels:
+ *     H_i  = M - b (n_i^T Kinv) / d_i                   (M = K_near R_rn K_ref^-1, b = K_near t_rn: HOST 3x3 / 3 arrays, row major)
+ *     ncc_i = clamp(1 - cross^2 / (var_ref var_near + 1e-8), 0, 2)  over the (2 patch + 1)^2 positions around pixels_i / ncc_scale,
+ * both grey images (height, width) sampled bilinearly with zero padding (F.grid_sample, align_corners=True).
+ * Backward: gradients to the normals (N, 3) and distances (N) only, as in the reference (everything else is detached or data).
+ * Device pointers, fp32.  Asynchronous on `stream`; return GS2M_OK (0) or a negative GS2M_ERR_* code (gs2m_raster.h). */
+#ifndef GS2M_MVS_H
+#define GS2M_MVS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gs2m_patch_ncc_forward(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                           const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                           float ncc_scale, int patch, float* ncc, void* stream);
+int gs2m_patch_ncc_backward(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                            const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                            float ncc_scale, int patch, const float* dL_dncc, float* dL_dnormals, float* dL_ddists, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,112 @@
+"""The photometric multi-view term: the fused patch-warp + NCC kernel (include/gs2m_mvs.h) against
+the reference's op-by-op formulation (gs2m_mvs.patch_ncc_torch, restating utils/loss_utils.py:303-349, 451-509) and against
+geometry: two views of a textured plane must correlate perfectly through the TRUE plane's homography."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _plane_scene(W=320, H=200, seed=0, dev="cuda"):
+    """Two cameras looking at the textured plane through (0, 0, 6) with normal towards them; grey images are the texture
+    evaluated at each pixel's ray / plane intersection (exact, no rasterizer involved)."""
+    import gs2m_synth as S
+    from gs2m_scene import Camera
+    cams = [Camera(S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0), fx=1.1 * W), dev) for eye in ((0.0, 0.0, 0.0), (0.9, -0.3, 0.4))]
+    n_w = torch.tensor([0.15, -0.1, -1.0], dtype=torch.float64)
+    n_w = n_w / n_w.norm()
+    p0 = torch.tensor([0.0, 0.0, 6.0], dtype=torch.float64)
+    e1 = torch.linalg.cross(n_w, torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64))
+    e1 = e1 / e1.norm()
+    e2 = torch.linalg.cross(n_w, e1)
+
+    def tex(u, v):
+        return 0.5 + 0.2 * torch.sin(3.1 * u + 0.3) * torch.cos(2.3 * v) + 0.15 * torch.sin(5.7 * v + 1.0) + 0.1 * torch.cos(4.1 * (u + v))
+
+    for c in cams:
+        V = c.world_view_transform.double().cpu()
+        Rcw, centre = V[:3, :3], c.camera_center.double().cpu()      # x_cam = x_w @ V[:3,:3] + V[3,:3]
+        rays_c = c.get_rays().double().cpu().reshape(-1, 3)
+        rays_w = rays_c @ Rcw.T
+        t = ((p0 - centre) @ n_w) / (rays_w @ n_w)
+        X = centre + t[:, None] * rays_w
+        c.gray_image = tex((X - p0) @ e1, (X - p0) @ e2).float().reshape(1, H, W).to(dev)
+        c.plane_n = (n_w @ Rcw).float().to(dev)                        # camera-space normal (faces the camera: n . X < 0)
+        c.plane_d = float(abs((centre - p0) @ n_w))
+    return cams
+
+
+@pytest.mark.parametrize("patch", [3, 1])
+def test_true_plane_correlates_and_fused_equals_op_by_op(patch):
+    assert torch.cuda.is_available()
+    import gs2m_mvs as MV
+    ref, near = _plane_scene()
+    W, H = ref.image_width, ref.image_height
+    g = torch.Generator().manual_seed(1)
+    N = 4000
+    pixels = torch.stack([torch.rand(N, generator=g) * (W - 40) + 20, torch.rand(N, generator=g) * (H - 40) + 20], dim=-1).cuda()
+    pixels[:200] = pixels[:200].round()
+    n = ref.plane_n[None].expand(N, 3).contiguous()
+    d = torch.full((N,), ref.plane_d, device="cuda")
+    assert (n @ torch.tensor([0.0, 0.0, 1.0], device="cuda") < 0).all()
+    ncc, mask = MV.patch_ncc(pixels, n, d, ref, near, 1.0, patch)
+    # the same surface seen twice: (almost) perfect correlation wherever the warped patch lands inside the other image
+    # (3x3 patches hold too little contrast on this smooth texture for the statement to be sharp: checked for 7x7)
+    assert ncc.shape == (N, 1)
+    worse, _ = MV.patch_ncc(pixels, n, d * 1.08, ref, near, 1.0, patch)           # a wrong plane decorrelates
+    if patch == 3:
+        assert torch.quantile(ncc, 0.8).item() < 2e-3 and mask.float().mean().item() > 0.8
+        assert torch.quantile(worse, 0.5).item() > 10 * torch.quantile(ncc, 0.5).item() + 1e-3
+    # fused kernel against the op-by-op formulation, on perturbed planes so that values and gradients are non-trivial
+    nn_ = torch.nn.functional.normalize(n + 0.05 * torch.randn(N, 3, generator=g).cuda(), dim=-1).requires_grad_(True)
+    dd = (d * (1.0 + 0.03 * torch.randn(N, generator=g).cuda())).requires_grad_(True)
+    Gw = torch.rand(N, 1, generator=g).cuda()
+    a, ma = MV.patch_ncc(pixels, nn_, dd, ref, near, 1.0, patch)
+    (a * Gw).sum().backward()
+    ga_n, ga_d = nn_.grad.clone(), dd.grad.clone()
+    nn_.grad = dd.grad = None
+    b, mb = MV.patch_ncc_torch(pixels, nn_, dd, ref, near, 1.0, patch)
+    (b * Gw).sum().backward()
+    gb_n, gb_d = nn_.grad.clone(), dd.grad.clone()
+    nn_.grad = dd.grad = None
+    t, _ = MV.patch_ncc_torch(pixels, nn_, dd, ref, near, 1.0, patch, dtype=torch.float64)   # the arbiter
+    (t * Gw.double()).sum().backward()
+    ea, eb = (a.double() - t).abs().reshape(-1), (b.double() - t).abs().reshape(-1)
+    # both fp32 evaluations sit at the same distance from the double-precision value (low-texture patches: ~1e-2)
+    assert ea.mean().item() < 1e-4 and torch.quantile(ea, 0.99).item() < 2e-3
+    assert ea.mean().item() < 3 * eb.mean().item() + 1e-6 and ea.max().item() < 3 * eb.max().item() + 1e-3
+    assert (ma != mb).float().mean().item() < 5e-3                                 # only samples sitting on the 0.9 threshold
+    gt_n, gt_d = nn_.grad.double(), dd.grad.double()
+    for x, y, z in ((ga_n, gb_n, gt_n), (ga_d, gb_d, gt_d)):
+        assert torch.isfinite(x).all()
+        ex, ey = (x.double() - z).norm().item(), (y.double() - z).norm().item()
+        assert ex < 3 * ey + 5e-3 * z.norm().item(), (ex, ey, z.norm().item())   # 3x3 patches: D^2 in the denominator
+
+
+def test_patch_ncc_edge_cases():
+    """Patches leaving either image (zero padding), degenerate planes, a down-scaled NCC image."""
+    assert torch.cuda.is_available()
+    import gs2m_mvs as MV
+    ref, near = _plane_scene(W=160, H=100)
+    g = torch.Generator().manual_seed(2)
+    N = 1500
+    pixels = torch.stack([torch.rand(N, generator=g) * 159, torch.rand(N, generator=g) * 99], dim=-1).cuda()   # up to the borders
+    n = torch.nn.functional.normalize(ref.plane_n[None] + 0.3 * torch.randn(N, 3, generator=g).cuda(), dim=-1)
+    d = ref.plane_d * (0.5 + torch.rand(N, generator=g).cuda())
+    d[:5] = 1e-6                                                    # nearly singular homographies
+    a, _ = MV.patch_ncc(pixels, n, d, ref, near, 1.0, 3)
+    b, _ = MV.patch_ncc_torch(pixels, n, d, ref, near, 1.0, 3)
+    ok = torch.isfinite(b.reshape(-1))
+    assert torch.isfinite(a.reshape(-1)[ok]).all() and (a.reshape(-1)[ok] - b.reshape(-1)[ok]).abs().max().item() < 2e-3
+    assert (a >= 0).all() and (a <= 2).all()
+    # NCC scale 2: grey images at half resolution, pixel coordinates still full resolution
+    for c in (ref, near):
+        c.gray_image = torch.nn.functional.avg_pool2d(c.gray_image[None], 2)[0].contiguous()
+    px = pixels[(pixels[:, 0] > 20) & (pixels[:, 0] < 140) & (pixels[:, 1] > 20) & (pixels[:, 1] < 80)]
+    nn_, dd = ref.plane_n[None].expand(len(px), 3).contiguous(), torch.full((len(px),), ref.plane_d, device="cuda")
+    a2, _ = MV.patch_ncc(px, nn_, dd, ref, near, 2.0, 3)
+    b2, _ = MV.patch_ncc_torch(px, nn_, dd, ref, near, 2.0, 3)
+    assert (a2 - b2).abs().max().item() < 5e-4
