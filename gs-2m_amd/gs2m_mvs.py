@@ -71,7 +71,16 @@ class _PatchNCC(torch.autograd.Function):
 
 
 def _homography_constants(ref_cam, near_cam, ncc_scale):
-    """M = K_near R_rn K_ref^-1, b = K_near t_rn, K_ref^-1 (utils/loss_utils.py:319-327), on the host in float64."""
+    """M = K_near R_rn K_ref^-1, b = K_near t_rn, K_ref^-1 (utils/loss_utils.py:319-327), on the host in float64; constant
+    per camera pair, kept on the reference camera (reading the poses back is a device synchronisation)."""
+    cache = ref_cam.__dict__.setdefault("_mvs_constants", {})
+    key = (id(near_cam), float(ncc_scale))
+    if key not in cache:
+        cache[key] = _compute_homography_constants(ref_cam, near_cam, ncc_scale)
+    return cache[key]
+
+
+def _compute_homography_constants(ref_cam, near_cam, ncc_scale):
     Vr, Vn = ref_cam.world_view_transform.double().cpu(), near_cam.world_view_transform.double().cpu()
     rn_R = Vn[:3, :3].transpose(-1, -2) @ Vr[:3, :3]
     rn_t = -rn_R @ Vr[3, :3] + Vn[3, :3]
