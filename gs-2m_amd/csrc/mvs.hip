@@ -136,6 +136,74 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
     d_dists[i] = dd;
 }
 
+
+// ---------------------------------------------------------------- roughness_loss variant (utils/loss_utils.py:138-243)
+// Forward only (the reference evaluates it under no_grad): besides the grey-value NCC it needs the NCC of the Sobel
+// gradient magnitudes of the two patches (_patch_gradient :232-238, 3x3 Sobel with zero padding on the patch) and the
+// reference patch's variance for the low-texture switch (:209-211).  The patches are staged in LDS (49 values x 2 per
+// thread), the rest is as above.
+constexpr int ROUGH_THREADS = 64;
+constexpr int ROUGH_MAX = 49;
+
+__device__ __forceinline__ float ncc_from_sums(const Sums& S, float tps, float* ref_var_out) {
+    const float ref_avg = S.r / tps, nea_avg = S.n / tps;
+    const float cross = S.rn - nea_avg * S.r;
+    const float ref_var = S.rr - ref_avg * S.r;
+    const float nea_var = S.nn - nea_avg * S.n;
+    if (ref_var_out != nullptr) *ref_var_out = ref_var;
+    return fminf(fmaxf(1.0f - cross * cross / (ref_var * nea_var + 1e-8f), 0.0f), 2.0f);
+}
+
+__global__ void __launch_bounds__(ROUGH_THREADS) patch_ncc_rough_kernel(int N, NccConst C, const float* __restrict__ pixels,
+                                                                        const float* __restrict__ normals, const float* __restrict__ dists,
+                                                                        const float* __restrict__ ref_gray, const float* __restrict__ near_gray,
+                                                                        float* __restrict__ ncc_gray, float* __restrict__ ncc_grad,
+                                                                        float* __restrict__ ref_var) {
+    __shared__ float s_r[ROUGH_MAX][ROUGH_THREADS], s_v[ROUGH_MAX][ROUGH_THREADS];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, t = threadIdx.x;
+    if (i >= N) return;
+    const float cx = pixels[2 * (size_t)i] * C.inv_scale, cy = pixels[2 * (size_t)i + 1] * C.inv_scale;
+    const float n[3] = {normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]};
+    const float inv_d = 1.0f / dists[i];
+    const int ps = 2 * C.P + 1;
+    const float tps = (float)(ps * ps);
+    const float r0 = sample_zero(ref_gray, C.w, C.h, cx, cy).v;
+    float v0;
+    {
+        const Warp W = warp_point(C, cx, cy, n, inv_d);
+        v0 = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v;
+    }
+    Sums S = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ps; a++)
+        for (int b = 0; b < ps; b++) {
+            const float px = cx + (float)(a - C.P), py = cy + (float)(b - C.P);
+            const float rr = sample_zero(ref_gray, C.w, C.h, px, py).v;
+            const Warp W = warp_point(C, px, py, n, inv_d);
+            const float vv = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v;
+            s_r[a * ps + b][t] = rr; s_v[a * ps + b][t] = vv;
+            const float r = rr - r0, v = vv - v0;
+            S.r += r; S.n += v; S.rr += r * r; S.nn += v * v; S.rn += r * v;
+        }
+    float rv;
+    ncc_gray[i] = ncc_from_sums(S, tps, &rv);
+    ref_var[i] = rv;
+    // Sobel magnitude of each patch (zero padding at the patch border), then the same statistic on the magnitudes
+    auto at = [&](const float (*P)[ROUGH_THREADS], int a, int b) { return (a >= 0 && a < ps && b >= 0 && b < ps) ? P[a * ps + b][t] : 0.f; };
+    auto sobel = [&](const float (*P)[ROUGH_THREADS], int a, int b) {
+        const float gx = (at(P, a - 1, b + 1) - at(P, a - 1, b - 1)) + 2.f * (at(P, a, b + 1) - at(P, a, b - 1)) + (at(P, a + 1, b + 1) - at(P, a + 1, b - 1));
+        const float gy = (at(P, a + 1, b - 1) - at(P, a - 1, b - 1)) + 2.f * (at(P, a + 1, b) - at(P, a - 1, b)) + (at(P, a + 1, b + 1) - at(P, a - 1, b + 1));
+        return sqrtf(gx * gx + gy * gy + 1e-6f);
+    };
+    const float g0r = sobel(s_r, C.P, C.P), g0v = sobel(s_v, C.P, C.P);
+    Sums G = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ps; a++)
+        for (int b = 0; b < ps; b++) {
+            const float r = sobel(s_r, a, b) - g0r, v = sobel(s_v, a, b) - g0v;
+            G.r += r; G.n += v; G.rr += r * r; G.nn += v * v; G.rn += r * v;
+        }
+    ncc_grad[i] = ncc_from_sums(G, tps, nullptr);
+}
+
 int fill(NccConst& C, const float* M, const float* b, const float* Kinv, float ncc_scale, int patch, int w, int h) {
     if (!M || !b || !Kinv || !(ncc_scale > 0.f) || patch < 0 || patch > 8 || w < 1 || h < 1) return GS2M_ERR_INVALID_ARG;
     for (int k = 0; k < 9; k++) { C.M[k] = M[k]; C.Kinv[k] = Kinv[k]; }
@@ -172,6 +240,20 @@ int gs2m_patch_ncc_backward(int N, const float* pixels, const float* normals, co
     if (rc != GS2M_OK) return rc;
     patch_ncc_kernel<true><<<(N + 127) / 128, 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, nullptr,
                                                                             dL_dncc, dL_dnormals, dL_ddists);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_patch_ncc_roughness(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                             const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                             float ncc_scale, int patch, float* ncc_gray, float* ncc_grad, float* ref_var, void* stream) {
+    if (N == 0) return GS2M_OK;
+    if (N < 0 || !pixels || !normals || !dists || !ref_gray || !near_gray || !ncc_gray || !ncc_grad || !ref_var) return GS2M_ERR_INVALID_ARG;
+    if (patch > 3) return GS2M_ERR_UNSUPPORTED;
+    NccConst C;
+    const int rc = fill(C, M, b, Kinv, ncc_scale, patch, width, height);
+    if (rc != GS2M_OK) return rc;
+    patch_ncc_rough_kernel<<<(N + ROUGH_THREADS - 1) / ROUGH_THREADS, ROUGH_THREADS, 0, (hipStream_t)stream>>>(
+        N, C, pixels, normals, dists, ref_gray, near_gray, ncc_gray, ncc_grad, ref_var);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

@@ -33,6 +33,12 @@ class MultiViewParams:
     mv_angle_factor = 2.0
     mv_occlusion_threshold = 5e-4
     mv_geo_weight_decay = 3.0
+    reflection_threshold = 1.0
+    nearby_cam_num = 16
+    nearby_cam_max_angle = 60
+    nearby_cam_min_angle = 10
+    nearby_cam_min_dist = 0.05
+    nearby_cam_max_dist = 2.5
 
 
 # ---------------------------------------------------------------- the fused photometric core
@@ -96,6 +102,27 @@ def patch_ncc(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch):
     return ncc, ncc < 0.9
 
 
+def patch_ncc_roughness(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch):
+    """-> (ncc_gray, ncc_grad, std_mask), each (N, 1): the grey-value NCC, the NCC of the Sobel gradient magnitudes of the two
+    patches, and the low-texture switch sqrt(ref_var) < 0.01 (utils/loss_utils.py:200-211).  No gradients (the reference
+    evaluates this under no_grad)."""
+    M, b, Kinv = _homography_constants(ref_cam, near_cam, ncc_scale)
+    f = lambda t: t.detach().contiguous().float()
+    pixels, normals, dists, rg, ng = f(pixels), f(normals), f(dists), f(ref_cam.gray_image), f(near_cam.gray_image)
+    if not pixels.is_cuda:
+        raise RuntimeError("patch_ncc_roughness: HIP kernel, there is no CPU path")
+    h, w = rg.shape[-2:]
+    N = pixels.shape[0]
+    out = torch.empty((3, N, 1), dtype=torch.float32, device=pixels.device)
+    consts = tuple((C.c_float * len(v))(*[float(x) for x in v]) for v in (M.reshape(-1).tolist(), b.reshape(-1).tolist(), Kinv.reshape(-1).tolist()))
+    with torch.cuda.device(pixels.device):
+        _native.check(_native.lib().gs2m_patch_ncc_roughness(
+            N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), rg.data_ptr(), ng.data_ptr(), w, h, *consts, float(ncc_scale), int(patch),
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)),
+            "gs2m_patch_ncc_roughness")
+    return out[0], out[1], torch.sqrt(out[2]) < 0.01
+
+
 # ---------------------------------------------------------------- the same, op by op (utils/loss_utils.py:303-349, 451-509)
 def _patch_offsets(h_patch_size, device):
     o = torch.arange(-h_patch_size, h_patch_size + 1, device=device)
@@ -109,7 +136,14 @@ def _patch_warp(H, uv):
     return g[..., :2] / (g[..., 2:] + 1e-10)
 
 
-def _loss_ncc(ref, nea):
+def _patch_gradient(patch, patch_size):
+    patch = patch.view(-1, 1, patch_size, patch_size)
+    sx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=patch.dtype, device=patch.device).view(1, 1, 3, 3)
+    gx, gy = F.conv2d(patch, sx, padding=1), F.conv2d(patch, sx.transpose(-1, -2), padding=1)
+    return torch.sqrt(gx ** 2 + gy ** 2 + 1e-6)
+
+
+def _loss_ncc(ref, nea, std_mask=False):
     bs, tps = nea.shape
     ps = int(np.sqrt(tps))
     filt = torch.ones(1, 1, ps, ps, device=ref.device, dtype=ref.dtype)
@@ -122,10 +156,10 @@ def _loss_ncc(ref, nea):
     nea_var = nea2_sum - nea_avg * nea_sum
     ncc = torch.clamp(1 - cross * cross / (ref_var * nea_var + 1e-8), 0.0, 2.0)
     ncc = torch.mean(ncc, dim=1, keepdim=True)
-    return ncc, ncc < 0.9
+    return ncc, (torch.sqrt(ref_var) < 0.01) if std_mask else (ncc < 0.9)
 
 
-def patch_ncc_torch(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch, dtype=torch.float32):
+def patch_ncc_torch(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch, dtype=torch.float32, roughness=False):
     """`dtype=torch.float64` evaluates the same formulation in double precision (the arbiter in the tests: the variances
     are differences of nearly equal sums, so two fp32 evaluations of a low-texture patch legitimately differ by ~1e-2)."""
     dev = pixels.device
@@ -150,6 +184,11 @@ def patch_ncc_torch(pixels, normals, dists, ref_cam, near_cam, ncc_scale, patch,
     gx = 2 * grid[:, :, 0] / (w - 1) - 1.0
     gy = 2 * grid[:, :, 1] / (h - 1) - 1.0
     samp = F.grid_sample(c(near_cam.gray_image)[None], torch.stack((gx, gy), dim=-1).reshape(1, -1, 1, 2), align_corners=True).reshape(-1, tps)
+    if roughness:  # utils/loss_utils.py:204-211
+        ps = patch * 2 + 1
+        ncc_grad, _ = _loss_ncc(_patch_gradient(ref_val, ps).view(-1, tps), _patch_gradient(samp, ps).view(-1, tps))
+        ncc_gray, std_mask = _loss_ncc(ref_val, samp, std_mask=True)
+        return ncc_gray, ncc_grad, std_mask
     return _loss_ncc(ref_val, samp)
 
 
@@ -179,6 +218,10 @@ class MultiViewScene:
             order = np.lexsort((ang[i], dist[i]))
             ok = (ang[i][order] <= opt.multi_view_max_angle) & (dist[i][order] > opt.multi_view_min_dist) & (dist[i][order] < opt.multi_view_max_dist)
             cam.nearest_indices = [int(k) for k in order[ok][:opt.multi_view_num]]
+            nb = order[(ang[i][order] <= opt.nearby_cam_max_angle) & (ang[i][order] >= opt.nearby_cam_min_angle) &
+                       (dist[i][order] >= opt.nearby_cam_min_dist) & (dist[i][order] <= opt.nearby_cam_max_dist)]
+            k = min(opt.nearby_cam_num, len(nb))
+            cam.nearby_indices = [int(nb[j]) for j in np.round(np.linspace(0, len(nb) - 1, k)).astype(int)] if k > 0 else []
 
 
 # ---------------------------------------------------------------- the loss (utils/loss_utils.py:245-349, 351-449)
@@ -256,3 +299,34 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
     m = mask.reshape(-1)
     ncc_loss = (ncc.reshape(-1) * w_ncc * m).sum() / m.sum().clamp(min=1)
     return opt.multi_view_geo_weight * geo_loss + opt.multi_view_ncc_weight * ncc_loss
+
+
+def roughness_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, render_fn, fused=True, rng=random):
+    """utils/loss_utils.py:138-230: where a NEARBY view (10-60 degrees away) still correlates photometrically the surface
+    is diffuse and its roughness is pushed up, where it does not (a highlight moved) it is pushed down; only the sampled
+    roughness values carry gradient."""
+    if pipe.z_depth or len(viewpoint_cam.nearby_indices) == 0:
+        return 0.0
+    near = scene.getTrainCameras()[rng.sample(viewpoint_cam.nearby_indices, 1)[0]]
+    with torch.no_grad():
+        pts = _get_points_from_depth(viewpoint_cam, render_pkg["depth_map"])
+        pts_near = pts @ near.world_view_transform[:3, :3] + near.world_view_transform[3, :3]
+        near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
+        map_z, _, valid = _sample_depth_normal(pts_near, near, near_pkg)
+        valid = valid & (pts_near[:, 2] - map_z <= opt.mv_occlusion_threshold)
+        idx = torch.nonzero(valid.reshape(-1)).squeeze(1)
+        if idx.numel() > opt.multi_view_sample_num:
+            idx = idx[torch.randperm(idx.numel(), device=idx.device)[:opt.multi_view_sample_num]]
+        if idx.numel() == 0:
+            return 0.0
+        pixels = scene.pixels.reshape(-1, 2)[idx]
+        local_n = render_pkg["local_normal_map"].permute(1, 2, 0).reshape(-1, 3)[idx]
+        local_d = render_pkg["distance_map"].reshape(-1)[idx]
+        if fused:
+            ncc_gray, ncc_grad, std_mask = patch_ncc_roughness(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size)
+        else:
+            ncc_gray, ncc_grad, std_mask = patch_ncc_torch(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size, roughness=True)
+        err = torch.tanh(8.0 * (torch.where(std_mask, ncc_grad, ncc_gray).reshape(-1) - opt.reflection_threshold))
+    rough = render_pkg["roughness_map"].reshape(-1)[idx]       # grid_sample at integer pixel positions = the pixel itself
+    m = ((err < 0.0) & (rough <= 0.8).detach()) | ((err > 0.0) & (rough > 0.08).detach())
+    return (err * rough * m).sum() / m.sum().clamp(min=1)

@@ -1,6 +1,6 @@
 """The reference's training iteration (train.py:76-262) on MI355X: the RGB stage, the geometry stage (with the multi-view
-geometric + photometric consistency term when `lambda_multi_view` > 0) and the material stage (without roughness_loss, the
-second term of SURVEY.md 8(f) row N4): render -> clamp ->
+geometric + photometric consistency term when `lambda_multi_view` > 0) and the material stage (with roughness_loss when
+`lambda_rough` > 0): render -> clamp ->
 (1 - l) L1 + l (1 - SSIM) + plane loss (+ depth-normal loss from `geometry_from_iter`; from `material_from_iter` the
 RGB term is replaced by the deferred PBR shading's L1 / D-SSIM plus the edge-aware smoothness terms, and the environment
 light gets its own Adam) -> backward -> densification statistics -> densify / prune / opacity reset on the reference's
@@ -110,7 +110,7 @@ def load_colmap_dataset(folder, images="images", device="cuda"):
 
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
-          lambda_multi_view=0.0, mv_opt=None):
+          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0):
     opt = opt or OptimizationParams()
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
@@ -126,7 +126,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             return sum(psnr(render(c, gaussians, pipe, bg)["render"].clamp(0, 1), gt) for c, gt in zip(cams, gts)) / len(cams)
 
     mv_scene = None
-    if lambda_multi_view > 0:  # train.py:121-130: the multi-view term of the geometry stage
+    if lambda_multi_view > 0 or lambda_rough > 0:  # train.py:121-130, 195: the multi-view terms
         import gs2m_mvs
         mv_opt = mv_opt or gs2m_mvs.MultiViewParams()
         mv_scene = gs2m_mvs.MultiViewScene(cams, gts, gaussians, mv_opt)
@@ -159,11 +159,11 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
             loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], gt_image=gt)
-            if mv_scene is not None:
+            if mv_scene is not None and lambda_multi_view > 0:
                 Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render)
                 loss = loss + lambda_multi_view * Lmv
                 stats.setdefault("mv_loss", []).append(float(Lmv.detach()) if torch.is_tensor(Lmv) else float(Lmv))
-        if material_stage:  # train.py:132-196 without roughness_loss
+        if material_stage:  # train.py:132-196
             if k not in rays:
                 rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
             pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
@@ -172,6 +172,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             Lsm = lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
             wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
             loss = loss + Lpbr + Lsm + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn)
+            if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
+                loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
             stats["pbr_loss"].append(Lpbr.item())
         loss.backward()
         with torch.no_grad():

@@ -21,6 +21,13 @@ int gs2m_patch_ncc_backward(int N, const float* pixels, const float* normals, co
                             const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
                             float ncc_scale, int patch, const float* dL_dncc, float* dL_dnormals, float* dL_ddists, void* stream);
 
+/* roughness_loss (utils/loss_utils.py:138-243), forward only as there: the grey-value NCC, the NCC of the 3x3-Sobel gradient
+ * magnitudes of the two patches (_patch_gradient :232-238) and the reference patch's unnormalised variance (the low-texture
+ * switch sqrt(ref_var) < 0.01, :209-211), each (N).  patch <= 3. */
+int gs2m_patch_ncc_roughness(int N, const float* pixels, const float* normals, const float* dists, const float* ref_gray,
+                             const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
+                             float ncc_scale, int patch, float* ncc_gray, float* ncc_grad, float* ref_var, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,3 +110,27 @@ def test_patch_ncc_edge_cases():
     a2, _ = MV.patch_ncc(px, nn_, dd, ref, near, 2.0, 3)
     b2, _ = MV.patch_ncc_torch(px, nn_, dd, ref, near, 2.0, 3)
     assert (a2 - b2).abs().max().item() < 5e-4
+
+
+def test_roughness_variant_matches_op_by_op():
+    """gs2m_patch_ncc_roughness (grey NCC, Sobel-gradient NCC, low-texture switch) against the op-by-op formulation with its
+    conv2d Sobel / sums (utils/loss_utils.py:200-211, 232-238), fp64 as arbiter."""
+    assert torch.cuda.is_available()
+    import gs2m_mvs as MV
+    ref, near = _plane_scene()
+    W, H = ref.image_width, ref.image_height
+    g = torch.Generator().manual_seed(4)
+    N = 3000
+    pixels = torch.stack([torch.rand(N, generator=g) * (W - 1), torch.rand(N, generator=g) * (H - 1)], dim=-1).cuda()
+    n = torch.nn.functional.normalize(ref.plane_n[None] + 0.05 * torch.randn(N, 3, generator=g).cuda(), dim=-1)
+    d = ref.plane_d * (1.0 + 0.03 * torch.randn(N, generator=g).cuda())
+    # a flat region in the reference image so that the low-texture switch fires for part of the samples
+    ref.gray_image[:, :60, :100] = 0.5 + 0.002 * torch.rand(60, 100, generator=g).cuda()
+    a = MV.patch_ncc_roughness(pixels, n, d, ref, near, 1.0, 3)
+    b = MV.patch_ncc_torch(pixels, n, d, ref, near, 1.0, 3, roughness=True)
+    t = MV.patch_ncc_torch(pixels, n, d, ref, near, 1.0, 3, roughness=True, dtype=torch.float64)
+    assert 0.02 < a[2].float().mean().item() < 0.5 and (a[2] != t[2]).float().mean().item() < 5e-3
+    for k in (0, 1):
+        ea, eb = (a[k].double() - t[k]).abs().reshape(-1), (b[k].double() - t[k]).abs().reshape(-1)
+        assert ea.mean().item() < 3 * eb.mean().item() + 2e-5, (k, ea.mean().item(), eb.mean().item())
+        assert torch.quantile(ea, 0.99).item() < 5e-3, (k, torch.quantile(ea, 0.99).item())

@@ -80,16 +80,22 @@ def test_material_stage_runs_and_its_loss_falls():
     opt = OptimizationParams()
     opt.densify_from_iter, opt.densification_interval, opt.opacity_reset_interval, opt.densify_until_iter = 100, 50, 10_000, 200
     scene = gs2m_train.synthetic_scene(n_true=20_000, n_views=8, W=320, H=180)
-    model, st = gs2m_train.train(iterations=420, geometry_from_iter=150, material_from_iter=260, opt=opt, scene=scene, light_res=64)
+    import gs2m_mvs
+    mv = gs2m_mvs.MultiViewParams()
+    mv.nearby_cam_max_dist, mv.multi_view_sample_num = 8.0, 20000        # 8 orbit cameras: 45 deg / ~4.6 units apart
+    model, st = gs2m_train.train(iterations=420, geometry_from_iter=150, material_from_iter=260, opt=opt, scene=scene, light_res=64,
+                                 lambda_rough=1e-2, mv_opt=mv)
+    assert all(len(c.nearby_indices) > 0 for c in scene[0])
     L = st["pbr_loss"]
     assert len(L) == 160
     first, last = sum(L[:15]) / 15, sum(L[-15:]) / 15
     assert last < 0.7 * first, (first, last)
     light = st["lighting"].cubemap
     assert torch.isfinite(light.base).all() and light.base.min().item() >= 0.0
-    # the albedo is being trained now (the roughness only through roughness_loss, row N4: pbr_render detaches it)
-    p = [g["params"][0] for g in model.optimizer.param_groups if g["name"] == "albedo"][0]
-    assert model.optimizer.state[p]["exp_avg"].abs().sum().item() > 0
+    # the albedo is being trained now, and the roughness through roughness_loss (pbr_render detaches it)
+    for name in ("albedo", "roughness"):
+        p = [g["params"][0] for g in model.optimizer.param_groups if g["name"] == name][0]
+        assert model.optimizer.state[p]["exp_avg"].abs().sum().item() > 0, name
 
 
 def test_colmap_format_dataset_round_trip_and_training(tmp_path):
