@@ -67,6 +67,20 @@ class _Lighting:
         self.light_optimizer = gs2m_optim.Adam([{"name": "cubemap", "params": list(self.cubemap.parameters()), "lr": lr}], lr=lr)
 
 
+def multi_view_observe_trim(gaussians, cams, pipe, bg, observe_threshold=2):
+    """train.py:229-240: prune every Gaussian that fewer than `observe_threshold` training views actually observe (the
+    rasterizer's `observe` output counts the pixels a Gaussian contributed to).  -> number of pruned points."""
+    with torch.no_grad():
+        count = torch.zeros_like(gaussians.get_opacity)
+        for view in cams:
+            count[render(view, gaussians, pipe, bg, sobel_normal=False)["observe"] > 0] += 1
+        prune = (count < observe_threshold).squeeze()
+        n = int(prune.sum())
+        if n > 0:
+            gaussians.prune_points(prune)
+    return n
+
+
 def export_colmap_dataset(folder, scene):
     """Write a scene (cameras, gt_images, points, colors, extent) as a COLMAP-format dataset the reference's loader
     understands (scene/dataset_readers.py:141-197): `sparse/0/{cameras,images,points3D}.bin` and `images/*.png`."""
@@ -110,7 +124,7 @@ def load_colmap_dataset(folder, images="images", device="cuda"):
 
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
-          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0):
+          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000):
     opt = opt or OptimizationParams()
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
@@ -185,6 +199,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                     gaussians.densify_and_prune(opt.densify_grad_threshold, opt.densify_grad_abs_threshold, opt.opacity_prune_threshold, extent, thr)
                 if it % opt.opacity_reset_interval == 0:
                     gaussians.reset_opacity()
+            if trim_interval and it % trim_interval == 0 and it < opt.densify_until_iter:
+                stats["trimmed"] = stats.get("trimmed", 0) + multi_view_observe_trim(gaussians, cams, pipe, bg)
             if it < iterations:
                 gaussians.optimizer.step()
                 gaussians.optimizer.zero_grad(set_to_none=True)

@@ -160,3 +160,21 @@ def test_geometry_stage_with_the_multi_view_term():
     assert vals[0][1].abs().sum().item() > 0
     for a, b in zip(vals[0][1:], vals[1][1:]):
         assert (a - b).norm().item() < 2e-2 * b.norm().item() + 1e-8
+
+
+def test_multi_view_observe_trim_prunes_unseen_points():
+    assert torch.cuda.is_available()
+    import gs2m_train
+    from gs2m_model import GaussianModel, OptimizationParams
+    from gs2m_scene import PipelineParams
+    scene = gs2m_train.synthetic_scene(n_true=5_000, n_views=6, W=160, H=90)
+    cams, _, pts, cols, extent = scene
+    import numpy as np
+    far = np.concatenate([pts, pts[:50] + np.array([[0.0, 500.0, 0.0]], dtype=np.float32)], axis=0)   # 50 points no camera sees
+    m = GaussianModel(3)
+    m.create_from_pcd(far, np.concatenate([cols, cols[:50]], axis=0), extent)
+    m.training_setup(OptimizationParams())
+    n0 = m.get_xyz.shape[0]
+    pruned = gs2m_train.multi_view_observe_trim(m, cams, PipelineParams(), torch.zeros(3, device="cuda"))
+    assert pruned >= 50 and m.get_xyz.shape[0] == n0 - pruned
+    assert (m.get_xyz[:, 1] < 100).all() and m.optimizer.param_groups[0]["params"][0] is m._xyz
