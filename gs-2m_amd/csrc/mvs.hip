@@ -8,7 +8,7 @@
 // neighbour grey images bilinearly (F.grid_sample, align_corners=True, zero padding, :317, :333) and scores the two
 // patches with 1 - NCC^2 (_loss_ncc :468-509).  In PyTorch that is two batched 3x3 matmuls over N matrices (BLAS at
 // K = 3), an einsum, two grid_samples over 49 N points and five 7x7 "ones" conv2d that are just sums, plus their
-// backward -- here one thread per sample keeps the five running sums in registers:
+// backward -- here eight lanes per sample keep the five running sums in registers:
 //     h = M p - b (n . r) / d,   M = K_near R_rn K_ref^-1,  b = K_near t_rn,  r = K_ref^-1 p      (p = (x, y, 1))
 // and the backward recomputes the samples, differentiates the bilinear lookups with respect to the warped position and
 // chains through h to n and d (the reference image, the pixel positions and the poses get no gradient, as there).
@@ -71,14 +71,26 @@ struct Sums {
     float r, n, rr, nn, rn;
 };
 
+// Eight lanes share one sample, one patch row each (a sample alone in a thread is a chain of ~100 dependent gathers, and
+// 102,400 samples are only 1.5 waves per SIMD: the kernel ran at the latency of that chain); the five moments -- and in the
+// backward the four gradient components -- are summed across the eight lanes.
+constexpr int NCC_LPS = 8;
+
+__device__ __forceinline__ float group_sum8(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+
 template <bool BWD>
 __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const float* __restrict__ pixels,
                                                         const float* __restrict__ normals, const float* __restrict__ dists,
                                                         const float* __restrict__ ref_gray, const float* __restrict__ near_gray,
                                                         float* __restrict__ ncc_out, const float* __restrict__ d_ncc,
                                                         float* __restrict__ d_normals, float* __restrict__ d_dists) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i_raw = gid / NCC_LPS, sub = gid % NCC_LPS;
+    const bool live = i_raw < N;
+    const int i = live ? i_raw : N - 1;  // whole groups stay converged for the shuffles
     const float cx = pixels[2 * (size_t)i] * C.inv_scale, cy = pixels[2 * (size_t)i + 1] * C.inv_scale;
     const float n[3] = {normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]};
     const float d = dists[i], inv_d = 1.0f / d;
@@ -93,7 +105,7 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
         v0 = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v;
     }
     Sums S = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int oy = -C.P; oy <= C.P; oy++)
+    for (int oy = -C.P + sub; oy <= C.P; oy += NCC_LPS)
         for (int ox = -C.P; ox <= C.P; ox++) {
             const float px = cx + (float)ox, py = cy + (float)oy;
             const float r = sample_zero(ref_gray, C.w, C.h, px, py).v - r0;
@@ -101,6 +113,7 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
             const float v = sample_zero(near_gray, C.w, C.h, W.qx, W.qy).v - v0;
             S.r += r; S.n += v; S.rr += r * r; S.nn += v * v; S.rn += r * v;
         }
+    S.r = group_sum8(S.r); S.n = group_sum8(S.n); S.rr = group_sum8(S.rr); S.nn = group_sum8(S.nn); S.rn = group_sum8(S.rn);
     const float ref_avg = S.r / tps, nea_avg = S.n / tps;
     const float cross = S.rn - nea_avg * S.r;
     const float ref_var = S.rr - ref_avg * S.r;
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
     const float D = ref_var * nea_var + 1e-8f;
     const float raw = 1.0f - cross * cross / D;
     if (!BWD) {
-        ncc_out[i] = fminf(fmaxf(raw, 0.0f), 2.0f);
+        if (live && sub == 0) ncc_out[i] = fminf(fmaxf(raw, 0.0f), 2.0f);
         return;
     }
     // d ncc / d v_k for the neighbour samples v_k; the clamp passes the gradient on [0, 2]
@@ -116,7 +129,7 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
     const float g_cross = g * 2.0f * cross / D, g_var = -g * cross * cross * ref_var / (D * D);
     float dn[3] = {0.f, 0.f, 0.f}, dd = 0.f;
     if (g != 0.0f) {
-        for (int oy = -C.P; oy <= C.P; oy++)
+        for (int oy = -C.P + sub; oy <= C.P; oy += NCC_LPS)
             for (int ox = -C.P; ox <= C.P; ox++) {
                 const float px = cx + (float)ox, py = cy + (float)oy;
                 const float r = sample_zero(ref_gray, C.w, C.h, px, py).v - r0;
@@ -132,10 +145,12 @@ __global__ void __launch_bounds__(128) patch_ncc_kernel(int N, NccConst C, const
                 dd += gb * W.s * inv_d * inv_d;
             }
     }
-    d_normals[3 * (size_t)i] = dn[0]; d_normals[3 * (size_t)i + 1] = dn[1]; d_normals[3 * (size_t)i + 2] = dn[2];
-    d_dists[i] = dd;
+    dn[0] = group_sum8(dn[0]); dn[1] = group_sum8(dn[1]); dn[2] = group_sum8(dn[2]); dd = group_sum8(dd);
+    if (live && sub == 0) {
+        d_normals[3 * (size_t)i] = dn[0]; d_normals[3 * (size_t)i + 1] = dn[1]; d_normals[3 * (size_t)i + 2] = dn[2];
+        d_dists[i] = dd;
+    }
 }
-
 
 // ---------------------------------------------------------------- roughness_loss variant (utils/loss_utils.py:138-243)
 // Forward only (the reference evaluates it under no_grad): besides the grey-value NCC it needs the NCC of the Sobel
@@ -224,7 +239,7 @@ int gs2m_patch_ncc_forward(int N, const float* pixels, const float* normals, con
     NccConst C;
     const int rc = fill(C, M, b, Kinv, ncc_scale, patch, width, height);
     if (rc != GS2M_OK) return rc;
-    patch_ncc_kernel<false><<<(N + 127) / 128, 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, ncc,
+    patch_ncc_kernel<false><<<(int)(((long long)N * NCC_LPS + 127) / 128), 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, ncc,
                                                                              nullptr, nullptr, nullptr);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
@@ -238,7 +253,7 @@ int gs2m_patch_ncc_backward(int N, const float* pixels, const float* normals, co
     NccConst C;
     const int rc = fill(C, M, b, Kinv, ncc_scale, patch, width, height);
     if (rc != GS2M_OK) return rc;
-    patch_ncc_kernel<true><<<(N + 127) / 128, 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, nullptr,
+    patch_ncc_kernel<true><<<(int)(((long long)N * NCC_LPS + 127) / 128), 128, 0, (hipStream_t)stream>>>(N, C, pixels, normals, dists, ref_gray, near_gray, nullptr,
                                                                             dL_dncc, dL_dnormals, dL_ddists);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
