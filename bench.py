@@ -112,6 +112,8 @@ def main():
     empty = torch.Tensor([])
     leaves = [prm["means3D"], means2D, prm["shs"], prm["opacities"], prm["scales"], prm["rotations"], prm["features"]]
     reducer = GradReducer(mode=a.dp_mode)
+    if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
+        gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
     info = {}
 
     def step():

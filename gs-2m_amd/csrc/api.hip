@@ -28,9 +28,17 @@ uint32_t higher_msb(uint32_t n) {
 // pinned landing zone for num_rendered, one per host thread (never freed: the HIP runtime
 // may already be gone when thread-local destructors run)
 struct Pinned {
-    uint32_t* p = nullptr;
+    uint32_t* p = nullptr;    // host pointer of the pinned landing zone
+    uint32_t* dev = nullptr;  // the same memory as the device sees it
 };
 thread_local Pinned t_pinned;
+
+// num_rendered -> the host: ONE aligned 32-bit store at system scope.  (A hipMemcpyAsync of 4 bytes may be carried out
+// byte by byte; a host that polls the landing zone then sees torn values -- 0xFFFFFF59 for a count ending in 0x59 --
+// which is what happened once the GPU was shared with a second process.)
+__global__ void publish_count_kernel(const uint32_t* __restrict__ counters, uint32_t* __restrict__ landing) {
+    __hip_atomic_store(landing, counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 // mode 0: off; 1: the two blend kernels only; 2: every stage.
@@ -139,14 +147,18 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
                                             g.sorted_off, g.counters, true, s));
         }
-        if (!t_pinned.p) HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocDefault));
+        if (!t_pinned.p) {
+            HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
+        }
         // The reference has a sync at the same point (rasterizer_impl.cu:269-270).  The GPU idles from here until the
         // host has seen num_rendered, sized the binning buffer and launched the next kernel, so the wake-up matters:
         // the host polls the pinned landing zone for the value (a sentinel no count can take: R < 2^30) instead of
         // sleeping in hipStreamSynchronize, whose wake-up costs tens of microseconds and far more on a loaded host.
         volatile uint32_t* land = t_pinned.p;
         land[0] = 0xFFFFFFFFu;
-        HIP_TRY(hipMemcpyAsync(t_pinned.p, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        publish_count_kernel<<<1, 1, 0, s>>>(g.counters, t_pinned.dev);
+        HIP_TRY(hipGetLastError());
         if (g_spin_wait) {
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
