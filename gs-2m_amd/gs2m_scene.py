@@ -168,7 +168,13 @@ class Camera:
     def get_inv_K(self, scale=1.0):  # scene/cameras.py:99-104
         return torch.tensor([[scale / self.Fx, 0.0, -self.Cx / self.Fx], [0.0, scale / self.Fy, -self.Cy / self.Fy], [0.0, 0.0, 1.0]], device=self.device)
 
-    def get_rays(self, scale=1.0):  # scene/cameras.py:72-81
+    def get_rays(self, scale=1.0):  # scene/cameras.py:72-81 (constant per camera: built once per scale, not per call)
+        cache = self.__dict__.setdefault("_rays", {})
+        if scale not in cache:
+            cache[scale] = self._build_rays(scale)
+        return cache[scale]
+
+    def _build_rays(self, scale):
         h, w = int(self.image_height / scale), int(self.image_width / scale)
         u, v = torch.meshgrid(torch.arange(w, device=self.device, dtype=torch.float32),
                               torch.arange(h, device=self.device, dtype=torch.float32), indexing='xy')
