@@ -155,12 +155,13 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
     // D_ggx at cos^2(theta_h) = V.H^2 = (1 + L.V) / 2 for unit vectors: no half vector, no square root; the clamp of
     // ndfGGX (cubemap.cu:193-198) cannot bind for L.V in [cutoff, 1]
     const float pi_inv_a2 = alpha_sqr / 3.14159265358979323846f, a2m1h = 0.5f * (alpha_sqr - 1.f);
-    auto accumulate = [&](float d, float area, const float c0, const float c1, const float c2) {
+    // (the file is compiled with -ffp-contract=off: the FMAs are spelled out where rounding symmetry is not at stake)
+    auto accumulate = [&](float d, float area, const float c0, const float c1, const float c2) {  // area: already x 1/4
         if (d >= cos_cut) {
-            const float den = (1.f + d) * a2m1h + 1.f;                      // cos^2 (alpha^2 - 1) + 1
+            const float den = __builtin_fmaf(1.f + d, a2m1h, 1.f);          // cos^2 (alpha^2 - 1) + 1
             const float k = fmaxf(d, 0.f) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
-            const float w = BWD ? k : k * area * 0.25f;
-            a0 += w * c0; a1 += w * c1; a2 += w * c2;
+            const float w = BWD ? k : k * area;
+            a0 = __builtin_fmaf(w, c0, a0); a1 = __builtin_fmaf(w, c1, a1); a2 = __builtin_fmaf(w, c2, a2);
             ws += w;
         }
     };
@@ -181,6 +182,22 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
             cone_range(c.y, c.z, sin_t, N, y0, y1);
             if (x0 > x1 || y0 > y1) continue;
         }
+        // (P_o . P_t) summed in world-axis order, (x + y) + z, with the face's selection hoisted out of the loops (left
+        // inside, the switch on the face costs ~20 scalar branches per pair): exactly one axis carries fx, the others
+        // are constant or carry fy, so  P_o . P_t = (c fx + b) + e  with b = bk + br fy, e = ek + er fy  (adding an
+        // exact 0 changes nothing, and the commuted first sum of faces 0 / 1 is the same number)
+        float dc, bk, br, ek, er;
+        switch (s) {
+            case 0: dc = -Po.z; bk = Po.x; br = -Po.y; ek = 0.f; er = 0.f; break;     // ( 1, -fy, -fx)
+            case 1: dc = Po.z; bk = -Po.x; br = -Po.y; ek = 0.f; er = 0.f; break;     // (-1, -fy,  fx)
+            case 2: dc = Po.x; bk = Po.y; br = 0.f; ek = 0.f; er = Po.z; break;       // (fx,  1,  fy)
+            case 3: dc = Po.x; bk = -Po.y; br = 0.f; ek = 0.f; er = -Po.z; break;     // (fx, -1, -fy)
+            case 4: dc = Po.x; bk = 0.f; br = -Po.y; ek = Po.z; er = 0.f; break;      // (fx, -fy,  1)
+            default: dc = -Po.x; bk = 0.f; br = -Po.y; ek = -Po.z; er = 0.f; break;   // (-fx, -fy, -1)
+        }
+        auto cosine = [&](float fx, float fy, float b, float e) {
+            return ((dc * fx + b) + e) * (ro * __builtin_amdgcn_rsqf((fx * fx + fy * fy) + 1.f));
+        };
         if (TPO == 64) {
             // one output per wave: the lanes tile the box in 16 x 4 blocks (a box is ~30 texels wide at the 256^2 level:
             // 64 lanes along one row would leave half of them idle), two blocks per step
@@ -189,18 +206,17 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
                 const int ya = yb + ly, yc = ya + 4;
                 const bool ra = ya <= y1, rc = yc <= y1;
                 const float fya = org + step * (float)ya, fyc = org + step * (float)yc;
-                const float aya = (BWD || !ra) ? 0.f : ax[ya], ayc = (BWD || !rc) ? 0.f : ax[yc];
+                const float aya = (BWD || !ra) ? 0.f : 0.25f * ax[ya], ayc = (BWD || !rc) ? 0.f : 0.25f * ax[yc];
+                const float ba = bk + br * fya, ea = ek + er * fya, bc = bk + br * fyc, ec = ek + er * fyc;
                 const int r0 = N * N * s + N * (ra ? ya : y0), r1 = N * N * s + N * (rc ? yc : y0);
                 for (int xb = x0; xb <= x1; xb += 16) {
                     const int x = xb + lx;
                     const bool cx = x <= x1;
                     const int xs = cx ? x : x0;
                     const float fx = org + step * (float)xs;
-                    const V3 Pa = face_point(s, fx, fya), Pb = face_point(s, fx, fyc);
-                    const float da = ((Po.x * Pa.x + Po.y * Pa.y) + Po.z * Pa.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fya * fya) + 1.f));
-                    const float db = ((Po.x * Pb.x + Po.y * Pb.y) + Po.z * Pb.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fyc * fyc) + 1.f));
-                    const float* pa = in + (size_t)(r0 + xs) * IC;
-                    const float* pb = in + (size_t)(r1 + xs) * IC;
+                    const float da = cosine(fx, fya, ba, ea), db = cosine(fx, fyc, bc, ec);
+                    const float* pa = in + (uint32_t)(r0 + xs) * (uint32_t)IC;  // 32-bit offset from the uniform base
+                    const float* pb = in + (uint32_t)(r1 + xs) * (uint32_t)IC;
                     const float ca0 = pa[0], ca1 = pa[1], ca2 = pa[2], cb0 = pb[0], cb1 = pb[1], cb2 = pb[2];
                     const float axx = BWD ? 0.f : ax[xs];
                     if (cx && ra) accumulate(da, axx * aya, ca0, ca1, ca2);
@@ -214,14 +230,13 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
             const bool two = y + 1 <= y1;
             const int r0 = N * N * s + N * y, r1 = two ? r0 + N : r0;
             const float fya = org + step * (float)y, fyb = fya + step;
-            const float aya = BWD ? 0.f : ax[y], ayb = BWD ? 0.f : ax[two ? y + 1 : y];
+            const float aya = BWD ? 0.f : 0.25f * ax[y], ayb = BWD ? 0.f : 0.25f * ax[two ? y + 1 : y];
+            const float ba = bk + br * fya, ea = ek + er * fya, bb = bk + br * fyb, eb = ek + er * fyb;
             for (int x = x0 + sub; x <= x1; x += TPO) {
                 const float fx = org + step * (float)x;
-                const V3 Pa = face_point(s, fx, fya), Pb = face_point(s, fx, fyb);
-                const float da = ((Po.x * Pa.x + Po.y * Pa.y) + Po.z * Pa.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fya * fya) + 1.f));
-                const float db = ((Po.x * Pb.x + Po.y * Pb.y) + Po.z * Pb.z) * (ro * __builtin_amdgcn_rsqf((fx * fx + fyb * fyb) + 1.f));
-                const float* pa = in + (size_t)(r0 + x) * IC;
-                const float* pb = in + (size_t)(r1 + x) * IC;
+                const float da = cosine(fx, fya, ba, ea), db = cosine(fx, fyb, bb, eb);
+                const float* pa = in + (uint32_t)(r0 + x) * (uint32_t)IC;  // 32-bit offset from the uniform base
+                const float* pb = in + (uint32_t)(r1 + x) * (uint32_t)IC;
                 const float ca0 = pa[0], ca1 = pa[1], ca2 = pa[2], cb0 = pb[0], cb1 = pb[1], cb2 = pb[2];
                 const float axx = BWD ? 0.f : ax[x];
                 accumulate(da, axx * aya, ca0, ca1, ca2);
