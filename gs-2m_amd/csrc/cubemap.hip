@@ -259,6 +259,22 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
     }
 }
 
+// the division by the weight sum (render_utils/ops.py:403) and its backward as part of the operator: in PyTorch the slice /
+// divide and their autograd nodes are ~13 launches per level, six levels per view
+__global__ void __launch_bounds__(256) specular_normalize_kernel(int n, const float4* __restrict__ raw, float* __restrict__ out3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = raw[i];
+    out3[3 * (size_t)i] = r.x / r.w; out3[3 * (size_t)i + 1] = r.y / r.w; out3[3 * (size_t)i + 2] = r.z / r.w;
+}
+__global__ void __launch_bounds__(256) specular_prescale_kernel(int n, const float4* __restrict__ raw, const float* __restrict__ g3,
+                                                                float4* __restrict__ g4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float w = raw[i].w;  // d(col / w)/d col = 1 / w; w does not depend on the cubemap
+    g4[i] = make_float4(g3[3 * (size_t)i] / w, g3[3 * (size_t)i + 1] / w, g3[3 * (size_t)i + 2] / w, 0.f);
+}
+
 template <bool BWD>
 int launch_specular(int res, float roughness, float cos_cut, const float* tab, const float* in, float* out, hipStream_t s) {
     const long long total = 6LL * res * res;
@@ -306,6 +322,27 @@ int gs2m_specular_cubemap_backward(int res, float roughness, float costheta_cuto
     if (res < 1 || res > 4096 || !texel_table || !dL_dout || !dL_dcubemap) return GS2M_ERR_INVALID_ARG;
     return launch_specular<true>(res, roughness, costheta_cutoff, texel_table, dL_dout, dL_dcubemap,
                                  (hipStream_t)stream);
+}
+
+int gs2m_specular_cubemap_normalized_forward(int res, float roughness, float costheta_cutoff, const float* texel_table,
+                                             const float* cubemap, float* raw, float* out, void* stream) {
+    if (res < 1 || res > 4096 || !texel_table || !cubemap || !raw || !out || ((uintptr_t)raw & 15)) return GS2M_ERR_INVALID_ARG;
+    const int rc = launch_specular<false>(res, roughness, costheta_cutoff, texel_table, cubemap, raw, (hipStream_t)stream);
+    if (rc != GS2M_OK) return rc;
+    const int n = 6 * res * res;
+    specular_normalize_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, reinterpret_cast<const float4*>(raw), out);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_specular_cubemap_normalized_backward(int res, float roughness, float costheta_cutoff, const float* texel_table,
+                                              const float* raw, const float* dL_dout, float* scratch, float* dL_dcubemap, void* stream) {
+    if (res < 1 || res > 4096 || !texel_table || !raw || !dL_dout || !scratch || !dL_dcubemap || (((uintptr_t)raw | (uintptr_t)scratch) & 15))
+        return GS2M_ERR_INVALID_ARG;
+    const int n = 6 * res * res;
+    specular_prescale_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, reinterpret_cast<const float4*>(raw), dL_dout,
+                                                                             reinterpret_cast<float4*>(scratch));
+    if (hipGetLastError() != hipSuccess) return GS2M_ERR_HIP;
+    return launch_specular<true>(res, roughness, costheta_cutoff, texel_table, scratch, dL_dcubemap, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -85,6 +85,38 @@ class _specular_cubemap(torch.autograd.Function):
         return g, None, None
 
 
+class _specular_cubemap_normalized(torch.autograd.Function):
+    """specular_cubemap's `out[..., 0:3] / out[..., 3:]` folded into the operator (forward: gather + divide; backward: prescale +
+    gather) -- two launches each way instead of ~16."""
+
+    @staticmethod
+    def forward(ctx, cubemap, roughness, costheta_cutoff):
+        cubemap = _check(cubemap, "cubemap", 3)
+        res = cubemap.shape[1]
+        raw = torch.empty((6, res, res, 4), dtype=torch.float32, device=cubemap.device)
+        out = torch.empty_like(cubemap)
+        with torch.cuda.device(cubemap.device):
+            _native.check(_native.lib().gs2m_specular_cubemap_normalized_forward(
+                res, float(roughness), float(costheta_cutoff), _texel_table(res, cubemap.device).data_ptr(), cubemap.data_ptr(), raw.data_ptr(),
+                out.data_ptr(), _stream(cubemap.device)), "gs2m_specular_cubemap_normalized_forward")
+        ctx.save_for_backward(raw)
+        ctx.args = (float(roughness), float(costheta_cutoff))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (raw,) = ctx.saved_tensors
+        dout = _check(dout, "grad", 3)
+        res = dout.shape[1]
+        scratch = torch.empty_like(raw)
+        g = torch.empty_like(dout)
+        with torch.cuda.device(dout.device):
+            _native.check(_native.lib().gs2m_specular_cubemap_normalized_backward(
+                res, ctx.args[0], ctx.args[1], _texel_table(res, dout.device).data_ptr(), raw.data_ptr(), dout.data_ptr(), scratch.data_ptr(),
+                g.data_ptr(), _stream(dout.device)), "gs2m_specular_cubemap_normalized_backward")
+        return g, None, None
+
+
 _cutoff_cache = {}
 
 
@@ -105,5 +137,4 @@ def ndf_cutoff(roughness, cutoff):
 def specular_cubemap(cubemap, roughness, cutoff=0.99, use_python=False):
     assert not use_python
     assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2], "Bad shape for cubemap tensor: %s" % str(cubemap.shape)
-    out = _specular_cubemap.apply(cubemap, roughness, ndf_cutoff(roughness, cutoff))
-    return out[..., 0:3] / out[..., 3:]
+    return _specular_cubemap_normalized.apply(cubemap, roughness, ndf_cutoff(roughness, cutoff))

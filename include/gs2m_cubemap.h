@@ -31,6 +31,14 @@ int gs2m_specular_cubemap_forward(int res, float roughness, float costheta_cutof
 int gs2m_specular_cubemap_backward(int res, float roughness, float costheta_cutoff, const float* texel_table, const float* dL_dout,
                                    float* dL_dcubemap, void* stream);
 
+/* The same operator INCLUDING the division by the weight sum (what `specular_cubemap` returns, render_utils/ops.py:391-403) and
+ * its backward: out, dL_dout (6, res, res, 3); raw (6, res, res, 4), 16-byte aligned, is written by the forward and must be
+ * handed to the backward unchanged; scratch: (6, res, res, 4) floats, 16-byte aligned. */
+int gs2m_specular_cubemap_normalized_forward(int res, float roughness, float costheta_cutoff, const float* texel_table,
+                                             const float* cubemap, float* raw, float* out, void* stream);
+int gs2m_specular_cubemap_normalized_backward(int res, float roughness, float costheta_cutoff, const float* texel_table,
+                                              const float* raw, const float* dL_dout, float* scratch, float* dL_dcubemap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
