@@ -96,3 +96,14 @@ def test_fused_ssim_refuses_cpu_tensors():
     from fused_ssim import fused_ssim
     with pytest.raises(RuntimeError, match="no CPU path"):
         fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+
+
+def test_every_header_is_valid_c99():
+    """The boundary is a C ABI: each header must compile as plain C on its own."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(inc)):
+        if fn.endswith(".h"):
+            r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", "-"],
+                               input=f'#include "{os.path.join(inc, fn)}"\nint main(void) {{ return 0; }}\n', text=True, capture_output=True)
+            assert r.returncode == 0, fn + "\n" + r.stderr
