@@ -113,7 +113,7 @@ def lib():
     L.gs2m_pbr_shade_forward.restype = i
     L.gs2m_pbr_shade_forward.argtypes = [i, p, p, p, p, p, p, i, i, p, i, i, p, p, f, f, p, p, p, p, p]
     L.gs2m_pbr_shade_backward.restype = i
-    L.gs2m_pbr_shade_backward.argtypes = [i, p, p, p, p, p, p, i, i, p, i, i, p, p, f, f, p, p, p, p, p, p]
+    L.gs2m_pbr_shade_backward.argtypes = [i, p, p, p, p, p, p, i, i, p, i, i, p, p, f, f, p, p, p, p, p, i, p]
     L.gs2m_patch_ncc_forward.restype = i
     L.gs2m_patch_ncc_forward.argtypes = [i, p, p, p, p, p, i, i, p, p, p, f, i, p, p]
     L.gs2m_patch_ncc_backward.restype = i

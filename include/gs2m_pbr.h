@@ -9,7 +9,8 @@
  *     rgb = clamp(E albedo + L (F0 A + B), 0, 1),  F0 = 0.04 (1 - metallic) + albedo metallic   (0.04 if metallic is NULL)
  * The reference runs ~30 PyTorch launches forward and ~50 backward around three `dr.texture` calls for this.
  * Backward: gradients to albedo, metallic (optional) and -- accumulated, zero them first -- the diffuse map and every level
- * of the specular stack; normals, view directions and roughness get none (pbr_render detaches them).
+ * of the specular stack; normals, view directions and roughness get none (pbr_render detaches them).  `image_width`: the pixels
+ * are an image of that width in row-major order (n a multiple of it) -- lets the backward work on 2-D pixel tiles -- or 0.
  * Device pointers, fp32; pixel arrays are (n, 3) / (n, 1); `specular`, `dL_dspecular`, `width` are HOST arrays of `levels`
  * entries.  Asynchronous on `stream`; return GS2M_OK (0) or a negative GS2M_ERR_* code (gs2m_raster.h). */
 #ifndef GS2M_PBR_H
@@ -29,7 +30,7 @@ int gs2m_pbr_shade_backward(int n, const float* normals, const float* view_dirs,
                             const float* metallic, const float* brdf_lut, int lut_width, int lut_height, const float* diffuse,
                             int diffuse_width, int levels, const float* const* specular, const int* width, float min_roughness,
                             float max_roughness, const float* dL_drender_rgb, float* dL_dalbedo, float* dL_dmetallic,
-                            float* dL_ddiffuse, float* const* dL_dspecular, void* stream);
+                            float* dL_ddiffuse, float* const* dL_dspecular, int image_width, void* stream);
 
 #ifdef __cplusplus
 }
