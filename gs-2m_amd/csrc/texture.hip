@@ -206,6 +206,71 @@ __device__ __forceinline__ bool run_merge(int key, float (&v)[C]) {
     return key >= 0 && (lr == 15 || next != key);  // this lane holds its run's sum and issues the add
 }
 
+// A combining table in LDS in front of the global atomics of the levels that are too large to privatise: key = (level, texel),
+// open addressing, 8 probes, then straight to memory; drained after every pixel tile.  A 32 x 32 tile of a smooth image puts its
+// ~8000 contributions on a few hundred distinct texels.
+constexpr int COMB_HT = 2048;
+
+template <int C>
+struct CombineTable {
+    int* key;     // [COMB_HT], -1 = empty
+    float* val;   // [COMB_HT][C]
+    __device__ __forceinline__ void clear(int tid, int nthreads) {
+        for (int k = tid; k < COMB_HT; k += nthreads) {
+            key[k] = -1;
+#pragma unroll
+            for (int c = 0; c < C; c++) val[C * k + c] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void add(int level, int texel, float* gptr, const float (&v)[C]) {
+        const int k = (level << 24) | texel;
+        unsigned h = ((unsigned)k * 2654435761u) >> 21;  // 11 bits
+#pragma unroll 1
+        for (int probe = 0; probe < 8; probe++) {
+            const int old = atomicCAS(&key[h], -1, k);
+            if (old == -1 || old == k) {
+#pragma unroll
+                for (int c = 0; c < C; c++) atomicAdd(&val[C * h + c], v[c]);
+                return;
+            }
+            h = (h + 1) & (COMB_HT - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(&gptr[(size_t)texel * C + c], v[c]);
+    }
+    template <class GradOf>
+    __device__ __forceinline__ void drain(int tid, int nthreads, GradOf grad_of) {  // all threads of the workgroup
+        __syncthreads();
+        for (int k = tid; k < COMB_HT; k += nthreads) {
+            const int kk = key[k];
+            if (kk >= 0) {
+                float* g = grad_of(kk >> 24) + (size_t)(kk & 0xFFFFFF) * C;
+#pragma unroll
+                for (int c = 0; c < C; c++) { unsafeAtomicAdd(&g[c], val[C * k + c]); val[C * k + c] = 0.f; }
+                key[k] = -1;
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// pixel index of thread t in tile `tile`: 32 x 32 image tiles when the image width is known (the 16 lanes of a DPP row are
+// horizontal neighbours), else runs of 1024 consecutive pixels
+__device__ __forceinline__ int tile_pixel(int tile, int t, int n, int img_w, bool& valid) {
+    if (img_w > 0) {
+        const int img_h = n / img_w, tiles_x = (img_w + 31) / 32;
+        const int x = (tile % tiles_x) * 32 + (t & 31), y = (tile / tiles_x) * 32 + (t >> 5);
+        valid = x < img_w && y < img_h;
+        return y * img_w + x;
+    }
+    const int i = tile * 1024 + t;
+    valid = i < n;
+    return i;
+}
+__host__ __device__ __forceinline__ int tile_count(int n, int img_w) {
+    return img_w > 0 ? ((img_w + 31) / 32) * ((n / img_w + 31) / 32) : (n + 1023) / 1024;
+}
+
 struct MipStack {
     const float* tex[GS2M_TEX_MAX_LEVELS];
     float* grad[GS2M_TEX_MAX_LEVELS];
@@ -251,10 +316,12 @@ __global__ void __launch_bounds__(256) texture_kernel(int n, MipStack M, int hei
 // backward: persistent workgroups (one per CU), grid-stride over the pixels; small levels accumulate in LDS and are
 // flushed once per workgroup
 template <int C, int MODE>
-__global__ void __launch_bounds__(TEX_BWD_THREADS) texture_bwd_kernel(int n, MipStack M, int height, const float* __restrict__ uv,
+__global__ void __launch_bounds__(TEX_BWD_THREADS) texture_bwd_kernel(int n, int img_w, MipStack M, int height, const float* __restrict__ uv,
                                                                       const float* __restrict__ bias, const float* __restrict__ dy) {
     extern __shared__ float s_acc[];
+    CombineTable<C> T = {reinterpret_cast<int*>(s_acc + M.lds_floats), s_acc + M.lds_floats + COMB_HT};
     for (int k = threadIdx.x; k < M.lds_floats; k += TEX_BWD_THREADS) s_acc[k] = 0.f;
+    T.clear(threadIdx.x, TEX_BWD_THREADS);
     __syncthreads();
     // wave-uniform: every lane walks the same number of pixels and footprints; lanes with nothing to add carry key -1
     auto add = [&](bool on, int level, const Footprint& F, const float (&g)[C], float scale) {
@@ -273,16 +340,15 @@ __global__ void __launch_bounds__(TEX_BWD_THREADS) texture_bwd_kernel(int n, Mip
 #pragma unroll
                     for (int c = 0; c < C; c++) atomicAdd(&s_acc[loff + F.t[k] * C + c], v[c]);  // ds_add_f32
                 } else {
-#pragma unroll
-                    for (int c = 0; c < C; c++) unsafeAtomicAdd(&M.grad[level][(size_t)F.t[k] * C + c], v[c]);
+                    T.add(level, F.t[k], M.grad[level], v);
                 }
             }
         }
     };
-    const int per_pass = gridDim.x * TEX_BWD_THREADS;
-    for (int base = blockIdx.x * TEX_BWD_THREADS; base < n; base += per_pass) {
-        const int i = base + threadIdx.x;
-        const bool valid = i < n;
+    const int ntiles = tile_count(n, img_w);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        bool valid;
+        const int i = tile_pixel(tile, threadIdx.x, n, img_w, valid);
         const size_t ii = valid ? (size_t)i : 0;
         float g[C];
         bool any = false;
@@ -304,6 +370,7 @@ __global__ void __launch_bounds__(TEX_BWD_THREADS) texture_bwd_kernel(int n, Mip
             add(any, l0, cube_footprint(x, y, z, M.width[l0]), g, two ? 1.f - fl : 1.f);
             if (MODE == 1) add(any && two, l1, cube_footprint(x, y, z, M.width[l1]), g, fl);
         }
+        T.drain(threadIdx.x, TEX_BWD_THREADS, [&](int level) { return M.grad[level]; });
     }
     __syncthreads();
     for (int l = 0; l < M.levels; l++) {
@@ -334,7 +401,7 @@ int launch_fwd(int C, int n, const MipStack& M, int height, const float* uv, con
 }
 
 template <int C, int MODE>
-int launch_bwd_c(int n, MipStack& M, int height, const float* uv, const float* bias, const float* dy, hipStream_t s) {
+int launch_bwd_c(int n, int img_w, MipStack& M, int height, const float* uv, const float* bias, const float* dy, hipStream_t s) {
     // private LDS copies for the small levels (2-D: small textures)
     M.lds_floats = 0;
     for (int l = 0; l < M.levels; l++) {
@@ -342,7 +409,19 @@ int launch_bwd_c(int n, MipStack& M, int height, const float* uv, const float* b
         M.lds_off[l] = small ? M.lds_floats : -1;
         if (small) M.lds_floats += (MODE == 2 ? M.width[l] * height : 6 * M.width[l] * M.width[l]) * C;
     }
-    const size_t lds = (size_t)M.lds_floats * sizeof(float);
+    // the table has to fit behind the private copies: give up the widest private level(s) if it does not (they then go
+    // through the table like the large ones)
+    while ((size_t)(M.lds_floats + COMB_HT * (1 + C)) * sizeof(float) > 159 * 1024) {
+        int widest = -1;
+        for (int l = 0; l < M.levels; l++)
+            if (M.lds_off[l] >= 0 && (widest < 0 || M.width[l] > M.width[widest])) widest = l;
+        if (widest < 0) return GS2M_ERR_UNSUPPORTED;
+        M.lds_off[widest] = -1;
+        M.lds_floats = 0;
+        for (int l = 0; l < M.levels; l++)
+            if (M.lds_off[l] >= 0) { M.lds_off[l] = M.lds_floats; M.lds_floats += (MODE == 2 ? M.width[l] * height : 6 * M.width[l] * M.width[l]) * C; }
+    }
+    const size_t lds = (size_t)(M.lds_floats + COMB_HT * (1 + C)) * sizeof(float);
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&texture_bwd_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -355,17 +434,17 @@ int launch_bwd_c(int n, MipStack& M, int height, const float* uv, const float* b
 #define GS2M_TEX_BWD_BLOCKS 256
 #endif
     if (blocks > GS2M_TEX_BWD_BLOCKS) blocks = GS2M_TEX_BWD_BLOCKS;  // one per CU: the flush costs (workgroups x private texels) atomics
-    texture_bwd_kernel<C, MODE><<<blocks, TEX_BWD_THREADS, lds, s>>>(n, M, height, uv, bias, dy);
+    texture_bwd_kernel<C, MODE><<<blocks, TEX_BWD_THREADS, lds, s>>>(n, img_w, M, height, uv, bias, dy);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 
 template <int MODE>
-int launch_bwd(int C, int n, MipStack& M, int height, const float* uv, const float* bias, const float* dy, hipStream_t s) {
+int launch_bwd(int C, int n, int img_w, MipStack& M, int height, const float* uv, const float* bias, const float* dy, hipStream_t s) {
     switch (C) {
-        case 1: return launch_bwd_c<1, MODE>(n, M, height, uv, bias, dy, s);
-        case 2: return launch_bwd_c<2, MODE>(n, M, height, uv, bias, dy, s);
-        case 3: return launch_bwd_c<3, MODE>(n, M, height, uv, bias, dy, s);
-        case 4: return launch_bwd_c<4, MODE>(n, M, height, uv, bias, dy, s);
+        case 1: return launch_bwd_c<1, MODE>(n, img_w, M, height, uv, bias, dy, s);
+        case 2: return launch_bwd_c<2, MODE>(n, img_w, M, height, uv, bias, dy, s);
+        case 3: return launch_bwd_c<3, MODE>(n, img_w, M, height, uv, bias, dy, s);
+        case 4: return launch_bwd_c<4, MODE>(n, img_w, M, height, uv, bias, dy, s);
         default: return GS2M_ERR_UNSUPPORTED;
     }
 }
@@ -448,44 +527,14 @@ __global__ void __launch_bounds__(256) shade_fwd_kernel(int n, ShadeIn P, MipSta
 // (image width given) and puts a small combining table in LDS in front of the atomics: key = (level, texel), open
 // addressing, 8 probes, then straight to memory; the table is drained after every tile.  A tile of a smooth image touches a
 // few hundred distinct texels with its ~8000 contributions.
-constexpr int SHADE_HT = 2048;
-
 __global__ void __launch_bounds__(TEX_BWD_THREADS) shade_bwd_kernel(int n, int img_w, ShadeIn P, MipStack M, const float* __restrict__ d_rgb,
                                                                     float* __restrict__ d_albedo, float* __restrict__ d_metallic) {
     extern __shared__ float s_acc[];
     const int lds_total = M.lds_floats + (P.diffuse_lds >= 0 ? 6 * P.diffuse_w * P.diffuse_w * 3 : 0);
-    int* s_key = reinterpret_cast<int*>(s_acc + lds_total);       // [SHADE_HT]
-    float* s_val = s_acc + lds_total + SHADE_HT;                   // [SHADE_HT][3]
+    CombineTable<3> T = {reinterpret_cast<int*>(s_acc + lds_total), s_acc + lds_total + COMB_HT};
     for (int k = threadIdx.x; k < lds_total; k += TEX_BWD_THREADS) s_acc[k] = 0.f;
-    for (int k = threadIdx.x; k < SHADE_HT; k += TEX_BWD_THREADS) { s_key[k] = -1; s_val[3 * k] = 0.f; s_val[3 * k + 1] = 0.f; s_val[3 * k + 2] = 0.f; }
+    T.clear(threadIdx.x, TEX_BWD_THREADS);
     __syncthreads();
-    auto combine = [&](int key, float* gptr, int texel, const float (&v)[3]) {
-        unsigned h = ((unsigned)key * 2654435761u) >> 21;           // 11 bits
-#pragma unroll 1
-        for (int probe = 0; probe < 8; probe++) {
-            const int old = atomicCAS(&s_key[h], -1, key);
-            if (old == -1 || old == key) {
-                atomicAdd(&s_val[3 * h], v[0]); atomicAdd(&s_val[3 * h + 1], v[1]); atomicAdd(&s_val[3 * h + 2], v[2]);
-                return;
-            }
-            h = (h + 1) & (SHADE_HT - 1);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) unsafeAtomicAdd(&gptr[(size_t)texel * 3 + c], v[c]);
-    };
-    auto drain = [&]() {  // all threads
-        __syncthreads();
-        for (int k = threadIdx.x; k < SHADE_HT; k += TEX_BWD_THREADS) {
-            const int key = s_key[k];
-            if (key >= 0) {
-                float* gptr = M.grad[key >> 24] + (size_t)(key & 0xFFFFFF) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; c++) { unsafeAtomicAdd(&gptr[c], s_val[3 * k + c]); s_val[3 * k + c] = 0.f; }
-                s_key[k] = -1;
-            }
-        }
-        __syncthreads();
-    };
     auto add = [&](bool on, int key_hi, int loff, float* gptr, const Footprint& F, const float (&g)[3], float scale) {
         float wt[4];
         footprint_weights(F, wt);
@@ -499,28 +548,19 @@ __global__ void __launch_bounds__(TEX_BWD_THREADS) shade_bwd_kernel(int n, int i
                 if (loff >= 0) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) atomicAdd(&s_acc[loff + F.t[k] * 3 + c], v[c]);
-                } else {
-                    combine((key_hi << 24) | F.t[k], gptr, F.t[k], v);
+                } else if (key_hi < M.levels) {
+                    T.add(key_hi, F.t[k], gptr, v);
+                } else {  // (an irradiance map too large for LDS: not a level of the stack)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) unsafeAtomicAdd(&gptr[(size_t)F.t[k] * 3 + c], v[c]);
                 }
             }
         }
     };
-    // pixel tiles: 32 x 32 when the image width is known (thread t -> (t & 31, t >> 5): the 16 lanes of a DPP row are
-    // horizontal neighbours), else runs of 1024 consecutive pixels
-    const int img_h = img_w > 0 ? n / img_w : 0;
-    const int tiles_x = img_w > 0 ? (img_w + 31) / 32 : 0;
-    const int ntiles = img_w > 0 ? tiles_x * ((img_h + 31) / 32) : (n + TEX_BWD_THREADS - 1) / TEX_BWD_THREADS;
+    const int ntiles = tile_count(n, img_w);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int i;
         bool valid;
-        if (img_w > 0) {
-            const int x = (tile % tiles_x) * 32 + (threadIdx.x & 31), y = (tile / tiles_x) * 32 + (threadIdx.x >> 5);
-            valid = x < img_w && y < img_h;
-            i = y * img_w + x;
-        } else {
-            i = tile * TEX_BWD_THREADS + threadIdx.x;
-            valid = i < n;
-        }
+        const int i = tile_pixel(tile, threadIdx.x, n, img_w, valid);
         const size_t ii = valid ? (size_t)i : 0;
         const ShadePixel s = shade_eval(P, M, ii);
         float g[3], gE[3], gL[3], dm = 0.f;
@@ -542,7 +582,7 @@ __global__ void __launch_bounds__(TEX_BWD_THREADS) shade_bwd_kernel(int n, int i
         add(any, 15, P.diffuse_lds, P.d_diffuse, s.Fd, gE, 1.f);
         add(any, s.l0, M.lds_off[any ? s.l0 : 0], M.grad[any ? s.l0 : 0], s.F0, gL, s.two ? 1.f - s.fl : 1.f);
         add(any && s.two, s.l1, M.lds_off[any ? s.l1 : 0], M.grad[any ? s.l1 : 0], s.F1, gL, s.fl);
-        drain();
+        T.drain(threadIdx.x, TEX_BWD_THREADS, [&](int level) { return M.grad[level]; });
     }
     __syncthreads();
     auto flush = [&](int loff, float* gptr, int cnt) {
@@ -587,14 +627,14 @@ int gs2m_texture_cube_forward(int n, int channels, int levels, const float* cons
 }
 
 int gs2m_texture_cube_backward(int n, int channels, int levels, float* const* grad_tex, const int* width, const float* dirs,
-                               const float* mip_level_bias, const float* dL_dout, void* stream) {
+                               const float* mip_level_bias, const float* dL_dout, int image_width, void* stream) {
     if (n == 0) return GS2M_OK;
-    if (n < 0 || !dirs || !dL_dout) return GS2M_ERR_INVALID_ARG;
+    if (n < 0 || !dirs || !dL_dout || image_width < 0 || (image_width > 0 && n % image_width != 0)) return GS2M_ERR_INVALID_ARG;
     MipStack M;
     const int rc = fill_stack(M, levels, nullptr, grad_tex, width, true);
     if (rc != GS2M_OK) return rc;
-    if (mip_level_bias) return launch_bwd<1>(channels, n, M, 0, dirs, mip_level_bias, dL_dout, (hipStream_t)stream);
-    return launch_bwd<0>(channels, n, M, 0, dirs, nullptr, dL_dout, (hipStream_t)stream);
+    if (mip_level_bias) return launch_bwd<1>(channels, n, image_width, M, 0, dirs, mip_level_bias, dL_dout, (hipStream_t)stream);
+    return launch_bwd<0>(channels, n, image_width, M, 0, dirs, nullptr, dL_dout, (hipStream_t)stream);
 }
 
 int gs2m_texture_2d_clamp_forward(int n, int channels, int width, int height, const float* tex, const float* uv, float* out,
@@ -612,7 +652,7 @@ int gs2m_texture_2d_clamp_backward(int n, int channels, int width, int height, f
     if (n < 0 || width < 1 || height < 1 || !grad_tex || !uv || !dL_dout) return GS2M_ERR_INVALID_ARG;
     MipStack M;
     M.levels = 1; M.tex[0] = nullptr; M.grad[0] = grad_tex; M.width[0] = width;
-    return launch_bwd<2>(channels, n, M, height, uv, nullptr, dL_dout, (hipStream_t)stream);
+    return launch_bwd<2>(channels, n, 0, M, height, uv, nullptr, dL_dout, (hipStream_t)stream);
 }
 
 int gs2m_pbr_shade_forward(int n, const float* normals, const float* view_dirs, const float* albedo, const float* roughness,
@@ -658,7 +698,7 @@ int gs2m_pbr_shade_backward(int n, const float* normals, const float* view_dirs,
                  min_roughness, max_roughness};
     int lds_floats = M.lds_floats;
     if (diffuse_width <= TEX_LDS_MAX_WIDTH) { P.diffuse_lds = lds_floats; lds_floats += 6 * diffuse_width * diffuse_width * 3; }
-    lds_floats += SHADE_HT * 4;  // the combining table behind the private copies
+    lds_floats += COMB_HT * 4;  // the combining table behind the private copies
     if ((size_t)lds_floats * sizeof(float) > 159 * 1024) return GS2M_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {

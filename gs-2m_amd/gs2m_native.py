@@ -95,7 +95,7 @@ def lib():
     L.gs2m_texture_cube_forward.restype = i
     L.gs2m_texture_cube_forward.argtypes = [i, i, i, p, p, p, p, p, p]
     L.gs2m_texture_cube_backward.restype = i
-    L.gs2m_texture_cube_backward.argtypes = [i, i, i, p, p, p, p, p, p]
+    L.gs2m_texture_cube_backward.argtypes = [i, i, i, p, p, p, p, p, i, p]
     L.gs2m_texture_2d_clamp_forward.restype = i
     L.gs2m_texture_2d_clamp_forward.argtypes = [i, i, i, i, p, p, p, p]
     L.gs2m_texture_2d_clamp_backward.restype = i

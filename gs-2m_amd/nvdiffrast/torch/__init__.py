@@ -57,7 +57,7 @@ class _CubeTexture(torch.autograd.Function):
             _native.check(_native.lib().gs2m_texture_cube_backward(
                 uv.numel() // 3, ctx.shapes[0][-1], len(grads), _arr([g.data_ptr() for g in grads]),
                 (C.c_int * len(grads))(*ctx.widths), uv.data_ptr(), None if bias is None else bias.data_ptr(), dy.data_ptr(),
-                _stream(uv.device)), "gs2m_texture_cube_backward")
+                int(uv.shape[-2]), _stream(uv.device)), "gs2m_texture_cube_backward")
         return (None, None) + tuple(grads)
 
 

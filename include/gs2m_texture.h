@@ -30,8 +30,10 @@ extern "C" {
  * be 1).  Non-NULL: 'linear-mipmap-linear' with level = clamp(bias, 0, levels - 1).  out: (n, C). */
 int gs2m_texture_cube_forward(int n, int channels, int levels, const float* const* tex, const int* width, const float* dirs,
                               const float* mip_level_bias, float* out, void* stream);
+/* image_width: the n lookups are an image of that width in row-major order (n a multiple of it; lets the backward work on 2-D
+ * pixel tiles, whose footprints overlap), or 0. */
 int gs2m_texture_cube_backward(int n, int channels, int levels, float* const* grad_tex, const int* width, const float* dirs,
-                               const float* mip_level_bias, const float* dL_dout, void* stream);
+                               const float* mip_level_bias, const float* dL_dout, int image_width, void* stream);
 
 /* uv: (n, 2) in texture units ([0, 1] spans the texture); coordinates clamp to the centres of the edge texels. */
 int gs2m_texture_2d_clamp_forward(int n, int channels, int width, int height, const float* tex, const float* uv, float* out,
