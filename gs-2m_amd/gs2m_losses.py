@@ -27,9 +27,17 @@ def image_gradient_weight(img):
     return F.pad(g[None, None], (1, 1, 1, 1), mode="constant", value=0.0)[0, 0]
 
 
-def depth_normal_loss(normal_map, sobel_map, gt_image, weight_map=None):
-    """L1 between the rendered normals and the normals of the rendered depth, down-weighted at image edges."""
-    weights = (1.0 - image_gradient_weight(gt_image)).clamp(0, 1).detach() ** 2
+def edge_weights(gt_image):
+    """(1 - normalised image gradient)^2: the per-pixel weight of depth_normal_loss.  Depends on the ground-truth image only,
+    so a training loop can compute it once per view."""
+    return (1.0 - image_gradient_weight(gt_image)).clamp(0, 1).detach() ** 2
+
+
+def depth_normal_loss(normal_map, sobel_map, gt_image=None, weight_map=None, weights=None):
+    """L1 between the rendered normals and the normals of the rendered depth, down-weighted at image edges
+    (`weights`: a precomputed `edge_weights(gt_image)`)."""
+    if weights is None:
+        weights = edge_weights(gt_image)
     if weight_map is not None:
         weights = weights * weight_map.squeeze()
     return (weights * (sobel_map - normal_map).abs().sum(dim=0)).mean()

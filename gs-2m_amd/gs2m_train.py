@@ -28,7 +28,7 @@ import torch
 import gs2m_synth as S
 from fused_ssim import fused_ssim
 from gaussian_renderer import render
-from gs2m_losses import depth_normal_loss, l1_loss, plane_loss, tv_loss
+from gs2m_losses import depth_normal_loss, edge_weights, l1_loss, plane_loss, tv_loss
 from gs2m_model import GaussianModel, OptimizationParams
 from gs2m_scene import Camera, GaussianParams, PipelineParams, inverse_sigmoid
 
@@ -144,7 +144,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         import gs2m_mvs
         mv_opt = mv_opt or gs2m_mvs.MultiViewParams()
         mv_scene = gs2m_mvs.MultiViewScene(cams, gts, gaussians, mv_opt)
-    lighting, rays = None, {}
+    lighting, rays, dn_weights = None, {}, {}
     if material_from_iter < iterations:
         from pbr import pbr_render
         import torch.nn.functional as F
@@ -172,7 +172,9 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
-            loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], gt_image=gt)
+            if k not in dn_weights:  # a function of the ground-truth image only (the reference recomputes it every iteration)
+                dn_weights[k] = edge_weights(gt)
+            loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
             if mv_scene is not None and lambda_multi_view > 0:
                 Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render)
                 loss = loss + lambda_multi_view * Lmv
