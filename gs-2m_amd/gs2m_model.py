@@ -42,7 +42,8 @@ def expon_lr(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1
 
 
 class OptimizationParams:
-    """arguments/__init__.py:81-134 defaults that this module reads."""
+    """arguments/__init__.py:81-134 defaults that the model and the training loop read (pinned against the reference's class
+    by tests/golden/ref_defaults.json)."""
     iterations = 30_000
     position_lr_init = 0.00016
     position_lr_final = 0.0000016
@@ -52,19 +53,29 @@ class OptimizationParams:
     opacity_lr = 0.05
     scaling_lr = 0.005
     rotation_lr = 0.001
-    percent_dense = 0.01
-    prune_init_points = False
+    percent_dense = 0.001
+    prune_init_points = True
     lambda_ssim = 0.2
-    lambda_plane = 0.01
-    lambda_depth_normal = 0.015
+    lambda_plane = 100.0
+    lambda_depth_normal = 0.03
+    lambda_multi_view = 1.0
+    lambda_normal = 0.1
+    lambda_smooth = 0.0
+    lambda_rough = 1e-4
+    lambda_alpha = 0.2
+    geometry_from_iter = 5000
+    material_from_iter = 30_000
     densification_interval = 100
     opacity_reset_interval = 3000
     densify_from_iter = 500
     densify_until_iter = 15_000
     densify_grad_threshold = 0.0002
     densify_grad_abs_threshold = 0.0008
-    opacity_prune_threshold = 0.05
+    opacity_prune_threshold = 0.005
     radii2D_threshold = 20
+    use_opacity_reduce = False
+    opacity_reduce_interval = 500
+    use_multi_view_trim = True
 
 
 _GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "albedo", "roughness", "metallic")

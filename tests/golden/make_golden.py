@@ -86,6 +86,20 @@ def ref_model_helpers():
     print("wrote ref_model.npz")
 
 
+def ref_defaults():
+    """(5) ref_defaults.json -- the reference's hyper-parameter defaults (arguments/__init__.py: OptimizationParams,
+    PipelineParams), read from the classes themselves."""
+    import json
+    from argparse import ArgumentParser
+    sys.path.insert(0, "/root/reference")
+    import arguments
+    p = ArgumentParser()
+    out = {"OptimizationParams": {k: v for k, v in vars(arguments.OptimizationParams(p)).items() if not k.startswith("_")},
+           "PipelineParams": {k: v for k, v in vars(arguments.PipelineParams(p)).items() if not k.startswith("_")}}
+    json.dump(out, open(os.path.join(HERE, "ref_defaults.json"), "w"), indent=1, sort_keys=True)
+    print("wrote ref_defaults.json")
+
+
 def colmap_small():
     """(4) colmap_small/ -- a small synthetic COLMAP binary model (written by gs2m_colmap.write_model: the files are test
     DATA) and colmap_small.npz -- what the REFERENCE's reader (scene/colmap_loader.py:123-240, loaded as a standalone
@@ -162,10 +176,14 @@ if __name__ == "__main__":
     if "--model-only" in sys.argv:
         ref_model_helpers()
         sys.exit(0)
+    if "--defaults-only" in sys.argv:
+        ref_defaults()
+        sys.exit(0)
     if "--colmap-only" in sys.argv:
         colmap_small()
         sys.exit(0)
     ref_helpers()
     ref_model_helpers()
+    ref_defaults()
     colmap_small()
     raster_small()

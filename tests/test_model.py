@@ -74,7 +74,10 @@ def test_prune_and_cat_keep_parameters_and_adam_state_aligned():
     from gs2m_model import OptimizationParams
     m = _random_model(50)
     m.spatial_lr_scale = 1.0
-    m.training_setup(OptimizationParams, optimizer_cls=torch.optim.Adam)
+    class Args(OptimizationParams):
+        prune_init_points = False          # (on by default as in the reference: it would drop the largest points here)
+
+    m.training_setup(Args, optimizer_cls=torch.optim.Adam)
     for p in m.parameters():
         p.grad = torch.ones_like(p)
     m.optimizer.step()
@@ -130,3 +133,21 @@ def test_colmap_reader_matches_the_reference_reader(tmp_path):
         assert open(os.path.join(folder, name), "rb").read() == open(os.path.join(str(tmp_path), name), "rb").read()
     for im in imgs.values():
         np.testing.assert_allclose(C.rotmat2qvec(C.qvec2rotmat(im.qvec)), im.qvec, atol=1e-12)
+
+
+def test_hyperparameter_defaults_match_the_reference():
+    """gs2m_model.OptimizationParams, gs2m_mvs.MultiViewParams and gs2m_scene.PipelineParams against the defaults of the
+    reference's own argument classes (tests/golden/ref_defaults.json, generated by make_golden.py)."""
+    import json
+    import gs2m_model, gs2m_mvs, gs2m_scene
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_defaults.json")))
+    seen = 0
+    for cls, ref in ((gs2m_model.OptimizationParams, gold["OptimizationParams"]), (gs2m_mvs.MultiViewParams, gold["OptimizationParams"]),
+                     (gs2m_scene.PipelineParams, gold["PipelineParams"])):
+        for k, v in vars(cls).items():
+            if k.startswith("_") or k in ("split_sh", "fused_render_ops", "fused_activations"):   # this repository's additions
+                continue
+            assert k in ref, f"{cls.__name__}.{k} is not a reference parameter"
+            assert ref[k] == v, f"{cls.__name__}.{k} = {v}, reference {ref[k]}"
+            seen += 1
+    assert seen >= 50
