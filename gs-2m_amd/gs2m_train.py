@@ -199,9 +199,11 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                     thr = opt.radii2D_threshold if it > opt.opacity_reset_interval else None
                     gaussians.densify_and_prune(opt.densify_grad_threshold, opt.densify_grad_abs_threshold, opt.opacity_prune_threshold, extent, thr)
+                if opt.use_opacity_reduce and it % opt.opacity_reduce_interval == 0:  # train.py:243-246
+                    gaussians.reduce_opacity()
                 if it % opt.opacity_reset_interval == 0:
                     gaussians.reset_opacity()
-            if trim_interval and it % trim_interval == 0 and it < opt.densify_until_iter:
+            if opt.use_multi_view_trim and trim_interval and it % trim_interval == 0 and it < opt.densify_until_iter:
                 stats["trimmed"] = stats.get("trimmed", 0) + multi_view_observe_trim(gaussians, cams, pipe, bg)
             if it < iterations:
                 gaussians.optimizer.step()
