@@ -76,6 +76,43 @@ class _PatchNCC(torch.autograd.Function):
         return None, dn, dd, None, None, None, None, None, None, None
 
 
+class _GridSampleBorder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, grid):
+        image, grid = image.contiguous().float(), grid.contiguous().float()
+        if not image.is_cuda:
+            raise RuntimeError("grid_sample_border: HIP kernel, there is no CPU path")
+        Cc, H, W = image.shape
+        N = grid.shape[0]
+        out = torch.empty((N, Cc), dtype=torch.float32, device=image.device)
+        with torch.cuda.device(image.device):
+            _native.check(_native.lib().gs2m_grid_sample_border_forward(N, Cc, H, W, image.data_ptr(), grid.data_ptr(), out.data_ptr(),
+                                                                        C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                          "gs2m_grid_sample_border_forward")
+        ctx.save_for_backward(image, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        image, grid = ctx.saved_tensors
+        Cc, H, W = image.shape
+        d_img = torch.zeros_like(image) if ctx.needs_input_grad[0] else None
+        d_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        d_out = d_out.contiguous().float()
+        with torch.cuda.device(image.device):
+            _native.check(_native.lib().gs2m_grid_sample_border_backward(
+                grid.shape[0], Cc, H, W, image.data_ptr(), grid.data_ptr(), d_out.data_ptr(), None if d_img is None else d_img.data_ptr(),
+                None if d_grid is None else d_grid.data_ptr(), C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                "gs2m_grid_sample_border_backward")
+        return d_img, d_grid
+
+
+def grid_sample_border(image, grid):
+    """F.grid_sample(image[None], grid.view(1, -1, 1, 2), mode='bilinear', padding_mode='border', align_corners=True) for a
+    (C, H, W) image, C <= 4, returned as (N, C); gradients to both."""
+    return _GridSampleBorder.apply(image, grid)
+
+
 def _homography_constants(ref_cam, near_cam, ncc_scale):
     """M = K_near R_rn K_ref^-1, b = K_near t_rn, K_ref^-1 (utils/loss_utils.py:319-327), on the host in float64; constant
     per camera pair, kept on the reference camera (reading the poses back is a device synchronisation)."""
@@ -225,21 +262,32 @@ class MultiViewScene:
 
 
 # ---------------------------------------------------------------- the loss (utils/loss_utils.py:245-349, 351-449)
+def _mm3(pts, M):
+    """pts (N, 3) @ M (3, 3) as three broadcast multiply-adds: on ROCm a K = 3 matmul goes to the BLAS library and costs
+    ~20 ms for the 2M pixels of a 1080p view (the same trap as in render()); this is three small kernels."""
+    return pts[:, 0:1] * M[0] + pts[:, 1:2] * M[1] + pts[:, 2:3] * M[2]
+
+
 def _get_points_from_depth(camera, depth_map):
     pts = (camera.get_rays() * depth_map.squeeze()[..., None]).reshape(-1, 3)
     R = torch.tensor(camera.R, dtype=torch.float32, device=pts.device)
     T = torch.tensor(camera.T, dtype=torch.float32, device=pts.device)
-    return (pts - T) @ R.transpose(-1, -2)
+    return _mm3(pts - T, R.transpose(-1, -2))
 
 
-def _sample_depth_normal(cam_points, camera, render_pkg):
+def _sample_depth_normal(cam_points, camera, render_pkg, fused=True):
     W, H = int(camera.image_width), int(camera.image_height)
     proj = torch.stack([cam_points[:, 0] * camera.Fx / cam_points[:, 2] + camera.Cx,
                         cam_points[:, 1] * camera.Fy / cam_points[:, 2] + camera.Cy], dim=-1).float()
     valid = (proj[:, 0] > 0) & (proj[:, 0] < W) & (proj[:, 1] > 0) & (proj[:, 1] < H) & (cam_points[:, 2] > 0.1)
-    grid = torch.stack([proj[:, 0] / ((W - 1) / 2) - 1, proj[:, 1] / ((H - 1) / 2) - 1], dim=-1).view(1, -1, 1, 2)
-    map_z = F.grid_sample(render_pkg["depth_map"][None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, 0, :, 0]
-    map_n = F.grid_sample(render_pkg["normal_map"][None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
+    grid = torch.stack([proj[:, 0] / ((W - 1) / 2) - 1, proj[:, 1] / ((H - 1) / 2) - 1], dim=-1)
+    if fused and grid.is_cuda:  # one 4-channel lookup, HIP forward and backward (include/gs2m_mvs.h)
+        zn = grid_sample_border(torch.cat((render_pkg["depth_map"], render_pkg["normal_map"]), dim=0), grid)
+        map_z, map_n = zn[:, 0], zn[:, 1:4]
+    else:
+        g4 = grid.view(1, -1, 1, 2)
+        map_z = F.grid_sample(render_pkg["depth_map"][None], g4, mode="bilinear", padding_mode="border", align_corners=True)[0, 0, :, 0]
+        map_n = F.grid_sample(render_pkg["normal_map"][None], g4, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
     return map_z, map_n / (map_n.norm(dim=1, keepdim=True) + 1e-8), valid
 
 
@@ -247,13 +295,17 @@ def _reproject_points(from_camera, to_camera, points, sampled_depth):
     pts = points / points[:, 2:3] * sampled_depth[..., None]
     R = torch.tensor(from_camera.R, dtype=torch.float32, device=pts.device)
     T = torch.tensor(from_camera.T, dtype=torch.float32, device=pts.device)
-    pts = (pts - T) @ R.transpose(-1, -2)
-    pts = pts @ to_camera.world_view_transform[:3, :3] + to_camera.world_view_transform[3, :3]
+    pts = _mm3(pts - T, R.transpose(-1, -2))
+    pts = _mm3(pts, to_camera.world_view_transform[:3, :3]) + to_camera.world_view_transform[3, :3]
     return torch.stack([pts[:, 0] * to_camera.Fx / pts[:, 2] + to_camera.Cx, pts[:, 1] * to_camera.Fy / pts[:, 2] + to_camera.Cy], dim=-1).float()
 
 
-def _sample_normal_map(pixels, normal_map):
+def _sample_normal_map(pixels, normal_map, fused=True):
+    """The reference samples the normal map bilinearly AT THE PIXEL CENTRES (utils/loss_utils.py:428-449): with align_corners that
+    is the pixel itself, weight 1 -- and a 2M-point grid_sample whose backward costs 20 ms here.  fused: the reshape it equals."""
     H, W = pixels.shape[:2]
+    if fused:
+        return normal_map.reshape(normal_map.shape[0], -1).permute(1, 0)
     p = pixels.view(-1, 2)
     grid = torch.stack([p[:, 0] / ((W - 1) / 2) - 1, p[:, 1] / ((H - 1) / 2) - 1], dim=-1).view(1, -1, 1, 2)
     return F.grid_sample(normal_map.unsqueeze(0), grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
@@ -266,12 +318,12 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
     near = cams[rng.sample(viewpoint_cam.nearest_indices, 1)[0]]
     near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
     pts = _get_points_from_depth(viewpoint_cam, render_pkg["depth_map"])
-    pts_near = pts @ near.world_view_transform[:3, :3] + near.world_view_transform[3, :3]
-    map_z, map_n, valid = _sample_depth_normal(pts_near, near, near_pkg)
+    pts_near = _mm3(pts, near.world_view_transform[:3, :3]) + near.world_view_transform[3, :3]
+    map_z, map_n, valid = _sample_depth_normal(pts_near, near, near_pkg, fused)
     valid = valid & (pts_near[:, 2] - map_z <= opt.mv_occlusion_threshold)
     reproj = _reproject_points(near, viewpoint_cam, pts_near, map_z)
     pixel_noise = torch.norm(reproj - scene.pixels.reshape(*reproj.shape), dim=-1)
-    normals = _sample_normal_map(scene.pixels, render_pkg["normal_map"])
+    normals = _sample_normal_map(scene.pixels, render_pkg["normal_map"], fused)
     normals = normals / (normals.norm(dim=1, keepdim=True) + 1e-8)
     angle = torch.acos(torch.sum(normals * map_n, dim=1).clamp(-1 + 1e-6, 1 - 1e-6))
     angle_valid = valid & (angle < opt.mv_angle_threshold * torch.pi / 180.0)
@@ -310,7 +362,7 @@ def roughness_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, render
     near = scene.getTrainCameras()[rng.sample(viewpoint_cam.nearby_indices, 1)[0]]
     with torch.no_grad():
         pts = _get_points_from_depth(viewpoint_cam, render_pkg["depth_map"])
-        pts_near = pts @ near.world_view_transform[:3, :3] + near.world_view_transform[3, :3]
+        pts_near = _mm3(pts, near.world_view_transform[:3, :3]) + near.world_view_transform[3, :3]
         near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
         map_z, _, valid = _sample_depth_normal(pts_near, near, near_pkg)
         valid = valid & (pts_near[:, 2] - map_z <= opt.mv_occlusion_threshold)

@@ -28,6 +28,15 @@ int gs2m_patch_ncc_roughness(int N, const float* pixels, const float* normals, c
                              const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
                              float ncc_scale, int patch, float* ncc_gray, float* ncc_grad, float* ref_var, void* stream);
 
+/* torch.nn.functional.grid_sample(image[None], grid.view(1, N, 1, 2), mode='bilinear', padding_mode='border',
+ * align_corners=True) for a (channels, height, width) image at N normalised positions -- how _sample_depth_normal
+ * (utils/loss_utils.py:368-409) looks the neighbour's depth and normal maps up; out, dL_dout: (N, channels), channels <= 4.
+ * Backward: dL_dimage (same shape as image) is ACCUMULATED into (zero it first), dL_dgrid (N, 2) is written; either may be NULL. */
+int gs2m_grid_sample_border_forward(int N, int channels, int height, int width, const float* image, const float* grid, float* out,
+                                    void* stream);
+int gs2m_grid_sample_border_backward(int N, int channels, int height, int width, const float* image, const float* grid,
+                                     const float* dL_dout, float* dL_dimage, float* dL_dgrid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,3 +134,26 @@ def test_roughness_variant_matches_op_by_op():
         ea, eb = (a[k].double() - t[k]).abs().reshape(-1), (b[k].double() - t[k]).abs().reshape(-1)
         assert ea.mean().item() < 3 * eb.mean().item() + 2e-5, (k, ea.mean().item(), eb.mean().item())
         assert torch.quantile(ea, 0.99).item() < 5e-3, (k, torch.quantile(ea, 0.99).item())
+
+
+@pytest.mark.parametrize("C", [1, 4])
+def test_grid_sample_border_matches_torch(C):
+    assert torch.cuda.is_available()
+    import torch.nn.functional as F
+    import gs2m_mvs as MV
+    g = torch.Generator().manual_seed(C)
+    H, W, N = 37, 53, 5000
+    img = torch.randn(C, H, W, generator=g).cuda().requires_grad_(True)
+    grid = (torch.rand(N, 2, generator=g) * 2.4 - 1.2).cuda()                       # 10 % outside on every side: border clamp
+    grid[:6] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0], [1.0, -1.0], [-1.3, 0.2], [0.2, 1.3]], device="cuda")
+    grid.requires_grad_(True)
+    G = torch.randn(N, C, generator=g).cuda()
+    ref = F.grid_sample(img[None], grid.view(1, -1, 1, 2), mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
+    (ref * G).sum().backward()
+    gi, gg = img.grad.clone(), grid.grad.clone()
+    img.grad = grid.grad = None
+    got = MV.grid_sample_border(img, grid)
+    (got * G).sum().backward()
+    assert (got - ref).abs().max().item() < 1e-5
+    assert (img.grad - gi).abs().max().item() < 1e-4 * max(1.0, gi.abs().max().item())
+    assert (grid.grad - gg).abs().max().item() < 1e-4 * max(1.0, gg.abs().max().item())
