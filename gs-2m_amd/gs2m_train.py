@@ -217,6 +217,16 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stats.update(psnr_end=evaluate(), points_end=gaussians.get_xyz.shape[0], seconds=dt, it_per_s=iterations / dt, loss_end=loss.item())
+    if lighting is not None:  # the material stage supervises the PBR image, not the SH colours (train.py:111-113): report that one too
+        with torch.no_grad():
+            tot = 0.0
+            for k, (c, gt) in enumerate(zip(cams, gts)):
+                out = render(c, gaussians, pipe, bg, True, True)
+                if k not in rays:
+                    rays[k] = F.normalize(c.get_rays().view(-1, 3), p=2, dim=-1)
+                pkg = pbr_render(lighting, c, rays[k], out, metallic=False)
+                tot += psnr(torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None]), gt)
+            stats["psnr_pbr_end"] = tot / len(cams)
     stats["lighting"] = lighting
     return gaussians, stats
 
@@ -229,6 +239,9 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=12)
     ap.add_argument("--true-gaussians", type=int, default=60_000)
     ap.add_argument("--save-ply", default=None)
+    ap.add_argument("--geometry-from", type=int, default=None, help="iteration the geometry stage starts at (default: half way)")
+    ap.add_argument("--material-from", type=int, default=None, help="iteration the material stage starts at (default: never)")
+    ap.add_argument("--multi-view", action="store_true", help="multi_view_loss in the geometry stage, roughness_loss in the material stage")
     ap.add_argument("--source-path", "-s", default=None, help="COLMAP-format dataset (sparse/0/*.bin + images/); default: synthetic scene")
     ap.add_argument("--export-colmap", default=None, help="write the synthetic scene as a COLMAP-format dataset to this folder and exit")
     a = ap.parse_args()
@@ -236,7 +249,16 @@ if __name__ == "__main__":
         export_colmap_dataset(a.export_colmap, synthetic_scene(a.true_gaussians, a.views, a.width, a.height))
         sys.exit(0)
     scene = load_colmap_dataset(a.source_path) if a.source_path else None
-    model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10), scene=scene)
+    mv = None
+    if a.multi_view:
+        import gs2m_mvs
+        mv = gs2m_mvs.MultiViewParams()
+        if scene is None:  # the synthetic orbit: cameras 6 units from the object, 30 degrees apart
+            mv.multi_view_max_dist, mv.multi_view_max_angle, mv.nearby_cam_max_dist = 8.0, 35, 8.0
+    model, st = train(a.iterations, a.width, a.height, a.views, a.true_gaussians, log=max(1, a.iterations // 10), scene=scene,
+                      geometry_from_iter=a.geometry_from, material_from_iter=a.material_from, mv_opt=mv,
+                      lambda_multi_view=OptimizationParams.lambda_multi_view if a.multi_view else 0.0,
+                      lambda_rough=OptimizationParams.lambda_rough if a.multi_view else 0.0)
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items() if k not in ("pbr_loss", "lighting", "mv_loss")})
     if a.save_ply:
         model.save_ply(a.save_ply)
