@@ -17,6 +17,7 @@ from gaussian_renderer import render
 from fused_ssim import fused_ssim
 
 REF = "--reference-formulation" in sys.argv
+MV = "--multi-view" in sys.argv   # + multi_view_loss against a second, nearby camera (fused path only)
 P, W, H = 1_000_000, 1920, 1080
 dev = "cuda"
 cam0 = S.make_camera(W, H)
@@ -58,14 +59,28 @@ else:
     ssim_fn = fused_ssim
 
 
+if MV:
+    import random
+    import gs2m_mvs
+    cam_b = Camera(S.look_at_camera(W, H, (0.35, -0.1, 0.0), (0.0, 0.0, 6.0)), dev)
+    cam_a = Camera(S.look_at_camera(W, H, (0.0, 0.0, 0.0), (0.0, 0.0, 6.0)), dev)
+    cam = cam_a
+    mvp = gs2m_mvs.MultiViewParams()
+    mvp.multi_view_max_dist = 8.0
+    mvs = gs2m_mvs.MultiViewScene([cam_a, cam_b], [gt, torch.rand(3, H, W, device=dev)], pc, mvp)
+    rng = random.Random(0)
+
+
 def step():
     global max_radii
-    out = render(cam, pc, pipe, bg, material_stage=False, sobel_normal=True)
+    out = render(cam, pc, pipe, bg, geometry_stage=MV, material_stage=False, sobel_normal=True)
     image, vis, radii = out["render"], out["visibility_filter"], out["radii"]
     rgb = image.clamp(0, 1)
     Lssim = 1.0 - ssim_fn(rgb.unsqueeze(0), gt.unsqueeze(0))
     loss = 0.8 * l1_loss(rgb, gt) + 0.2 * Lssim + 0.01 * plane_loss(vis, pc)
     loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+    if MV:
+        loss = loss + gs2m_mvs.multi_view_loss(mvs, cam, mvp, out, pipe, bg, False, render, rng=rng)
     loss.backward()
     with torch.no_grad():  # train.py:223-227, GM:569-573
         if REF:
