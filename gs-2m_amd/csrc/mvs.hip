@@ -267,6 +267,156 @@ __global__ void __launch_bounds__(256) grid_border_kernel(int N, int H, int W, c
     if (BWD && d_grid != nullptr) { d_grid[2 * (size_t)i] = gx * mx; d_grid[2 * (size_t)i + 1] = gy * my; }
 }
 
+
+// ---------------------------------------------------------------- geometric consistency of multi_view_loss, per pixel
+// utils/loss_utils.py:256-291: back-project the pixel with the rendered depth, move it into the neighbour's camera, project,
+// look the neighbour's depth / normal up there (bilinear, border), reproject with THAT depth into the reference image and
+// measure the distance to the pixel (pixel_noise); compare the two normals (angle).  ~60 PyTorch launches over 2M pixels
+// forward + backward; one kernel each way here.  The backward recomputes the chain and differentiates it by hand down to
+// the four maps (reference depth / normal: one write per pixel; neighbour depth / normal: bilinear scatter, fp32 atomics).
+struct GeoConst {
+    float A[9], b[3];    // reference camera space -> neighbour camera space: Y = A P + b
+    float A2[9], b2[3];  // neighbour camera space -> reference camera space
+    float fx, fy, cx, cy;      // reference intrinsics
+    float fxn, fyn, cxn, cyn;  // neighbour intrinsics
+    int W, H, Wn, Hn;
+    float occlusion;
+};
+
+struct GeoPix {
+    float rx, ry, d;            // ray, depth
+    float Y[3], iz, qx, qy;     // neighbour-space point, 1 / z, projection
+    float zs, nraw[3], nn;      // sampled depth, sampled normal and its length
+    float gzx, gzy, gnx[3], gny[3];  // d(sample)/d(q) with the border clip applied
+    int x0, y0; float fx, fy; bool bx, by;  // bilinear footprint
+    float s, Yp[3], Z[3], izz, ex, ey, noise;
+    float nr[3], nrl, c;
+    bool valid;
+};
+
+__device__ __forceinline__ GeoPix geo_eval(const GeoConst& C, int u, int v, const float* __restrict__ depth, const float* __restrict__ normal,
+                                           const float* __restrict__ depth_n, const float* __restrict__ normal_n) {
+    GeoPix g;
+    const size_t p = (size_t)v * C.W + u, HW = (size_t)C.H * C.W, HWn = (size_t)C.Hn * C.Wn;
+    g.rx = ((float)u - C.cx) / C.fx; g.ry = ((float)v - C.cy) / C.fy; g.d = depth[p];
+    const float P[3] = {g.rx * g.d, g.ry * g.d, g.d};
+#pragma unroll
+    for (int i = 0; i < 3; i++) g.Y[i] = C.A[3 * i] * P[0] + C.A[3 * i + 1] * P[1] + C.A[3 * i + 2] * P[2] + C.b[i];
+    g.iz = 1.0f / g.Y[2];
+    g.qx = g.Y[0] * C.fxn * g.iz + C.cxn; g.qy = g.Y[1] * C.fyn * g.iz + C.cyn;
+    g.valid = g.qx > 0.f && g.qx < (float)C.Wn && g.qy > 0.f && g.qy < (float)C.Hn && g.Y[2] > 0.1f;
+    // grid_sample(border, align_corners): clip to [0, W-1]; the clip kills the position gradient where it binds
+    float x = g.qx, y = g.qy, mx = 1.f, my = 1.f;
+    if (!(x > 0.f)) { x = 0.f; mx = 0.f; } else if (x >= (float)(C.Wn - 1)) { x = (float)(C.Wn - 1); mx = 0.f; }
+    if (!(y > 0.f)) { y = 0.f; my = 0.f; } else if (y >= (float)(C.Hn - 1)) { y = (float)(C.Hn - 1); my = 0.f; }
+    const float xf = floorf(x), yf = floorf(y);
+    g.x0 = (int)xf; g.y0 = (int)yf; g.fx = x - xf; g.fy = y - yf;
+    g.bx = g.x0 + 1 <= C.Wn - 1; g.by = g.y0 + 1 <= C.Hn - 1;
+    auto tap = [&](const float* img, float& val, float& dx, float& dy) {
+        const float v00 = img[(size_t)g.y0 * C.Wn + g.x0];
+        const float v10 = g.bx ? img[(size_t)g.y0 * C.Wn + g.x0 + 1] : 0.f;
+        const float v01 = g.by ? img[(size_t)(g.y0 + 1) * C.Wn + g.x0] : 0.f;
+        const float v11 = (g.bx && g.by) ? img[(size_t)(g.y0 + 1) * C.Wn + g.x0 + 1] : 0.f;
+        val = v00 * (1.f - g.fx) * (1.f - g.fy) + v10 * g.fx * (1.f - g.fy) + v01 * (1.f - g.fx) * g.fy + v11 * g.fx * g.fy;
+        dx = ((v10 - v00) * (1.f - g.fy) + (v11 - v01) * g.fy) * mx;
+        dy = ((v01 - v00) * (1.f - g.fx) + (v11 - v10) * g.fx) * my;
+    };
+    tap(depth_n, g.zs, g.gzx, g.gzy);
+#pragma unroll
+    for (int c = 0; c < 3; c++) tap(normal_n + c * HWn, g.nraw[c], g.gnx[c], g.gny[c]);
+    g.nn = sqrtf(g.nraw[0] * g.nraw[0] + g.nraw[1] * g.nraw[1] + g.nraw[2] * g.nraw[2]);
+    g.valid = g.valid && (g.Y[2] - g.zs <= C.occlusion);
+    g.s = g.zs * g.iz;
+#pragma unroll
+    for (int i = 0; i < 3; i++) g.Yp[i] = g.Y[i] * g.s;
+#pragma unroll
+    for (int i = 0; i < 3; i++) g.Z[i] = C.A2[3 * i] * g.Yp[0] + C.A2[3 * i + 1] * g.Yp[1] + C.A2[3 * i + 2] * g.Yp[2] + C.b2[i];
+    g.izz = 1.0f / g.Z[2];
+    g.ex = g.Z[0] * C.fx * g.izz + C.cx - (float)u;
+    g.ey = g.Z[1] * C.fy * g.izz + C.cy - (float)v;
+    g.noise = sqrtf(g.ex * g.ex + g.ey * g.ey);
+#pragma unroll
+    for (int c = 0; c < 3; c++) g.nr[c] = normal[c * HW + p];
+    g.nrl = sqrtf(g.nr[0] * g.nr[0] + g.nr[1] * g.nr[1] + g.nr[2] * g.nr[2]);
+    const float ir = 1.0f / (g.nrl + 1e-8f), is = 1.0f / (g.nn + 1e-8f);
+    g.c = (g.nr[0] * g.nraw[0] + g.nr[1] * g.nraw[1] + g.nr[2] * g.nraw[2]) * ir * is;
+    return g;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __restrict__ depth, const float* __restrict__ normal,
+                                                     const float* __restrict__ depth_n, const float* __restrict__ normal_n,
+                                                     float* __restrict__ noise, float* __restrict__ angle, uint8_t* __restrict__ valid,
+                                                     const float* __restrict__ d_noise, const float* __restrict__ d_angle,
+                                                     float* __restrict__ d_depth, float* __restrict__ d_normal,
+                                                     float* __restrict__ d_depth_n, float* __restrict__ d_normal_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C.W * C.H) return;
+    const int u = i % C.W, v = i / C.W;
+    const GeoPix g = geo_eval(C, u, v, depth, normal, depth_n, normal_n);
+    const float lo = -1.0f + 1e-6f, hi = 1.0f - 1e-6f;
+    const float cc = fminf(fmaxf(g.c, lo), hi);
+    if (!BWD) {
+        noise[i] = g.noise; angle[i] = acosf(cc); valid[i] = g.valid ? 1 : 0;
+        return;
+    }
+    const size_t HW = (size_t)C.H * C.W, HWn = (size_t)C.Hn * C.Wn;
+    const float gn = d_noise[i], ga = d_angle[i];
+    float dY[3] = {0.f, 0.f, 0.f}, dzs = 0.f, dnraw[3] = {0.f, 0.f, 0.f}, dnr[3] = {0.f, 0.f, 0.f};
+    if (gn != 0.f && g.noise > 0.f) {   // noise = |e|, e = project(A2 Y' + b2) - pixel
+        const float dex = gn * g.ex / g.noise, dey = gn * g.ey / g.noise;
+        const float dZ[3] = {dex * C.fx * g.izz, dey * C.fy * g.izz, -(dex * C.fx * g.Z[0] + dey * C.fy * g.Z[1]) * g.izz * g.izz};
+        float dYp[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) dYp[k] = C.A2[k] * dZ[0] + C.A2[3 + k] * dZ[1] + C.A2[6 + k] * dZ[2];
+        const float ds = dYp[0] * g.Y[0] + dYp[1] * g.Y[1] + dYp[2] * g.Y[2];   // Y' = Y s, s = zs / Y.z
+#pragma unroll
+        for (int k = 0; k < 3; k++) dY[k] += dYp[k] * g.s;
+        dzs += ds * g.iz;
+        dY[2] -= ds * g.zs * g.iz * g.iz;
+    }
+    if (ga != 0.f && g.c >= lo && g.c <= hi) {  // angle = acos(clamp(m . n_s))
+        const float dc = -ga / sqrtf(1.0f - cc * cc);
+        const float er = g.nrl + 1e-8f, es = g.nn + 1e-8f;
+        float m[3], ns[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m[k] = g.nr[k] / er; ns[k] = g.nraw[k] / es; }
+        // y = x / (|x| + eps): dx = dy / (|x| + eps) - x (dy . x) / (|x| (|x| + eps)^2)
+        const float dot_s = dc * (m[0] * g.nraw[0] + m[1] * g.nraw[1] + m[2] * g.nraw[2]);
+        const float dot_r = dc * (ns[0] * g.nr[0] + ns[1] * g.nr[1] + ns[2] * g.nr[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dnraw[k] += dc * m[k] / es - (g.nn > 0.f ? g.nraw[k] * dot_s / (g.nn * es * es) : 0.f);
+            dnr[k] += dc * ns[k] / er - (g.nrl > 0.f ? g.nr[k] * dot_r / (g.nrl * er * er) : 0.f);
+        }
+    }
+    // the lookups: scatter to the neighbour's maps, and the position gradient
+    float dqx = dzs * g.gzx, dqy = dzs * g.gzy;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dqx += dnraw[k] * g.gnx[k]; dqy += dnraw[k] * g.gny[k]; }
+    const float w00 = (1.f - g.fx) * (1.f - g.fy), w10 = g.fx * (1.f - g.fy), w01 = (1.f - g.fx) * g.fy, w11 = g.fx * g.fy;
+    auto scatter = [&](float* img, float gv) {
+        if (gv == 0.f) return;
+        unsafeAtomicAdd(&img[(size_t)g.y0 * C.Wn + g.x0], gv * w00);
+        if (g.bx) unsafeAtomicAdd(&img[(size_t)g.y0 * C.Wn + g.x0 + 1], gv * w10);
+        if (g.by) unsafeAtomicAdd(&img[(size_t)(g.y0 + 1) * C.Wn + g.x0], gv * w01);
+        if (g.bx && g.by) unsafeAtomicAdd(&img[(size_t)(g.y0 + 1) * C.Wn + g.x0 + 1], gv * w11);
+    };
+    scatter(d_depth_n, dzs);
+#pragma unroll
+    for (int k = 0; k < 3; k++) scatter(d_normal_n + k * HWn, dnraw[k]);
+    // q = (Y.x fxn / Y.z + cxn, Y.y fyn / Y.z + cyn)
+    dY[0] += dqx * C.fxn * g.iz;
+    dY[1] += dqy * C.fyn * g.iz;
+    dY[2] -= (dqx * C.fxn * g.Y[0] + dqy * C.fyn * g.Y[1]) * g.iz * g.iz;
+    float dP[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dP[k] = C.A[k] * dY[0] + C.A[3 + k] * dY[1] + C.A[6 + k] * dY[2];
+    d_depth[i] = dP[0] * g.rx + dP[1] * g.ry + dP[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) d_normal[k * HW + i] = dnr[k];
+}
+
 int fill(NccConst& C, const float* M, const float* b, const float* Kinv, float ncc_scale, int patch, int w, int h) {
     if (!M || !b || !Kinv || !(ncc_scale > 0.f) || patch < 0 || patch > 8 || w < 1 || h < 1) return GS2M_ERR_INVALID_ARG;
     for (int k = 0; k < 9; k++) { C.M[k] = M[k]; C.Kinv[k] = Kinv[k]; }
@@ -347,6 +497,45 @@ int gs2m_grid_sample_border_backward(int N, int channels, int height, int width,
         case 4: grid_border_kernel<4, true><<<g, b, 0, (hipStream_t)stream>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid); break;
         default: return GS2M_ERR_UNSUPPORTED;
     }
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+static int fill_geo(GeoConst& C, const float* A, const float* b, const float* A2, const float* b2, const float* intr_ref, const float* intr_near,
+                    int width, int height, int width_n, int height_n, float occlusion) {
+    if (!A || !b || !A2 || !b2 || !intr_ref || !intr_near || width < 1 || height < 1 || width_n < 2 || height_n < 2) return GS2M_ERR_INVALID_ARG;
+    for (int k = 0; k < 9; k++) { C.A[k] = A[k]; C.A2[k] = A2[k]; }
+    for (int k = 0; k < 3; k++) { C.b[k] = b[k]; C.b2[k] = b2[k]; }
+    C.fx = intr_ref[0]; C.fy = intr_ref[1]; C.cx = intr_ref[2]; C.cy = intr_ref[3];
+    C.fxn = intr_near[0]; C.fyn = intr_near[1]; C.cxn = intr_near[2]; C.cyn = intr_near[3];
+    C.W = width; C.H = height; C.Wn = width_n; C.Hn = height_n; C.occlusion = occlusion;
+    return GS2M_OK;
+}
+
+int gs2m_mv_geo_forward(int width, int height, int width_n, int height_n, const float* depth, const float* normal, const float* depth_n,
+                        const float* normal_n, const float* A, const float* b, const float* A2, const float* b2, const float* intr_ref,
+                        const float* intr_near, float occlusion, float* pixel_noise, float* angle, uint8_t* valid, void* stream) {
+    if (!depth || !normal || !depth_n || !normal_n || !pixel_noise || !angle || !valid) return GS2M_ERR_INVALID_ARG;
+    GeoConst C;
+    const int rc = fill_geo(C, A, b, A2, b2, intr_ref, intr_near, width, height, width_n, height_n, occlusion);
+    if (rc != GS2M_OK) return rc;
+    const int n = width * height;
+    mv_geo_kernel<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, depth, normal, depth_n, normal_n, pixel_noise, angle, valid, nullptr,
+                                                                          nullptr, nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_mv_geo_backward(int width, int height, int width_n, int height_n, const float* depth, const float* normal, const float* depth_n,
+                         const float* normal_n, const float* A, const float* b, const float* A2, const float* b2, const float* intr_ref,
+                         const float* intr_near, float occlusion, const float* dL_dnoise, const float* dL_dangle, float* dL_ddepth,
+                         float* dL_dnormal, float* dL_ddepth_n, float* dL_dnormal_n, void* stream) {
+    if (!depth || !normal || !depth_n || !normal_n || !dL_dnoise || !dL_dangle || !dL_ddepth || !dL_dnormal || !dL_ddepth_n || !dL_dnormal_n)
+        return GS2M_ERR_INVALID_ARG;
+    GeoConst C;
+    const int rc = fill_geo(C, A, b, A2, b2, intr_ref, intr_near, width, height, width_n, height_n, occlusion);
+    if (rc != GS2M_OK) return rc;
+    const int n = width * height;
+    mv_geo_kernel<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise,
+                                                                         dL_dangle, dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

@@ -113,6 +113,81 @@ def grid_sample_border(image, grid):
     return _GridSampleBorder.apply(image, grid)
 
 
+def _relative_pose(ref_cam, near_cam):
+    """Y = A P + b takes a point from the reference camera's space to the neighbour's, Z = A2 Y + b2 back (host, float64; kept on
+    the reference camera per neighbour)."""
+    cache = ref_cam.__dict__.setdefault("_mvs_pose", {})
+    if id(near_cam) not in cache:
+        Vr, Vn = ref_cam.world_view_transform.double().cpu(), near_cam.world_view_transform.double().cpu()
+        Rr, tr, Rn, tn = Vr[:3, :3].T, Vr[3, :3], Vn[:3, :3].T, Vn[3, :3]     # x_cam = R x_world + t
+        A, A2 = Rn @ Rr.T, Rr @ Rn.T
+        arr = lambda t: (C.c_float * t.numel())(*[float(x) for x in t.reshape(-1).tolist()])
+        intr = lambda c: (C.c_float * 4)(float(c.Fx), float(c.Fy), float(c.Cx), float(c.Cy))
+        cache[id(near_cam)] = (arr(A), arr(tn - A @ tr), arr(A2), arr(tr - A2 @ tn), intr(ref_cam), intr(near_cam))
+    return cache[id(near_cam)]
+
+
+class _MVGeo(torch.autograd.Function):
+    """pixel_noise, angle, valid of multi_view_loss's geometric part as one kernel each way (include/gs2m_mvs.h)."""
+
+    @staticmethod
+    def forward(ctx, depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion):
+        f = lambda t: t.contiguous().float()
+        depth, normal, depth_n, normal_n = f(depth), f(normal), f(depth_n), f(normal_n)
+        if not depth.is_cuda:
+            raise RuntimeError("mv_geo: HIP kernel, there is no CPU path")
+        H, W = depth.shape[-2:]
+        Hn, Wn = depth_n.shape[-2:]
+        consts = _relative_pose(ref_cam, near_cam)
+        noise = torch.empty(H * W, dtype=torch.float32, device=depth.device)
+        angle = torch.empty_like(noise)
+        valid = torch.empty(H * W, dtype=torch.uint8, device=depth.device)
+        with torch.cuda.device(depth.device):
+            _native.check(_native.lib().gs2m_mv_geo_forward(
+                W, H, Wn, Hn, depth.data_ptr(), normal.data_ptr(), depth_n.data_ptr(), normal_n.data_ptr(), *consts, float(occlusion),
+                noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), C.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream)),
+                "gs2m_mv_geo_forward")
+        ctx.save_for_backward(depth, normal, depth_n, normal_n)
+        ctx.args = (W, H, Wn, Hn, consts, float(occlusion))
+        valid = valid.bool()
+        ctx.mark_non_differentiable(valid)
+        return noise, angle, valid
+
+    @staticmethod
+    def backward(ctx, d_noise, d_angle, _dv):
+        depth, normal, depth_n, normal_n = ctx.saved_tensors
+        W, H, Wn, Hn, consts, occlusion = ctx.args
+        z = lambda t: torch.zeros(W * H, dtype=torch.float32, device=depth.device) if t is None else t.contiguous().float()
+        d_noise, d_angle = z(d_noise), z(d_angle)
+        dd, dn = torch.empty_like(depth), torch.empty_like(normal)
+        ddn, dnn = torch.zeros_like(depth_n), torch.zeros_like(normal_n)
+        with torch.cuda.device(depth.device):
+            _native.check(_native.lib().gs2m_mv_geo_backward(
+                W, H, Wn, Hn, depth.data_ptr(), normal.data_ptr(), depth_n.data_ptr(), normal_n.data_ptr(), *consts, occlusion,
+                d_noise.data_ptr(), d_angle.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddn.data_ptr(), dnn.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream)), "gs2m_mv_geo_backward")
+        return dd, dn, ddn, dnn, None, None, None
+
+
+def mv_geo(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion):
+    """-> pixel_noise (H W), angle (H W) [rad], valid (H W) bool; gradients to the four maps."""
+    return _MVGeo.apply(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion)
+
+
+def mv_geo_torch(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion, pixels):
+    """The same quantities op by op (utils/loss_utils.py:256-276)."""
+    pts = _get_points_from_depth(ref_cam, depth)
+    pts_near = _mm3(pts, near_cam.world_view_transform[:3, :3]) + near_cam.world_view_transform[3, :3]
+    map_z, map_n, valid = _sample_depth_normal(pts_near, near_cam, {"depth_map": depth_n, "normal_map": normal_n}, fused=False)
+    valid = valid & (pts_near[:, 2] - map_z <= occlusion)
+    reproj = _reproject_points(near_cam, ref_cam, pts_near, map_z)
+    noise = torch.norm(reproj - pixels.reshape(*reproj.shape), dim=-1)
+    normals = _sample_normal_map(pixels, normal, fused=False)
+    normals = normals / (normals.norm(dim=1, keepdim=True) + 1e-8)
+    angle = torch.acos(torch.sum(normals * map_n, dim=1).clamp(-1 + 1e-6, 1 - 1e-6))
+    return noise, angle, valid
+
+
 def _homography_constants(ref_cam, near_cam, ncc_scale):
     """M = K_near R_rn K_ref^-1, b = K_near t_rn, K_ref^-1 (utils/loss_utils.py:319-327), on the host in float64; constant
     per camera pair, kept on the reference camera (reading the poses back is a device synchronisation)."""
@@ -317,15 +392,12 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
         return 0.0
     near = cams[rng.sample(viewpoint_cam.nearest_indices, 1)[0]]
     near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
-    pts = _get_points_from_depth(viewpoint_cam, render_pkg["depth_map"])
-    pts_near = _mm3(pts, near.world_view_transform[:3, :3]) + near.world_view_transform[3, :3]
-    map_z, map_n, valid = _sample_depth_normal(pts_near, near, near_pkg, fused)
-    valid = valid & (pts_near[:, 2] - map_z <= opt.mv_occlusion_threshold)
-    reproj = _reproject_points(near, viewpoint_cam, pts_near, map_z)
-    pixel_noise = torch.norm(reproj - scene.pixels.reshape(*reproj.shape), dim=-1)
-    normals = _sample_normal_map(scene.pixels, render_pkg["normal_map"], fused)
-    normals = normals / (normals.norm(dim=1, keepdim=True) + 1e-8)
-    angle = torch.acos(torch.sum(normals * map_n, dim=1).clamp(-1 + 1e-6, 1 - 1e-6))
+    if fused:
+        pixel_noise, angle, valid = mv_geo(render_pkg["depth_map"], render_pkg["normal_map"], near_pkg["depth_map"], near_pkg["normal_map"],
+                                           viewpoint_cam, near, opt.mv_occlusion_threshold)
+    else:
+        pixel_noise, angle, valid = mv_geo_torch(render_pkg["depth_map"], render_pkg["normal_map"], near_pkg["depth_map"], near_pkg["normal_map"],
+                                                 viewpoint_cam, near, opt.mv_occlusion_threshold, scene.pixels)
     angle_valid = valid & (angle < opt.mv_angle_threshold * torch.pi / 180.0)
     pixel_valid = valid & (pixel_noise < 1.0)
     geo_w = torch.where(pixel_valid, torch.exp(-pixel_noise * opt.mv_geo_weight_decay), 0.0).detach()

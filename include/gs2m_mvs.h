@@ -10,6 +10,8 @@
 #ifndef GS2M_MVS_H
 #define GS2M_MVS_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,6 +38,20 @@ int gs2m_grid_sample_border_forward(int N, int channels, int height, int width, 
                                     void* stream);
 int gs2m_grid_sample_border_backward(int N, int channels, int height, int width, const float* image, const float* grid,
                                      const float* dL_dout, float* dL_dimage, float* dL_dgrid, void* stream);
+
+/* The geometric half of multi_view_loss per pixel (utils/loss_utils.py:256-283): pixel -> reference-camera point (rendered depth)
+ * -> neighbour camera (Y = A P + b) -> projection -> bilinear border lookup of the neighbour's depth / normal maps -> reprojection
+ * with that depth (Z = A2 Y' + b2) -> pixel_noise = distance to the pixel; angle = acos(clamp(n_ref . n_near)); valid = projects
+ * inside, z > 0.1, passes the occlusion test.  depth (H, W), normal (3, H, W), neighbour maps (Hn, Wn) / (3, Hn, Wn); A, A2 (3x3 row
+ * major), b, b2 (3), intr_* = (fx, fy, cx, cy): HOST arrays.  Backward: dL_ddepth (H, W) and dL_dnormal (3, H, W) are written,
+ * dL_ddepth_n / dL_dnormal_n are ACCUMULATED into (zero them first). */
+int gs2m_mv_geo_forward(int width, int height, int width_n, int height_n, const float* depth, const float* normal, const float* depth_n,
+                        const float* normal_n, const float* A, const float* b, const float* A2, const float* b2, const float* intr_ref,
+                        const float* intr_near, float occlusion, float* pixel_noise, float* angle, uint8_t* valid, void* stream);
+int gs2m_mv_geo_backward(int width, int height, int width_n, int height_n, const float* depth, const float* normal, const float* depth_n,
+                         const float* normal_n, const float* A, const float* b, const float* A2, const float* b2, const float* intr_ref,
+                         const float* intr_near, float occlusion, const float* dL_dnoise, const float* dL_dangle, float* dL_ddepth,
+                         float* dL_dnormal, float* dL_ddepth_n, float* dL_dnormal_n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -157,3 +157,49 @@ def test_grid_sample_border_matches_torch(C):
     assert (got - ref).abs().max().item() < 1e-5
     assert (img.grad - gi).abs().max().item() < 1e-4 * max(1.0, gi.abs().max().item())
     assert (grid.grad - gg).abs().max().item() < 1e-4 * max(1.0, gg.abs().max().item())
+
+
+def test_mv_geo_matches_op_by_op():
+    """gs2m_mv_geo_* (pixel_noise, angle, valid per pixel; hand-derived backward to the four maps) against the op-by-op chain of
+    utils/loss_utils.py:256-276 with autograd, on maps that keep the chain well conditioned (normals 10-40 degrees apart: away from
+    acos' clamp; a smooth depth)."""
+    assert torch.cuda.is_available()
+    import gs2m_synth as S
+    import gs2m_mvs as MV
+    from gs2m_scene import Camera
+    W, H = 160, 96
+    ref = Camera(S.look_at_camera(W, H, (0.0, 0.0, 0.0), (0.0, 0.0, 6.0), fx=1.1 * W), "cuda")
+    near = Camera(S.look_at_camera(W, H, (0.5, -0.2, 0.3), (0.0, 0.0, 6.0), fx=1.1 * W), "cuda")
+    g = torch.Generator().manual_seed(0)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    mk = lambda t: t.cuda().requires_grad_(True)
+    depth = mk((5.5 + 0.4 * torch.sin(2 * xx) * torch.cos(1.5 * yy))[None])
+    depth_n = mk((5.3 + 0.4 * torch.cos(1.7 * xx + 0.3) * torch.cos(1.2 * yy))[None])
+    base = torch.stack([0.3 * xx, 0.3 * yy, -torch.ones_like(xx)], 0)
+    normal = mk(base * (0.6 + torch.rand(1, H, W, generator=g)) + 0.15 * torch.randn(3, H, W, generator=g))        # not unit length
+    normal_n = mk(torch.stack([0.3 * xx + 0.4, 0.3 * yy - 0.3, -torch.ones_like(xx)], 0) * 0.8 + 0.05 * torch.randn(3, H, W, generator=g))
+    ix, iy = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy")
+    pixels = torch.stack([ix, iy], dim=-1).float().cuda()
+    G1, G2 = torch.rand(H * W, generator=g).cuda(), torch.rand(H * W, generator=g).cuda()
+    leaves = (depth, normal, depth_n, normal_n)
+
+    def run(fn):
+        for t in leaves:
+            t.grad = None
+        noise, angle, valid = fn()
+        ((noise * G1 + angle * G2) * valid).sum().backward()
+        return noise.detach(), angle.detach(), valid, [t.grad.clone() for t in leaves]
+
+    a = run(lambda: MV.mv_geo(depth, normal, depth_n, normal_n, ref, near, 5.0))
+    b = run(lambda: MV.mv_geo_torch(depth, normal, depth_n, normal_n, ref, near, 5.0, pixels))
+    assert 0.3 < b[2].float().mean().item() and (a[2] != b[2]).float().mean().item() < 2e-3
+    both = a[2] & b[2]
+    assert (a[0] - b[0])[both].abs().max().item() < 2e-3 * max(1.0, b[0][both].abs().max().item())
+    assert (a[1] - b[1])[both].abs().max().item() < 1e-4
+    assert 0.005 < b[1][both].min().item()                                    # away from acos clamp (angle 0.0014)
+    for name, x, y in zip(("depth", "normal", "neighbour depth", "neighbour normal"), a[3], b[3]):
+        assert torch.isfinite(x).all(), name
+        assert (x - y).norm().item() < 5e-3 * y.norm().item(), (name, (x - y).norm().item(), y.norm().item())
+    # the occlusion test and the image border switch pixels off
+    a2 = MV.mv_geo(depth, normal, depth_n, normal_n, ref, near, 5e-4)
+    assert a2[2].float().mean().item() < a[2].float().mean().item()
