@@ -176,7 +176,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 dn_weights[k] = edge_weights(gt)
             loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
             if mv_scene is not None and lambda_multi_view > 0:
-                Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render)
+                Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render,
+                                               fused=os.environ.get("GS2M_MV_OP_BY_OP") is None)  # debugging aid: the op-by-op formulation
                 loss = loss + lambda_multi_view * Lmv
                 stats.setdefault("mv_loss", []).append(float(Lmv.detach()) if torch.is_tensor(Lmv) else float(Lmv))
         if material_stage:  # train.py:132-196
