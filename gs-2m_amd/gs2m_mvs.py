@@ -9,6 +9,7 @@ op as the reference writes it (batched 3x3 matmuls, einsum, grid_sample, "ones" 
 is tested against.  The geometric part (reprojection error, normal agreement) stays PyTorch here.
 """
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -392,7 +393,7 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
         return 0.0
     near = cams[rng.sample(viewpoint_cam.nearest_indices, 1)[0]]
     near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
-    if fused:
+    if fused and os.environ.get("GS2M_MV_GEO_TORCH") is None:  # (env: debugging aid, the op-by-op geometric chain with the fused NCC)
         pixel_noise, angle, valid = mv_geo(render_pkg["depth_map"], render_pkg["normal_map"], near_pkg["depth_map"], near_pkg["normal_map"],
                                            viewpoint_cam, near, opt.mv_occlusion_threshold)
     else:
