@@ -102,7 +102,7 @@ def export_colmap_dataset(folder, scene):
                   (np.asarray(cols) * 255.0 + 0.5).astype(np.uint8))
 
 
-def load_colmap_dataset(folder, images="images", device="cuda"):
+def load_colmap_dataset(folder, images="images", device="cuda", resolution=1):
     """COLMAP-format dataset -> the `scene` tuple `train()` takes: cameras with the reference's matrices
     (scene/cameras.py:58-67), ground-truth images, the sparse points and colours, and the scene radius
     (readColmapSceneInfo, scene/dataset_readers.py:141-197; images sorted by name, PINHOLE / SIMPLE_PINHOLE only)."""
@@ -115,16 +115,54 @@ def load_colmap_dataset(folder, images="images", device="cuda"):
     cams, gts = [], []
     for info in infos:
         img = PILImage.open(os.path.join(folder, images, info.image_name)).convert("RGB")
-        assert img.size == (info.width, info.height), "image size differs from the COLMAP camera (rescaling is not implemented)"
+        assert img.size == (info.width, info.height), "image size differs from the COLMAP camera"
+        w, h, fx, fy = info.width, info.height, info.Fx, info.Fy
+        if resolution != 1:  # `-r 2`: images and intrinsics scaled down together (utils/camera_utils.py loadCam)
+            w, h = round(info.width / resolution), round(info.height / resolution)
+            img = img.resize((w, h), PILImage.LANCZOS)
+            fx, fy = fx * w / info.width, fy * h / info.height
         gts.append(torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous().to(device))
-        cams.append(Camera(S.make_camera(info.width, info.height, fx=info.Fx, fy=info.Fy, R=info.R, T=info.T), device))
+        cams.append(Camera(S.make_camera(w, h, fx=fx, fy=fy, R=info.R, T=info.T), device))
     xyz, rgb, _ = C.read_points3D_binary(os.path.join(sparse, "points3D.bin"))
     return cams, gts, xyz.astype(np.float32), (rgb / 255.0).astype(np.float32), C.nerf_normalization(infos)["radius"]
 
 
+def load_blender_dataset(folder, transforms="transforms_train.json", extension=".png", white_background=False, n_points=100_000, seed=0,
+                         device="cuda"):
+    """NeRF-synthetic ("Blender") dataset -> the `scene` tuple `train()` takes (readCamerasFromTransforms / readNerfSyntheticInfo,
+    scene/dataset_readers.py:199-274): `camera_angle_x` + per-frame camera-to-world matrices in OpenGL axes (y up, z back), flipped
+    to COLMAP axes, inverted, rotation stored transposed; RGBA images composited on the background; no sparse points, so a random
+    cloud in [-1.3, 1.3]^3 with near-black colours as there."""
+    import json
+    import numpy as np
+    from PIL import Image as PILImage
+    import gs2m_colmap as C
+    with open(os.path.join(folder, transforms)) as f:
+        meta = json.load(f)
+    cams, gts, infos = [], [], []
+    for idx, frame in enumerate(meta["frames"]):
+        c2w = np.array(frame["transform_matrix"], dtype=np.float64)
+        c2w[:3, 1:3] *= -1
+        w2c = np.linalg.inv(c2w)
+        R, T = np.transpose(w2c[:3, :3]), w2c[:3, 3]
+        img = PILImage.open(os.path.join(folder, frame["file_path"] + extension))
+        rgba = np.asarray(img.convert("RGBA"), dtype=np.float32) / 255.0
+        bgc = 1.0 if white_background else 0.0
+        rgb = rgba[..., :3] * rgba[..., 3:4] + bgc * (1.0 - rgba[..., 3:4])
+        W, H = img.size
+        focal = W / (2.0 * math.tan(meta["camera_angle_x"] / 2.0))            # fov2focal
+        gts.append(torch.from_numpy(rgb).permute(2, 0, 1).contiguous().to(device))
+        cams.append(Camera(S.make_camera(W, H, fx=focal, fy=focal, R=R, T=T), device))
+        infos.append(C.CameraInfo(idx, R, T, focal, focal, os.path.basename(frame["file_path"]) + extension, W, H))
+    rng = np.random.default_rng(seed)
+    xyz = (rng.random((n_points, 3)) * 2.6 - 1.3).astype(np.float32)
+    cols = (rng.random((n_points, 3)) / 255.0 * 0.28209479177387814 + 0.5).astype(np.float32)   # SH2RGB of near-zero coefficients
+    return cams, gts, xyz, cols, C.nerf_normalization(infos)["radius"]
+
+
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
-          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000):
+          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000, alpha_masks=None):
     opt = opt or OptimizationParams()
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
@@ -168,6 +206,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         vis, radii = out["visibility_filter"], out["radii"]
         rgb = out["render"].clamp(0, 1)
         loss = opt.lambda_plane * plane_loss(vis, gaussians)
+        if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
+            loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
         if not material_stage:  # train.py:101-115
             Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
@@ -244,12 +284,16 @@ if __name__ == "__main__":
     ap.add_argument("--material-from", type=int, default=None, help="iteration the material stage starts at (default: never)")
     ap.add_argument("--multi-view", action="store_true", help="multi_view_loss in the geometry stage, roughness_loss in the material stage")
     ap.add_argument("--source-path", "-s", default=None, help="COLMAP-format dataset (sparse/0/*.bin + images/); default: synthetic scene")
+    ap.add_argument("--resolution", "-r", type=int, default=1, help="down-scale factor for a COLMAP dataset's images")
+    ap.add_argument("--blender", action="store_true", help="--source-path is a NeRF-synthetic (transforms_train.json) dataset")
     ap.add_argument("--export-colmap", default=None, help="write the synthetic scene as a COLMAP-format dataset to this folder and exit")
     a = ap.parse_args()
     if a.export_colmap:
         export_colmap_dataset(a.export_colmap, synthetic_scene(a.true_gaussians, a.views, a.width, a.height))
         sys.exit(0)
-    scene = load_colmap_dataset(a.source_path) if a.source_path else None
+    scene = None
+    if a.source_path:
+        scene = load_blender_dataset(a.source_path) if a.blender else load_colmap_dataset(a.source_path, resolution=a.resolution)
     mv = None
     if a.multi_view:
         import gs2m_mvs

@@ -151,3 +151,36 @@ def test_hyperparameter_defaults_match_the_reference():
             assert ref[k] == v, f"{cls.__name__}.{k} = {v}, reference {ref[k]}"
             seen += 1
     assert seen >= 50
+
+
+def test_blender_dataset_reader(tmp_path):
+    """transforms_train.json (camera-to-world, OpenGL axes) -> the reference's camera convention: a camera written from known COLMAP-style
+    (R, T) must come back with the same view matrix and centre; RGBA images are composited on the background."""
+    import json
+    from PIL import Image as PILImage
+    import gs2m_synth as S
+    import gs2m_train
+    W, H, fx = 64, 48, 70.0
+    frames, want = [], []
+    os.makedirs(tmp_path / "train")
+    for k, eye in enumerate(((0.0, 0.0, -4.0), (3.0, 1.0, -2.0), (-2.0, -1.5, 3.0))):
+        cam = S.look_at_camera(W, H, eye, (0.0, 0.0, 0.0), fx=fx)
+        w2c = np.eye(4)
+        w2c[:3, :3], w2c[:3, 3] = cam["R"].T, cam["T"]
+        c2w = np.linalg.inv(w2c)
+        c2w[:3, 1:3] *= -1                      # COLMAP axes -> OpenGL axes (the reader flips them back)
+        frames.append({"file_path": f"train/r_{k}", "transform_matrix": c2w.tolist()})
+        want.append(cam)
+        rgba = np.zeros((H, W, 4), dtype=np.uint8)
+        rgba[:, : W // 2] = (255, 0, 0, 255)    # left half opaque red, right half transparent
+        PILImage.fromarray(rgba, "RGBA").save(tmp_path / "train" / f"r_{k}.png")
+    json.dump({"camera_angle_x": 2 * np.arctan(W / (2 * fx)), "frames": frames}, open(tmp_path / "transforms_train.json", "w"))
+    for white in (False, True):
+        cams, gts, xyz, cols, radius = gs2m_train.load_blender_dataset(str(tmp_path), white_background=white, n_points=500, device="cpu")
+        for c, w in zip(cams, want):
+            assert (c.image_width, c.image_height) == (W, H) and abs(c.Fx - fx) < 1e-4
+            assert (c.world_view_transform - w["viewmatrix"]).abs().max().item() < 1e-5
+            assert (c.camera_center - w["campos"]).abs().max().item() < 1e-5
+        assert gts[0].shape == (3, H, W) and gts[0][0, 0, 0].item() == 1.0
+        assert gts[0][:, 0, W - 1].tolist() == ([1.0, 1.0, 1.0] if white else [0.0, 0.0, 0.0])
+        assert xyz.shape == (500, 3) and np.abs(xyz).max() <= 1.3 and radius > 0
