@@ -56,7 +56,11 @@ struct Prof {
 Prof g_prof;
 int g_reference_binning = 0;
 int g_spin_wait = 1;  // forward: poll the pinned num_rendered instead of hipStreamSynchronize
-int g_bwd_impl = 1;  // 1: survivor-per-lane + MFMA (blend_bwd_mfma.hip), 0: pixel-per-lane + permlane reduction
+// blend kernels: 2 (default): per-quadrant lists (quad_lists_kernel + blend_fwd_q.hip + blend_bwd_q.hip);
+// 1: tile lists, forward blend_fwd.hip, backward survivor-per-lane + MFMA (blend_bwd_mfma.hip);
+// 0: tile lists, forward blend_fwd.hip, backward pixel-per-lane + permlane reduction (blend_bwd.hip).
+// A forward and its backward must run under the same setting (the quadrant lists are built by the forward).
+int g_bwd_impl = 2;
 
 struct StageTimer {
     hipStream_t s;
@@ -198,7 +202,14 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     }
-    {
+    if (g_bwd_impl == 2) {
+        {
+            StageTimer t(ST_RANGES, s);  // second binning level: counted with the ranges stage
+            gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
+        }
+        StageTimer t(ST_BLEND_FWD, s);
+        gs2m_launch_blend_fwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
+    } else {
         StageTimer t(ST_BLEND_FWD, s);
         gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
     }
@@ -237,8 +248,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
-    const int rpi = g_bwd_impl == 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
-    const int rowf = g_bwd_impl == 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
+    const int rpi = g_bwd_impl >= 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
+    const int rowf = g_bwd_impl >= 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
     const int rstride = rowf;
     const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rstride * sizeof(float));
     const size_t valid_bytes = gs2m_align_up(Rn * rpi);
@@ -253,7 +264,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s);
-        if (g_bwd_impl == 1)
+        if (g_bwd_impl == 2)
+            gs2m_launch_blend_bwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
+                                    grad_buffer, rows, row_valid, s);
+        else if (g_bwd_impl == 1)
             gs2m_launch_blend_bwd_mfma(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
                                        grad_buffer, rows, row_valid, s);
         else
@@ -342,7 +356,7 @@ int gs2m_set_spin_wait(int on) {
 }
 
 int gs2m_set_bwd_impl(int impl) {
-    if (impl < 0 || impl > 1) return GS2M_ERR_INVALID_ARG;
+    if (impl < 0 || impl > 2) return GS2M_ERR_INVALID_ARG;
     g_bwd_impl = impl;
     return GS2M_OK;
 }

@@ -53,6 +53,7 @@ BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
     b.tile_keys = (uint32_t*)take(R * 4);
     b.point_list = (uint32_t*)take(R * 4);
     b.inst_obs = (uint32_t*)take(R * 4);
+    b.qlist = (uint2*)take(R * 4 * sizeof(uint2));
     b.temp = take(temp_bytes);
     b.temp_bytes = temp_bytes;
     b.total_bytes = off + GS2M_ALIGN;
@@ -70,6 +71,8 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     im.final_T = (float*)take(N * 4);
     im.n_contrib = (uint32_t*)take(N * 4);
     im.ranges = (uint2*)take(tiles * sizeof(uint2));
+    im.qcount = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
+    im.qlast = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.total_bytes = off + GS2M_ALIGN;
     return im;
 }
@@ -155,6 +158,64 @@ __global__ void ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uin
     if (idx == L - 1) ranges[cur].y = L;
 }
 
+// Second binning level: the sorted list of a 16x16 tile -> four order-preserving lists, one per 8x8 quadrant,
+// holding only the instances that can reach the quadrant with alpha >= 1/255 (the exact ellipse-vs-rectangle
+// test of common.h; dropped instances contribute to no pixel of the quadrant, so every output is unchanged).
+// The blend kernels then run one wave per quadrant straight down its list: no staging of instances that
+// are skipped anyway, no tests, no ballot walks.  Entries keep the position in the tile list, so n_contrib
+// (a tile-list position, as in the reference) and the gradient-row addressing stay what they were.
+// One workgroup per tile; 256 instances per step, one per thread.
+__global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                         const float4* __restrict__ rec, int W, int H, int tiles_x,
+                                                         uint2* __restrict__ qlist, uint32_t* __restrict__ qcount) {
+    __shared__ uint32_t s_cnt[2][4][4];  // [parity][wave][quadrant]
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+    const float x0 = (float)(tile_x * GS2M_TILE), y0 = (float)(tile_y * GS2M_TILE);
+    uint2* out = qlist + (size_t)4 * range.x;
+    uint32_t run[4] = {0u, 0u, 0u, 0u};
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int par = 0;
+    for (int base = 0; base < len; base += 256, par ^= 1) {
+        const int k = base + tid;
+        bool hit[4] = {false, false, false, false};
+        uint32_t gid = 0;
+        if (k < len) {
+            gid = point_list[range.x + k];
+            const float4* r = rec + (size_t)gid * REC_Q;
+            const float4 a = r[REC_GEO0];
+            const float cC = r[REC_GEO1].x, t2 = r[REC_BIN].w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float bx0 = x0 + (float)((q & 1) * 8), by0 = y0 + (float)((q >> 1) * 8);
+                hit[q] = gs2m_reaches_rect(a.x, a.y, a.z, a.w, cC, t2, bx0, bx0 + 7.0f, by0, by0 + 7.0f);
+            }
+        }
+        unsigned long long m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            m[q] = __builtin_amdgcn_ballot_w64(hit[q]);
+            if (lane == 0) s_cnt[par][wave][q] = (uint32_t)__popcll(m[q]);
+        }
+        gs2m_sync();  // one barrier per step: the counters alternate between two sets
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t c = s_cnt[par][w][q];
+                before += w < wave ? c : 0u;
+                total += c;
+            }
+            if (hit[q]) out[(size_t)q * len + run[q] + before + (uint32_t)__popcll(m[q] & lt)] = make_uint2(gid, (uint32_t)k);
+            run[q] += total;
+        }
+    }
+    if (tid < 4) qcount[tile * 4 + tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
+}
+
 // observe[g] = sum of the per-instance counts the forward blend stored in emission order
 // (replaces the per-pixel atomicAdd at forward.cu:348-350).
 __global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ sorted_tt,
@@ -196,6 +257,10 @@ hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s) {
 
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s) {
     if (R > 0) ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, b.tile_keys, im.ranges);
+}
+void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
+                            const ImageState& im, hipStream_t s) {
+    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, b.qlist, im.qcount);
 }
 void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s) {
     observe_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, b.inst_obs, out_observe);

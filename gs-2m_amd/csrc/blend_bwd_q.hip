@@ -1,0 +1,370 @@
+// Backward of the alpha compositing for gfx950, list-driven matrix-core variant.
+//
+// Semantics: renderCUDA (bwd), diff-gaussian-rasterization/cuda_rasterizer/backward.cu:413-598 -- same per-pixel tests,
+// same gradients as blend_bwd_mfma.hip (whose header explains the lane layout: 16 survivors x 4 pixel columns per
+// instruction, DPP scans across survivors, fp32 MFMAs for the sums over pixels, packed fp32 pixel pairs) and the
+// SAME group arithmetic, instruction for instruction.  What changed is how a group gets its 16 survivors: the wave
+// owns one 8x8 quadrant and walks the quadrant's own list (binning.hip:quad_lists_kernel) from the quadrant's last
+// contributor backwards, 16 entries at a time.  Every entry survives the quadrant test by construction, so the
+// batch machinery of blend_bwd_mfma.hip -- staging 32 instances of the TILE list in LDS, testing them against the
+// quadrant, compacting the hits, refilling lanes across batch borders: a third of that kernel's issue slots -- is
+// gone: lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2), the
+// loads for the next group are issued before the current group's epilogue and land behind it.
+// One wave per quadrant (64-thread workgroups, no barriers), XCD-aware block ids, one partial-gradient row per
+// (instance, quadrant), addressed by the instance's emission slot -- gaussian_bwd.hip sums them.
+#include "common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef GS2M_BWDQ_WAVES
+#define GS2M_BWDQ_WAVES
+#endif
+#ifndef GS2M_BWDQ_UNROLL_B
+#define GS2M_BWDQ_UNROLL_B 1
+#endif
+
+// Inclusive prefix product / sum over the 16 lanes of a DPP row, for a PAIR of independent values with the two
+// chains interleaved.  One v_mul/add_f32_dpp per level and value: lanes whose source falls outside the row are
+// disabled by the DPP and keep x (product) or add 0 (sum, bound_ctrl:1); hipcc does not fold mov_dpp + mul for a
+// float identity, hence the asm.  A DPP read needs 2 wait states after the VALU write of its source, and the
+// other chain's instruction is one of them: one `s_nop 0` per level (the compiler does not track the hazard
+// through inline asm, so the nops are explicit).
+__device__ __forceinline__ void row_scan_mul2(float& x, float& y) {
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ void row_scan_add2(float& x, float& y) {  // bound_ctrl:1: lanes without a source add 0
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(x), "+v"(y));
+}
+
+template <int FC>
+__global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
+    const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qlast,
+    const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
+    const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
+    const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
+    constexpr int NV = ROW_FEAT + FC;
+    constexpr int ROWF = ((NV + 3) / 4) * 4;
+    constexpr int RSTRIDE = ROWF;  // rows are packed (a 128-B stride was tried: random single lines read no faster)
+    constexpr int NC = 3 + FC;  // colour + feature columns of the W x Ggrad product
+    constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each) = channel quads
+#ifndef GS2M_BWDQ_GSTRIDE
+#define GS2M_BWDQ_GSTRIDE 20  // 16 + 4: with a 16-float stride the A-operand reads (16 pixel rows x 4 columns) fall on 16 banks
+#endif
+    constexpr int GST = GS2M_BWDQ_GSTRIDE;
+    __shared__ __align__(16) float s_g[64][GST];   // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
+    // per pixel pair {(x, y), (x + 4, y)}, index 4 y + (x & 3): running T, running suffix sum Sg, n_contrib
+    __shared__ float2 s_T2[32];
+    __shared__ float2 s_S2[32];
+    __shared__ uint2 s_N2[32];
+    __shared__ __align__(16) float s_d[16][8];     // per survivor of the current group: 6 moments, 2 |.| sums
+    __shared__ uint32_t s_slotg[16];               // emission slot of each survivor of the current group
+
+    const int b = blockIdx.x;
+    const int tile = (b >> 5) * 8 + (b & 7);
+    const int quad = (b >> 3) & 3;
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int qx0 = tile_x * GS2M_TILE + (quad & 1) * 8, qy0 = tile_y * GS2M_TILE + (quad >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;
+    const uint2 range = ranges[tile];
+
+    // ---- pixel-per-lane prologue: lane = pixel (lx = lane & 7, ly = lane >> 3) ----
+    uint32_t lastp;
+    {
+        const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+        const float Tf = inside ? final_T[pix] : 0.f;
+        lastp = inside ? n_contrib[pix] : 0u;
+        float g[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) g[k] = 0.f;
+        if (inside) {
+            g[0] = grad_color[pix]; g[1] = grad_color[HW + pix]; g[2] = grad_color[2 * HW + pix];
+#pragma unroll
+            for (int ch = 0; ch < FC; ch++) g[3 + ch] = ch < fc ? grad_buffer[ch * HW + pix] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4*>(&s_g[lane][4 * q]) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        // suffix sum seeded with the background term (backward.cu:562-566)
+        const int pe = ((lane >> 3) * 4 + (lane & 3)) * 2 + ((lane >> 2) & 1);  // pair index * 2 + element
+        reinterpret_cast<float*>(s_T2)[pe] = Tf;
+        reinterpret_cast<float*>(s_S2)[pe] = Tf * (bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2]);
+        reinterpret_cast<uint32_t*>(s_N2)[pe] = lastp;
+    }
+    gs2m_sync();
+
+    // ---- survivor-per-lane state ----
+    const int j = lane & 15, r = lane >> 4;
+    // The running per-pixel transmittance / suffix sum live in LDS (s_T2, s_S2): read by the 16 survivor lanes
+    // of the pixel's row each step, written back by its last lane.  LDS operations of one wave execute
+    // in order, so the next group's read sees this group's write.
+    const float qxr = (float)(qx0 + r), qyf = (float)qy0;
+    const float halfW = 0.5f * W, halfH = 0.5f * H;
+    const float xq = (float)qx0 + 3.5f, yq = (float)qy0 + 3.5f;
+
+    float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f;
+    // colour . gradient dot products gc[survivor][pixel] come from the matrix pipe as well:
+    //   D[i][n] = sum_k A[i][k] B[k][n],  i = pixel slot of a 16-pixel block, n = survivor, k = channel.
+    // Lane (j, r) receives D[4r + rr][j] in accumulator element rr, so with pixel slot 4r + rr := the pixel
+    // this lane evaluates in step 4b + rr (p = 16b + 4rr + r) the four elements are exactly the four
+    // steps' gc -- no transposition.  A[i][k] = s_g[16b + 4(i & 3) + (i >> 2)][4kk + k] (lane i = j, k = r),
+    // B[k][n] = channel 4kk + r of survivor j: KK registers per lane instead of 3 + FC.
+    float scB[KK];
+#pragma unroll
+    for (int k = 0; k < KK; k++) scB[k] = 0.f;
+    // channel 4kk + r is float 4 (REC_CH + kk) + r of the record (pad channels are 0 in the record and in s_g)
+    const float* gA = &s_g[4 * (j & 3) + (j >> 2)][r];  // + 16 b rows, + 4 kk columns
+    uint32_t spos = 0xFFFFFFFFu;  // empty slot: behind every pixel's last contributor
+    const v2f pxf2 = {qxr, qxr + 4.0f};                      // this lane's two pixel columns
+    const float cx0 = (float)r - 3.5f, cx1 = (float)r + 0.5f;  // ... relative to the quadrant centre
+
+    // The quadrant's list, from its last contributor backwards: group g holds entries top - 16 g - j, j = 0..15
+    // (j = 0 is the back-most).  `np` = entries up to and including the last one that contributes to any pixel of
+    // the quadrant (written by the forward); later entries are never touched (backward.cu:493-494, 519-520).
+    const uint32_t len = range.y - range.x;
+    const uint2* list = qlist + (size_t)4 * range.x + (size_t)quad * len;
+    const int np = (int)qlast[tile * 4 + quad];
+    const int ngroups = (np + 15) >> 4;
+    // what a lane takes from its survivor's record: geometry, its channel of every quad, the emission-slot words
+    struct Fill {
+        float4 g0;       // x, y, A, B
+        float2 g1;       // C, opacity
+        float ch[KK];
+        float4 bin;      // emission offset, rect min, rect w|h, (t2)
+        uint32_t pos1;   // position in the tile list + 1
+    };
+    // list entry of survivor j in group g.  Lanes past the front of the list (the last group may be partial) take
+    // entry 0 with position ~0 = behind every pixel's last contributor: real, finite record data that no pixel accepts.
+    auto load_entry = [&](int g) {
+        const int p = np - 1 - (16 * g + j);
+        uint2 e = list[max(p, 0)];
+        e.y = p >= 0 ? e.y + 1u : 0xFFFFFFFFu;  // position in the tile list + 1
+        return e;
+    };
+    auto load_fill = [&](const uint2 e) {
+        Fill f;
+        const float4* p = rec + (size_t)e.x * REC_Q;
+        f.g0 = p[REC_GEO0];
+        f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
+        f.bin = p[REC_BIN];
+#pragma unroll
+        for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
+        f.pos1 = e.y;
+        return f;
+    };
+    Fill f;
+    uint2 e_next = make_uint2(0u, 0u);
+    int g_cur = 0;
+    // the next group's record values are requested between this group's steps and its epilogue and land behind the
+    // epilogue; the list entries one group further ahead
+    auto issue_next = [&]() {
+        if (g_cur + 1 < ngroups) f = load_fill(e_next);
+        if (g_cur + 2 < ngroups) e_next = load_entry(g_cur + 2);
+    };
+    // one group = up to 16 survivors: 16 steps of (16 survivors x 4 pixels), then the epilogue
+    auto process_group = [&](int nvalid) {
+        v4f acc1 = {0.f, 0.f, 0.f, 0.f};
+        float U1 = 0.f, U2 = 0.f;  // per-lane partial |.| sums over this lane's 16 pixels
+        // per-lane moments of s over its 16 pixels, per pixel column (.x: cx0, .y: cx1): sum s, sum s cy, sum s cy^2
+        v2f m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
+        auto gc_block = [&](int b) {
+            v4f a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * GST + 4 * k], scB[k], a, 0, 0, 0);
+            return a;
+        };
+        v4f gnext = gc_block(0);
+        const v2f sx2 = {sx, sx}, sA2 = {sA, sA}, sB2 = {sB, sB}, so2 = {so, so};
+#pragma unroll GS2M_BWDQ_UNROLL_B
+        for (int b = 0; b < 4; b++) {
+            const v4f gcur = gnext;
+            const float pyb = qyf + (float)(2 * b), cyb = (float)(2 * b) - 3.5f;
+            // the block's LDS operands up front: the compiler cannot move these reads above the s_T2/s_S2 writes
+            // of earlier steps on its own (it cannot see that the pixels differ), and every step would wait out
+            // a full LDS latency twice
+            v2f T2[2], S2[2];
+            uint2 N2[2];
+            float gBv[4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int pi = (2 * b + h) * 4 + r;
+                const float2 t = s_T2[pi], q = s_S2[pi];
+                T2[h] = v2f{t.x, t.y};
+                S2[h] = v2f{q.x, q.y};
+                N2[h] = s_N2[pi];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
+            float gAn[KK];  // A operand of the NEXT block's colour . gradient product
+#pragma unroll
+            for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * GST + 4 * k] : 0.f;  // the last block has no successor
+#pragma unroll
+            for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
+                const int pi = (2 * b + h) * 4 + r;
+                const float pyf = h ? pyb + 1.0f : pyb, cy = h ? cyb + 1.0f : cyb;
+                const float dy = sy - pyf;
+                const v2f dx = sx2 - pxf2;
+                // gs2m_power's operation order (the forward's alpha must be reproduced bit for bit)
+                const float cdy = sC * dy;
+                const float t2 = cdy * dy;
+                const v2f t1 = (sA2 * dx) * dx;
+                const v2f t3 = (sB2 * dx) * dy;
+                const v2f power = (-0.5f * (t1 + t2)) - t3;
+                const v2f e = power * GS2M_LOG2E;
+                const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
+                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
+                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
+                const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
+                const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
+                const v2f om = 1.0f - am;
+                const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                float Px = inv.x, Py = inv.y;
+                row_scan_mul2(Px, Py);
+                const v2f Pinc = {Px, Py};
+                const v2f Ti = T2[h] * Pinc;  // transmittance in front of survivor j at the two pixels
+                const v2f w = am * Ti;
+                const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
+                const v2f qv = gc * w;
+                float Sx = qv.x, Sy = qv.y;
+                row_scan_add2(Sx, Sy);
+                const v2f Sinc = {Sx, Sy};
+                const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
+                const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of blend_bwd.hip)
+                if (j == 15) {
+                    const v2f Sn = S2[h] + Sinc;
+                    s_T2[pi] = make_float2(Ti.x, Ti.y);
+                    s_S2[pi] = make_float2(Sn.x, Sn.y);
+                }
+                const v2f sv = da * sg;  // s = opacity * dL/dalpha * G
+                const v2f u1 = dx * sA2 + dy * sB, u2 = cdy + dx * sB2;
+                const v2f a1 = sv * u1, a2 = sv * u2;
+                U1 += fabsf(a1.x); U1 += fabsf(a1.y);
+                U2 += fabsf(a2.x); U2 += fabsf(a2.y);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, gBv[2 * h], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, gBv[2 * h + 1], acc1, 0, 0, 0);
+                m0 += sv;
+                m1 = __builtin_elementwise_fma(sv, v2f{cy, cy}, m1);
+                m2 = __builtin_elementwise_fma(sv, v2f{cy * cy, cy * cy}, m2);
+                if (h == 0 && b < 3) {  // one block ahead, operands long since loaded: the result is there when the next block starts
+                    v4f a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
+                    gnext = a;
+                }
+            }
+        }
+        issue_next();
+        // ---- per-survivor totals: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48) ----
+        // two values at a time: permlane32_swap + add leaves value A's two half sums in lanes 0-31 and value B's in
+        // lanes 32-63; permlane16_swap + add on two such registers leaves the totals of (A, C, B, D) in rows 0..3
+        auto reduce4 = [&](float va, float vb, float vc, float vd) {
+            const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+            const float hab = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+            const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(vc), __float_as_uint(vd), false, false);
+            const float hcd = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+            const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(hab), __float_as_uint(hcd), false, false);
+            return __uint_as_float(z[0]) + __uint_as_float(z[1]);  // row 0: A, row 1: C, row 2: B, row 3: D
+        };
+        // moments about the quadrant centre: M0, Mx, My, Mxx, Mxy, Myy
+        const float M0 = m0.x + m0.y, Mx = cx0 * m0.x + cx1 * m0.y, My = m1.x + m1.y;
+        const float Mxx = cx0 * cx0 * m0.x + cx1 * cx1 * m0.y, Mxy = cx0 * m1.x + cx1 * m1.y, Myy = m2.x + m2.y;
+        const float R1 = reduce4(M0, My, Mx, Mxx);   // rows: M0, Mx, My, Mxx
+        const float R2 = reduce4(Mxy, U1, Myy, U2);  // rows: Mxy, Myy, U1, U2
+        gs2m_sync();
+        s_d[j][r] = R1;
+        s_d[j][4 + r] = R2;
+        gs2m_sync();
+        // ---- epilogue: lane (j, r) holds the colour / feature sums D[4r + rr][j], rr = 0..3 ----
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
+            const int i = 4 * r + rr;
+            if (i < nvalid && j < ROWF - ROW_COL) {
+                const size_t rslot = (size_t)s_slotg[i] * 4 + quad;
+                rows[rslot * RSTRIDE + ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
+            }
+        }
+        if (r == 0 && j < nvalid) {  // geometry sums of survivor j from its moments
+            const float4 m0 = *reinterpret_cast<const float4*>(&s_d[j][0]);  // M0, Mx, My, Mxx
+            const float4 m1 = *reinterpret_cast<const float4*>(&s_d[j][4]);  // Mxy, Myy, U1, U2
+            const float xc = sx - xq, yc = sy - yq;  // dx = xc - cx, dy = yc - cy
+            const float Sdx = xc * m0.x - m0.y, Sdy = yc * m0.x - m0.z;
+            const float Sdxx = xc * xc * m0.x - 2.f * xc * m0.y + m0.w;
+            const float Sdxy = xc * yc * m0.x - xc * m0.z - yc * m0.y + m1.x;
+            const float Sdyy = yc * yc * m0.x - 2.f * yc * m0.z + m1.y;
+            const size_t rslot = (size_t)s_slotg[j] * 4 + quad;
+            float4* o4 = reinterpret_cast<float4*>(rows + rslot * RSTRIDE);
+            o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
+            o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)
+            row_valid[rslot] = 1;
+        }
+    };
+
+    if (ngroups > 0) {
+        f = load_fill(load_entry(0));
+        e_next = load_entry(1);
+        for (g_cur = 0; g_cur < ngroups; g_cur++) {
+            // install the group's survivors
+            sx = f.g0.x; sy = f.g0.y; sA = f.g0.z; sB = f.g0.w; sC = f.g1.x; so = f.g1.y;
+#pragma unroll
+            for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
+            spos = f.pos1;
+            if (r == 0) {
+                const uint32_t off = f2u(f.bin.x), rm = f2u(f.bin.y), rw = f2u(f.bin.z) & 0xFFFFu;
+                s_slotg[j] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
+            }
+            process_group(min(16, np - 16 * g_cur));
+        }
+    }
+}
+
+int fc_template(int fc) { return fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10)); }
+
+}  // namespace
+
+void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                                const BinningState& b, const ImageState& im, const float* grad_color,
+                                const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s) {
+    const int tiles = tiles_x * tiles_y;
+    const int grid = ((tiles + 7) / 8) * 32;
+#define GS2M_BWDQ(FC)                                                                                                      \
+    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
+                                                  im.n_contrib, grad_color, grad_buffer, rows, row_valid)
+    switch (fc_template(fc)) {
+        case 1: GS2M_BWDQ(1); break;
+        case 5: GS2M_BWDQ(5); break;
+        case 9: GS2M_BWDQ(9); break;
+        default: GS2M_BWDQ(10); break;
+    }
+#undef GS2M_BWDQ
+}

@@ -56,6 +56,8 @@ struct BinningState {
     uint32_t* tile_keys;     // R (sorted)
     uint32_t* point_list;    // R (sorted Gaussian ids)
     uint32_t* inst_obs;      // R
+    uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id, position in the tile list};
+                             //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
     char* temp;
     size_t temp_bytes;
     size_t total_bytes;
@@ -64,6 +66,8 @@ struct ImageState {
     float* final_T;      // N
     uint32_t* n_contrib; // N
     uint2* ranges;       // tiles
+    uint32_t* qcount;    // tiles * 4: entries in each quadrant list
+    uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;
 };
 
@@ -225,6 +229,14 @@ void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const 
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
+void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
+                            const ImageState& im, hipStream_t s);
+void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                             const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
+                             hipStream_t s);
+void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
+                             const BinningState& b, const ImageState& im, const float* grad_color,
+                             const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
 void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                            const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
                            hipStream_t s);

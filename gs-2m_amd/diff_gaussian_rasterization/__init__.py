@@ -144,7 +144,16 @@ class _CModule:
             if sh_rest.data_ptr() % 16:
                 sh_rest = sh_rest.clone()
             M = 1 + sh_rest.size(1)
+        # every tensor goes through .contiguous() as in the forward (and as the reference binding does in both
+        # directions, rasterize_points.cu:170-196): the reference Camera builds world_view_transform as
+        # torch.tensor(...).transpose(0, 1).cuda(), which is NOT contiguous (scene/cameras.py:64)
         grad_colors = _f32c(grad_colors, "grad_colors"); grad_buffer = _f32c(grad_buffer, "grad_buffer")
+        background = _f32c(background, "bg"); colors = _f32c(colors, "colors_precomp")
+        scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
+        cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp"); features = _f32c(features, "features")
+        viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
+        sh = _f32c(sh, "shs"); campos = _f32c(campos, "campos"); buffer = _f32c(buffer, "buffer")
+        radii = radii.contiguous()
         mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=device)) if P == 0 else \
              (lambda *s: torch.empty(s, dtype=torch.float32, device=device))
         dL_dmeans3D = mk(P, 3); dL_dmeans2D = mk(P, 4); dL_dcolors = mk(P, NUM_CHANNELS)

@@ -188,6 +188,7 @@ def set_reference_binning(on):
 
 
 def set_bwd_impl(impl):
-    """1 (default): survivor-per-lane backward blend, DPP row scans + fp32 MFMA reductions; 0: pixel-per-lane
-    with permlane/DPP reductions; 2: pixel-per-lane evaluation + MFMA reductions through an LDS transpose."""
+    """Blend kernels, forward and backward (include/gs2m_raster.h): 2 (default) per-quadrant lists; 1 tile lists
+    with the survivor-per-lane MFMA backward; 0 tile lists with the pixel-per-lane backward.  Must not change
+    between a forward and its backward."""
     check(lib().gs2m_set_bwd_impl(int(impl)), "gs2m_set_bwd_impl")

@@ -263,12 +263,15 @@ int gs2m_activate_backward(int P, const float* rotation, const float* scales, co
  * (falls back to a stream synchronize after 2 s); 0: hipStreamSynchronize.  Same results. */
 int gs2m_set_spin_wait(int on);
 
-/* Backward blend implementation (same results within fp32 rounding, all covered by the parity tests):
- *   1 (default) survivor-per-lane layout: DPP row scans for the per-pixel recurrences, fp32 MFMA for the
- *     per-Gaussian sums, one row per (instance, quadrant)                     csrc/blend_bwd_mfma.hip
- *   0 pixel-per-lane, permlane/DPP reductions, one row per instance           csrc/blend_bwd.hip
- * Measured at 1M Gaussians / 1080p: 0.66 / 1.13 ms for the blend kernel; variant 1 costs 0.08 ms more in
- * the per-Gaussian pass (4 rows per instance) and 4x the row scratch. */
+/* Blend implementation, forward AND backward (same results within fp32 rounding, every variant runs through the
+ * parity tests).  A forward and its backward must run under the same setting.
+ *   2 (default) per-quadrant lists: a second binning level splits every 16x16 tile list into four 8x8 quadrant
+ *     lists; one wave per quadrant walks its own list -- forward with scalar loads and SGPR operands, backward
+ *     in the survivor-per-lane / DPP-scan / fp32-MFMA layout        csrc/blend_fwd_q.hip, csrc/blend_bwd_q.hip
+ *   1 tile lists; forward: one workgroup per tile, quadrant test + ballot walk (csrc/blend_fwd.hip); backward:
+ *     survivor-per-lane layout on batches of the tile list                    csrc/blend_bwd_mfma.hip
+ *   0 tile lists; same forward; backward pixel-per-lane, permlane/DPP reductions, one row per instance
+ *                                                                             csrc/blend_bwd.hip */
 int gs2m_set_bwd_impl(int impl);
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----

@@ -583,6 +583,110 @@ static void computeCov3D_bwd(int idx, const float* scale, float mod, const float
 
 /* CR/rasterizer_impl.cu:334-438.  All output arrays are zeroed here, as
  * rasterize_points.cu:150-159 does with torch::zeros. */
+/* The per-Gaussian half of the backward: computeCov2DCUDA (CR/backward.cu:153-281) and preprocessCUDA
+ * (CR/backward.cu:352-410, with computeColorFromSH :23-148 and computeCov3D :285-347) from the per-Gaussian sums the
+ * blend backward produced (dL_dmeans2D, dL_dconics, dL_dcolors).  Shared by gs2m_oracle_backward and by
+ * gs2m_oracle_backward_pergaussian, which lets a test feed it ANOTHER implementation's sums: the chain downstream of
+ * the sums amplifies their last-bit differences for ill-conditioned covariances, so the two halves are checked
+ * separately (tests/helpers.py). */
+static void pergaussian_bwd(
+    const oracle_state* s, int P, int D, int M, int width, int height,
+    const float* means3D, const float* shs, const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    const float* dL_dmeans2D, const float* dL_dconics, const float* dL_dcolors,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales, float* dL_drots) {
+    const float h_x = width / (2.0f * tan_fovx), h_y = height / (2.0f * tan_fovy);
+    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+
+    /* ---- computeCov2DCUDA, CR/backward.cu:153-281 ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        const float* cov3D = cov3Ds + 6 * (size_t)idx;
+        f3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        float dcx = dL_dconics[4 * idx], dcy = dL_dconics[4 * idx + 1], dcz = dL_dconics[4 * idx + 3];
+        cov2d_tmp c2;
+        computeCov2D(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &c2);
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float x_grad_mul = c2.txtz < -limx || c2.txtz > limx ? 0 : 1;
+        const float y_grad_mul = c2.tytz < -limy || c2.tytz > limy ? 0 : 1;
+        f3 t = c2.t;
+        m3 T = c2.T, W_ = c2.W, Vrk = c2.Vrk;
+        float a = c2.cov.c[0][0] += 0.3f; /* backward-only low-pass, backward.cu:205-207 */
+        float b = c2.cov.c[0][1];
+        float c = c2.cov.c[1][1] += 0.3f;
+        float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float* dcov = dL_dcov3D + 6 * (size_t)idx;
+#define TT(i, j) T.c[i][j]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; i++) dcov[i] = 0;
+        }
+#define VV(i, j) Vrk.c[i][j]
+        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                        (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                        (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                        (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                        (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                        (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                        (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+#undef VV
+#undef TT
+#define WW(i, j) W_.c[i][j]
+        float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+        float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+        float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+        float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef WW
+        float tz = 1.f / t.z;
+        float tz2 = tz * tz;
+        float tz3 = tz2 * tz;
+        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+        f3 dt = {dL_dtx, dL_dty, dL_dtz};
+        f3 dL_dmean = transformVec4x3Transpose(dt, viewmatrix);
+        dL_dmeans3D[3 * idx] = dL_dmean.x; dL_dmeans3D[3 * idx + 1] = dL_dmean.y; dL_dmeans3D[3 * idx + 2] = dL_dmean.z;
+    }
+
+    /* ---- preprocessCUDA backward, CR/backward.cu:352-410 ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        f3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        const float* proj = projmatrix;
+        float m_hom[4];
+        transformPoint4x4(m, proj, m_hom);
+        float m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+        float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+        float g0 = dL_dmeans2D[4 * idx], g1 = dL_dmeans2D[4 * idx + 1];
+        float dmx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
+        float dmy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
+        float dmz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
+        dL_dmeans3D[3 * idx] += dmx; dL_dmeans3D[3 * idx + 1] += dmy; dL_dmeans3D[3 * idx + 2] += dmz;
+        if (shs) sh_to_rgb_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolors, dL_dmeans3D, dL_dshs);
+        if (scales) computeCov3D_bwd(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscales, dL_drots);
+    }
+}
+
 void gs2m_oracle_backward(
     const oracle_state* s, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp,
@@ -716,95 +820,27 @@ void gs2m_oracle_backward(
     for (size_t i = 0; i < NUM_FEATURES * Pn; i++) dL_dfeatures[i] = (float)a_fea[i];
     free(a_m2d); free(a_con); free(a_opa); free(a_col); free(a_fea);
 
-    const float h_x = width / (2.0f * tan_fovx), h_y = height / (2.0f * tan_fovy);
-    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+    pergaussian_bwd(s, P, D, M, width, height, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                    projmatrix, campos, tan_fovx, tan_fovy, radii, dL_dmeans2D, dL_dconics, dL_dcolors, dL_dmeans3D,
+                    dL_dcov3D, dL_dshs, dL_dscales, dL_drots);
+}
 
-    /* ---- computeCov2DCUDA, CR/backward.cu:153-281 ---- */
-#pragma omp parallel for schedule(static)
-    for (int idx = 0; idx < P; idx++) {
-        if (!(radii[idx] > 0)) continue;
-        const float* cov3D = cov3Ds + 6 * (size_t)idx;
-        f3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        float dcx = dL_dconics[4 * idx], dcy = dL_dconics[4 * idx + 1], dcz = dL_dconics[4 * idx + 3];
-        cov2d_tmp c2;
-        computeCov2D(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &c2);
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float x_grad_mul = c2.txtz < -limx || c2.txtz > limx ? 0 : 1;
-        const float y_grad_mul = c2.tytz < -limy || c2.tytz > limy ? 0 : 1;
-        f3 t = c2.t;
-        m3 T = c2.T, W_ = c2.W, Vrk = c2.Vrk;
-        float a = c2.cov.c[0][0] += 0.3f; /* backward-only low-pass, backward.cu:205-207 */
-        float b = c2.cov.c[0][1];
-        float c = c2.cov.c[1][1] += 0.3f;
-        float denom = a * c - b * b;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float* dcov = dL_dcov3D + 6 * (size_t)idx;
-#define TT(i, j) T.c[i][j]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
-            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
-            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
-            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
-        } else {
-            for (int i = 0; i < 6; i++) dcov[i] = 0;
-        }
-#define VV(i, j) Vrk.c[i][j]
-        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
-                        (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
-                        (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
-                        (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
-                        (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
-                        (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
-                        (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-#undef VV
-#undef TT
-#define WW(i, j) W_.c[i][j]
-        float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
-        float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
-        float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
-        float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
-#undef WW
-        float tz = 1.f / t.z;
-        float tz2 = tz * tz;
-        float tz3 = tz2 * tz;
-        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-        f3 dt = {dL_dtx, dL_dty, dL_dtz};
-        f3 dL_dmean = transformVec4x3Transpose(dt, viewmatrix);
-        dL_dmeans3D[3 * idx] = dL_dmean.x; dL_dmeans3D[3 * idx + 1] = dL_dmean.y; dL_dmeans3D[3 * idx + 2] = dL_dmean.z;
-    }
-
-    /* ---- preprocessCUDA backward, CR/backward.cu:352-410 ---- */
-#pragma omp parallel for schedule(static)
-    for (int idx = 0; idx < P; idx++) {
-        if (!(radii[idx] > 0)) continue;
-        f3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        const float* proj = projmatrix;
-        float m_hom[4];
-        transformPoint4x4(m, proj, m_hom);
-        float m_w = 1.0f / (m_hom[3] + 0.0000001f);
-        float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
-        float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-        float g0 = dL_dmeans2D[4 * idx], g1 = dL_dmeans2D[4 * idx + 1];
-        float dmx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
-        float dmy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
-        float dmz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
-        dL_dmeans3D[3 * idx] += dmx; dL_dmeans3D[3 * idx + 1] += dmy; dL_dmeans3D[3 * idx + 2] += dmz;
-        if (shs) sh_to_rgb_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolors, dL_dmeans3D, dL_dshs);
-        if (scales) computeCov3D_bwd(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscales, dL_drots);
-    }
+/* Per-Gaussian half only, from given sums (zero-fills its outputs first, as the binding does). */
+void gs2m_oracle_backward_pergaussian(
+    const oracle_state* s, int P, int D, int M, int width, int height,
+    const float* means3D, const float* shs, const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    const float* dL_dmeans2D, const float* dL_dconics, const float* dL_dcolors,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dscales, float* dL_drots) {
+    const size_t Pn = P > 0 ? (size_t)P : 1;
+    memset(dL_dmeans3D, 0, 3 * Pn * sizeof(float)); memset(dL_dcov3D, 0, 6 * Pn * sizeof(float));
+    if (M > 0) memset(dL_dshs, 0, 3 * (size_t)M * Pn * sizeof(float));
+    memset(dL_dscales, 0, 3 * Pn * sizeof(float)); memset(dL_drots, 0, 4 * Pn * sizeof(float));
+    if (P == 0) return;
+    pergaussian_bwd(s, P, D, M, width, height, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                    projmatrix, campos, tan_fovx, tan_fovy, radii, dL_dmeans2D, dL_dconics, dL_dcolors, dL_dmeans3D,
+                    dL_dcov3D, dL_dshs, dL_dscales, dL_drots);
 }
 
 /* CR/rasterizer_impl.cu:48-59, 132-143 */

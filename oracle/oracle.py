@@ -162,6 +162,29 @@ def backward(fwd, grad_color, grad_buffer):
     return out
 
 
+def backward_pergaussian(fwd, dL_dmeans2D, dL_dconics, dL_dcolors):
+    """The per-Gaussian half of the backward (cov2D / projection / SH / cov3D chains) applied to GIVEN per-Gaussian
+    sums (means2D (P,4), conics (P,4) = (P,2,2) flattened, colours (P,3)) -- e.g. another implementation's."""
+    L = lib()
+    i = fwd._inputs
+    P, M, W, H = fwd.P, fwd.M, fwd.W, fwd.H
+    Pn = max(P, 1)
+    z = lambda *sh: np.zeros(sh, np.float32)
+    g = dict(means3D=z(Pn, 3), cov3D=z(Pn, 6), shs=z(Pn, max(M, 1), 3), scales=z(Pn, 3), rotations=z(Pn, 4))
+    radii = np.ascontiguousarray(fwd.radii if P else np.zeros(1, np.int32), dtype=np.int32)
+    m2 = _f32(np.asarray(dL_dmeans2D).reshape(-1, 4)); co = _f32(np.asarray(dL_dconics).reshape(-1, 4))
+    cl = _f32(np.asarray(dL_dcolors).reshape(-1, 3))
+    L.gs2m_oracle_backward_pergaussian(
+        fwd._h, C.c_int(P), C.c_int(i["sh_degree"]), C.c_int(M), C.c_int(W), C.c_int(H), _p(i["means3D"]), _p(i["shs"]),
+        _p(i["scales"]), C.c_float(i["scale_modifier"]), _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["viewmatrix"]),
+        _p(i["projmatrix"]), _p(i["campos"]), C.c_float(i["tanfovx"]), C.c_float(i["tanfovy"]), _p(radii), _p(m2), _p(co),
+        _p(cl), _p(g["means3D"]), _p(g["cov3D"]), _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]))
+    out = {k: v[:P] for k, v in g.items()}
+    if M == 0:
+        out["shs"] = np.zeros((P, 0, 3), np.float32)
+    return out
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     means3D = _f32(means3D)
     P = means3D.shape[0]

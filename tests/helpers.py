@@ -86,6 +86,45 @@ def run_hip(sc, device="cuda", colors_precomp=None, cov3D_precomp=None, backward
     return out, grads
 
 
+def run_hip_sums(sc, device="cuda"):
+    """Forward + backward through the `_C` functions (the reference's pybind surface), keeping the per-Gaussian SUMS
+    the blend backward produces (dL/dmeans2D, dL/dconic, dL/dcolour, dL/dopacity, dL/dfeatures) next to the final
+    gradients: the two halves of the backward are checked separately (assert_two_stage)."""
+    import diff_gaussian_rasterization as dgr
+    g = {k: v.to(device) for k, v in sc["g"].items()}
+    st = settings_for(sc, device)
+    e = torch.Tensor([])
+    R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
+        st.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
+        st.projmatrix, st.tanfovx, st.tanfovy, sc["H"], sc["W"], g["shs"], sc["sh_degree"], st.campos, False, sc["fc"])
+    res = dgr._C.rasterize_gaussians_backward(
+        st.bg, g["means3D"], radii, buffer, e, g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
+        st.projmatrix, st.tanfovx, st.tanfovy, sc["Gc"].to(device), sc["Gb"].to(device), g["shs"], sc["sh_degree"],
+        st.campos, geomB, R, binB, imgB, sc["fc"], return_conics=True)
+    names = ("means2D", "colors", "opacities", "means3D", "cov3D", "shs", "scales", "rotations", "features", "conics")
+    return {k: v.cpu().numpy() for k, v in zip(names, res)}
+
+
+def assert_two_stage(oracle, f, gr, hip, floor_frac=1e-5):
+    """Parity of the backward in two halves.  (A) the per-Gaussian sums of the blend backward (CR/backward.cu:413-598:
+    what the reference accumulates with atomicAdd) against the oracle's, element-wise at north_star's 1e-3.  (B) the
+    per-Gaussian chain downstream of them (cov2D / projection / SH / cov3D backward, CR/backward.cu:23-410) against
+    the oracle's evaluation of the SAME chain on the HIP path's own sums.  The chain divides by denom^2 of the 2-D
+    covariance and multiplies 3x3 matrices whose entries span orders of magnitude: for needle-like Gaussians it
+    amplifies last-bit differences of the sums (any two summation orders, the reference's atomics included, differ
+    there), so an end-to-end element-wise comparison of dL/dscale, dL/drot measures conditioning, not correctness;
+    the split removes that amplification from both halves."""
+    for k in ("means2D", "conics", "opacities", "colors", "features"):
+        ref = gr[k].reshape(hip[k].shape)
+        # dL/dconic is a SIGNED sum of terms s * dx * dy whose magnitudes grow with the square of the distance to the
+        # centre: for splats centred far off-screen its small elements sit 1e4 below the terms they are summed from
+        assert_grad_close("sum:" + k, hip[k], ref, floor_frac=10 * floor_frac if k == "conics" else floor_frac)
+    chain = oracle.backward_pergaussian(f, hip["means2D"], hip["conics"], hip["colors"])
+    for k in ("means3D", "shs", "scales", "rotations"):
+        # measured: bit-identical (tools/parity_report.py); the bound leaves room for a compiler reassociating one product
+        assert_grad_close("chain:" + k, hip[k], chain[k].reshape(hip[k].shape), rel=1e-5, floor_frac=1e-6, max_exceptions=0.0)
+
+
 def rel_err(a, b):
     """max |a-b| relative to the largest reference magnitude (scale-aware max-norm error)."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
@@ -99,22 +138,103 @@ def frac_exceeding(a, b, tol):
     return float((np.abs(a - b) > tol).mean()) if a.size else 0.0
 
 
-def assert_image_close(name, got, ref, tol=ABS_TOL_BUFFERS, scale=None, max_outlier_frac=2e-5):
-    """abs tolerance `tol` (times the channel's magnitude scale when given); a threshold flip of one
-    alpha ~ 1/255 pair (different exp rounding between CPU and GPU) may move single pixels,
-    so a vanishing fraction of outliers is tolerated, bounded in size by 2/255 * scale."""
+def pixel_threshold_events(f, x, y, band=1e-4, full=False):
+    """Walk pixel (x, y)'s tile list of the oracle forward `f` in the reference's order and arithmetic
+    (CR/forward.cu:304-357, fp32, written operation order) and report how close the pixel comes to one of the
+    discontinuities of the blend: alpha crossing 1/255 (`:336`), power crossing 0 (`:329`), test_T crossing 1e-4
+    (`:339-343`).  Returns the smallest relative distance to a threshold seen before the pixel terminates; a pixel
+    whose value may legitimately flip between two correct fp32 implementations (exp() differs by an ulp) has an
+    event within `band`."""
+    f32 = np.float32
+    tile = (y // 16) * f.tiles_x + (x // 16)
+    lo, hi = int(f.ranges[tile, 0]), int(f.ranges[tile, 1])
+    T = f32(1.0)
+    best = np.inf
+    last = 0
+    for k, gid in enumerate(f.vals_sorted[lo:hi]):
+        mx, my = f.means2D[gid]
+        A, B, C, op = f.conic_opacity[gid]
+        dx = f32(mx - f32(x)); dy = f32(my - f32(y))
+        t1 = f32(f32(A * dx) * dx); t2 = f32(f32(C * dy) * dy); t3 = f32(f32(B * dx) * dy)
+        power = f32(f32(f32(-0.5) * f32(t1 + t2)) - t3)
+        best = min(best, abs(float(power)) / 1e-2)  # power within 1e-6 of 0 counts as an event at band 1e-4
+        if power > 0:
+            continue
+        a_raw = float(op) * float(np.exp(np.float64(power)))
+        best = min(best, abs(a_raw * 255.0 - 1.0))
+        alpha = min(0.99, a_raw)
+        if alpha < 1.0 / 255.0:
+            continue
+        test_T = float(T) * (1.0 - alpha)
+        best = min(best, abs(test_T / 1e-4 - 1.0))
+        if f32(T * f32(1.0 - f32(alpha))) < f32(1e-4):
+            break
+        T = f32(T * f32(1.0 - f32(alpha)))
+        last = k + 1
+    return (best, float(T), last) if full else best
+
+
+def assert_image_close(name, got, ref, tol=ABS_TOL_BUFFERS, scale=None, max_outlier_frac=2e-5, oracle_fwd=None,
+                       band=1e-4):
+    """abs tolerance `tol` (times the channel's magnitude scale when given).  Pixels outside the tolerance are only
+    accepted when they are few AND (with `oracle_fwd`, the OracleForward that produced `ref`) each of them provably
+    sits on a discontinuity of the blend: some list entry has alpha within `band` (relative) of 1/255, or test_T
+    within `band` of 1e-4, computed from the oracle's own state -- two correct fp32 implementations whose exp()
+    differ by an ulp may then take different branches.  Anything else fails."""
     got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     s = 1.0 if scale is None else scale
     d = np.abs(got - ref)
-    frac = float((d > tol * s).mean())
+    bad = d > tol * s
+    frac = float(bad.mean())
     assert frac <= max_outlier_frac, f"{name}: {frac:.2e} of pixels differ by more than {tol * s:g} (max {d.max():g})"
     assert d.max() <= 2.0 / 255.0 * s * 4 + tol * s, f"{name}: max abs diff {d.max():g}"
+    if oracle_fwd is not None and bad.any():
+        pix = bad.reshape(-1, bad.shape[-2], bad.shape[-1]).any(0)
+        for y, x in zip(*np.nonzero(pix)):
+            ev = pixel_threshold_events(oracle_fwd, int(x), int(y), band)
+            assert ev <= band, (f"{name}: pixel ({x},{y}) differs by {d.reshape(-1, *pix.shape)[:, y, x].max():g} but is "
+                                f"not at a threshold (closest event {ev:.3e} > {band:g})")
 
 
-def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS):
-    e = rel_err(got, ref)
-    assert e <= rel, f"{name}: relative error {e:.3e} > {rel:g}"
+def grad_stats(got, ref, rel=REL_TOL_GRADS, floor_frac=1e-5):
+    """Element-wise comparison: an element passes when |a-b| <= rel*|b| + floor, floor = floor_frac * rms(b) over
+    b's non-zero elements (the absolute error an fp32 sum of that tensor's typical terms carries; the oracle
+    accumulates in double).  Returns (fraction of elements failing, worst |a-b| / max|b|, floor)."""
+    a = np.asarray(got, dtype=np.float64).ravel(); b = np.asarray(ref, dtype=np.float64).ravel()
+    if a.size == 0:
+        return 0.0, 0.0, 0.0
+    nz = b[b != 0]
+    rms = float(np.sqrt(np.mean(nz * nz))) if nz.size else 0.0
+    floor = floor_frac * rms
+    d = np.abs(a - b)
+    fail = d > rel * np.abs(b) + floor
+    return float(fail.mean()), float(d.max() / (np.abs(b).max() + 1e-30)), floor
+
+
+# Gaussians whose footprint holds an alpha ~ 1/255 pixel that flips between the two implementations change by that
+# pixel's (small) term; such elements may exceed the element-wise bound, but they are few and small:
+MAX_GRAD_EXCEPTIONS = 2e-4  # fraction of a tensor's elements
+# end to end, dL/dscale and dL/drot additionally carry the conditioning of the cov2D -> cov3D -> (S, R) chain (see
+# assert_two_stage, which checks the two halves without it): measured <= 1.7e-3 of the elements on the needle scene
+MAX_GRAD_EXCEPTIONS_CHAIN = 3e-3
+def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS, max_exceptions=None, floor_frac=None):
+    """north_star: 1e-3 relative on gradients, ELEMENT-WISE (`|a-b| <= 1e-3 |b| + floor`, see grad_stats), with a
+    counted exception set (<= `max_exceptions` of the elements) that is itself bounded in the max norm
+    (every element within 1e-3 of the tensor's largest magnitude).  Defaults: floor 1e-5 of the tensor's rms and
+    2e-4 exceptions; for the tensors at the end of the covariance chain (scales, rotations, cov3D) compared end to
+    end, floor 1e-4 and MAX_GRAD_EXCEPTIONS_CHAIN."""
+    chain = name in ("scales", "rotations", "cov3D", "scaling", "rotation")
+    if max_exceptions is None:
+        max_exceptions = MAX_GRAD_EXCEPTIONS_CHAIN if chain else MAX_GRAD_EXCEPTIONS
+    if floor_frac is None:
+        floor_frac = 1e-4 if chain else 1e-5
+    got = np.asarray(got); ref = np.asarray(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.all(np.isfinite(got)), f"{name}: non-finite gradient"
+    frac, worst, floor = grad_stats(got, ref, rel, floor_frac)
+    assert frac <= max_exceptions, f"{name}: {frac:.3e} of the elements are outside {rel:g}*|ref| + {floor:.3g}"
+    assert worst <= rel, f"{name}: max-norm relative error {worst:.3e} > {rel:g}"
 
 
 # ---------------------------------------------------------------------------------------

@@ -179,3 +179,23 @@ def test_torch_ref_gradcheck():
         op[i, 0] += eps; om[i, 0] -= eps
         fd = (fn(m, op, s) - fn(m, om, s)) / (2 * eps)
         assert abs(fd.item() - go[i, 0].item()) <= 1e-4 * max(1.0, abs(fd.item()))
+
+
+def test_pixel_walk_used_to_explain_outliers_reproduces_the_oracle(oracle_lib):
+    """helpers.pixel_threshold_events (the per-pixel walk the GPU parity tests use to prove that an out-of-tolerance
+    pixel sits on an alpha = 1/255 or T = 1e-4 threshold) follows the oracle's blend: same final T and the same
+    last contributor on every sampled pixel that is not itself at a threshold."""
+    import helpers as Hh
+    sc = Hh.make_scene(3000, 96, 80, seed=21, fc=9, scale_hi=0.08)
+    f, _ = Hh.run_oracle(oracle_lib, sc, backward=False)
+    rng = np.random.default_rng(0)
+    n_ok = 0
+    for _ in range(300):
+        x, y = int(rng.integers(0, 96)), int(rng.integers(0, 80))
+        ev, T, last = Hh.pixel_threshold_events(f, x, y, full=True)
+        if ev <= 1e-5:
+            continue  # the walk evaluates exp in double: a pixel AT a threshold may legitimately differ
+        assert abs(T - float(f.final_T[y, x])) <= 2e-6 * max(1.0, T), (x, y, T, f.final_T[y, x])
+        assert last == int(f.n_contrib[y, x]), (x, y)
+        n_ok += 1
+    assert n_ok > 250

@@ -11,15 +11,15 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["bwd_mfma", "bwd_permlane"])
+@pytest.fixture(autouse=True, params=[2, 1, 0], ids=["quad_lists", "bwd_mfma", "bwd_permlane"])
 def bwd_impl(request):
-    """every test runs against both backward blend implementations"""
+    """every test runs against all three blend implementations (include/gs2m_raster.h: gs2m_set_bwd_impl)"""
     import gs2m_native
     if torch.cuda.is_available():
         gs2m_native.set_bwd_impl(request.param)
     yield request.param
     if torch.cuda.is_available():
-        gs2m_native.set_bwd_impl(1)
+        gs2m_native.set_bwd_impl(2)
 
 
 def _require_gpu():
@@ -32,18 +32,21 @@ def _check(oracle, sc, grads=True, tol=Hh.ABS_TOL_BUFFERS, **kw):
     f, gr = Hh.run_oracle(oracle, sc, backward=grads, **kw)
     out, g = Hh.run_hip(sc, backward=grads, **kw)
     assert np.array_equal(out["radii"], f.radii), "radii"
-    # observe counts depend on exp() only through T > 0.5 / alpha thresholds: allow a vanishing mismatch
-    mism = int((out["observe"] != f.observe).sum())
-    assert mism <= max(1, f.P // 2000), f"observe mismatches {mism}"
-    Hh.assert_image_close("color", out["color"], f.color, tol=tol)
+    # observe counts depend on exp() only through T > 0.5 / alpha thresholds: a vanishing number of Gaussians may
+    # differ, each by the one or two pixels that sit on a threshold
+    dobs = np.abs(out["observe"].astype(np.int64) - f.observe.astype(np.int64))
+    assert int((dobs != 0).sum()) <= max(1, f.P // 2000), f"observe mismatches {int((dobs != 0).sum())}"
+    assert dobs.max(initial=0) <= 2, f"observe differs by {dobs.max()} pixels on one Gaussian"
+    Hh.assert_image_close("color", out["color"], f.color, tol=tol, oracle_fwd=f)
     for ch in range(10):
         scale = max(1.0, float(np.abs(f.buffer[ch]).max()))
-        Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], f.buffer[ch], tol=tol, scale=scale)
+        Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], f.buffer[ch], tol=tol, scale=scale, oracle_fwd=f)
     assert np.all(out["buffer"][sc["fc"]:] == 0), "channels >= feature_count must stay zero"
     if grads:
         for k, v in g.items():
-            ok = {"colors": "colors", "cov3D": "cov3D"}.get(k, k)
-            Hh.assert_grad_close(k, v, gr[ok])
+            Hh.assert_grad_close(k, v, gr[k])
+        if not kw:  # SH + scale/rotation path: the two halves of the backward, each element-wise
+            Hh.assert_two_stage(oracle, f, gr, Hh.run_hip_sums(sc))
     return f, out
 
 
@@ -117,6 +120,26 @@ def test_precomputed_colors_and_cov(oracle_lib):
         torch.full((2500, 3), 0.5), torch.full((2500, 1), 0.5), torch.full((2500, 1), 0.5))
     cov = prm.get_covariance().contiguous()
     _check(oracle_lib, sc, colors_precomp=colors, cov3D_precomp=cov)
+
+
+def test_non_contiguous_camera_matrices(oracle_lib):
+    """The reference Camera builds world_view_transform as torch.tensor(...).transpose(0, 1).cuda()
+    (scene/cameras.py:64): a NON-contiguous (4,4) tensor, and full_proj_transform from it.  Forward and backward must
+    both see the logical matrix (the reference binding calls .contiguous() in both directions); a rotated, translated
+    camera makes the transposed read differ."""
+    _require_gpu()
+    import gs2m_synth as S
+    cam = S.look_at_camera(160, 120, eye=(1.5, -0.7, 0.5), target=(0.0, 0.0, 6.0))
+    sc = Hh.make_scene(2500, 160, 120, seed=31, fc=9, scale_hi=0.06, cam=cam)
+    f, gr = Hh.run_oracle(oracle_lib, sc)
+    for k in ("viewmatrix", "projmatrix"):
+        m = cam[k]
+        cam[k] = m.t().contiguous().t()  # same values, strides (1, 4)
+        assert not cam[k].is_contiguous() and torch.equal(cam[k], m)
+    out, g = Hh.run_hip(sc)
+    Hh.assert_image_close("color", out["color"], f.color, oracle_fwd=f)
+    for k, v in g.items():
+        Hh.assert_grad_close(k, v, gr[k])
 
 
 def test_empty_and_invisible(oracle_lib):
