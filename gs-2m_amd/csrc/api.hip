@@ -139,7 +139,8 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_PREPROCESS, s);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g, g_reference_binning ? 0 : 1, zj, s);
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g_bwd_impl == 2 ? out_observe : nullptr, g,
+                                   g_reference_binning ? 0 : 1, zj, s);
         }
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s);
@@ -188,7 +189,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s);
             ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, tiles_x, g, b, zj, s);
+            gs2m_launch_emit(P, tiles_x, g, b, g_bwd_impl != 2, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s);
@@ -208,12 +209,12 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
         }
         StageTimer t(ST_BLEND_FWD, s);
-        gs2m_launch_blend_fwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
+        gs2m_launch_blend_fwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, out_observe, s);
     } else {
         StageTimer t(ST_BLEND_FWD, s);
         gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
     }
-    if (P > 0) {
+    if (P > 0 && g_bwd_impl != 2) {  // the list-driven forward adds into out_observe itself
         StageTimer t(ST_OBSERVE, s);
         gs2m_launch_observe(P, g, b, out_observe, s);
     }

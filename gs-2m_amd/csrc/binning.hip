@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
             const uint32_t rm = s_rmin[wave][lo];
             keys_out[base + j] = ((rm >> 16) + ry) * (uint32_t)tiles_x + (rm & 0xFFFFu) + rx;
             vals_out[base + j] = s_gid[wave][lo];
-            inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
+            if (inst_obs) inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
         }
     }
 }
@@ -231,9 +231,9 @@ __global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, c
 
 }  // namespace
 
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, bool zero_inst_obs, const ZeroJobs& zero, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, b.inst_obs, zero);
+                                                b.vals_unsorted, zero_inst_obs ? b.inst_obs : nullptr, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

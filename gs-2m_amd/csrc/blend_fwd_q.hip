@@ -13,8 +13,13 @@
 // as wave masks.  A first version fetched the records with SCALAR loads (s_load_dwordx8 one entry ahead, SGPR
 // operands): it ran at half the speed -- scalar loads return out of order, so the only wait is "all of them", the
 // prefetch distance is one evaluation, and the ~0.45 us load latency was exposed on every entry.
-// `observe` (forward.cu:348-350) is one integer atomic per (instance, quadrant) that sees a pixel with T > 0.5:
-// only the first few entries of a list do, and the wave stops looking once no live pixel has T > 0.5.
+// Two other forms were built and measured: the alpha of two consecutive entries as packed fp32
+// pairs out of a component-wise LDS layout (5 fewer vector instructions per entry, but 76 VGPRs = 6 waves per SIMD
+// and the LDS reads right in front of their use: 0.30 instead of 0.27 ms), and the scalar-load form above with the
+// record lines touched ahead by a vector load (no better: the scalar path itself is the latency).
+// `observe` (forward.cu:348-350: one atomicAdd per pixel) is one integer atomic per (list entry, quadrant) that sees
+// a pixel with T > 0.5, straight into the output tensor (zeroed by the preprocess kernel): only the first few
+// entries of a list do, and the wave stops looking once no live pixel has T > 0.5.
 #include "common.h"
 
 namespace {
@@ -29,7 +34,7 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qcount,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     float* __restrict__ out_color, float* __restrict__ out_buffer, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ inst_obs, uint32_t* __restrict__ qlast) {
+    uint32_t* __restrict__ n_contrib, int* __restrict__ observe, uint32_t* __restrict__ qlast) {
     constexpr int NC = 3 + FC;        // blended channels: r, g, b, features
     constexpr int KQ = (NC + 3) / 4;  // channel quads of the record
     constexpr int NP = (NC + 1) / 2;  // channel pairs accumulated
@@ -55,7 +60,7 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     constexpr int CH = 16;       // entries per chunk
     constexpr int NS = 2 + KQ;   // quads staged
     __shared__ float4 s_q[2][NS][CH];
-    __shared__ uint2 s_e[2][CH];  // the chunk's list entries {Gaussian id, position in the tile list}
+    __shared__ uint2 s_e[2][CH];  // the chunk's list entries {Gaussian id, position in the tile list + 1}
     const int ej = lane & 15, eq = lane >> 4;  // staging role: entry ej of the chunk, quad slot eq (and eq + 4)
     auto quad_of = [](int slot) { return slot < 2 ? slot : slot + 1; };  // staged slot -> record quad (skips REC_BIN)
 
@@ -98,15 +103,12 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
             if (4 * q < NC) acc[2 * q] = __builtin_elementwise_fma(v2f{c[q].x, c[q].y}, ww, acc[2 * q]);
             if (4 * q + 2 < NC) acc[2 * q + 1] = __builtin_elementwise_fma(v2f{c[q].z, c[q].w}, ww, acc[2 * q + 1]);
         }
-        const uint32_t pos1 = ec.y + 1u;  // position in the tile list + 1, as the reference counts contributors
+        const uint32_t pos1 = ec.y;  // position in the tile list + 1 (parked that way), as the reference counts contributors
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(last_contributor) : "v"(pos1), "s"(contrib));
         if (watch) {
             const mask_t half = contrib & __builtin_amdgcn_ballot_w64(T > 0.5f);
             if (half != 0ull) {  // rare: only the front of a list
-                const float4 bin = rec[(size_t)__builtin_amdgcn_readfirstlane(ec.x) * REC_Q + REC_BIN];
-                const uint32_t off = f2u(bin.x), rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
-                const uint32_t slot = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
-                if (lane == 0) atomicAdd(&inst_obs[slot], (uint32_t)__popcll(half));
+                if (lane == 0) atomicAdd(&observe[__builtin_amdgcn_readfirstlane(ec.x)], (int)__popcll(half));  // integer: the order does not matter
             }
             // T only falls: once no live pixel is above 0.5 nothing later can be
             watch = (live & __builtin_amdgcn_ballot_w64(T > 0.5f)) != 0ull;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     auto park = [&](int buf, const uint2 e, const Stage& st) {
         s_q[buf][eq][ej] = st.a;
         if (eq + 4 < NS) s_q[buf][eq + 4][ej] = st.b;
-        if (eq == 0) s_e[buf][ej] = e;
+        if (eq == 0) s_e[buf][ej] = make_uint2(e.x, e.y + 1u);
     };
     if (nchunks > 0) {
         uint2 e1 = load_entry(0);
@@ -176,13 +178,13 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
 
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                              const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
-                             hipStream_t s) {
+                             int* out_observe, hipStream_t s) {
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
     const int fct = fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10));
 #define GS2M_FWDQ(FC)                                                                                                   \
     blend_fwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qcount, g.rec, W, H, tiles_x, tiles, bg, fc, out_color, \
-                                               out_buffer, im.final_T, im.n_contrib, b.inst_obs, im.qlast)
+                                               out_buffer, im.final_T, im.n_contrib, out_observe, im.qlast)
     switch (fct) {
         case 1: GS2M_FWDQ(1); break;
         case 5: GS2M_FWDQ(5); break;

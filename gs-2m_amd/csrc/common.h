@@ -222,8 +222,8 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
+                            int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, bool zero_inst_obs, const ZeroJobs& zero, hipStream_t s);
 void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                             int rstride, int rpi, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
@@ -233,7 +233,7 @@ void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomSt
                             const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                              const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
-                             hipStream_t s);
+                             int* out_observe, hipStream_t s);
 void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                              const BinningState& b, const ImageState& im, const float* grad_color,
                              const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ shs_rest, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, float4* __restrict__ rec,
+    int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, int* __restrict__ observe_zero, float4* __restrict__ rec,
     uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, ZeroJobs zero) {
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         }
     }
     radii[idx] = out_radius;
+    if (observe_zero) observe_zero[idx] = 0;  // the list-driven forward adds its counts with integer atomics
     tiles_touched[idx] = out_tt;
     depth_key[idx] = out_key;
 }
@@ -264,12 +265,12 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* cov3D_precomp, const float* colors_precomp, const float* features,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
-                            int* radii, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s) {
+                            int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s) {
 #define GS2M_PRE(LDS)                                                                                                  \
     preprocess_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, \
                                                            shs, shs_rest, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
-                                                           focal_y, tiles_x, tiles_y, shrink, radii, g.rec,             \
+                                                           focal_y, tiles_x, tiles_y, shrink, radii, observe_zero, g.rec,             \
                                                            g.tiles_touched, g.depth_key, g.clamped, zero)
     // split SH (shs = DC, shs_rest = the other 15 coefficients) exists in the LDS-staged form only: api.hip checks
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 &&
