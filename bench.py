@@ -1,12 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- train views/s (fwd+bwd raster) at 1M Gaussians 1080p on N MI355X.
 
-One "step" = one view per GPU: GaussianRasterizer forward + backward with dense upstream
-gradients on colour and the G-buffer, timed at the op boundary; at N > 1
-every rank renders its own camera of the same replicated 1M-Gaussian scene and the step ends
-with the RCCL sum of the per-Gaussian gradients (gs2m_dp).  Prints ONE JSON line on rank 0.
+One "step" = one view per GPU: GaussianRasterizer forward + backward with dense upstream gradients on colour and
+the G-buffer, timed at the op boundary.  At N > 1 every rank renders its own camera of the same
+replicated scene and the step ENDS with the blocking RCCL sum of the view's per-Gaussian gradients -- one collective
+over the binding's gradient arena -- plus the densification side channels (gs2m_dp); the pipelined form (the sum of
+step k overlapping step k + 1) is timed as well and reported beside it.  Prints ONE JSON line on rank 0.
+
+  --config c3 (default)  BASELINE.json configs[2]: 1M Gaussians, 1920x1080, feature_count 9 (material G-buffers) -- the
+                         configuration the metric is quoted on; kept at every N so that the driver's scaling efficiency
+                         compares equal per-GPU work
+  --config c2            configs[1]: 500k Gaussians, 1080p, feature_count 5 (colour + depth + normal)
+  --config c5            configs[4]'s per-GPU shape: 2M Gaussians, 1080p, feature_count 9
+  --config c1            configs[0]: 10k Gaussians, 256x256, feature_count 10 (the CPU-runnable case)
+At N = 1 the line also carries `cpu_baseline` (the oracle timed on this box's host cores), `render_level_ms` and
+`train_step_ms` (render() and a full geometry-stage training iteration around the same op).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -20,6 +32,34 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 1024           # 256 CUs x 4 SIMDs
+CONFIGS = {  # name -> (Gaussians, width, height, feature_count)
+    "c1": (10_000, 256, 256, 10), "c2": (500_000, 1920, 1080, 5), "c3": (1_000_000, 1920, 1080, 9),
+    "c5": (2_000_000, 1920, 1080, 9)}
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources the library is built from: ties a counter file to the kernels it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gs-2m_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gs-2m_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "gs-2m_amd", "csrc", "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters_for(kernel, workload):
+    """PMC counters of `kernel` ("blend_fwd" / "blend_bwd") from profiles/pmc_counters.json -- written by
+    tools/profile.sh + tools/summarize_prof.py from separate `rocprofv3 --pmc` passes over this very command -- or
+    None when the file was taken on other kernel sources or another workload (a stale file is refused, not trusted)."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("source_hash") != kernel_source_hash() or d.get("workload") != workload:
+        return None
+    return d.get("kernels", {}).get(kernel)
 
 
 def cpu_baseline(P, W, H, fc, seed):
@@ -48,20 +88,85 @@ def cpu_baseline(P, W, H, fc, seed):
                       f"({dt:.2f} s on {cores} OpenMP threads" + ("" if Ps == P else f"; value scaled by {Ps}/{P}") + ")"}
 
 
+def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
+    """the same op one and two levels up.  render_level_ms: gaussian_renderer.render(material stage)
+    forward + backward of a weighted sum of its maps.  train_step_ms: one geometry-stage training iteration
+    (train.py:94-130, 223-227, 258-259 without the multi-view term): render with the Sobel normal, clamp,
+    L1 + D-SSIM + plane + depth-normal losses, backward, densification statistics, fused Adam step."""
+    import gs2m_optim
+    import gs2m_synth as S
+    from fused_ssim import fused_ssim
+    from gaussian_renderer import render
+    from gs2m_losses import depth_normal_loss, l1_loss, plane_loss
+    from gs2m_scene import Camera, GaussianParams, PipelineParams
+    cam0 = S.make_camera(W, H)
+    g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=seed).items()}
+    u = lambda c: torch.rand(P, c, device=dev) * 0.8 + 0.1
+    pc = GaussianParams.from_activated(g["means3D"], g["shs"], g["scales"], g["rotations"], g["opacities"].clamp(0.01, 0.99), u(3), u(1), u(1))
+    params = [torch.nn.Parameter(t) for t in pc.parameters()]
+    (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, pc._albedo, pc._roughness, pc._metallic) = params
+    names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, albedo=0.05, roughness=0.05, metallic=0.05)
+    opt = gs2m_optim.Adam([{"params": [p], "lr": lrs[n], "name": n} for p, n in zip(params, names)], lr=0.0, eps=1e-15)
+    cam, pipe, bg = Camera(cam0, dev), PipelineParams(), torch.zeros(3, device=dev)
+    wts = {k: torch.rand(s, device=dev) for k, s in (("render", (3, H, W)), ("depth_map", (1, H, W)), ("normal_map", (3, H, W)),
+                                                     ("albedo_map", (3, H, W)), ("roughness_map", (1, H, W)), ("local_normal_map", (3, H, W)))}
+    gt = torch.rand(3, H, W, device=dev)
+    accum, accum_abs, denom = (torch.zeros(P, 1, device=dev) for _ in range(3))
+    state = {"max_radii": torch.zeros(P, device=dev)}
+
+    def render_step():
+        for t in params:
+            t.grad = None
+        out = render(cam, pc, pipe, bg, material_stage=True)
+        sum((out[k] * w).sum() for k, w in wts.items()).backward()
+
+    def train_step():
+        out = render(cam, pc, pipe, bg, geometry_stage=False, material_stage=False, sobel_normal=True)
+        vis, radii = out["visibility_filter"], out["radii"]
+        rgb = out["render"].clamp(0, 1)
+        loss = 0.8 * l1_loss(rgb, gt) + 0.2 * (1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))) + 0.01 * plane_loss(vis, pc)
+        loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+        loss.backward()
+        with torch.no_grad():  # train.py:223-227, GM:569-573 in gs2m_model's masked form
+            mask = (out["observe"] > 0) & vis
+            state["max_radii"] = torch.where(mask, torch.max(state["max_radii"], radii), state["max_radii"])
+            vg, f = out["viewspace_points"].grad, vis[:, None]
+            accum.add_(torch.where(f, torch.norm(vg[:, :2], dim=-1, keepdim=True), 0.0))
+            accum_abs.add_(torch.where(f, torch.norm(vg[:, 2:], dim=-1, keepdim=True), 0.0))
+            denom.add_(f)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+
+    res = {}
+    for key, fn in (("render_level_ms", render_step), ("train_step_ms", train_step)):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        res[key] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--fc", type=int, default=9, help="feature_count (9 = --material stage)")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--fc", type=int, default=None, help="feature_count (9 = --material stage)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
-    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1],
-                    help="backward blend implementation (default: the library's default)")
+    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1, 2],
+                    help="blend implementation (default: the library's default, 2 = per-quadrant lists)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +196,9 @@ def main():
 
     if a.bwd_impl is not None:
         gs2m_native.set_bwd_impl(a.bwd_impl)
-    P, W, H, fc = a.gaussians, a.width, a.height, a.fc
+    P, W, H, fc = CONFIGS[a.config]
+    P, W, H, fc = a.gaussians or P, a.width or W, a.height or H, fc if a.fc is None else a.fc
+    preset = (P, W, H, fc) == CONFIGS[a.config]
     if world == 1:
         cam = S.make_camera(W, H)
     else:  # same cloud, cameras on a small arc around its centre: statistically equal per-rank work
@@ -115,8 +222,13 @@ def main():
     if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
         gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
     info = {}
+    pending = []
 
-    def step():
+    def drain():
+        while pending:
+            pending.pop(0).wait()
+
+    def step(pipelined=False):
         for t in leaves:
             t.grad = None
         color, radii, observe, buffer = rasterize_gaussians(
@@ -124,23 +236,19 @@ def main():
             prm["features"], st)
         torch.autograd.backward([color, buffer], [Gc, Gb])
         if world > 1:
-            # The RCCL sum of this view's gradients (276 MB per rank at M = 16) is started here and waited for at the
-            # END of the next step, right before that step starts its own: it runs on RCCL's stream beside the next
-            # view's rasterization instead of in front of it.  Every step's gradients are fully reduced (fence()
-            # drains the last one inside the timed region); a training loop consumes them one step late.
-            drain()
-            pending.append(reducer.reduce_grads_async({"means3D": prm["means3D"].grad, "shs": prm["shs"].grad,
-                                                       "opacities": prm["opacities"].grad, "scales": prm["scales"].grad,
-                                                       "rotations": prm["rotations"].grad, "features": prm["features"].grad}))
+            # The sum of this view's gradients: ONE collective over the arena the binding allocated them in (the leaves'
+            # .grad are views of it), plus the densification side channels.  Blocking form (the metric): the step ends
+            # when the sums have landed.  Pipelined form: started here, waited for right before the NEXT step's own
+            # reduction starts, so it runs on RCCL's stream beside the next view's rasterization; every step's
+            # gradients are still fully reduced, a training loop built that way applies them one step late.
+            if pipelined:
+                drain()
+            pending.append(reducer.reduce_flat_async([t.grad for t in leaves]))
             pending.append(reducer.reduce_densification_stats_async(means2D.grad, radii, observe))
+            if not pipelined:
+                drain()
         info["radii"] = radii
         info["R"] = color.grad_fn.num_rendered if hasattr(color.grad_fn, "num_rendered") else None
-
-    pending = []
-
-    def drain():
-        while pending:
-            pending.pop(0).wait()
 
     def fence():
         drain()
@@ -149,27 +257,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(pipelined):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(pipelined)
+        fence()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        if world > 1:
+            t = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        return ms
+
     for _ in range(a.warmup):
         step()
     gs2m_native.profile_mode(1)  # HIP events around the two blend kernels, on their launch stream
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
+    ms = timed(False)
     blend = gs2m_native.profile_collect()
-    ms = (t1 - t0) / a.steps * 1e3
-    if world > 1:
-        t = torch.tensor([ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
+    gs2m_native.profile_mode(0)
+    ms_pipelined = timed(True) if world > 1 else None
 
     # untimed: per-stage breakdown of the same step
     gs2m_native.profile_mode(2)
     for _ in range(5):
         step()
-    torch.cuda.synchronize()
+    fence()
     stages = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
 
@@ -181,31 +294,48 @@ def main():
         k_ms = {k: blend[k][0] / max(blend[k][1], 1) for k in ("blend_fwd", "blend_bwd")}
         dom = max(k_ms, key=k_ms.get)
         achieved = ab[dom] / (k_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # filled from rocprofv3 --pmc passes
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom)
-            except Exception:
-                traffic = None
+        workload = f"{P}x{W}x{H}x{fc}"
+        ctr = counters_for(dom, workload) or {}
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
+                # (2 x FETCH + WRITE per the guide's gfx950 correction); null when profiles/pmc_counters.json was taken
+                # on other kernel sources or another workload
+                "traffic": ctr.get("hbm_bytes"),
+                "algo_bytes_per_launch": ab[dom], "avg_launch_ms": round(k_ms[dom], 5),
+                "blend_fwd_ms": round(k_ms["blend_fwd"], 5), "blend_bwd_ms": round(k_ms["blend_bwd"], 5),
+                "whole_path_GBps": round(ab["total"] / (ms * 1e-3) / 1e9, 2)}
+        if ctr.get("SQ_INSTS_VALU"):
+            # the bound the blend kernels actually run against: vector-ALU issue slots (one wave64 instruction
+            # occupies its SIMD for 4 cycles; MFMA busy cycles come on top, the two do not overlap on a SIMD)
+            clk = float(ctr.get("clock_ghz", 2.4))
+            issue_ms = ((ctr["SQ_INSTS_VALU"] - ctr.get("SQ_INSTS_MFMA", 0.0)) * 4.0 + ctr.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)) / (SIMDS * clk * 1e9) * 1e3
+            roof["issue"] = {"bound": "valu+mfma issue", "SQ_INSTS_VALU": ctr["SQ_INSTS_VALU"],
+                             "SQ_INSTS_MFMA": ctr.get("SQ_INSTS_MFMA"), "SQ_VALU_MFMA_BUSY_CYCLES": ctr.get("SQ_VALU_MFMA_BUSY_CYCLES"), "clock_ghz": clk,
+                             "issue_bound_ms": round(issue_ms, 5), "frac": round(issue_ms / k_ms[dom], 4)}
         out = {
             "metric": "train views/s (fwd+bwd raster) at 1M Gaussians 1080p",
             "value": round(world * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, "
-                                   f"fwd+bwd at the op boundary" + ("" if world == 1 else ", RCCL gradient sum per step (overlapping the next view)"),
+            "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
+                                   + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
+                                   + ("" if world == 1 else ", blocking RCCL sum of the view's gradients (one collective) at step end"),
                        "gaussians": P, "visible": V, "num_rendered": R, "width": W, "height": H, "feature_count": fc,
                        "parallelism": f"view-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algo_bytes_per_launch": ab[dom], "avg_launch_ms": round(k_ms[dom], 5),
-                         "blend_fwd_ms": round(k_ms["blend_fwd"], 5), "blend_bwd_ms": round(k_ms["blend_bwd"], 5),
-                         "whole_path_GBps": round(ab["total"] / (ms * 1e-3) / 1e9, 2)},
+            "roofline": roof,
             "stages_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in stages.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if ms_pipelined is not None:
+            out["pipelined_ms_per_step"] = round(ms_pipelined, 4)
+            out["pipelined_value"] = round(world * 1e3 / ms_pipelined, 3)
+    if world == 1 and rank == 0:
+        torch.cuda.empty_cache()
+        if not a.no_caller_levels:
+            out.update(caller_levels(P, W, H, a.seed, dev))
+        if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, W, H, fc, a.seed)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

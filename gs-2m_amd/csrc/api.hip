@@ -3,7 +3,9 @@
 // CudaRasterizer::Rasterizer::forward/backward (cuda_rasterizer/rasterizer_impl.cu:185-438)
 // with the pipeline described in binning.hip.
 #include "common.h"
+#include <atomic>
 #include <chrono>
+#include <dlfcn.h>
 
 #define HIP_TRY(expr)                          \
     do {                                       \
@@ -54,18 +56,51 @@ struct Prof {
     int created = 0;
 };
 Prof g_prof;
-int g_reference_binning = 0;
-int g_spin_wait = 1;  // forward: poll the pinned num_rendered instead of hipStreamSynchronize
+// Mode switches: process-wide, read once at the top of a call (atomic: setting them from another thread is safe, and a
+// call in flight keeps the values it started with).
+std::atomic<int> g_reference_binning{0};
+std::atomic<int> g_spin_wait{1};  // forward: poll the pinned num_rendered instead of hipStreamSynchronize
+std::atomic<int> g_debug{0};      // gs2m_set_debug: synchronize + check after every stage
+std::atomic<int> g_markers{0};    // gs2m_set_markers: roctx ranges around the stages
 // blend kernels: 2 (default): per-quadrant lists (quad_lists_kernel + blend_fwd_q.hip + blend_bwd_q.hip);
 // 1: tile lists, forward blend_fwd.hip, backward survivor-per-lane + MFMA (blend_bwd_mfma.hip);
 // 0: tile lists, forward blend_fwd.hip, backward pixel-per-lane + permlane reduction (blend_bwd.hip).
 // A forward and its backward must run under the same setting (the quadrant lists are built by the forward).
-int g_bwd_impl = 2;
+std::atomic<int> g_bwd_impl{2};
 
+const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges+quad_lists",
+                                           "blend_fwd", "observe", "blend_bwd", "gaussian_bwd"};
+
+// roctx ranges (rocprofv3 --marker-trace): resolved at run time so that the library has no link-time dependency
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    void load() {
+        if (tried) return;
+        tried = true;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+    }
+};
+Roctx g_roctx;
+
+// One stage of a call: optional roctx range, optional HIP-event timing, and in debug mode a stream synchronize +
+// error check when the stage ends, so that a fault is reported by the stage that caused it (`failed` = stage + 1).
 struct StageTimer {
     hipStream_t s;
     int slot = -1;
-    StageTimer(int stage, hipStream_t s_) : s(s_) {
+    int stage;
+    int* failed;
+    bool marked = false;
+    StageTimer(int stage_, hipStream_t s_, int* failed_ = nullptr) : s(s_), stage(stage_), failed(failed_) {
+        if (g_markers.load(std::memory_order_relaxed)) {
+            g_roctx.load();
+            if (g_roctx.push) { g_roctx.push(kStageNames[stage]); marked = true; }
+        }
         const bool blend = stage == ST_BLEND_FWD || stage == ST_BLEND_BWD;
         if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || g_prof.n >= kMaxRecords) return;
         slot = g_prof.n++;
@@ -79,14 +114,24 @@ struct StageTimer {
     }
     ~StageTimer() {
         if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], s);
+        if (failed && g_debug.load(std::memory_order_relaxed) && *failed == 0) {
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) *failed = stage + 1;
+        }
+        if (marked && g_roctx.pop) g_roctx.pop();
     }
 };
+#define DEBUG_CHECK()                                        \
+    do {                                                     \
+        if (failed_stage) return GS2M_ERR_STAGE(failed_stage - 1); \
+    } while (0)
 
 }  // namespace
 
 extern "C" {
 
-const char* gs2m_version(void) { return "gs2m_raster 0.1 (gfx950, round 1)"; }
+const char* gs2m_version(void) { return "gs2m_raster 0.2 (gfx950, round 2)"; }
 
 static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
                         void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
@@ -98,6 +143,8 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                         int* out_observe, float* out_buffer, void* stream_) {
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream_;
+    const int bwd_impl = g_bwd_impl.load(), reference_binning = g_reference_binning.load(), spin_wait = g_spin_wait.load();
+    int failed_stage = 0;  // debug mode: 1 + the first stage whose kernels faulted
     if (P < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geometry_alloc || !binning_alloc || !image_alloc || !out_color || !out_buffer || !background) return GS2M_ERR_INVALID_ARG;
     if (P > 0 && (!means3D || !opacities || !out_radii || !out_observe || !viewmatrix || !projmatrix)) return GS2M_ERR_INVALID_ARG;
@@ -136,19 +183,19 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
         gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
         {
-            StageTimer t(ST_PREPROCESS, s);
+            StageTimer t(ST_PREPROCESS, s, &failed_stage);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, g_bwd_impl == 2 ? out_observe : nullptr, g,
-                                   g_reference_binning ? 0 : 1, zj, s);
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, bwd_impl == 2 ? out_observe : nullptr, g,
+                                   reference_binning ? 0 : 1, zj, s);
         }
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
-            StageTimer t(ST_DEPTH_SORT, s);
+            StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
             HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
                                           g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s));
         }
         {   // 2. emission offsets in that order
-            StageTimer t(ST_SCAN, s);
+            StageTimer t(ST_SCAN, s, &failed_stage);
             HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
                                             g.sorted_off, g.counters, true, s));
         }
@@ -164,7 +211,8 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         land[0] = 0xFFFFFFFFu;
         publish_count_kernel<<<1, 1, 0, s>>>(g.counters, t_pinned.dev);
         HIP_TRY(hipGetLastError());
-        if (g_spin_wait) {
+        DEBUG_CHECK();
+        if (spin_wait) {
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
             while (land[0] == 0xFFFFFFFFu) {
@@ -173,6 +221,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             }
         }
         if (land[0] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
+        if (land[0] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // the look-back status words carry 30 value bits
         R = (int)land[0];
     }
 
@@ -186,38 +235,41 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
 
     if (R > 0) {
         {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the per-instance observe counts
-            StageTimer t(ST_EMIT, s);
+            StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, tiles_x, g, b, g_bwd_impl != 2, zj, s);
+            gs2m_launch_emit(P, tiles_x, g, b, bwd_impl != 2, zj, s);
         }
         {
-            StageTimer t(ST_TILE_SORT, s);
+            StageTimer t(ST_TILE_SORT, s, &failed_stage);
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
                                           b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s));
         }
         {
-            StageTimer t(ST_RANGES, s);
+            StageTimer t(ST_RANGES, s, &failed_stage);
             gs2m_launch_ranges(R, b, im, s);
         }
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     }
-    if (g_bwd_impl == 2) {
+    DEBUG_CHECK();
+    if (bwd_impl == 2) {
         {
-            StageTimer t(ST_RANGES, s);  // second binning level: counted with the ranges stage
+            StageTimer t(ST_RANGES, s, &failed_stage);  // second binning level: counted with the ranges stage
             gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
         }
-        StageTimer t(ST_BLEND_FWD, s);
+        StageTimer t(ST_BLEND_FWD, s, &failed_stage);
         gs2m_launch_blend_fwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, out_observe, s);
     } else {
-        StageTimer t(ST_BLEND_FWD, s);
+        StageTimer t(ST_BLEND_FWD, s, &failed_stage);
         gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
     }
-    if (P > 0 && g_bwd_impl != 2) {  // the list-driven forward adds into out_observe itself
-        StageTimer t(ST_OBSERVE, s);
+    DEBUG_CHECK();
+    if (P > 0 && bwd_impl != 2) {  // the list-driven forward adds into out_observe itself
+        StageTimer t(ST_OBSERVE, s, &failed_stage);
         gs2m_launch_observe(P, g, b, out_observe, s);
     }
+    DEBUG_CHECK();
     HIP_TRY(hipGetLastError());
     return R;
 }
@@ -234,6 +286,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          void* stream_) {
     (void)buffer; (void)features;
     hipStream_t s = (hipStream_t)stream_;
+    const int bwd_impl = g_bwd_impl.load();
+    int failed_stage = 0;
     if (P == 0) return GS2M_OK;
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geom_buffer || !binning_buffer || !image_buffer || !scratch_alloc || !grad_colors || !radii) return GS2M_ERR_INVALID_ARG;
@@ -249,8 +303,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
-    const int rpi = g_bwd_impl >= 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
-    const int rowf = g_bwd_impl >= 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
+    const int rpi = bwd_impl >= 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
+    const int rowf = bwd_impl >= 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
     const int rstride = rowf;
     const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rstride * sizeof(float));
     const size_t valid_bytes = gs2m_align_up(Rn * rpi);
@@ -264,23 +318,27 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 
     HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
-        StageTimer t(ST_BLEND_BWD, s);
-        if (g_bwd_impl == 2)
+        StageTimer t(ST_BLEND_BWD, s, &failed_stage);
+        if (bwd_impl == 2)
             gs2m_launch_blend_bwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
                                     grad_buffer, rows, row_valid, s);
-        else if (g_bwd_impl == 1)
+        else if (bwd_impl == 1)
             gs2m_launch_blend_bwd_mfma(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
                                        grad_buffer, rows, row_valid, s);
         else
             gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
                                   grad_buffer, rows, row_valid, s);
     }
-    StageTimer tg(ST_GAUSSIAN_BWD, s);
+    DEBUG_CHECK();
+    {
+    StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);
     if (P > 0) gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
     gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
                              sums, row_valid, rowf, 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
                              dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures, s);
+    }
+    DEBUG_CHECK();
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
 }
@@ -350,6 +408,22 @@ int gs2m_set_reference_binning(int on) {
     g_reference_binning = on ? 1 : 0;
     return GS2M_OK;
 }
+
+int gs2m_set_debug(int on) {
+    g_debug = on ? 1 : 0;
+    return GS2M_OK;
+}
+
+int gs2m_set_markers(int on) {
+    g_markers = on ? 1 : 0;
+    if (on) {
+        g_roctx.load();
+        if (!g_roctx.push || !g_roctx.pop) return GS2M_ERR_UNSUPPORTED;  // libroctx64 not found
+    }
+    return GS2M_OK;
+}
+
+const char* gs2m_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : "?"; }
 
 int gs2m_set_spin_wait(int on) {
     g_spin_wait = on ? 1 : 0;

@@ -18,6 +18,7 @@
 //    payload are needed; tile ids are handed out by an atomic ticket, so a tile only ever waits for
 //    tiles that were started before it (forward progress without co-residency assumptions).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 #ifndef LB_WIN
@@ -28,7 +29,19 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_MAXPASS = 4;
-constexpr int RS_RESIDENT_TILES = 768;  // 3 workgroups per CU x 256 CUs fit for certain (LDS 34 KB, 256 threads each)
+// Passes of at most this many tiles take their tile ids from blockIdx (see launch_pass): 3 workgroups per compute
+// unit of the CURRENT device (the kernel's LDS, 34 KB, and 256 threads allow 4) -- a
+// partitioned device (CPX: 32 CUs) gets a proportionally smaller bound.
+int resident_tiles() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        cached[dev] = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? 3 * cus : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
 constexpr uint32_t FLAG_AGG = 1u << 30, FLAG_PFX = 2u << 30, VAL_MASK = (1u << 30) - 1;
 
 struct SortPlan {
@@ -213,10 +226,15 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
 template <int BITS>
 void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
                  const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s) {
-    // Tile ids: blockIdx when every workgroup of the pass is resident at once (then no tile can wait for one that
-    // cannot start, whatever the dispatch order); beyond that an atomic ticket hands them out in start order.  The
-    // ticket serialises the starts on one address: 0.088 -> 0.074 ms for the 661-tile instance sort without it.
-    rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist, tiles <= RS_RESIDENT_TILES ? nullptr : ticket, status);
+    // Tile ids: blockIdx when every workgroup of the pass fits on the device at once with room to spare (then no tile
+    // waits for one that cannot start, as long as the device is not shared with another resident kernel -- the call is
+    // stream-ordered, and a look-back that does stall is still released by the dispatch of the earlier blocks, which
+    // the hardware starts in id order); beyond that an atomic ticket hands them out in start order.  The ticket
+    // serialises the starts on one address: 0.088 -> 0.074 ms for the 661-tile instance sort without it.
+    // GS2M_SORT_TICKETS=1 forces tickets (shared / CU-masked devices).
+    static const bool force_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
+    rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist,
+                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status);
 }
 
 }  // namespace

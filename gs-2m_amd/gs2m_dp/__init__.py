@@ -93,6 +93,63 @@ class GradReducer:
         """grads: dict name -> contiguous tensor (summed in place across ranks). Returns the dict."""
         return self.reduce_grads_async(grads).wait()
 
+    # ---- one collective per step --------------------------------------------------------------------------------
+    @staticmethod
+    def common_arena(tensors):
+        """The flat fp32 tensor over the storage the given tensors all live in, or None.  The rasterizer binding
+        allocates every gradient it returns inside ONE buffer (diff_gaussian_rasterization: _grad_arena), so the
+        nine per-Gaussian gradients of a view can be summed with a single collective and no copy."""
+        ts = [t for t in tensors if t is not None and t.numel() > 0]
+        if not ts or any(t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
+            return None
+        st = ts[0].untyped_storage()
+        if any(t.untyped_storage().data_ptr() != st.data_ptr() for t in ts[1:]):
+            return None
+        covered = sum(t.numel() for t in ts)
+        total = st.nbytes() // 4
+        if covered * 2 < total:  # mostly something else's memory (e.g. slices of a large parameter blob)
+            return None
+        return torch.empty(0, dtype=torch.float32, device=ts[0].device).set_(st, 0, (total,))
+
+    def reduce_flat_async(self, tensors):
+        """Sum of a LIST of gradient tensors across ranks with ONE collective: in place on their common arena when they
+        share one, otherwise through one concatenated copy (the returned tensors are then views of that copy).
+        -> PendingReduce whose .wait() gives the list of reduced tensors (same order; None entries stay None)."""
+        live = [t for t in tensors if t is not None]
+        pend = PendingReduce(list(tensors))
+        if self.world_size == 1 or not live:
+            return pend
+        arena = self.common_arena(live)
+        if arena is not None:
+            self._sum(arena, pend.handles)
+            return pend
+        flat = torch.cat([t.reshape(-1) for t in live])
+        pad = (-flat.numel()) % self.world_size
+        if pad:
+            flat = torch.cat([flat, flat.new_zeros(pad)])
+        self._sum(flat, pend.handles)
+        out, off = [], 0
+        for t in tensors:
+            if t is None:
+                out.append(None)
+            else:
+                out.append(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+        pend.result = out
+        return pend
+
+    def reduce_flat(self, tensors):
+        return self.reduce_flat_async(tensors).wait()
+
+    def reduce_parameter_grads(self, params):
+        """`p.grad` of every parameter <- sum over ranks, one collective (the parameters keep views of one flat buffer
+        as their .grad, which is what the optimizer then reads)."""
+        params = [p for p in params if p.grad is not None]
+        red = self.reduce_flat([p.grad for p in params])
+        for p, g in zip(params, red):
+            if g is not p.grad:
+                p.grad = g
+
     def reduce_densification_stats_async(self, viewspace_grad, radii, observe):
         """Per-view statistics -> what a single process would have accumulated over all ranks' views; returns a
         PendingReduce whose `.wait()` gives (grad_norm_sum (P,1), grad_abs_norm_sum (P,1), visible_count (P,1),

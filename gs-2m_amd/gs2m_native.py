@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_raster_forward_split_sh", "gs2m_raster_backward_split_sh", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
+           "gs2m_debug_layout", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
@@ -68,6 +68,12 @@ def lib():
     L.gs2m_knn_dist2.argtypes = [i, p, p, ALLOC_FN, p, p]
     L.gs2m_debug_layout.restype = i
     L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
+    L.gs2m_set_debug.restype = i
+    L.gs2m_set_debug.argtypes = [i]
+    L.gs2m_set_markers.restype = i
+    L.gs2m_set_markers.argtypes = [i]
+    L.gs2m_stage_name.restype = C.c_char_p
+    L.gs2m_stage_name.argtypes = [i]
     L.gs2m_set_reference_binning.restype = i
     L.gs2m_set_reference_binning.argtypes = [i]
     L.gs2m_set_bwd_impl.restype = i
@@ -151,9 +157,28 @@ ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocati
 
 
 def check(rc, what):
+    if rc <= -100:  # debug mode: GS2M_ERR_STAGE(stage)
+        raise RuntimeError(f"gs2m: {what} failed in stage `{lib().gs2m_stage_name(-100 - rc).decode()}` (debug mode)")
     if rc < 0:
         raise RuntimeError(f"gs2m: {what} failed: {ERRORS.get(rc, rc)}")
     return rc
+
+
+def set_debug(on):
+    """1: synchronize and check the stream after every pipeline stage; a fault is raised naming the stage."""
+    check(lib().gs2m_set_debug(int(bool(on))), "gs2m_set_debug")
+
+
+def set_markers(on):
+    """1: roctx ranges around the pipeline stages (rocprofv3 --marker-trace)."""
+    check(lib().gs2m_set_markers(int(bool(on))), "gs2m_set_markers")
+
+
+def reset_modes():
+    """Every process-wide switch back to its default (tests/conftest.py calls this after each test)."""
+    L = lib()
+    L.gs2m_set_bwd_impl(2); L.gs2m_set_reference_binning(0); L.gs2m_set_spin_wait(1); L.gs2m_set_debug(0)
+    L.gs2m_set_markers(0); L.gs2m_profile_mode(0)
 
 
 def debug_layout(P, R, W, H):

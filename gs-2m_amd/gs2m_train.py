@@ -81,6 +81,22 @@ def multi_view_observe_trim(gaussians, cams, pipe, bg, observe_threshold=2):
     return n
 
 
+def _reduced_densification_stats(reducer, out, vis, radii):
+    """What a single process that rendered every rank's view would have added to the densification statistics this
+    iteration (train.py:223-227, GM:569-573): sums of the per-view screen-space gradient norms over the views that
+    see the Gaussian, the number of such views, and the largest radius among the views that both see and observe it."""
+    import torch.distributed as dist
+    g = out["viewspace_points"].grad
+    f = vis[:, None]
+    packed = torch.cat([torch.where(f, torch.norm(g[:, :2], dim=-1, keepdim=True), 0.0),
+                        torch.where(f, torch.norm(g[:, 2:], dim=-1, keepdim=True), 0.0), f.to(g.dtype)], dim=1).contiguous()
+    mr = torch.where((out["observe"] > 0) & vis, radii, torch.zeros_like(radii)).to(torch.float32)
+    h1 = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=reducer.group, async_op=True)
+    h2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=reducer.group, async_op=True)
+    h1.wait(); h2.wait()
+    return packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr
+
+
 def export_colmap_dataset(folder, scene):
     """Write a scene (cameras, gt_images, points, colors, extent) as a COLMAP-format dataset the reference's loader
     understands (scene/dataset_readers.py:141-197): `sparse/0/{cameras,images,points3D}.bin` and `images/*.png`."""
@@ -162,16 +178,34 @@ def load_blender_dataset(folder, transforms="transforms_train.json", extension="
 
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
-          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000, alpha_masks=None):
+          lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000, alpha_masks=None,
+          white_background=False, dp=False, dp_mode="allreduce", ssim_fn=None, optimizer_cls=None, pipe=None):
+    """`dp=True`: view-parallel data parallelism over the initialised torch.distributed group: every
+    rank holds the full model, an iteration renders `world_size` different views (rank r takes the r-th of the next
+    `world_size` entries of the shared random view order), the parameter gradients are SUMMED over the ranks with one
+    blocking collective before the optimizer step, and the densification side channels are reduced with the
+    single-process semantics (per-view gradient norms and visibility counts summed, radii max-reduced, train.py:223-227,
+    scene/gaussian_model.py:569-573).  Every rank then takes the same densify / prune / reset decisions -- the
+    generator behind densify_and_split's torch.normal is seeded identically and consumed identically -- so the
+    replicas stay bit-identical (tests/test_dp.py).  Schedules (densification, resets, stages) count iterations, i.e.
+    one iteration consumes `world_size` views."""
     opt = opt or OptimizationParams()
+    ssim = ssim_fn or fused_ssim
+    rank, world, reducer = 0, 1, None
+    if dp:
+        import torch.distributed as dist
+        from gs2m_dp import GradReducer
+        assert dist.is_initialized(), "train(dp=True) needs an initialised torch.distributed process group"
+        rank, world = dist.get_rank(), dist.get_world_size()
+        reducer = GradReducer(mode=dp_mode)
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
     cams, gts, pts, cols, extent = scene or synthetic_scene(n_true, n_views, W, H, seed=seed, device=device)
     torch.manual_seed(seed)
     gaussians = GaussianModel(3, device)
     gaussians.create_from_pcd(pts, cols, extent)
-    gaussians.training_setup(opt)
-    pipe, bg = PipelineParams(), torch.zeros(3, device=device)
+    gaussians.training_setup(opt, **({"optimizer_cls": optimizer_cls} if optimizer_cls else {}))
+    pipe, bg = pipe or PipelineParams(), torch.zeros(3, device=device)
 
     def evaluate():
         with torch.no_grad():
@@ -190,7 +224,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     stats = dict(psnr_start=evaluate(), points_start=gaussians.get_xyz.shape[0], pbr_loss=[])
     order = torch.Generator().manual_seed(seed)
     stack = []
-    torch.cuda.synchronize()
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(1, iterations + 1):
         gaussians.update_learning_rate(it)
@@ -198,7 +233,13 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             gaussians.oneupSHdegree()
         if not stack:
             stack = torch.randperm(len(cams), generator=order).tolist()
-        k = stack.pop()
+        if dp:  # the next `world` views of the shared order, one per rank (the order is refilled when it runs short)
+            while len(stack) < world:
+                stack = torch.randperm(len(cams), generator=order).tolist() + stack
+            mine = [stack.pop() for _ in range(world)]
+            k = mine[rank]
+        else:
+            k = stack.pop()
         cam, gt = cams[k], gts[k]
         geometry_stage = it > geometry_from_iter
         material_stage = it > material_from_iter
@@ -209,7 +250,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
             loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
         if not material_stage:  # train.py:101-115
-            Lssim = 1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
+            Lssim = 1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
             if k not in dn_weights:  # a function of the ground-truth image only (the reference recomputes it every iteration)
@@ -225,7 +266,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
             pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
             pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
-            Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - fused_ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+            Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
             Lsm = lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
             wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
             loss = loss + Lpbr + Lsm + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn)
@@ -234,18 +275,33 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             stats["pbr_loss"].append(Lpbr.item())
         loss.backward()
         with torch.no_grad():
+            # ---- train.py:219-254, in the reference's order: densification statistics and densify / prune, the
+            # multi-view observe trim, THEN the opacity reduce / reset (a trim that ran after a reset would count
+            # `observe` with every opacity at 0.01) ----
+            if dp:  # the sum of the ranks' parameter gradients, one blocking collective (gs2m_dp)
+                reducer.reduce_parameter_grads([g["params"][0] for g in gaussians.optimizer.param_groups])
+                if lighting is not None and material_stage:
+                    reducer.reduce_parameter_grads(list(lighting.cubemap.parameters()))
             if it <= opt.densify_until_iter:
-                gaussians.update_max_radii(out["observe"], vis, radii)
-                gaussians.add_densification_stats(out["viewspace_points"], vis)
+                if dp:
+                    gn, ga, cnt, mr = _reduced_densification_stats(reducer, out, vis, radii)
+                    gaussians.max_radii2D = torch.max(gaussians.max_radii2D, mr)
+                    gaussians.xyz_gradient_accum += gn
+                    gaussians.xyz_gradient_accum_abs += ga
+                    gaussians.denom += cnt
+                else:
+                    gaussians.update_max_radii(out["observe"], vis, radii)
+                    gaussians.add_densification_stats(out["viewspace_points"], vis)
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                     thr = opt.radii2D_threshold if it > opt.opacity_reset_interval else None
                     gaussians.densify_and_prune(opt.densify_grad_threshold, opt.densify_grad_abs_threshold, opt.opacity_prune_threshold, extent, thr)
-                if opt.use_opacity_reduce and it % opt.opacity_reduce_interval == 0:  # train.py:243-246
-                    gaussians.reduce_opacity()
-                if it % opt.opacity_reset_interval == 0:
-                    gaussians.reset_opacity()
             if opt.use_multi_view_trim and trim_interval and it % trim_interval == 0 and it < opt.densify_until_iter:
                 stats["trimmed"] = stats.get("trimmed", 0) + multi_view_observe_trim(gaussians, cams, pipe, bg)
+            if it <= opt.densify_until_iter:
+                if opt.use_opacity_reduce and it % opt.opacity_reduce_interval == 0:  # train.py:243-246
+                    gaussians.reduce_opacity()
+                if it % opt.opacity_reset_interval == 0 or (white_background and it == opt.densify_from_iter):  # train.py:248-250
+                    gaussians.reset_opacity()
             if it < iterations:
                 gaussians.optimizer.step()
                 gaussians.optimizer.zero_grad(set_to_none=True)
@@ -255,7 +311,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                     lighting.cubemap.clamp_(min=0.0)
         if log and it % log == 0:
             print(f"[{it:6d}] loss {loss.item():.5f}  points {gaussians.get_xyz.shape[0]}", flush=True)
-    torch.cuda.synchronize()
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stats.update(psnr_end=evaluate(), points_end=gaussians.get_xyz.shape[0], seconds=dt, it_per_s=iterations / dt, loss_end=loss.item())
     if lighting is not None:  # the material stage supervises the PBR image, not the SH colours (train.py:111-113): report that one too

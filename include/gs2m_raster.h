@@ -53,6 +53,8 @@ extern "C" {
 #define GS2M_ERR_HIP (-2)
 #define GS2M_ERR_ALLOC (-3)
 #define GS2M_ERR_UNSUPPORTED (-4)
+/* debug mode (gs2m_set_debug): the kernels of pipeline stage `st` (order below, GS2M_NUM_STAGES) faulted */
+#define GS2M_ERR_STAGE(st) (-100 - (st))
 
 /* Scratch allocator: must return a DEVICE pointer to at least `bytes` bytes (any
  * alignment; the library aligns internally) that stays valid until the matching
@@ -273,6 +275,18 @@ int gs2m_set_spin_wait(int on);
  *   0 tile lists; same forward; backward pixel-per-lane, permlane/DPP reductions, one row per instance
  *                                                                             csrc/blend_bwd.hip */
 int gs2m_set_bwd_impl(int impl);
+
+/* Debug mode ("race detection / sanitizers"): 1 = after every pipeline stage the stream is
+ * synchronized and checked; a fault is returned as GS2M_ERR_STAGE(stage) by the call that launched it, with
+ * gs2m_stage_name(stage) naming it.  0 (default): launch errors only, checked once per call.
+ * Markers: 1 = roctx ranges named after the stages around their launches (rocprofv3 --marker-trace); needs
+ * libroctx64.so at run time (GS2M_ERR_UNSUPPORTED otherwise). */
+int gs2m_set_debug(int on);
+int gs2m_set_markers(int on);
+const char* gs2m_stage_name(int stage);
+
+/* Limits: num_rendered (the emitted instance count) must stay below 2^30 -- the look-back status words of the scan
+ * and sort kernels carry 30 value bits; gs2m_raster_forward returns GS2M_ERR_UNSUPPORTED beyond that. */
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage.  Setting the mode clears

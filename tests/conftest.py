@@ -18,3 +18,14 @@ def oracle_lib():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _restore_native_modes():
+    """The library's mode switches (blend implementation, reference binning, spin wait, debug, markers, profiling) are
+    process-wide: whatever a test sets is put back to the defaults afterwards, also when the test fails."""
+    yield
+    import torch
+    if torch.cuda.is_available():
+        import gs2m_native
+        gs2m_native.reset_modes()

@@ -76,3 +76,96 @@ def test_two_rank_gradient_sum(mode):
         assert np.array_equal(stats[2], (v0 + v1).numpy())
         assert np.array_equal(stats[3], torch.maximum(r0, r1).numpy())
         assert np.array_equal(stats[4], (o0 + o1).numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the training loop under data parallelism: replicas must stay bit-identical
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    for p in (ROOT, os.path.join(ROOT, "gs-2m_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gaussian_renderer
+    import gs2m_synth as S
+    import gs2m_train
+    import helpers as Hh
+    import simple_knn._C as knn
+    from gs2m_model import OptimizationParams
+    from gs2m_scene import Camera, PipelineParams
+    from oracle import oracle
+    # CPU stand-ins for the device pieces (test infrastructure): the oracle-backed rasterizer behind the same render()
+    # code, the oracle's distCUDA2, torch's Adam, and a plain differentiable image similarity in place of fused SSIM --
+    # what is under test is the sharding of the loop, not the kernels
+    gaussian_renderer.GaussianRasterizer = Hh.oracle_rasterizer_class(oracle)
+    knn.distCUDA2 = lambda pts: torch.tensor(oracle.knn_dist2(pts.detach().cpu().numpy()))
+    ssim = lambda a, b: 1.0 - ((a - b) ** 2).mean()
+    pipe = PipelineParams()
+    pipe.fused_render_ops = False
+    W, H = 48, 32
+    cams = [Camera(c, "cpu") for c in S.orbit_cameras(4, W, H, radius=2.0, centre=(0.0, 0.0, 6.0), fx=1.2 * W)]
+    g = torch.Generator().manual_seed(5)
+    gts = [torch.rand(3, H, W, generator=g) for _ in cams]
+    pts = (torch.rand(260, 3, generator=g) - 0.5) * torch.tensor([1.6, 1.0, 1.0]) + torch.tensor([0.0, 0.0, 6.0])
+    cols = torch.rand(260, 3, generator=g)
+    scene = (cams, gts, pts.numpy(), cols.numpy(), 3.0)
+
+    class Opt(OptimizationParams):
+        densify_from_iter = 2
+        densification_interval = 3
+        opacity_reset_interval = 6
+        densify_until_iter = 11
+        densify_grad_threshold = 1e-7      # so that clone AND split both fire on this tiny problem
+        densify_grad_abs_threshold = 1e-7
+        percent_dense = 0.012
+    model, st = gs2m_train.train(iterations=12, W=W, H=H, scene=scene, device="cpu", opt=Opt(), dp=world > 1, ssim_fn=ssim,
+                                 optimizer_cls=torch.optim.Adam, pipe=pipe, trim_interval=4, geometry_from_iter=7, seed=3)
+    state = {}
+    for grp in model.optimizer.param_groups:
+        p = grp["params"][0]
+        sd = model.optimizer.state.get(p, {})
+        state[grp["name"]] = (p.detach().numpy().copy(), sd.get("exp_avg", torch.zeros(0)).numpy().copy(),
+                              sd.get("exp_avg_sq", torch.zeros(0)).numpy().copy())
+    q.put((rank, state, model.max_radii2D.numpy().copy(), model.denom.numpy().copy(), st["points_start"], st["points_end"],
+           st.get("trimmed", 0)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_training_replicas_stay_bit_identical():
+    """gs2m_train.train(dp=True) on two gloo ranks, 12 iterations spanning densify (clone + split, with the shared
+    generator behind torch.normal), prune, the multi-view observe trim and an opacity reset: both ranks must end with
+    bit-identical parameters, Adam moments, statistics and point count (train.py:223-254, scene/gaussian_model.py:489-573
+    applied to all-reduced side channels)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res = []
+    for _ in range(600):  # up to 10 minutes, but fail at once when a worker has died
+        try:
+            res.append(q.get(timeout=1.0))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(res) == 2:
+            break
+    assert len(res) == 2
+    res.sort(key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, mr0, dn0, n0a, n0b, t0), (_, s1, mr1, dn1, n1a, n1b, t1) = res
+    assert n0b == n1b and n0a == n1a and t0 == t1
+    assert n0b != n0a, "the run should change the point count (densify / prune / trim)"
+    for name in s0:
+        for a, b, what in zip(s0[name], s1[name], ("param", "exp_avg", "exp_avg_sq")):
+            assert a.shape == b.shape and np.array_equal(a, b), (name, what)
+    assert np.array_equal(mr0, mr1) and np.array_equal(dn0, dn1)

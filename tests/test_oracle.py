@@ -199,3 +199,36 @@ def test_pixel_walk_used_to_explain_outliers_reproduces_the_oracle(oracle_lib):
         assert last == int(f.n_contrib[y, x]), (x, y)
         n_ok += 1
     assert n_ok > 250
+
+
+def test_config_c1_oracle_vs_cpu_autograd(oracle_lib):
+    """BASELINE.json configs[0] at its stated size: 10k random Gaussians, 1 camera, 256x256, feature_count 10 -- the
+    oracle's forward and hand-written backward against the PyTorch CPU autograd rasterizer (float64, composited tile
+    by tile), "plumbing + grad check" as the config says.  The same scene is run on the GPU against the oracle in
+    tests/test_configs_gpu.py::test_config_c1."""
+    from torch_ref import rasterize_dense
+    P, W, H, fc = 10_000, 256, 256, 10
+    sc = Hh.make_scene(P, W, H, seed=1, fc=fc)
+    f, gr = Hh.run_oracle(oracle_lib, sc)
+    cam = sc["cam"]
+    d = {k: v.double().requires_grad_(True) for k, v in sc["g"].items()}
+    color, buf, radii, aux = rasterize_dense(
+        d["means3D"], d["opacities"], d["shs"], None, d["scales"], d["rotations"], None, d["features"], bg=sc["bg"],
+        viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"], W=W, H=H,
+        tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=3, feature_count=fc, tiled=True)
+    assert np.array_equal(radii.numpy(), f.radii)
+    # 1e-4 on the images; a pixel outside it must sit on an alpha = 1/255 / T = 1e-4 threshold (fp64 vs fp32 power)
+    Hh.assert_image_close("color", color.detach().numpy(), f.color, oracle_fwd=f)
+    for ch in range(fc):
+        scale = max(1.0, float(np.abs(f.buffer[ch]).max()))
+        Hh.assert_image_close(f"buffer[{ch}]", buf[ch].detach().numpy(), f.buffer[ch], scale=scale, oracle_fwd=f)
+    ((color * sc["Gc"].double()).sum() + (buf * sc["Gb"].double()).sum()).backward()
+    # the oracle evaluates the reference's fp32 formulas; against exact (float64) derivatives its elements carry the
+    # fp32 conditioning of the projection / covariance chains, and a pixel whose alpha sits on 1/255 contributes in one
+    # arithmetic and not in the other (one such pixel moves means3D by 2e-3 of the tensor's maximum here), so:
+    # max-norm 5e-3 on every tensor, element-wise 1e-3 (+ 1e-4 of the tensor's rms) on all but a counted 1 %
+    for k in ("means3D", "opacities", "shs", "scales", "rotations", "features"):
+        ref = d[k].grad.numpy()
+        frac, worst, _ = Hh.grad_stats(gr[k], ref, 1e-3, 1e-4)
+        assert worst < 5e-3, (k, worst)
+        assert frac <= 1e-2, (k, frac)

@@ -332,3 +332,26 @@ def test_render_end_to_end_gradients(oracle_lib):
     for n, a, b in zip(names, dev["param_grads"], ref["param_grads"]):
         assert Hh.rel_err(a, b) < 2e-3, (n, Hh.rel_err(a, b))
     assert Hh.rel_err(dev["viewspace_grad"], ref["viewspace_grad"]) < 1e-3
+
+
+def test_debug_mode_and_markers_do_not_change_results():
+    """gs2m_set_debug(1): stream synchronize + error check after every stage (a fault would be raised naming the
+    stage); gs2m_set_markers(1): roctx ranges around the stages.  Same bits out, and scratch release works."""
+    _require_gpu()
+    import gs2m_native
+    import diff_gaussian_rasterization as dgr
+    sc = Hh.make_scene(3000, 160, 96, seed=41, fc=9, scale_hi=0.06)
+    out0, g0 = Hh.run_hip(sc)
+    gs2m_native.set_debug(True)
+    gs2m_native.set_markers(True)
+    out1, g1 = Hh.run_hip(sc)
+    gs2m_native.set_debug(False)
+    gs2m_native.set_markers(False)
+    for k in ("color", "buffer", "radii", "observe"):
+        assert np.array_equal(out0[k], out1[k]), k
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    assert gs2m_native.lib().gs2m_stage_name(8) == b"blend_bwd"
+    dgr.release_scratch()
+    out2, g2 = Hh.run_hip(sc)  # the scratch is simply allocated again
+    assert np.array_equal(g0["means3D"], g2["means3D"])

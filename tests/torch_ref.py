@@ -66,8 +66,12 @@ class _ConicQ2(torch.autograd.Function):
 
 def rasterize_dense(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, features, *,
                     bg, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree, scale_modifier=1.0,
-                    feature_count=0):
-    """Returns (color (3,H,W), buffer (10,H,W), radii (P), aux).  All float64 tensors."""
+                    feature_count=0, tiled=False):
+    """Returns (color (3,H,W), buffer (10,H,W), radii (P), aux).  All float64 tensors.
+    tiled=True composites tile by tile over the Gaussians whose rectangle reaches the tile (same per-pixel sequence:
+    a Gaussian outside a pixel's tile rectangle never passes `in_rect`), which keeps the autograd graph proportional
+    to the number of (tile, Gaussian) instances instead of pixels x Gaussians -- config C1 (10k Gaussians, 256x256)
+    then fits in a few seconds and ~1 GB."""
     dt = torch.float64
     P = means3D.shape[0]
     vm = viewmatrix.to(dt)
@@ -139,36 +143,67 @@ def rasterize_dense(means3D, opacities, shs, colors_precomp, scales, rotations, 
         order = torch.argsort(p_view[:, 2].float(), stable=True)  # fp32 depth key, ties by index
         order = order[ok[order]]
     ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
-    pxf, pyf = xs.reshape(-1), ys.reshape(-1)
-    G_ = order.shape[0]
+    pxf_all, pyf_all = xs.reshape(-1), ys.reshape(-1)
     N = W * H
-    color = torch.zeros(3, N, dtype=dt)
-    buf = [torch.zeros(N, dtype=dt) for _ in range(10)]
-    T = torch.ones(N, dtype=dt)
-    done = torch.zeros(N, dtype=torch.bool)
-    n_contrib = torch.zeros(N, dtype=torch.int64)
-    tile_x, tile_y = torch.floor(pxf / 16), torch.floor(pyf / 16)
-    for gi in range(G_):
-        i = int(order[gi])
-        with torch.no_grad():
-            in_rect = (tile_x >= rminx[i]) & (tile_x < rmaxx[i]) & (tile_y >= rminy[i]) & (tile_y < rmaxy[i])
-        dx = pix[i, 0] - pxf
-        dy = pix[i, 1] - pyf
-        power = -0.5 * (A[i] * dx * dx + Cc[i] * dy * dy) - B[i] * dx * dy
-        Gv = torch.exp(power)
-        raw = opacities[i, 0] * Gv
-        alpha = raw + (torch.clamp(raw, max=0.99) - raw).detach()  # Q1
-        with torch.no_grad():
-            m = in_rect & (~done) & (power <= 0) & (alpha >= 1.0 / 255.0)
-            test_T = T * (1 - alpha)
-            term = m & (test_T < 1e-4)
-            done = done | term
-            m = m & (~term)
-        w = torch.where(m, alpha * T, torch.zeros_like(T))
-        color = color + rgb[i][:, None] * w[None]
-        for ch in range(feature_count):
-            buf[ch] = buf[ch] + features[i, ch] * w
-        T = torch.where(m, T * (1 - alpha), T)
-    color = color + T[None] * bg.to(dt)[:, None]
-    buffer = torch.stack(buf, 0)
-    return color.reshape(3, H, W), buffer.reshape(10, H, W), radii, dict(final_T=T.reshape(H, W).detach())
+    bgd = bg.to(dt)
+
+    def composite(cand, pxf, pyf, tile_x, tile_y):
+        """front-to-back over the Gaussians `cand` (depth order) on the given pixels -> (color (3,n), buf (10,n), T (n))"""
+        n = pxf.shape[0]
+        color = torch.zeros(3, n, dtype=dt)
+        buf = [torch.zeros(n, dtype=dt) for _ in range(10)]
+        T = torch.ones(n, dtype=dt)
+        done = torch.zeros(n, dtype=torch.bool)
+        for i in cand:
+            with torch.no_grad():
+                in_rect = (tile_x >= rminx[i]) & (tile_x < rmaxx[i]) & (tile_y >= rminy[i]) & (tile_y < rmaxy[i])
+            dx = pix[i, 0] - pxf
+            dy = pix[i, 1] - pyf
+            power = -0.5 * (A[i] * dx * dx + Cc[i] * dy * dy) - B[i] * dx * dy
+            Gv = torch.exp(power)
+            raw = opacities[i, 0] * Gv
+            alpha = raw + (torch.clamp(raw, max=0.99) - raw).detach()  # Q1
+            with torch.no_grad():
+                m = in_rect & (~done) & (power <= 0) & (alpha >= 1.0 / 255.0)
+                test_T = T * (1 - alpha)
+                term = m & (test_T < 1e-4)
+                done = done | term
+                m = m & (~term)
+            w = torch.where(m, alpha * T, torch.zeros_like(T))
+            color = color + rgb[i][:, None] * w[None]
+            for ch in range(feature_count):
+                buf[ch] = buf[ch] + features[i, ch] * w
+            T = torch.where(m, T * (1 - alpha), T)
+        color = color + T[None] * bgd[:, None]
+        return color, torch.stack(buf, 0), T
+
+    if not tiled:
+        color, buffer, T = composite([int(i) for i in order], pxf_all, pyf_all, torch.floor(pxf_all / 16), torch.floor(pyf_all / 16))
+        return color.reshape(3, H, W), buffer.reshape(10, H, W), radii, dict(final_T=T.reshape(H, W).detach())
+    gx_, gy_ = (W + 15) // 16, (H + 15) // 16
+    color = torch.zeros(3, H, W, dtype=dt)
+    buffer = torch.zeros(10, H, W, dtype=dt)
+    final_T = torch.zeros(H, W, dtype=dt)
+    rx0, rx1, ry0, ry1 = rminx[order], rmaxx[order], rminy[order], rmaxy[order]
+    pieces = []
+    for ty in range(gy_):
+        for tx in range(gx_):
+            with torch.no_grad():
+                cand = order[(rx0 <= tx) & (tx < rx1) & (ry0 <= ty) & (ty < ry1)]
+            y0, y1, x0, x1 = ty * 16, min(ty * 16 + 16, H), tx * 16, min(tx * 16 + 16, W)
+            pyf, pxf = torch.meshgrid(torch.arange(y0, y1, dtype=dt), torch.arange(x0, x1, dtype=dt), indexing="ij")
+            pxf, pyf = pxf.reshape(-1), pyf.reshape(-1)
+            c, b_, T = composite([int(i) for i in cand], pxf, pyf, torch.full_like(pxf, float(tx)), torch.full_like(pyf, float(ty)))
+            pieces.append((y0, y1, x0, x1, c, b_, T))
+    # assemble without in-place writes into a tensor that requires grad: rows of tiles are concatenated
+    rows_c, rows_b = [], []
+    k = 0
+    for ty in range(gy_):
+        rc, rb = [], []
+        for tx in range(gx_):
+            y0, y1, x0, x1, c, b_, T = pieces[k]; k += 1
+            rc.append(c.reshape(3, y1 - y0, x1 - x0)); rb.append(b_.reshape(10, y1 - y0, x1 - x0))
+            final_T[y0:y1, x0:x1] = T.detach().reshape(y1 - y0, x1 - x0)
+        rows_c.append(torch.cat(rc, dim=2)); rows_b.append(torch.cat(rb, dim=2))
+    color, buffer = torch.cat(rows_c, dim=1), torch.cat(rows_b, dim=1)
+    return color, buffer, radii, dict(final_T=final_T)

@@ -35,7 +35,7 @@ if stats:
     lines.append("")
 
 pmc = defaultdict(lambda: defaultdict(list))
-for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_lds", "pmc_mfma", "pmc_fetch", "pmc_write"):
     f = find(sub, "*counter_collection.csv")
     if not f:
         continue
@@ -50,14 +50,20 @@ if pmc:
         lines.append(f"| {k} | " + " | ".join(f"{avg[k].get(c, float('nan')):.4g}" for c in names) + " |")
     lines += ["", "HBM traffic per launch = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide streaming reads, "
               "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB."]
-    traffic = {}
+    # profiles/pmc_counters.json: what bench.py's roofline.traffic / roofline.issue are read from.  Stamped with the
+    # hash of the kernel sources and the workload the passes ran on: bench.py refuses the file when either differs.
+    sys.path.insert(0, ROOT)
+    import bench
+    workload = sys.argv[2] if len(sys.argv) > 2 else "1000000x1920x1080x9"
+    kernels = {}
     for k, a in avg.items():
+        role = "blend_fwd" if k.startswith("blend_fwd") else "blend_bwd" if k.startswith("blend_bwd") else k
+        e = {c: a[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                               "SQ_LDS_IDX_ACTIVE", "SQ_WAVES") if c in a}
         if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
-            traffic[k] = {"fetch_kib": a["FETCH_SIZE"], "write_kib": a["WRITE_SIZE"],
-                          "hbm_bytes": (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024}
-    json.dump({"per_kernel": traffic,
-               "blend_fwd": next((v["hbm_bytes"] for k, v in traffic.items() if k.startswith("blend_fwd")), None),
-               "blend_bwd": next((v["hbm_bytes"] for k, v in traffic.items() if k.startswith("blend_bwd")), None)},
-              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+            e.update(fetch_kib=a["FETCH_SIZE"], write_kib=a["WRITE_SIZE"], hbm_bytes=(2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024)
+        kernels[role] = e
+    json.dump({"source_hash": bench.kernel_source_hash(), "workload": workload, "tag": tag, "kernels": kernels},
+              open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
