@@ -184,3 +184,158 @@ def test_blender_dataset_reader(tmp_path):
         assert gts[0].shape == (3, H, W) and gts[0][0, 0, 0].item() == 1.0
         assert gts[0][:, 0, W - 1].tolist() == ([1.0, 1.0, 1.0] if white else [0.0, 0.0, 0.0])
         assert xyz.shape == (500, 3) and np.abs(xyz).max() <= 1.3 and radius > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# densification / pruning / opacity reset against a functional restatement of scene/gaussian_model.py:372-567
+def _restated_build_rotation(r):  # utils/general_utils.py:76-98
+    q = r / torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])[:, None]
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.zeros((q.size(0), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+class _RestatedModel:
+    """The reference's densification written as plain tensor bookkeeping: a dict of parameters, a dict of Adam moments
+    per parameter, the three statistics and max_radii2D.  Each step cites the reference lines it follows."""
+    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "albedo", "roughness", "metallic")
+
+    def __init__(self, params, moments, percent_dense):
+        self.p = {k: v.clone() for k, v in params.items()}
+        self.m = {k: (a.clone(), b.clone()) for k, (a, b) in moments.items()}
+        self.percent_dense = percent_dense
+        n = self.p["xyz"].shape[0]
+        self.accum, self.accum_abs, self.denom = torch.zeros(n, 1), torch.zeros(n, 1), torch.zeros(n, 1)
+        self.max_radii = torch.zeros(n)
+
+    def _append(self, new):  # cat_tensors_to_optimizer GM:430-455 + densification_postfix GM:459-492
+        for k in self.NAMES:
+            self.p[k] = torch.cat((self.p[k], new[k]), dim=0)
+            a, b = self.m[k]
+            self.m[k] = (torch.cat((a, torch.zeros_like(new[k])), dim=0), torch.cat((b, torch.zeros_like(new[k])), dim=0))
+        n = self.p["xyz"].shape[0]
+        self.accum, self.accum_abs, self.denom = torch.zeros(n, 1), torch.zeros(n, 1), torch.zeros(n, 1)
+        self.max_radii = torch.zeros(n)
+
+    def _prune(self, mask):  # prune_points GM:396-415 (+ _prune_optimizer GM:378-394)
+        keep = ~mask
+        for k in self.NAMES:
+            self.p[k] = self.p[k][keep]
+            self.m[k] = (self.m[k][0][keep], self.m[k][1][keep])
+        self.accum, self.accum_abs, self.denom = self.accum[keep], self.accum_abs[keep], self.denom[keep]
+        self.max_radii = self.max_radii[keep]
+
+    def densify_and_prune(self, max_grad, max_grad_abs, min_opacity, extent, max_screen_size=None):  # GM:538-560
+        grads = self.accum / self.denom
+        grads[grads.isnan()] = 0.0
+        grads_abs = self.accum_abs / self.denom
+        grads_abs[grads_abs.isnan()] = 0.0
+        # densify_and_clone GM:516-536
+        big = torch.max(torch.exp(self.p["scaling"]), dim=1).values
+        sel = (torch.norm(grads, dim=-1) >= max_grad) & (big <= self.percent_dense * extent)
+        self._append({k: self.p[k][sel] for k in self.NAMES})
+        # densify_and_split GM:489-514, N = 2
+        N = 2
+        n = self.p["xyz"].shape[0]
+        padded = torch.zeros(n)
+        padded[:grads_abs.shape[0]] = grads_abs.squeeze()
+        act = torch.exp(self.p["scaling"])
+        sel = (padded >= max_grad_abs) & (torch.max(act, dim=1).values > self.percent_dense * extent)
+        stds = act[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3)), std=stds)
+        rots = _restated_build_rotation(self.p["rotation"][sel]).repeat(N, 1, 1)
+        new = {k: self.p[k][sel].repeat(N, *([1] * (self.p[k].dim() - 1))) for k in self.NAMES}
+        new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.p["xyz"][sel].repeat(N, 1)
+        new["scaling"] = torch.log(act[sel].repeat(N, 1) / (0.8 * N))
+        self._append(new)
+        self._prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool))))
+        # transparent / large GM:549-558 (max_radii2D was just reset by the postfix, as in the reference)
+        prune = (torch.sigmoid(self.p["opacity"]) < min_opacity).squeeze()
+        if max_screen_size:
+            prune = prune | (self.max_radii > max_screen_size) | (torch.exp(self.p["scaling"]).max(dim=1).values > 0.1 * extent)
+        self._prune(prune)
+
+    def reset_opacity(self):  # GM:362-365 + replace_tensor_to_optimizer GM:372-386
+        s = torch.sigmoid(self.p["opacity"])
+        v = torch.min(s, torch.ones_like(s) * 0.01)
+        self.p["opacity"] = torch.log(v / (1 - v))
+        self.m["opacity"] = (torch.zeros_like(self.p["opacity"]), torch.zeros_like(self.p["opacity"]))
+
+
+def test_densify_prune_reset_match_the_restated_reference():
+    """clone + split (torch.normal under a fixed generator) + prune with the Adam-moment surgery, then an opacity reset
+    and a second round with max_screen_size: GaussianModel on the CPU vs the restatement above, bit for bit."""
+    from gs2m_model import GaussianModel, OptimizationParams
+    g = torch.Generator().manual_seed(11)
+    n, extent = 400, 4.0
+    prm = dict(xyz=torch.randn(n, 3, generator=g), f_dc=torch.randn(n, 1, 3, generator=g), f_rest=torch.randn(n, 15, 3, generator=g),
+               opacity=torch.randn(n, 1, generator=g) * 2.5, scaling=torch.randn(n, 3, generator=g) * 0.8 - 3.0,
+               rotation=torch.randn(n, 4, generator=g), albedo=torch.randn(n, 3, generator=g), roughness=torch.randn(n, 1, generator=g),
+               metallic=torch.randn(n, 1, generator=g))
+    model = GaussianModel(3, "cpu")
+    model.parameterize([prm[k].clone() for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
+
+    class Opt(OptimizationParams):
+        prune_init_points = False
+        percent_dense = 0.01
+    model.training_setup(Opt, optimizer_cls=torch.optim.Adam)
+    # one optimizer step so that every parameter has non-trivial Adam moments
+    for grp in model.optimizer.param_groups:
+        p = grp["params"][0]
+        p.grad = torch.randn(p.shape, generator=g)
+    model.optimizer.step()
+    model.optimizer.zero_grad(set_to_none=True)
+    params = {grp["name"]: grp["params"][0].detach().clone() for grp in model.optimizer.param_groups}
+    moments = {grp["name"]: (model.optimizer.state[grp["params"][0]]["exp_avg"].clone(),
+                             model.optimizer.state[grp["params"][0]]["exp_avg_sq"].clone()) for grp in model.optimizer.param_groups}
+    ref = _RestatedModel(params, moments, Opt.percent_dense)
+
+    def check(tag):
+        assert model.get_xyz.shape[0] == ref.p["xyz"].shape[0], tag
+        for grp in model.optimizer.param_groups:
+            k, p = grp["name"], grp["params"][0]
+            assert torch.equal(p.detach(), ref.p[k]), (tag, k)
+            st = model.optimizer.state.get(p)
+            assert st is not None and torch.equal(st["exp_avg"], ref.m[k][0]) and torch.equal(st["exp_avg_sq"], ref.m[k][1]), (tag, k)
+        assert torch.equal(model.max_radii2D, ref.max_radii) and torch.equal(model.denom, ref.denom)
+
+    for rnd, screen in ((0, None), (1, 20)):
+        m = model.get_xyz.shape[0]
+        acc = torch.rand(m, 1, generator=g) * 6e-4
+        acc_abs = torch.rand(m, 1, generator=g) * 2.4e-3
+        den = (torch.rand(m, 1, generator=g) > 0.1).float() * 3  # some Gaussians never seen: 0 / 0 -> NaN -> 0
+        rad = torch.rand(m, generator=g) * 40
+        model.xyz_gradient_accum, model.xyz_gradient_accum_abs, model.denom, model.max_radii2D = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
+        ref.accum, ref.accum_abs, ref.denom, ref.max_radii = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
+        torch.manual_seed(500 + rnd)
+        model.densify_and_prune(0.0002, 0.0008, 0.005, extent, screen)
+        torch.manual_seed(500 + rnd)
+        ref.densify_and_prune(0.0002, 0.0008, 0.005, extent, screen)
+        check(f"round {rnd}")
+        assert model.get_xyz.shape[0] != m
+        if rnd == 0:
+            model.reset_opacity()
+            ref.reset_opacity()
+            check("reset")
+
+
+def test_ply_bytes_match_the_reference_layout(tmp_path):
+    """tests/golden/model_small.ply was assembled byte by byte in the layout GaussianModel.save_ply of the reference
+    produces (tests/golden/make_ply_golden.py): our writer must produce the same bytes from the same tensors, and our
+    reader must recover the tensors from it."""
+    from gs2m_model import GaussianModel
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "model_small.npz"))
+    model = GaussianModel(3, "cpu")
+    model.parameterize([torch.tensor(z[k]) for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
+    out = tmp_path / "out.ply"
+    model.save_ply(str(out))
+    assert out.read_bytes() == open(os.path.join(here, "model_small.ply"), "rb").read()
+    back = GaussianModel(3, "cpu")
+    back.load_ply(os.path.join(here, "model_small.ply"))
+    for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                    ("rotation", "_rotation"), ("albedo", "_albedo"), ("roughness", "_roughness"), ("metallic", "_metallic")):
+        assert np.array_equal(getattr(back, attr).detach().numpy(), z[k]), k
