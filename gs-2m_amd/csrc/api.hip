@@ -143,7 +143,9 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                         int* out_observe, float* out_buffer, void* stream_) {
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream_;
-    const int bwd_impl = g_bwd_impl.load(), reference_binning = g_reference_binning.load(), spin_wait = g_spin_wait.load();
+    const int reference_binning = g_reference_binning.load(), spin_wait = g_spin_wait.load();
+    // the list-driven kernels pack a 4-bit quadrant mask above the Gaussian id in the sorted values: P < 2^28 for them
+    const int bwd_impl = (g_bwd_impl.load() == 2 && P >= (1 << GS2M_GID_BITS)) ? 1 : g_bwd_impl.load();
     int failed_stage = 0;  // debug mode: 1 + the first stage whose kernels faulted
     if (P < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geometry_alloc || !binning_alloc || !image_alloc || !out_color || !out_buffer || !background) return GS2M_ERR_INVALID_ARG;
@@ -238,12 +240,14 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, tiles_x, g, b, bwd_impl != 2, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, g, b, bwd_impl == 2, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);
+            // side job (list-driven kernels): the first gradient row of every emit wave, read by the backward
+            const SideScan side = {bwd_impl == 2 ? (P + 63) / 64 : 0, g.wave_rows, g.wave_base};
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
-                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s));
+                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, side));
         }
         {
             StageTimer t(ST_RANGES, s, &failed_stage);
@@ -286,7 +290,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          void* stream_) {
     (void)buffer; (void)features;
     hipStream_t s = (hipStream_t)stream_;
-    const int bwd_impl = g_bwd_impl.load();
+    const int bwd_impl = (g_bwd_impl.load() == 2 && P >= (1 << GS2M_GID_BITS)) ? 1 : g_bwd_impl.load();
     int failed_stage = 0;
     if (P == 0) return GS2M_OK;
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
@@ -316,7 +320,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
     float* sums = (float*)(al + rows_bytes + valid_bytes);
 
-    HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
+    if (bwd_impl != 2) HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s, &failed_stage);
         if (bwd_impl == 2)
@@ -332,7 +336,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     DEBUG_CHECK();
     {
     StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);
-    if (P > 0) gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
+    if (P > 0 && bwd_impl == 2) {
+        if (R > 0) gs2m_launch_row_reduce_dense(P, g, b, rows, rowf, sums, s);
+        else HIP_TRY(gs2m_zero_async(sums, (size_t)P * rowf * sizeof(float), s));
+    } else if (P > 0) {
+        gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
+    }
     gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                              viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
                              sums, row_valid, rowf, 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,

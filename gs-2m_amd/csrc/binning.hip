@@ -32,6 +32,9 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     g.sorted_off = (uint32_t*)take(P * 4);
     g.clamped = (uint8_t*)take(P);
     g.counters = (uint32_t*)take(64 * 4);
+    g.sorted_rows = (uint32_t*)take(P * 4);
+    g.wave_rows = (uint32_t*)take(((P + 63) / 64 + 2) * 4);
+    g.wave_base = (uint32_t*)take(((P + 63) / 64 + 2) * 4);
     g.temp = take(temp_bytes);
     g.temp_bytes = temp_bytes;
     g.total_bytes = off + GS2M_ALIGN;
@@ -90,15 +93,27 @@ namespace {
 // One wave owns 64 depth-sorted Gaussians whose instances occupy one contiguous slot range;
 // each step the wave writes 64 consecutive slots, each lane locating its source Gaussian by
 // binary search in the wave's prefix sums.  Also stores the emission offset into the record.
-__global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uint32_t* __restrict__ sorted_gid,
+// QUAD (list-driven blend kernels): every instance is also tested against the four 8x8 quadrants of its tile with the
+// exact ellipse-vs-rectangle test (common.h) -- here the Gaussian's geometry is loaded once per Gaussian, the second
+// binning level (quad_lists_kernel) then needs no record gather at all -- and the 4-bit hit mask travels through the
+// tile sort above the Gaussian id.  The backward writes one gradient row per set bit; the rows of a wave's 64
+// Gaussians are numbered densely in emission order (instance by instance, quadrant by quadrant): an instance gets its
+// offset inside the wave's range here, the wave's row total goes to wave_rows[] (prefix: wave_base_kernel).  So the
+// rows of every Gaussian are one dense run and the per-Gaussian sum streams them (gaussian_bwd.hip).
+template <bool QUAD>
+__global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint32_t* __restrict__ sorted_gid,
                                                    const uint32_t* __restrict__ sorted_tt,
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                   uint32_t* __restrict__ inst_obs, ZeroJobs zero) {
+                                                   uint32_t* __restrict__ inst_obs, uint32_t* __restrict__ wave_rows,
+                                                   uint32_t* __restrict__ sorted_rows, ZeroJobs zero) {
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
+    __shared__ float4 s_geo[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];   // x, y, A, B
+    __shared__ float2 s_ct[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];    // C, t2
+    __shared__ uint32_t s_rc[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];  // gradient rows per Gaussian
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
@@ -114,6 +129,11 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
         rmin = f2u(bin.y);
         rw = f2u(bin.z) & 0xFFFFu;
         reinterpret_cast<uint32_t*>(r)[0] = off;
+        if (QUAD) {
+            s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
+            s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
+            reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = (uint32_t)(i >> 6);  // the emit wave's index
+        }
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
@@ -122,9 +142,12 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
     s_gid[wave][lane] = gid;
     s_rmin[wave][lane] = rmin;
     s_rw[wave][lane] = rw;
+    if (QUAD) s_rc[wave][lane] = 0u;
     gs2m_sync();
+    uint32_t rows_run = 0;  // gradient rows of the wave's instances so far
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
         const uint32_t j = k + lane;
+        uint32_t pc = 0;
         if (j < total) {
             int lo = 0;
 #pragma unroll
@@ -134,11 +157,40 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, const uin
             const uint32_t w = s_rw[wave][lo];
             const uint32_t ry = t / w, rx = t - ry * w;
             const uint32_t rm = s_rmin[wave][lo];
-            keys_out[base + j] = ((rm >> 16) + ry) * (uint32_t)tiles_x + (rm & 0xFFFFu) + rx;
-            vals_out[base + j] = s_gid[wave][lo];
-            if (inst_obs) inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
+            const uint32_t tx = (rm & 0xFFFFu) + rx, ty = (rm >> 16) + ry;
+            uint32_t val = s_gid[wave][lo];
+            if (QUAD) {
+                const float4 a = s_geo[wave][lo];
+                const float2 ct = s_ct[wave][lo];
+                const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
+                uint32_t mask = gs2m_reaches_quads(a.x, a.y, a.z, a.w, ct.x, ct.y, (float)px0, (float)py0);
+                // quadrants outside the image have no pixels: no list entry, no gradient row
+                if (px0 + 8 >= W) mask &= 0x5u;
+                if (py0 + 8 >= H) mask &= 0x3u;
+                val |= mask << GS2M_GID_BITS;
+                pc = (uint32_t)__popc(mask);
+                if (pc) atomicAdd(&s_rc[wave][lo], pc);
+            }
+            keys_out[base + j] = ty * (uint32_t)tiles_x + tx;
+            vals_out[base + j] = val;
+            if (!QUAD) inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
+        }
+        if (QUAD) {
+            const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
+            if (j < total) inst_obs[base + j] = rows_run + pin - pc;  // the instance's first row, relative to the wave's range
+            rows_run += __shfl(pin, 63, 64);
         }
     }
+    if (QUAD) {
+        if (lane == 0 && (i >> 6) <= ((P - 1) >> 6)) wave_rows[i >> 6] = rows_run;
+        if (i < P) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
+    }
+}
+
+// exclusive prefix of the emit waves' row counts as a kernel of its own (the tile sort's histogram kernel normally does
+// it on the side, radix_sort.hip)
+__global__ void __launch_bounds__(256) wave_base_kernel(int nw, const uint32_t* __restrict__ wave_rows, uint32_t* __restrict__ wave_base) {
+    gs2m_wave_base_scan(nw, wave_rows, wave_base);
 }
 
 // identifyTileRanges (rasterizer_impl.cu:108-129) on the sorted tile ids.
@@ -160,57 +212,56 @@ __global__ void ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uin
 
 // Second binning level: the sorted list of a 16x16 tile -> four order-preserving lists, one per 8x8 quadrant,
 // holding only the instances that can reach the quadrant with alpha >= 1/255 (the exact ellipse-vs-rectangle
-// test of common.h; dropped instances contribute to no pixel of the quadrant, so every output is unchanged).
+// test of common.h, evaluated by emit_kernel<true>, whose 4-bit result arrives above the Gaussian id in the sorted
+// values; dropped instances contribute to no pixel of the quadrant, so every output is unchanged).
 // The blend kernels then run one wave per quadrant straight down its list: no staging of instances that
 // are skipped anyway, no tests, no ballot walks.  Entries keep the position in the tile list, so n_contrib
 // (a tile-list position, as in the reference) and the gradient-row addressing stay what they were.
 // One workgroup per tile; 256 instances per step, one per thread.
 __global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                                                         const float4* __restrict__ rec, int W, int H, int tiles_x,
                                                          uint2* __restrict__ qlist, uint32_t* __restrict__ qcount) {
-    __shared__ uint32_t s_cnt[2][4][4];  // [parity][wave][quadrant]
+    // 512 instances per step, two per thread (k and k + 256)
+    constexpr int SLOTS = 2;
+    __shared__ uint32_t s_cnt[2][SLOTS][4][4];  // [parity][slot][wave][quadrant]
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint2 range = ranges[tile];
     const int len = (int)(range.y - range.x);
-    const float x0 = (float)(tile_x * GS2M_TILE), y0 = (float)(tile_y * GS2M_TILE);
     uint2* out = qlist + (size_t)4 * range.x;
     uint32_t run[4] = {0u, 0u, 0u, 0u};
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int par = 0;
-    for (int base = 0; base < len; base += 256, par ^= 1) {
-        const int k = base + tid;
-        bool hit[4] = {false, false, false, false};
-        uint32_t gid = 0;
-        if (k < len) {
-            gid = point_list[range.x + k];
-            const float4* r = rec + (size_t)gid * REC_Q;
-            const float4 a = r[REC_GEO0];
-            const float cC = r[REC_GEO1].x, t2 = r[REC_BIN].w;
+    for (int base = 0; base < len; base += 256 * SLOTS, par ^= 1) {
+        uint32_t v[SLOTS];
+        unsigned long long m[SLOTS][4];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int k = base + s * 256 + tid;
+            v[s] = k < len ? point_list[range.x + k] : 0u;  // Gaussian id | quadrant-hit mask << 28 (emit_kernel<true>)
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float bx0 = x0 + (float)((q & 1) * 8), by0 = y0 + (float)((q >> 1) * 8);
-                hit[q] = gs2m_reaches_rect(a.x, a.y, a.z, a.w, cC, t2, bx0, bx0 + 7.0f, by0, by0 + 7.0f);
+                m[s][q] = __builtin_amdgcn_ballot_w64(((v[s] >> (GS2M_GID_BITS + q)) & 1u) != 0);
+                if (lane == 0) s_cnt[par][s][wave][q] = (uint32_t)__popcll(m[s][q]);
             }
-        }
-        unsigned long long m[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            m[q] = __builtin_amdgcn_ballot_w64(hit[q]);
-            if (lane == 0) s_cnt[par][wave][q] = (uint32_t)__popcll(m[q]);
-        }
         gs2m_sync();  // one barrier per step: the counters alternate between two sets
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t before = 0, total = 0;
+        for (int s = 0; s < SLOTS; s++) {
+            const int k = base + s * 256 + tid;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const uint32_t c = s_cnt[par][w][q];
-                before += w < wave ? c : 0u;
-                total += c;
+            for (int q = 0; q < 4; q++) {
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t c = s_cnt[par][s][w][q];
+                    before += w < wave ? c : 0u;
+                    total += c;
+                }
+                if ((v[s] >> (GS2M_GID_BITS + q)) & 1u)
+                    out[(size_t)q * len + run[q] + before + (uint32_t)__popcll(m[s][q] & lt)] = make_uint2(v[s], (uint32_t)k);
+                run[q] += total;
             }
-            if (hit[q]) out[(size_t)q * len + run[q] + before + (uint32_t)__popcll(m[q] & lt)] = make_uint2(gid, (uint32_t)k);
-            run[q] += total;
         }
     }
     if (tid < 4) qcount[tile * 4 + tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
@@ -231,9 +282,16 @@ __global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, c
 
 }  // namespace
 
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, bool zero_inst_obs, const ZeroJobs& zero, hipStream_t s) {
-    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, zero_inst_obs ? b.inst_obs : nullptr, zero);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, bool quad_masks, const ZeroJobs& zero, hipStream_t s) {
+    if (quad_masks)
+        emit_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
+                                                          b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
+    else
+        emit_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
+                                                           b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
+}
+void gs2m_launch_wave_base(int P, const GeomState& g, hipStream_t s) {
+    wave_base_kernel<<<1, 256, 0, s>>>((P + 63) / 64, g.wave_rows, g.wave_base);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them
@@ -260,7 +318,8 @@ void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipS
 }
 void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
                             const ImageState& im, hipStream_t s) {
-    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges, b.point_list, g.rec, W, H, tiles_x, b.qlist, im.qcount);
+    (void)W; (void)H; (void)g;
+    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges, b.point_list, b.qlist, im.qcount);
 }
 void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s) {
     observe_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, b.inst_obs, out_observe);

@@ -11,7 +11,9 @@
 // gone: lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2), the
 // loads for the next group are issued before the current group's epilogue and land behind it.
 // One wave per quadrant (64-thread workgroups, no barriers), XCD-aware block ids, one partial-gradient row per
-// (instance, quadrant), addressed by the instance's emission slot -- gaussian_bwd.hip sums them.
+// (instance, quadrant) in the DENSE numbering emit_kernel<true> prepared (binning.hip): the rows of a Gaussian are one
+// contiguous run, every row is written (zeros for the entries behind a quadrant's last contributor), and
+// gaussian_bwd.hip streams them.
 #include "common.h"
 
 namespace {
@@ -65,10 +67,11 @@ __device__ __forceinline__ void row_scan_add2(float& x, float& y) {  // bound_ct
 template <int FC>
 __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qlast,
+    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row, const uint32_t* __restrict__ wave_base,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
-    const float* __restrict__ grad_buffer, float* __restrict__ rows, uint8_t* __restrict__ row_valid) {
+    const float* __restrict__ grad_buffer, float* __restrict__ rows) {
     constexpr int NV = ROW_FEAT + FC;
     constexpr int ROWF = ((NV + 3) / 4) * 4;
     constexpr int RSTRIDE = ROWF;  // rows are packed (a 128-B stride was tried: random single lines read no faster)
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     __shared__ float2 s_S2[32];
     __shared__ uint2 s_N2[32];
     __shared__ __align__(16) float s_d[16][8];     // per survivor of the current group: 6 moments, 2 |.| sums
-    __shared__ uint32_t s_slotg[16];               // emission slot of each survivor of the current group
+    __shared__ uint32_t s_rowg[16];                // gradient-row index of each survivor of the current group
 
     const int b = blockIdx.x;
     const int tile = (b >> 5) * 8 + (b & 7);
@@ -161,7 +164,17 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         float2 g1;       // C, opacity
         float ch[KK];
         float4 bin;      // emission offset, rect min, rect w|h, (t2)
+        uint32_t wave;   // emit wave that owns the Gaussian's gradient rows (record quad REC_AUX)
         uint32_t pos1;   // position in the tile list + 1
+        uint32_t below;  // this instance's rows in the quadrants before this one
+    };
+    // Gradient-row index of (instance, quadrant): the rows of an emit wave's 64 Gaussians are numbered densely in
+    // emission order (binning.hip: emit_kernel<true>): wave_base[wave] + the instance's offset inside the wave's range
+    // + the number of its quadrants before this one.
+    auto row_of = [&](const float4 bin, uint32_t wave, uint32_t below) {
+        const uint32_t off = f2u(bin.x), rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
+        const uint32_t slot = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
+        return wave_base[wave] + inst_row[slot] + below;
     };
     // list entry of survivor j in group g.  Lanes past the front of the list (the last group may be partial) take
     // entry 0 with position ~0 = behind every pixel's last contributor: real, finite record data that no pixel accepts.
@@ -173,16 +186,19 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     };
     auto load_fill = [&](const uint2 e) {
         Fill f;
-        const float4* p = rec + (size_t)e.x * REC_Q;
+        const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
         f.g0 = p[REC_GEO0];
         f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
         f.bin = p[REC_BIN];
 #pragma unroll
         for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
+        f.wave = reinterpret_cast<const uint32_t*>(p + REC_AUX)[0];
         f.pos1 = e.y;
+        f.below = (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u));
         return f;
     };
     Fill f;
+    uint32_t row_cur = 0;  // gradient row of this lane's survivor in the current group
     uint2 e_next = make_uint2(0u, 0u);
     int g_cur = 0;
     // the next group's record values are requested between this group's steps and its epilogue and land behind the
@@ -304,13 +320,14 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         gs2m_sync();
         s_d[j][r] = R1;
         s_d[j][4 + r] = R2;
+        if (r == 0) s_rowg[j] = row_cur;
         gs2m_sync();
         // ---- epilogue: lane (j, r) holds the colour / feature sums D[4r + rr][j], rr = 0..3 ----
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
             const int i = 4 * r + rr;
             if (i < nvalid && j < ROWF - ROW_COL) {
-                const size_t rslot = (size_t)s_slotg[i] * 4 + quad;
+                const size_t rslot = (size_t)s_rowg[i];
                 rows[rslot * RSTRIDE + ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
             }
         }
@@ -322,14 +339,27 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             const float Sdxx = xc * xc * m0.x - 2.f * xc * m0.y + m0.w;
             const float Sdxy = xc * yc * m0.x - xc * m0.z - yc * m0.y + m1.x;
             const float Sdyy = yc * yc * m0.x - 2.f * yc * m0.z + m1.y;
-            const size_t rslot = (size_t)s_slotg[j] * 4 + quad;
+            const size_t rslot = (size_t)row_cur;
             float4* o4 = reinterpret_cast<float4*>(rows + rslot * RSTRIDE);
             o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
             o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)
-            row_valid[rslot] = 1;
         }
     };
 
+    // Entries behind the quadrant's last contributor are never processed (backward.cu:493-494) but own a row each:
+    // zeros, so that the per-Gaussian sum can stream every row of its range without a validity map.
+    {
+        const int n = (int)qcount[tile * 4 + quad];
+        for (int i = np + lane; i < n; i += GS2M_WAVE) {
+            const uint2 e = list[i];
+            const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
+            const uint32_t row = row_of(p[REC_BIN], reinterpret_cast<const uint32_t*>(p + REC_AUX)[0],
+                                        (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u)));
+            float4* o4 = reinterpret_cast<float4*>(rows + (size_t)row * RSTRIDE);
+#pragma unroll
+            for (int q4 = 0; q4 < ROWF / 4; q4++) o4[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (ngroups > 0) {
         f = load_fill(load_entry(0));
         e_next = load_entry(1);
@@ -339,10 +369,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;
-            if (r == 0) {
-                const uint32_t off = f2u(f.bin.x), rm = f2u(f.bin.y), rw = f2u(f.bin.z) & 0xFFFFu;
-                s_slotg[j] = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
-            }
+            row_cur = row_of(f.bin, f.wave, f.below);  // two dependent gathers, in flight while the group's steps run
             process_group(min(16, np - 16 * g_cur));
         }
     }
@@ -355,11 +382,12 @@ int fc_template(int fc) { return fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10)
 void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                                 const BinningState& b, const ImageState& im, const float* grad_color,
                                 const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s) {
+    (void)row_valid;  // every row of the dense numbering is written (zeros behind a quadrant's last contributor)
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
 #define GS2M_BWDQ(FC)                                                                                                      \
-    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
-                                                  im.n_contrib, grad_color, grad_buffer, rows, row_valid)
+    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.wave_base, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
+                                                  im.n_contrib, grad_color, grad_buffer, rows)
     switch (fc_template(fc)) {
         case 1: GS2M_BWDQ(1); break;
         case 5: GS2M_BWDQ(5); break;

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     struct Stage { float4 a, b; };
     auto load_quads = [&](const uint2 e) {  // this lane's two quads of its entry's record
         Stage st;
-        const float4* p = rec + (size_t)e.x * REC_Q;
+        const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;  // the entry carries the quadrant-hit mask above the id
         st.a = p[quad_of(eq)];
         st.b = eq + 4 < NS ? p[quad_of(eq + 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
         return st;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     auto park = [&](int buf, const uint2 e, const Stage& st) {
         s_q[buf][eq][ej] = st.a;
         if (eq + 4 < NS) s_q[buf][eq + 4][ej] = st.b;
-        if (eq == 0) s_e[buf][ej] = make_uint2(e.x, e.y + 1u);
+        if (eq == 0) s_e[buf][ej] = make_uint2(e.x & GS2M_GID_MASK, e.y + 1u);
     };
     if (nchunks > 0) {
         uint2 e1 = load_entry(0);

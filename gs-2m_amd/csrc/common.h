@@ -17,12 +17,17 @@
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
 //         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
 //         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
-// q7: unused
+// q7: x = u32 index of the emit wave (depth rank / 64) that owns the Gaussian's gradient rows (list-driven blend
+//     kernels, binning.hip); y, z, w unused
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
 #define REC_BIN 2
 #define REC_CH 3
+#define REC_AUX 7
+// list-driven blend kernels: the sorted values carry the instance's quadrant-hit mask above the Gaussian id
+#define GS2M_GID_BITS 28
+#define GS2M_GID_MASK 0x0FFFFFFFu
 
 // per tile-instance partial-gradient row produced by the blend backward (floats):
 // 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature
@@ -44,6 +49,9 @@ struct GeomState {
     uint32_t* sorted_off;    // P
     uint8_t* clamped;        // P
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
+    uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order (list-driven kernels)
+    uint32_t* wave_rows;     // ceil(P / 64) + 1: gradient rows of each emit wave's 64 Gaussians (list-driven kernels)
+    uint32_t* wave_base;     // ceil(P / 64) + 1: exclusive prefix of wave_rows; [nw] = total rows
     char* temp;              // radix sort / scan temporary storage
     size_t temp_bytes;
     size_t total_bytes;      // including alignment slack
@@ -55,7 +63,8 @@ struct BinningState {
     uint32_t* sort_valA;     // R
     uint32_t* tile_keys;     // R (sorted)
     uint32_t* point_list;    // R (sorted Gaussian ids)
-    uint32_t* inst_obs;      // R
+    uint32_t* inst_obs;      // R: per-instance observe counts (tile-list kernels) / per-instance row offset inside its
+                             //    emit wave's row range (list-driven kernels)
     uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id, position in the tile list};
                              //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
     char* temp;
@@ -207,8 +216,15 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 size_t gs2m_geom_temp_bytes(size_t P);
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
+// side job of a sort's histogram kernel: one extra workgroup runs gs2m_wave_base_scan (nw == 0: none)
+struct SideScan {
+    int nw;
+    const uint32_t* wave_rows;
+    uint32_t* wave_base;
+};
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
-                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s);
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
+                                 SideScan side = SideScan{0, nullptr, nullptr});
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
@@ -223,7 +239,9 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_emit(int P, int tiles_x, const GeomState& g, const BinningState& b, bool zero_inst_obs, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, bool quad_masks, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_wave_base(int P, const GeomState& g, hipStream_t s);
+void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const BinningState& b, const float* rows, int rowf, float* sums, hipStream_t s);
 void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
                             int rstride, int rpi, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
@@ -319,6 +337,49 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane
     return v;
 }
 
+// Exclusive prefix of the emit waves' gradient-row counts by ONE 256-thread workgroup (ceil(P / 64) values):
+// wave_base[w] = first row of wave w, wave_base[nw] = total.  Run as a side job by one extra workgroup of the tile
+// sort's histogram kernel, so it costs no launch and no time on the forward's critical path.
+__device__ __forceinline__ void gs2m_wave_base_scan(int nw, const uint32_t* __restrict__ wave_rows, uint32_t* __restrict__ wave_base) {
+    constexpr int MAXI = 32, T = 256;
+    __shared__ uint32_t s_wbw[4];
+    __shared__ uint32_t s_wbrun;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_wbrun = 0;
+    for (int b0 = 0; b0 < nw; b0 += MAXI * T) {
+        const int n = min(nw - b0, MAXI * T);
+        const int per = (n + T - 1) / T;  // consecutive items per thread
+        const int i0 = b0 + tid * per;
+        uint32_t v[MAXI], sum = 0;
+#pragma unroll
+        for (int k = 0; k < MAXI; k++) {
+            v[k] = (k < per && i0 + k < b0 + n) ? wave_rows[i0 + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t incl = wave_inclusive_scan_u32(sum, lane);
+        gs2m_sync();  // s_wbrun of the previous pass is final, s_wbw free
+        if (lane == 63) s_wbw[wave] = incl;
+        gs2m_sync();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) wb += s_wbw[w];
+            tot += s_wbw[w];
+        }
+        uint32_t run = s_wbrun + wb + incl - sum;
+#pragma unroll
+        for (int k = 0; k < MAXI; k++)
+            if (k < per && i0 + k < b0 + n) {
+                wave_base[i0 + k] = run;
+                run += v[k];
+            }
+        gs2m_sync();
+        if (tid == 0) s_wbrun += tot;
+    }
+    gs2m_sync();
+    if (tid == 0) wave_base[nw] = s_wbrun;
+}
+
 // alpha evaluation shared bit-for-bit by the forward and backward blend kernels:
 //   power = -0.5f * (A*dx*dx + C*dy*dy) - B*dx*dy      (CR/forward.cu:326-329)
 // evaluated UNFUSED and in the reference's written order.  For splats hundreds of pixels long
@@ -357,6 +418,48 @@ __device__ __forceinline__ bool gs2m_reaches_rect(float gx, float gy, float A, f
     const float b2 = B + B;
     const float qmin = fminf(gs2m_edge_pair_qmin(A, b2, C, lx, ux, ly, uy), gs2m_edge_pair_qmin(C, b2, A, ly, uy, lx, ux));
     return !(t2 < 3.0e38f) || inside || qmin <= __builtin_fmaf(1.0e-3f, fabsf(qmin), t2);
+}
+// gs2m_reaches_rect for the four 8x8 quadrants of the 16x16 tile whose first pixel is (x0, y0), sharing what the four
+// tests have in common (two reciprocals instead of eight, the per-line products): bit q of the result is EXACTLY
+// gs2m_reaches_rect(..., x0 + 8 (q & 1), + 7, y0 + 8 (q >> 1), + 7) -- same operations on the same values per edge.
+__device__ __forceinline__ uint32_t gs2m_reaches_quads(float gx, float gy, float A, float B, float C, float t2, float x0, float y0) {
+    const float b2 = B + B;
+    const float nhrC = -0.5f * __builtin_amdgcn_rcpf(C), nhrA = -0.5f * __builtin_amdgcn_rcpf(A);
+    float xl[4], yl[4], blx[4], bly[4], basex[4], basey[4], mx[4], my[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float o = (float)((i >> 1) * 8 + (i & 1) * 7);  // 0, 7, 8, 15
+        xl[i] = (x0 + o) - gx; yl[i] = (y0 + o) - gy;
+        blx[i] = b2 * xl[i]; bly[i] = b2 * yl[i];
+        basex[i] = (A * xl[i]) * xl[i]; basey[i] = (C * yl[i]) * yl[i];
+        mx[i] = blx[i] * nhrC;  // unclamped minimiser in y along the vertical line dx = xl[i]
+        my[i] = bly[i] * nhrA;  // ... in x along the horizontal line dy = yl[i]
+    }
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int qx = q & 1, qy = q >> 1;
+        const float lx = xl[2 * qx], ux = xl[2 * qx + 1], ly = yl[2 * qy], uy = yl[2 * qy + 1];
+        const bool inside = lx <= 0.f && ux >= 0.f && ly <= 0.f && uy >= 0.f;
+        float qe[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {  // the two vertical edges over [ly, uy]
+            const int i = 2 * qx + e;
+            const float fm = __builtin_amdgcn_fmed3f(mx[i], ly, uy);
+            qe[e] = __builtin_fmaf(__builtin_fmaf(C, fm, blx[i]), fm, basex[i]);
+        }
+        const float qv = fminf(qe[0], qe[1]);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {  // the two horizontal edges over [lx, ux]
+            const int k = 2 * qy + e;
+            const float fm = __builtin_amdgcn_fmed3f(my[k], lx, ux);
+            qe[e] = __builtin_fmaf(__builtin_fmaf(A, fm, bly[k]), fm, basey[k]);
+        }
+        const float qmin = fminf(qv, fminf(qe[0], qe[1]));
+        const bool hit = !(t2 < 3.0e38f) || inside || qmin <= __builtin_fmaf(1.0e-3f, fabsf(qmin), t2);
+        mask |= hit ? (1u << q) : 0u;
+    }
+    return mask;
 }
 // The same test with the work of one instance split over two lanes (lane and lane ^ 32): `swap` lanes take
 // the horizontal edges by exchanging the roles of x and y, then the halves are combined.

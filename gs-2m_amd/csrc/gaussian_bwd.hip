@@ -452,6 +452,78 @@ __global__ void __launch_bounds__(256) row_reduce_kernel(int P, const uint32_t* 
     }
 }
 
+
+// The same per-Gaussian sum for the list-driven backward (blend_bwd_q.hip), whose rows are numbered DENSELY: emit wave
+// w (the same 64 depth-sorted Gaussians this kernel's wave w owns) has the rows [wave_base[w], wave_base[w + 1]), Gaussian
+// by Gaussian (sorted_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows
+// per window as five fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked
+// in LDS, then rq lanes per Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance
+// gather (the slot-major layout of the tile-list kernels fetches 1.7x the useful bytes with 20 strided loads per lane).
+// Fixed summation order (the dense numbering: quadrants ascending within an instance, instances in emission order):
+// bitwise reproducible, and the same order as the slot-major kernel's.
+__global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint32_t* __restrict__ sorted_gid,
+                                                               const uint32_t* __restrict__ sorted_rows,
+                                                               const uint32_t* __restrict__ wave_base,
+                                                               const float* __restrict__ rows, int rowf, float* __restrict__ sums) {
+    constexpr int MAXQ = 6;
+    __shared__ float4 s_row[4][GS2M_WAVE * MAXQ];  // one window: 64 rows x rq float4, row-major
+    __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t cnt = 0, gid = 0xFFFFFFFFu;
+    if (i < P) {
+        cnt = sorted_rows[i];
+        gid = sorted_gid[i];
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
+    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's Gaussians
+    const uint32_t wb = (i >> 6) <= ((P - 1) >> 6) ? wave_base[i >> 6] : 0u;
+    s_excl[wave][lane] = incl - cnt;
+    s_cnt[wave][lane] = cnt;
+    s_gidw[wave][lane] = gid;
+    const int rq = rowf >> 2;
+    const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
+    const bool worker = g < G;
+    uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nwin = (total + GS2M_WAVE - 1) / GS2M_WAVE;
+    const float4* r4 = reinterpret_cast<const float4*>(rows) + (size_t)wb * rq;  // the wave's rows as one float4 stream
+    const uint32_t nq = total * (uint32_t)rq;
+    auto load_window = [&](uint32_t w, float4* a) {
+#pragma unroll
+        for (int e = 0; e < MAXQ; e++) {
+            const uint32_t q = w * (GS2M_WAVE * (uint32_t)rq) + (uint32_t)e * GS2M_WAVE + lane;
+            a[e] = (e < rq && q < nq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 anext[MAXQ];
+    load_window(0, anext);
+    for (uint32_t w = 0; w <= nwin; w++) {
+        const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
+        if (w < nwin) {
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++)
+                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = anext[e];
+            load_window(w + 1, anext);
+        }
+        // LDS operations of one wave execute in order: the reads below see the writes above
+        while (j < GS2M_WAVE) {
+            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
+            if (ex >= k1 && cn > 0) break;  // starts in a later window
+            const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
+            for (uint32_t t = t0; t < t1; t++) {
+                const float4 v = s_row[wave][(t - k0) * rq + c];
+                racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
+            }
+            if (ex + cn > k1) break;  // continues in the next window
+            const uint32_t gj = s_gidw[wave][j];
+            if (gj != 0xFFFFFFFFu) reinterpret_cast<float4*>(sums + (size_t)gj * rowf)[c] = racc;
+            racc = make_float4(0.f, 0.f, 0.f, 0.f);
+            j += (uint32_t)G;
+        }
+    }
+}
+
 }  // namespace
 
 void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
@@ -461,6 +533,11 @@ void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const 
         row_reduce_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
     else
         row_reduce_kernel<1><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
+}
+
+void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const BinningState& b, const float* rows, int rowf, float* sums, hipStream_t s) {
+    (void)b;
+    row_reduce_dense_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.wave_base, rows, rowf, sums);
 }
 
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,

@@ -69,9 +69,14 @@ SortPlan make_plan(int total_bits) {
 
 // ---- histogram of every digit of every pass, one read of the keys ----
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npass,
-                                                             int4 bits, int4 shift, uint32_t* __restrict__ ghist) {
+                                                             int4 bits, int4 shift, uint32_t* __restrict__ ghist, int tiles,
+                                                             SideScan side) {
     __shared__ uint32_t s_h[RS_MAXPASS][256];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x == tiles) {  // the extra workgroup: a small scan that is due at about this point of the stream
+        gs2m_wave_base_scan(side.nw, side.wave_rows, side.wave_base);
+        return;
+    }
     for (int p = 0; p < RS_MAXPASS; p++) s_h[p][tid] = 0;
     gs2m_sync();
     const int b[4] = {bits.x, bits.y, bits.z, bits.w}, sh[4] = {shift.x, shift.y, shift.z, shift.w};
@@ -259,7 +264,8 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 }
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
-                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s) {
+                                 uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
+                                 SideScan side) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -271,8 +277,8 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
-    rs_hist_kernel<<<tiles, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
-                                                make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist);
+    rs_hist_kernel<<<tiles + (side.nw > 0 ? 1 : 0), RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
+                                                                        make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, side);
     const uint32_t *ki = kin, *vi = vin;
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;

@@ -214,7 +214,7 @@ def _binning_bit_exact(oracle_lib, gs2m_native, dgr):
     assert np.array_equal(dk[vis], f.depths[vis].view(np.uint32)) and np.all(dk[~vis] == 0xFFFFFFFF)
     rec = view(geomB, lay.rec, P * 32, np.float32).reshape(P, 32)
     assert np.array_equal(rec[vis, 0:2], f.means2D[vis])
-    pl = view(binB, lay.point_list, R, np.uint32)
+    pl = view(binB, lay.point_list, R, np.uint32) & np.uint32(0x0FFFFFFF)  # list-driven kernels: quadrant mask above the id
     tk = view(binB, lay.tile_keys, R, np.uint32)
     assert np.array_equal(pl, f.vals_sorted), "sorted Gaussian ids"
     keys = (tk.astype(np.uint64) << np.uint64(32)) | f.depths[pl].view(np.uint32).astype(np.uint64)
@@ -249,7 +249,7 @@ def test_default_binning_is_a_safe_subset(oracle_lib):
     lay = gs2m_native.debug_layout(P, R, W, H)
     al = lambda t: (-t.data_ptr()) % 256
     view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
-    pl = view(binB, lay.point_list, R, np.uint32)
+    pl = view(binB, lay.point_list, R, np.uint32) & np.uint32(0x0FFFFFFF)  # list-driven kernels: quadrant mask above the id
     Tn = f.tiles_x * f.tiles_y
     rg = view(imgB, lay.ranges, 2 * Tn, np.uint32).reshape(Tn, 2)
     dropped = 0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: ab3.sh rounds "envA" "envB" ...
+# usage: ab_stage.sh rounds "envA" "envB" ... : prints all stage times (speed experiments only; results may be wrong)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 ROUNDS=$1; shift
 for i in $(seq $ROUNDS); do
@@ -8,6 +8,6 @@ for i in $(seq $ROUNDS); do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 s = d['stages_ms']
-print('%-50s %.3f ms  rng %.3f fwd %.3f bwd %.3f gbwd %.3f' % ('''$v''', d['ms_per_step'], s['ranges'], s['blend_fwd'], s['blend_bwd'], s['gaussian_bwd']))"
+print('%-46s %.3f ms | ' % ('''$v'''[-46:], d['ms_per_step']) + ' '.join('%s %.3f' % (k[:6], v) for k, v in s.items()))"
   done
 done
