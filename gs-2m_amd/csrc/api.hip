@@ -35,13 +35,6 @@ struct Pinned {
 };
 thread_local Pinned t_pinned;
 
-// num_rendered -> the host: ONE aligned 32-bit store at system scope.  (A hipMemcpyAsync of 4 bytes may be carried out
-// byte by byte; a host that polls the landing zone then sees torn values -- 0xFFFFFF59 for a count ending in 0x59 --
-// which is what happened once the GPU was shared with a second process.)
-__global__ void publish_count_kernel(const uint32_t* __restrict__ counters, uint32_t* __restrict__ landing) {
-    __hip_atomic_store(landing, counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 // mode 0: off; 1: the two blend kernels only; 2: every stage.
 static_assert(GS2M_NUM_STAGES == 10, "stage table");
@@ -131,6 +124,14 @@ struct StageTimer {
 
 extern "C" {
 
+char* gs2m_prealloc_alloc(size_t bytes, void* user) {
+    gs2m_prealloc* p = static_cast<gs2m_prealloc*>(user);
+    if (!p) return nullptr;
+    if (p->ptr && bytes <= p->capacity) return p->ptr;
+    p->used_fallback = 1;
+    return p->fallback ? p->fallback(bytes, p->fallback_user) : nullptr;
+}
+
 const char* gs2m_version(void) { return "gs2m_raster 0.2 (gfx950, round 2)"; }
 
 static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
@@ -196,11 +197,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
                                           g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s));
         }
-        {   // 2. emission offsets in that order
-            StageTimer t(ST_SCAN, s, &failed_stage);
-            HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
-                                            g.sorted_off, g.counters, true, s));
-        }
         if (!t_pinned.p) {
             HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
@@ -209,9 +205,14 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         // host has seen num_rendered, sized the binning buffer and launched the next kernel, so the wake-up matters:
         // the host polls the pinned landing zone for the value (a sentinel no count can take: R < 2^30) instead of
         // sleeping in hipStreamSynchronize, whose wake-up costs tens of microseconds and far more on a loaded host.
+        // The scan's last tile stores the total there itself (one system-scope 32-bit store): no extra launch.
         volatile uint32_t* land = t_pinned.p;
         land[0] = 0xFFFFFFFFu;
-        publish_count_kernel<<<1, 1, 0, s>>>(g.counters, t_pinned.dev);
+        {   // 2. emission offsets in that order
+            StageTimer t(ST_SCAN, s, &failed_stage);
+            HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
+                                            g.sorted_off, g.counters, true, s, t_pinned.dev));
+        }
         HIP_TRY(hipGetLastError());
         DEBUG_CHECK();
         if (spin_wait) {

@@ -229,7 +229,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
                                    const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, bool prezeroed, hipStream_t s);
+                                   uint32_t* counters, bool prezeroed, hipStream_t s, uint32_t* landing = nullptr);
 void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words);
 
 // kernel launchers

@@ -304,7 +304,8 @@ constexpr int SC_ITEMS = 16;
 __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t* __restrict__ sorted_gid,
                                                       const uint32_t* __restrict__ tiles_touched,
                                                       uint32_t* __restrict__ sorted_tt, uint32_t* __restrict__ sorted_off,
-                                                      uint32_t* __restrict__ counters, uint32_t* ticket, uint32_t* status) {
+                                                      uint32_t* __restrict__ counters, uint32_t* ticket, uint32_t* status,
+                                                      uint32_t* __restrict__ landing) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile, s_base;
     __shared__ uint32_t s_t[256 * SC_ITEMS + 128], s_o[256 * SC_ITEMS + 128];
@@ -369,7 +370,12 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
             __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_base = excl;
-        if ((tile + 1) * (256 * SC_ITEMS) >= n) counters[0] = excl + total;  // last tile: num_rendered
+        if ((tile + 1) * (256 * SC_ITEMS) >= n) {  // last tile: num_rendered
+            counters[0] = excl + total;
+            // ... and straight to the host: ONE aligned 32-bit store at system scope into the mapped pinned word the host
+            // polls (a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen, api.hip)
+            if (landing) __hip_atomic_store(landing, excl + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     gs2m_sync();
     // results leave the way the inputs came: through LDS, so that every global store is a coalesced 256-B run
@@ -403,13 +409,13 @@ void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words) 
 
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
                                    const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, bool prezeroed, hipStream_t s) {
+                                   uint32_t* counters, bool prezeroed, hipStream_t s, uint32_t* landing) {
     if (n == 0) return hipSuccess;
     const int tiles = (int)((n + 4095) / 4096);
     if (temp_bytes < gs2m_scan_temp_bytes(n)) return hipErrorInvalidValue;
     uint32_t* base = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, (size_t)(tiles + 64) * 4, s);
     if (e != hipSuccess) return e;
-    scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64);
+    scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64, landing);
     return hipGetLastError();
 }

@@ -14,6 +14,8 @@ There is no fallback: tensors must live on a HIP device and the HIP library must
 """
 from typing import NamedTuple
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -88,6 +90,32 @@ class _ScratchCache(_Alloc):
         return super()._alloc(nbytes, _user)
 
 
+class _BinningCache:
+    """The binning buffer can only be sized after the forward's host wait for num_rendered, and the GPU idles from that
+    wait until the next kernel is launched: a Python allocator callback in that window is pure GPU idle time.  So one
+    buffer per device is kept from call to call (grown 25 % past the largest request seen) and handed to the library
+    through its C-level gs2m_prealloc_alloc; Python is only called when it does not fit.  The buffer belongs to the
+    forward that took it until that forward's backward has run (or, when nothing requires grad, until the forward
+    returns); a forward that finds it taken -- two views rendered before either backward -- allocates as before."""
+    _cache = {}
+
+    def __init__(self):
+        self.tensor = None
+        self.busy = None  # token of the forward that holds the buffer
+
+    @classmethod
+    def get(cls, device):
+        key = torch.device(device).index
+        c = cls._cache.get(key)
+        if c is None:
+            c = cls._cache[key] = cls()
+        return c
+
+    @classmethod
+    def release(cls):
+        cls._cache.clear()
+
+
 class _CModule:
     """Function-for-function mirror of the reference's `_C` extension module."""
 
@@ -121,17 +149,31 @@ class _CModule:
         radii = torch.empty((P,), dtype=torch.int32, device=device)
         observe = torch.empty((P,), dtype=torch.int32, device=device)
         geom, binning, img = _Alloc(device), _Alloc(device), _Alloc(device)
+        cache = _BinningCache.get(device)
+        pre = None
+        if cache.busy is None and cache.tensor is not None:
+            pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0)
+            bin_cb, bin_user = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN), C.byref(pre)
+        else:
+            bin_cb, bin_user = binning.cb, None
         with torch.cuda.device(device):
             fwd = L.gs2m_raster_forward_split_sh if split else L.gs2m_raster_forward
             sh_args = (_ptr(sh), _ptr(sh_rest)) if split else (_ptr(sh),)
             rendered = fwd(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
+                geom.cb, None, bin_cb, bin_user, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
                 _ptr(means3D), *sh_args, _ptr(colors), _ptr(opacities), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(features), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), int(featureCount), _ptr(out_color),
                 _ptr(radii), _ptr(observe), _ptr(out_buffer), _stream())
         _native.check(rendered, "gs2m_raster_forward")
-        return rendered, out_color, radii, observe, out_buffer, geom.tensor, binning.tensor, img.tensor
+        if pre is not None and not pre.used_fallback:
+            bin_tensor = cache.tensor
+            cache.busy = True  # released by the matching backward (or by the autograd forward when no grad is needed)
+        else:
+            bin_tensor = binning.tensor
+            if cache.busy is None:  # remember a buffer 25 % larger than this request for the next call
+                cache.tensor = torch.empty(int(bin_tensor.numel() * 1.25) + 4096, dtype=torch.uint8, device=device)
+        return rendered, out_color, radii, observe, out_buffer, geom.tensor, bin_tensor, img.tensor
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
@@ -198,6 +240,7 @@ class _CModule:
                 _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), *dsh_args, _ptr(dL_dscales),
                 _ptr(dL_drotations), _ptr(dL_dfeatures), scratch.cb, None, _stream())
         _native.check(rc, "gs2m_raster_backward")
+        _release_binning(binningBuffer)
         out = (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drotations,
                dL_dfeatures)
         if split:
@@ -218,12 +261,21 @@ class _CModule:
         return present
 
 
+def _release_binning(t):
+    """The cached binning buffer is free again once the backward of the forward that took it has been enqueued (same
+    stream: the next forward's kernels run after it)."""
+    c = _BinningCache.get(t.device)
+    if c.busy and c.tensor is not None and t.data_ptr() == c.tensor.data_ptr():
+        c.busy = None
+
+
 _C = _CModule()
 
 
 def release_scratch():
     """Free the backward's cached row scratch (~0.9 GB at 1M Gaussians / 1080p, kept per device and stream between calls)."""
     _ScratchCache.release()
+    _BinningCache.release()
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
@@ -250,6 +302,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
                               geomBuffer, binningBuffer, imgBuffer, shs_rest)
         ctx.mark_non_differentiable(radii, observe)
+        if not any(ctx.needs_input_grad):
+            _release_binning(binningBuffer)  # no backward will come for this forward
         return color, radii, observe, buffer
 
     @staticmethod

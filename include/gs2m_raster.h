@@ -276,6 +276,20 @@ int gs2m_set_spin_wait(int on);
  *                                                                             csrc/blend_bwd.hip */
 int gs2m_set_bwd_impl(int impl);
 
+/* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)
+ * allocated AHEAD of that wait: pass gs2m_prealloc_alloc as the callback and a gs2m_prealloc as its user pointer.  A
+ * request that fits `capacity` returns `ptr` without leaving the library -- the GPU idles between the wait and the next
+ * launch, so a Python allocator call there costs a few per cent of a step on a slow host; a larger request goes to
+ * `fallback` (and sets used_fallback). */
+typedef struct gs2m_prealloc {
+    char* ptr;
+    size_t capacity;
+    gs2m_alloc_fn fallback;
+    void* fallback_user;
+    int used_fallback;
+} gs2m_prealloc;
+char* gs2m_prealloc_alloc(size_t bytes, void* user);
+
 /* Debug mode ("race detection / sanitizers"): 1 = after every pipeline stage the stream is
  * synchronized and checked; a fault is returned as GS2M_ERR_STAGE(stage) by the call that launched it, with
  * gs2m_stage_name(stage) naming it.  0 (default): launch errors only, checked once per call.
