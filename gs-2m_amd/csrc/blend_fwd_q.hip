@@ -59,8 +59,16 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     // record quads parked per entry: geo0, geo1, channel quads (the bin quad is only needed on the rare observe path)
     constexpr int CH = 16;       // entries per chunk
     constexpr int NS = 2 + KQ;   // quads staged
-    __shared__ float4 s_q[2][NS][CH];
-    __shared__ uint2 s_e[2][CH];  // the chunk's list entries {Gaussian id, position in the tile list + 1}
+    // one LDS block, [buffer][NS quads + the chunk's list entries {Gaussian id, position in the tile list + 1}][CH],
+    // addressed from ONE per-buffer base kept in a VGPR the compiler cannot rematerialise: with separate arrays at
+    // known addresses it re-creates two address registers from SGPRs for every entry (2 of 32 vector instructions)
+    constexpr int BUFQ = NS * CH + CH / 2;  // float4 per buffer
+    __shared__ float4 s_buf[2 * BUFQ];
+    uint32_t lds_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lds_zero));  // opaque 0
+    float4* const s_base = s_buf + lds_zero;
+    auto q_at = [&](int buf, int slot, int jj) -> float4& { return s_base[buf * BUFQ + slot * CH + jj]; };
+    auto e_at = [&](int buf, int jj) -> uint2& { return reinterpret_cast<uint2*>(s_base + buf * BUFQ + NS * CH)[jj]; };
     const int ej = lane & 15, eq = lane >> 4;  // staging role: entry ej of the chunk, quad slot eq (and eq + 4)
     auto quad_of = [](int slot) { return slot < 2 ? slot : slot + 1; };  // staged slot -> record quad (skips REC_BIN)
 
@@ -79,12 +87,12 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
 
     // one list entry (index i of the list, slot jj of LDS buffer `buf`): returns true when every pixel has finished
     auto eval = [&](const int i, const int buf, const int jj) {
-        const float4 a = s_q[buf][0][jj];
-        const float2 b = *reinterpret_cast<const float2*>(&s_q[buf][1][jj]);
+        const float4 a = q_at(buf, 0, jj);
+        const float2 b = *reinterpret_cast<const float2*>(&q_at(buf, 1, jj));
         float4 c[KQ];
 #pragma unroll
-        for (int q = 0; q < KQ; q++) c[q] = s_q[buf][2 + q][jj];
-        const uint2 ec = s_e[buf][jj];
+        for (int q = 0; q < KQ; q++) c[q] = q_at(buf, 2 + q, jj);
+        const uint2 ec = e_at(buf, jj);
         const float dx = a.x - pxf, dy = a.y - pyf;
         const float p2 = gs2m_power(dx, dy, a.z, a.w, b.x);
         const float alpha = fminf(0.99f, b.y * gs2m_exp(p2));
@@ -133,9 +141,9 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
         return st;
     };
     auto park = [&](int buf, const uint2 e, const Stage& st) {
-        s_q[buf][eq][ej] = st.a;
-        if (eq + 4 < NS) s_q[buf][eq + 4][ej] = st.b;
-        if (eq == 0) s_e[buf][ej] = make_uint2(e.x & GS2M_GID_MASK, e.y + 1u);
+        q_at(buf, eq, ej) = st.a;
+        if (eq + 4 < NS) q_at(buf, eq + 4, ej) = st.b;
+        if (eq == 0) e_at(buf, ej) = make_uint2(e.x & GS2M_GID_MASK, e.y + 1u);
     };
     if (nchunks > 0) {
         uint2 e1 = load_entry(0);

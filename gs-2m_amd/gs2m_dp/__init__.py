@@ -62,7 +62,14 @@ class GradReducer:
         flat = t.view(-1)
         if self.mode == "rs_ag" and flat.numel() % ws == 0 and flat.numel() >= ws:
             shard = torch.empty(flat.numel() // ws, dtype=flat.dtype, device=flat.device)
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+            h = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # RCCL runs a group's collectives in issue order on its own stream: the all-gather can be queued behind the
+            # reduce-scatter without the host waiting in between.  Other backends (gloo in the CPU tests) give no such
+            # ordering: wait there.
+            if dist.get_backend(self.group) != "nccl":
+                h.wait()
+            else:
+                handles.append(h)
             handles.append(dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True))
         else:
             handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
