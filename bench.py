@@ -272,7 +272,9 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    gs2m_native.profile_mode(1)  # HIP events around the two blend kernels, on their launch stream
+    # HIP events on the launch stream around the dominant kernel (the backward blend) inside the timed region; every
+    # bracketed kernel costs the stream ~6 us of bubble, so the other stages are timed in the untimed pass below
+    gs2m_native.profile_mode(3)
     ms = timed(False)
     blend = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
@@ -291,8 +293,11 @@ def main():
         R = int(info["R"]) if info["R"] is not None else -1
         Tn = ((W + 15) // 16) * ((H + 15) // 16)
         ab = S.algo_bytes(P, V, R, W * H, Tn, fc)
-        k_ms = {k: blend[k][0] / max(blend[k][1], 1) for k in ("blend_fwd", "blend_bwd")}
-        dom = max(k_ms, key=k_ms.get)
+        k_ms = {"blend_bwd": blend["blend_bwd"][0] / max(blend["blend_bwd"][1], 1),            # live, timed region
+                "blend_fwd": stages["blend_fwd"][0] / max(stages["blend_fwd"][1], 1)}          # untimed stage pass
+        dom = "blend_bwd" if k_ms["blend_bwd"] >= k_ms["blend_fwd"] else "blend_fwd"
+        if dom == "blend_fwd":  # never seen; keep the contract (live measurement of the dominant kernel) honest
+            raise SystemExit("bench.py: the forward blend dominates -- bracket it in the timed region instead")
         achieved = ab[dom] / (k_ms[dom] * 1e-3) / 1e9
         workload = f"{P}x{W}x{H}x{fc}"
         ctr = counters_for(dom, workload) or {}

@@ -36,7 +36,8 @@ struct Pinned {
 thread_local Pinned t_pinned;
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
-// mode 0: off; 1: the two blend kernels only; 2: every stage.
+// mode 0: off; 1: the two blend kernels only; 2: every stage; 3: the backward blend kernel only (an event pair costs
+// ~6 us of stream bubble around the kernel it brackets: bench.py's timed region brackets the dominant kernel alone).
 static_assert(GS2M_NUM_STAGES == 10, "stage table");
 enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_OBSERVE,
              ST_BLEND_BWD, ST_GAUSSIAN_BWD, ST_COUNT };
@@ -95,7 +96,7 @@ struct StageTimer {
             if (g_roctx.push) { g_roctx.push(kStageNames[stage]); marked = true; }
         }
         const bool blend = stage == ST_BLEND_FWD || stage == ST_BLEND_BWD;
-        if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || g_prof.n >= kMaxRecords) return;
+        if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || (g_prof.mode == 3 && stage != ST_BLEND_BWD) || g_prof.n >= kMaxRecords) return;
         slot = g_prof.n++;
         if (slot >= g_prof.created) {
             (void)hipEventCreate(&g_prof.ev[slot][0]);
@@ -447,7 +448,7 @@ int gs2m_set_bwd_impl(int impl) {
 }
 
 int gs2m_profile_mode(int mode) {
-    if (mode < 0 || mode > 2) return GS2M_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 3) return GS2M_ERR_INVALID_ARG;
     g_prof.mode = mode;
     g_prof.n = 0;
     return GS2M_OK;

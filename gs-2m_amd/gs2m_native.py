@@ -199,7 +199,7 @@ def set_spin_wait(on):
 
 
 def profile_mode(mode):
-    """0 off, 1 blend kernels only, 2 every stage (HIP events on the launch stream)."""
+    """0 off, 1 blend kernels only, 2 every stage, 3 backward blend only (HIP events on the launch stream)."""
     check(lib().gs2m_profile_mode(int(mode)), "gs2m_profile_mode")
 
 

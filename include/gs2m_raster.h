@@ -303,7 +303,7 @@ const char* gs2m_stage_name(int stage);
  * and sort kernels carry 30 value bits; gs2m_raster_forward returns GS2M_ERR_UNSUPPORTED beyond that. */
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
- * mode 0 = off, 1 = the two blend kernels only, 2 = every stage.  Setting the mode clears
+ * mode 0 = off, 1 = the two blend kernels only, 2 = every stage, 3 = the backward blend kernel only.  Setting the mode clears
  * the records.  gs2m_profile_collect waits for the recorded events and returns, per
  * stage, the summed milliseconds and the number of launches since the last collect.
  * Stage order: preprocess, depth_sort, scan, emit, tile_sort, ranges, blend_fwd, observe,
