@@ -92,16 +92,19 @@ class _ScratchCache(_Alloc):
 
 class _BinningCache:
     """The binning buffer can only be sized after the forward's host wait for num_rendered, and the GPU idles from that
-    wait until the next kernel is launched: a Python allocator callback in that window is pure GPU idle time.  So one
-    buffer per device is kept from call to call (grown 25 % past the largest request seen) and handed to the library
-    through its C-level gs2m_prealloc_alloc; Python is only called when it does not fit.  The buffer belongs to the
-    forward that took it until that forward's backward has run (or, when nothing requires grad, until the forward
-    returns); a forward that finds it taken -- two views rendered before either backward -- allocates as before."""
+    wait until the next kernel is launched: a Python allocator callback in that window is pure GPU idle time.  So the
+    autograd path keeps one buffer per device from call to call (25 % larger than the largest request seen) and hands
+    it to the library through its C-level gs2m_prealloc_alloc; Python is only called when it does not fit.
+    The buffer is FREE exactly when nothing but this cache references it: autograd holds a reference from
+    save_for_backward until the backward has released its saved tensors (retain_graph keeps it), so a forward that finds
+    the count above one -- two views rendered before either backward, a retained graph -- allocates as before."""
     _cache = {}
 
     def __init__(self):
         self.tensor = None
-        self.busy = None  # token of the forward that holds the buffer
+
+    def free(self):
+        return self.tensor is not None and self.tensor._use_count() == 1
 
     @classmethod
     def get(cls, device):
@@ -122,7 +125,7 @@ class _CModule:
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                             features, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, featureCount, sh_rest=None):
+                            campos, prefiltered, featureCount, sh_rest=None, _cached_binning=False):
         """`sh_rest` (this repository's extension): when given, `sh` is the DC part (P,1,3) and `sh_rest` the other
         coefficients (P,M-1,3), as the reference model stores them -- no concatenation needed (M = 16 only)."""
         if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -149,9 +152,9 @@ class _CModule:
         radii = torch.empty((P,), dtype=torch.int32, device=device)
         observe = torch.empty((P,), dtype=torch.int32, device=device)
         geom, binning, img = _Alloc(device), _Alloc(device), _Alloc(device)
-        cache = _BinningCache.get(device)
+        cache = _BinningCache.get(device) if _cached_binning else None  # the autograd path only: `_C` callers own what they get
         pre = None
-        if cache.busy is None and cache.tensor is not None:
+        if cache is not None and cache.free():
             pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0)
             bin_cb, bin_user = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN), C.byref(pre)
         else:
@@ -168,10 +171,9 @@ class _CModule:
         _native.check(rendered, "gs2m_raster_forward")
         if pre is not None and not pre.used_fallback:
             bin_tensor = cache.tensor
-            cache.busy = True  # released by the matching backward (or by the autograd forward when no grad is needed)
         else:
             bin_tensor = binning.tensor
-            if cache.busy is None:  # remember a buffer 25 % larger than this request for the next call
+            if cache is not None and (cache.tensor is None or cache.free()):  # a buffer 25 % larger than this request for the next call
                 cache.tensor = torch.empty(int(bin_tensor.numel() * 1.25) + 4096, dtype=torch.uint8, device=device)
         return rendered, out_color, radii, observe, out_buffer, geom.tensor, bin_tensor, img.tensor
 
@@ -240,7 +242,6 @@ class _CModule:
                 _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), *dsh_args, _ptr(dL_dscales),
                 _ptr(dL_drotations), _ptr(dL_dfeatures), scratch.cb, None, _stream())
         _native.check(rc, "gs2m_raster_backward")
-        _release_binning(binningBuffer)
         out = (dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dscales, dL_drotations,
                dL_dfeatures)
         if split:
@@ -259,14 +260,6 @@ class _CModule:
                                                 _ptr(_f32c(projmatrix, "projmatrix")), present.data_ptr(), _stream())
             _native.check(rc, "gs2m_raster_mark_visible")
         return present
-
-
-def _release_binning(t):
-    """The cached binning buffer is free again once the backward of the forward that took it has been enqueued (same
-    stream: the next forward's kernels run after it)."""
-    c = _BinningCache.get(t.device)
-    if c.busy and c.tensor is not None and t.data_ptr() == c.tensor.data_ptr():
-        c.busy = None
 
 
 _C = _CModule()
@@ -296,14 +289,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.image_height, raster_settings.image_width, shs, raster_settings.sh_degree,
                 raster_settings.campos, raster_settings.prefiltered, raster_settings.feature_count)
         num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
-            *args, sh_rest=shs_rest)
+            *args, sh_rest=shs_rest, _cached_binning=True)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
                               geomBuffer, binningBuffer, imgBuffer, shs_rest)
         ctx.mark_non_differentiable(radii, observe)
-        if not any(ctx.needs_input_grad):
-            _release_binning(binningBuffer)  # no backward will come for this forward
         return color, radii, observe, buffer
 
     @staticmethod

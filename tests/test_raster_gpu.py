@@ -355,3 +355,35 @@ def test_debug_mode_and_markers_do_not_change_results():
     dgr.release_scratch()
     out2, g2 = Hh.run_hip(sc)  # the scratch is simply allocated again
     assert np.array_equal(g0["means3D"], g2["means3D"])
+
+
+def test_two_forwards_before_their_backwards_and_a_retained_graph():
+    """The autograd path reuses one binning buffer per device from call to call, but only when nothing references it any
+    more: a second view rendered before the first one's backward (multi_view_loss does that) and a backward repeated
+    with retain_graph must see their own forward's state."""
+    _require_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    import gs2m_synth as S
+    sc_a = Hh.make_scene(3000, 160, 96, seed=51, fc=9, scale_hi=0.06)
+    sc_b = Hh.make_scene(3000, 160, 96, seed=51, fc=9, scale_hi=0.06, cam=S.look_at_camera(160, 96, eye=(0.8, 0.2, 0.0), target=(0.0, 0.0, 6.0)))
+    _, ga = Hh.run_hip(sc_a)
+    _, gb = Hh.run_hip(sc_b)
+
+    def fwd(sc):
+        g = {k: v.cuda().requires_grad_(True) for k, v in sc["g"].items()}
+        m2 = torch.zeros(3000, 4, device="cuda", requires_grad=True)
+        color, _, _, buffer = GaussianRasterizer(Hh.settings_for(sc, "cuda"))(g["means3D"], m2, g["opacities"], shs=g["shs"], scales=g["scales"],
+                                                                          rotations=g["rotations"], features=g["features"])
+        return g, (color * sc["Gc"].cuda()).sum() + (buffer * sc["Gb"].cuda()).sum()
+    pa, la = fwd(sc_a)
+    pb, lb = fwd(sc_b)          # second forward while the first one's graph is alive
+    la.backward(retain_graph=True)
+    pc, lc = fwd(sc_b)          # third forward while the first graph is retained
+    lb.backward()
+    first = pa["means3D"].grad.clone()
+    pa["means3D"].grad = None
+    la.backward()               # the retained graph again: same gradients
+    lc.backward()
+    assert np.array_equal(first.cpu().numpy(), ga["means3D"]) and torch.equal(pa["means3D"].grad, first)
+    assert np.array_equal(pb["means3D"].grad.cpu().numpy(), gb["means3D"])
+    assert np.array_equal(pc["means3D"].grad.cpu().numpy(), gb["means3D"])
