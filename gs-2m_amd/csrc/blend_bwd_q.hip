@@ -197,6 +197,12 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         f.below = (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u));
         return f;
     };
+    // start of gradient row `row`: the row count is far below 2^32 / 6, so row * (floats per row / 4) is formed in 32 bits
+    // (one shift-add) and only widened for the shift by 16 bytes -- `rows + (size_t)row * RSTRIDE` compiles to a
+    // quarter-rate 64-bit multiply-add, five of them per group epilogue
+    auto row_ptr = [&](uint32_t row) -> float* {
+        return reinterpret_cast<float*>(reinterpret_cast<float4*>(rows) + (size_t)(row * (uint32_t)(RSTRIDE / 4)));
+    };
     Fill f;
     uint32_t row_cur = 0;  // gradient row of this lane's survivor in the current group
     uint2 e_next = make_uint2(0u, 0u);
@@ -327,8 +333,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
             const int i = 4 * r + rr;
             if (i < nvalid && j < ROWF - ROW_COL) {
-                const size_t rslot = (size_t)s_rowg[i];
-                rows[rslot * RSTRIDE + ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
+                row_ptr(s_rowg[i])[ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
             }
         }
         if (r == 0 && j < nvalid) {  // geometry sums of survivor j from its moments
@@ -339,8 +344,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             const float Sdxx = xc * xc * m0.x - 2.f * xc * m0.y + m0.w;
             const float Sdxy = xc * yc * m0.x - xc * m0.z - yc * m0.y + m1.x;
             const float Sdyy = yc * yc * m0.x - 2.f * yc * m0.z + m1.y;
-            const size_t rslot = (size_t)row_cur;
-            float4* o4 = reinterpret_cast<float4*>(rows + rslot * RSTRIDE);
+            float4* o4 = reinterpret_cast<float4*>(row_ptr(row_cur));
             o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
             o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)
         }
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
             const uint32_t row = row_of(p[REC_BIN], reinterpret_cast<const uint32_t*>(p + REC_AUX)[0],
                                         (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u)));
-            float4* o4 = reinterpret_cast<float4*>(rows + (size_t)row * RSTRIDE);
+            float4* o4 = reinterpret_cast<float4*>(row_ptr(row));
 #pragma unroll
             for (int q4 = 0; q4 < ROWF / 4; q4++) o4[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
