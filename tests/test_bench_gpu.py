@@ -27,3 +27,21 @@ def test_bench_line_has_the_contract_fields():
     assert d["render_level_ms"] > d["ms_per_step"] * 0.9 and d["train_step_ms"] > d["ms_per_step"] * 0.9  # the callers
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 path of bench.py (launch contract, one collective per step over the gradient arena, blocking and
+    pipelined timings, max over ranks) run functionally: two ranks on the one GPU of the box, gloo instead of RCCL."""
+    env = dict(os.environ, GS2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--gaussians", "30000", "--width", "320", "--height", "192"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"], "whole-job views/s"
+    assert d["pipelined_ms_per_step"] > 0 and "cpu_baseline" not in d
+    assert "one collective" in d["config"]["workload"]
