@@ -18,6 +18,7 @@ dev = "cuda"
 cam = S.make_camera(W, H)
 g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam, seed=0).items()}
 e = torch.Tensor([])
+gs2m_native.set_bwd_impl(1)  # the statistics below are those of the tile-list kernels (slot-major rows with validity bytes)
 R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
     torch.zeros(3, device=dev), g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"],
     cam["viewmatrix"].to(dev), cam["projmatrix"].to(dev), cam["tanfovx"], cam["tanfovy"], H, W, g["shs"], 3,
