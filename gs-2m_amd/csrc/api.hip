@@ -447,6 +447,8 @@ int gs2m_set_bwd_impl(int impl) {
     return GS2M_OK;
 }
 
+int gs2m_get_bwd_impl(void) { return g_bwd_impl.load(); }
+
 int gs2m_profile_mode(int mode) {
     if (mode < 0 || mode > 3) return GS2M_ERR_INVALID_ARG;
     g_prof.mode = mode;

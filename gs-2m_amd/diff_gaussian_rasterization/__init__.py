@@ -292,6 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             *args, sh_rest=shs_rest, _cached_binning=True)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.blend_impl = _native.lib().gs2m_get_bwd_impl()  # the scratch buffers are private to the kernels that wrote them
         ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
                               geomBuffer, binningBuffer, imgBuffer, shs_rest)
         ctx.mark_non_differentiable(radii, observe)
@@ -301,6 +302,10 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_out_radii, grad_out_observe, grad_out_buffer):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
+        now = _native.lib().gs2m_get_bwd_impl()
+        if (now == 2) != (ctx.blend_impl == 2):
+            raise RuntimeError(f"gs2m rasterizer: the blend implementation was switched between this forward ({ctx.blend_impl}) and its "
+                               f"backward ({now}): the list-driven kernels (2) and the tile-list kernels (0, 1) keep different private state")
         (buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs, geomBuffer,
          binningBuffer, imgBuffer, shs_rest) = ctx.saved_tensors
         if grad_out_color is None:

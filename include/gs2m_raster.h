@@ -275,6 +275,7 @@ int gs2m_set_spin_wait(int on);
  *   0 tile lists; same forward; backward pixel-per-lane, permlane/DPP reductions, one row per instance
  *                                                                             csrc/blend_bwd.hip */
 int gs2m_set_bwd_impl(int impl);
+int gs2m_get_bwd_impl(void);
 
 /* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)
  * allocated AHEAD of that wait: pass gs2m_prealloc_alloc as the callback and a gs2m_prealloc as its user pointer.  A

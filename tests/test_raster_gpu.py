@@ -387,3 +387,18 @@ def test_two_forwards_before_their_backwards_and_a_retained_graph():
     assert np.array_equal(first.cpu().numpy(), ga["means3D"]) and torch.equal(pa["means3D"].grad, first)
     assert np.array_equal(pb["means3D"].grad.cpu().numpy(), gb["means3D"])
     assert np.array_equal(pc["means3D"].grad.cpu().numpy(), gb["means3D"])
+
+
+def test_switching_the_blend_implementation_between_forward_and_backward_is_refused():
+    _require_gpu()
+    import gs2m_native
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = Hh.make_scene(500, 64, 48, seed=61, fc=9)
+    g = {k: v.cuda().requires_grad_(True) for k, v in sc["g"].items()}
+    m2 = torch.zeros(500, 4, device="cuda", requires_grad=True)
+    gs2m_native.set_bwd_impl(2)
+    color, _, _, buffer = GaussianRasterizer(Hh.settings_for(sc, "cuda"))(g["means3D"], m2, g["opacities"], shs=g["shs"], scales=g["scales"],
+                                                                      rotations=g["rotations"], features=g["features"])
+    gs2m_native.set_bwd_impl(1)
+    with pytest.raises(RuntimeError, match="switched between this forward"):
+        (color.sum() + buffer.sum()).backward()
