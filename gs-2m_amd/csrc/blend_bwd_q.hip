@@ -48,10 +48,12 @@ __device__ __forceinline__ void row_scan_mul2(float& x, float& y) {
         "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf"
         : "+v"(x), "+v"(y));
 }
-__device__ __forceinline__ void row_scan_add2(float& x, float& y) {  // bound_ctrl:1: lanes without a source add 0
+// The sum scan leaves its inputs alone: with bound_ctrl:1 a lane without a source reads 0, so the first level can write a
+// fresh register (x shifted + x) -- no copies in front of the chain (the product scan needs them: its identity is 1).
+__device__ __forceinline__ void row_scan_add2(const float x, const float y, float& ox, float& oy) {
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 0\n\t"
         "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -61,7 +63,8 @@ __device__ __forceinline__ void row_scan_add2(float& x, float& y) {  // bound_ct
         "s_nop 0\n\t"
         "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(x), "+v"(y));
+        : "=&v"(ox), "=&v"(oy)
+        : "v"(x), "v"(y));
 }
 
 template <int FC>
@@ -278,8 +281,8 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f w = am * Ti;
                 const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
                 const v2f qv = gc * w;
-                float Sx = qv.x, Sy = qv.y;
-                row_scan_add2(Sx, Sy);
+                float Sx, Sy;
+                row_scan_add2(qv.x, qv.y, Sx, Sy);
                 const v2f Sinc = {Sx, Sy};
                 const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
                 const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of blend_bwd.hip)
