@@ -169,3 +169,83 @@ def test_training_replicas_stay_bit_identical():
         for a, b, what in zip(s0[name], s1[name], ("param", "exp_avg", "exp_avg_sq")):
             assert a.shape == b.shape and np.array_equal(a, b), (name, what)
     assert np.array_equal(mr0, mr1) and np.array_equal(dn0, dn1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one collective per step: tensors that share one arena, and the concatenating fallback
+def _flat_worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gs-2m_amd"))
+    from gs2m_dp import GradReducer
+    g = torch.Generator().manual_seed(100 + rank)
+    red = GradReducer(mode=mode)
+    # (a) views of ONE buffer at aligned offsets, as the rasterizer binding returns its gradients
+    arena = torch.zeros(128 + 512)
+    views = [arena[0:30].view(10, 3), arena[64:104].view(10, 4), arena[128:608].view(10, 16, 3)]
+    for v in views:
+        v.copy_(torch.randn(v.shape, generator=g))
+    assert GradReducer.common_arena(views) is not None
+    calls = {"n": 0}
+    orig_ar, orig_rs = dist.all_reduce, dist.reduce_scatter_tensor
+
+    def count_ar(*a, **k):
+        calls["n"] += 1
+        return orig_ar(*a, **k)
+
+    def count_rs(*a, **k):
+        calls["n"] += 1
+        return orig_rs(*a, **k)
+    dist.all_reduce, dist.reduce_scatter_tensor = count_ar, count_rs
+    out_a = red.reduce_flat(views)
+    n_a = calls["n"]
+    # (b) unrelated tensors (and a None): one concatenated copy
+    calls["n"] = 0
+    loose = [torch.randn(7, 3, generator=g), None, torch.randn(5, generator=g), torch.randn(2, 2, 2, generator=g)]
+    assert GradReducer.common_arena([t for t in loose if t is not None]) is None
+    out_b = red.reduce_flat(loose)
+    n_b = calls["n"]
+    dist.all_reduce, dist.reduce_scatter_tensor = orig_ar, orig_rs
+    q.put((rank, [t.clone().numpy() for t in out_a], [None if t is None else t.clone().numpy() for t in out_b], n_a, n_b,
+           all(o is v for o, v in zip(out_a, views))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_one_collective_per_step(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (0 if mode == "allreduce" else 1)
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res = []
+    for _ in range(300):
+        try:
+            res.append(q.get(timeout=1.0))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(res) == 2:
+            break
+    assert len(res) == 2
+    res.sort(key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_a, exp_b = None, None
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        a = [torch.randn(s, generator=g) for s in ((10, 3), (10, 4), (10, 16, 3))]
+        b = [torch.randn(7, 3, generator=g), None, torch.randn(5, generator=g), torch.randn(2, 2, 2, generator=g)]
+        exp_a = a if exp_a is None else [x + y for x, y in zip(exp_a, a)]
+        exp_b = b if exp_b is None else [None if x is None else x + y for x, y in zip(exp_b, b)]
+    for rank, out_a, out_b, n_a, n_b, in_place in res:
+        assert n_a == 1 and n_b == 1, "one collective each"
+        assert in_place, "arena tensors are reduced in place"
+        for got, want in zip(out_a, exp_a):
+            assert np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)
+        for got, want in zip(out_b, exp_b):
+            assert (got is None) == (want is None) and (got is None or np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-6))
