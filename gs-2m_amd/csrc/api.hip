@@ -32,6 +32,7 @@ uint32_t higher_msb(uint32_t n) {
 struct Pinned {
     uint32_t* p = nullptr;    // host pointer of the pinned landing zone
     uint32_t* dev = nullptr;  // the same memory as the device sees it
+    uint32_t* acc[16] = {};   // per device: two zeroed words the side sum of the histogram kernel works in
 };
 thread_local Pinned t_pinned;
 
@@ -193,26 +194,39 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                                    tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, bwd_impl == 2 ? out_observe : nullptr, g,
                                    reference_binning ? 0 : 1, zj, s);
         }
-        {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
-            StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
-            HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
-                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s));
-        }
         if (!t_pinned.p) {
             HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
         }
-        // The reference has a sync at the same point (rasterizer_impl.cu:269-270).  The GPU idles from here until the
-        // host has seen num_rendered, sized the binning buffer and launched the next kernel, so the wake-up matters:
-        // the host polls the pinned landing zone for the value (a sentinel no count can take: R < 2^30) instead of
-        // sleeping in hipStreamSynchronize, whose wake-up costs tens of microseconds and far more on a loaded host.
-        // The scan's last tile stores the total there itself (one system-scope 32-bit store): no extra launch.
+        int dev_id = 0;
+        HIP_TRY(hipGetDevice(&dev_id));
+        uint32_t* acc = nullptr;
+        if (dev_id >= 0 && dev_id < 16) {
+            if (!t_pinned.acc[dev_id]) {
+                HIP_TRY(hipMalloc((void**)&t_pinned.acc[dev_id], 64));
+                HIP_TRY(hipMemset(t_pinned.acc[dev_id], 0, 64));
+            }
+            acc = t_pinned.acc[dev_id];
+        }
+        // The reference waits for num_rendered after its scan (rasterizer_impl.cu:269-270) and the GPU idles until the
+        // host has seen the value, sized the binning buffer and launched the next kernel.  Here the value -- the plain sum
+        // of tiles_touched, whatever the order -- is added up on the side by the depth sort's histogram kernel, the first
+        // kernel behind the preprocessing, and its last workgroup stores it into a mapped pinned word (one aligned
+        // system-scope 32-bit store; a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen).
+        // The host polls that word (a sentinel no count can take: R < 2^30) while the sort passes and the scan still
+        // run, and has the binning kernels queued behind them before they finish: no idle gap.
         volatile uint32_t* land = t_pinned.p;
         land[0] = 0xFFFFFFFFu;
-        {   // 2. emission offsets in that order
+        {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
+            StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
+            const SideSum sum = {acc ? g.tiles_touched : nullptr, acc, t_pinned.dev};
+            HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
+                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, SideScan{0, nullptr, nullptr}, sum));
+        }
+        {   // 2. emission offsets in that order (publishes the count itself when the side sum is not available)
             StageTimer t(ST_SCAN, s, &failed_stage);
             HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
-                                            g.sorted_off, g.counters, true, s, t_pinned.dev));
+                                            g.sorted_off, g.counters, true, s, acc ? nullptr : t_pinned.dev));
         }
         HIP_TRY(hipGetLastError());
         DEBUG_CHECK();

@@ -222,9 +222,17 @@ struct SideScan {
     const uint32_t* wave_rows;
     uint32_t* wave_base;
 };
+// second side job of a histogram kernel: sum of an n-element u32 array (the same indices the kernel reads keys at),
+// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = two words that
+// are zero before the launch and are left zero by the kernel (accumulator, finished-workgroup count).
+struct SideSum {
+    const uint32_t* tt;
+    uint32_t* acc;
+    uint32_t* landing;
+};
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideScan side = SideScan{0, nullptr, nullptr});
+                                 SideScan side = SideScan{0, nullptr, nullptr}, SideSum sum = SideSum{nullptr, nullptr, nullptr});
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,

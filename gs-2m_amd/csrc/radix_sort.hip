@@ -70,9 +70,11 @@ SortPlan make_plan(int total_bits) {
 // ---- histogram of every digit of every pass, one read of the keys ----
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npass,
                                                              int4 bits, int4 shift, uint32_t* __restrict__ ghist, int tiles,
-                                                             SideScan side) {
+                                                             SideScan side, SideSum sum) {
     __shared__ uint32_t s_h[RS_MAXPASS][256];
+    __shared__ uint32_t s_sum;
     const int tid = threadIdx.x;
+    if (tid == 0) s_sum = 0;
     if ((int)blockIdx.x == tiles) {  // the extra workgroup: a small scan that is due at about this point of the stream
         gs2m_wave_base_scan(side.nw, side.wave_rows, side.wave_base);
         return;
@@ -87,9 +89,26 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
         if (i < n) {
             const uint32_t key = keys[i];
             for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key >> sh[p]) & ((1u << b[p]) - 1u)], 1u);
+            if (sum.tt) {
+                const uint32_t t = sum.tt[i];
+                if (t) atomicAdd(&s_sum, t);
+            }
         }
     }
     gs2m_sync();
+    if (sum.tt && tid == 0) {
+        // the total of `tt` (num_rendered) leaves for the host as soon as the LAST workgroup has added its share: long
+        // before the sort and the scan behind this kernel are done (api.hip).  Relaxed agent-scope atomics on one word
+        // each; the finishing workgroup puts both words back to zero for the next call.
+        __hip_atomic_fetch_add(sum.acc, s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const uint32_t done = __hip_atomic_fetch_add(sum.acc + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (uint32_t)tiles - 1u) {
+            const uint32_t total = __hip_atomic_exchange(sum.acc, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sum.acc + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sum.landing, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     for (int p = 0; p < npass; p++) {
         const uint32_t c = s_h[p][tid];
         if (c) atomicAdd(&ghist[p * 256 + tid], c);
@@ -265,7 +284,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideScan side) {
+                                 SideScan side, SideSum sum) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -278,7 +297,7 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     rs_hist_kernel<<<tiles + (side.nw > 0 ? 1 : 0), RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
-                                                                        make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, side);
+                                                                        make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, side, sum);
     const uint32_t *ki = kin, *vi = vin;
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;
