@@ -15,6 +15,7 @@ There is no fallback: tensors must live on a HIP device and the HIP library must
 from typing import NamedTuple
 
 import ctypes as C
+import threading
 
 import torch
 import torch.nn as nn
@@ -47,8 +48,27 @@ class _Alloc:
 
     def __init__(self, device):
         self.device = device
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _native.ALLOC_FN(self._alloc)
+        self.tensor = None
+        self.cb = _native.ALLOC_FN(self._alloc)  # creating a ctypes callback costs microseconds: the objects are pooled
+
+    _pool = threading.local()
+
+    @classmethod
+    def three(cls, device):
+        """(geometry, binning, image) allocators of this thread for `device`, reused from call to call: the forward runs
+        on the host's critical path between two GPU phases, so its fixed Python cost matters on a slow host."""
+        pool = cls._pool.__dict__.setdefault("by_device", {})
+        key = torch.device(device).index
+        a = pool.get(key)
+        if a is None:
+            a = pool[key] = (cls(device), cls(device), cls(device))
+        for x in a:
+            x.tensor = None
+        return a
+
+    def take(self):
+        t, self.tensor = self.tensor, None
+        return t if t is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
 
     def _alloc(self, nbytes, _user):
         try:
@@ -84,9 +104,9 @@ class _ScratchCache(_Alloc):
         cls._cache.clear()
 
     def _alloc(self, nbytes, _user):
-        if self.tensor.numel() >= int(nbytes):
+        if self.tensor is not None and self.tensor.numel() >= int(nbytes):
             return self.tensor.data_ptr()
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=self.device)  # drop the old block before growing
+        self.tensor = None  # drop the old block before growing
         return super()._alloc(nbytes, _user)
 
 
@@ -121,6 +141,7 @@ class _BinningCache:
 
 class _CModule:
     """Function-for-function mirror of the reference's `_C` extension module."""
+    _prealloc_cb = None
 
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
@@ -151,12 +172,14 @@ class _CModule:
         out_buffer = torch.empty((NUM_FEATURES, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((P,), dtype=torch.int32, device=device)
         observe = torch.empty((P,), dtype=torch.int32, device=device)
-        geom, binning, img = _Alloc(device), _Alloc(device), _Alloc(device)
+        geom, binning, img = _Alloc.three(device)
         cache = _BinningCache.get(device) if _cached_binning else None  # the autograd path only: `_C` callers own what they get
         pre = None
         if cache is not None and cache.free():
             pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0)
-            bin_cb, bin_user = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN), C.byref(pre)
+            if _CModule._prealloc_cb is None:
+                _CModule._prealloc_cb = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN)
+            bin_cb, bin_user = _CModule._prealloc_cb, C.byref(pre)
         else:
             bin_cb, bin_user = binning.cb, None
         with torch.cuda.device(device):
@@ -172,10 +195,10 @@ class _CModule:
         if pre is not None and not pre.used_fallback:
             bin_tensor = cache.tensor
         else:
-            bin_tensor = binning.tensor
+            bin_tensor = binning.take()
             if cache is not None and (cache.tensor is None or cache.free()):  # a buffer 25 % larger than this request for the next call
                 cache.tensor = torch.empty(int(bin_tensor.numel() * 1.25) + 4096, dtype=torch.uint8, device=device)
-        return rendered, out_color, radii, observe, out_buffer, geom.tensor, bin_tensor, img.tensor
+        return rendered, out_color, radii, observe, out_buffer, geom.take(), bin_tensor, img.take()
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
