@@ -2,7 +2,7 @@
 //
 // Semantics: renderCUDA, diff-gaussian-rasterization/cuda_rasterizer/forward.cu:246-372 -- the same per-pixel
 // sequence of tests and updates as blend_fwd.hip (which stays in the library as the cross-check,
-// gs2m_set_fwd_impl), on the per-quadrant lists binning.hip:quad_lists_kernel builds.
+// gs2m_set_bwd_impl(1 / 0)), on the per-quadrant lists binning.hip:quad_lists_kernel builds.
 //
 // One wave per 8x8 quadrant, pixel per lane, no workgroup barriers: every list entry survives the quadrant test by
 // construction, so the wave walks its list straight down, 16 entries per chunk.  The chunk's blend records are
@@ -15,8 +15,8 @@
 // prefetch distance is one evaluation, and the ~0.45 us load latency was exposed on every entry.
 // Two other forms were built and measured: the alpha of two consecutive entries as packed fp32
 // pairs out of a component-wise LDS layout (5 fewer vector instructions per entry, but 76 VGPRs = 6 waves per SIMD
-// and the LDS reads right in front of their use: 0.30 instead of 0.27 ms), and the scalar-load form above with the
-// record lines touched ahead by a vector load (no better: the scalar path itself is the latency).
+// and the LDS reads right in front of their use: 0.30 instead of 0.27 ms), and the scalar-load form with the record
+// lines touched ahead by a vector load (no better: the scalar path itself is the latency).
 // `observe` (forward.cu:348-350: one atomicAdd per pixel) is one integer atomic per (list entry, quadrant) that sees
 // a pixel with T > 0.5, straight into the output tensor (zeroed by the preprocess kernel): only the first few
 // entries of a list do, and the wave stops looking once no live pixel has T > 0.5.
@@ -25,9 +25,6 @@
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-#define GS2M_CONST __attribute__((address_space(4)))
 
 template <int FC>  // feature channels blended (compile time); runtime fc <= FC
 __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
