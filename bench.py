@@ -69,6 +69,7 @@ def cpu_baseline(P, W, H, fc, seed):
     from oracle import oracle
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    flags = oracle.use_native_build() or "-O2 -fopenmp (native build not possible here)"  # -O3 -march=native, built on this box
     Ps = P if cores >= 48 else min(P, 250_000)
     cam = S.make_camera(W, H)
     g = S.make_gaussians(P, cam, seed=seed)
@@ -83,9 +84,24 @@ def cpu_baseline(P, W, H, fc, seed):
     oracle.backward(f, Gc.numpy(), Gb.numpy())
     dt = time.time() - t0
     scale = Ps / P
-    return {"value": round(scale / dt, 5), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"1 view fwd+bwd of the first {Ps} of {P} Gaussians at {W}x{H}, fc={fc} "
-                      f"({dt:.2f} s on {cores} OpenMP threads" + ("" if Ps == P else f"; value scaled by {Ps}/{P}") + ")"}
+    out = {"value": round(scale / dt, 5), "unit": "views/s", "cores": cores, "kind": "port",
+           "sample": f"1 view fwd+bwd of the first {Ps} of {P} Gaussians at {W}x{H}, fc={fc} "
+                     f"({dt:.2f} s on {cores} OpenMP threads, oracle built here with {flags}" + ("" if Ps == P else f"; value scaled by {Ps}/{P}") + ")"}
+    if P <= 20_000:
+        # also the PyTorch-autograd variant (tests/torch_ref.py, float64, single process) -- the CPU
+        # autograd rasterizer BASELINE.json configs[0] names
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from torch_ref import rasterize_dense
+        d = {k: v.double().requires_grad_(True) for k, v in g.items()}
+        t0 = time.time()
+        color, buf, _, _ = rasterize_dense(d["means3D"], d["opacities"], d["shs"], None, d["scales"], d["rotations"], None, d["features"],
+                                           bg=torch.zeros(3), viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                                           W=W, H=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=3, feature_count=fc)
+        ((color * Gc.double()).sum() + (buf * Gb.double()).sum()).backward()
+        dta = time.time() - t0
+        out["autograd"] = {"value": round(1.0 / dta, 5), "unit": "views/s", "kind": "PyTorch CPU autograd restatement (tests/torch_ref.py), float64, "
+                           f"{torch.get_num_threads()} torch threads", "seconds": round(dta, 2)}
+    return out
 
 
 def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
@@ -165,8 +181,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
-    ap.add_argument("--bwd-impl", type=int, default=None, choices=[0, 1, 2],
-                    help="blend implementation (default: the library's default, 2 = per-quadrant lists)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,18 +208,19 @@ def main():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, rasterize_gaussians
     from gs2m_dp import GradReducer
 
-    if a.bwd_impl is not None:
-        gs2m_native.set_bwd_impl(a.bwd_impl)
     P, W, H, fc = CONFIGS[a.config]
     P, W, H, fc = a.gaussians or P, a.width or W, a.height or H, fc if a.fc is None else a.fc
     preset = (P, W, H, fc) == CONFIGS[a.config]
+    # the N-GPU workload renders cameras on a circle of radius 6 around the cloud centre (0, 0, 6), looking at
+    # it, 8 positions 45 degrees apart; rank r takes position r (position 0 is the single-GPU camera at the origin).  The
+    # views differ in work (instances per view): the step time is the slowest rank's.
     if world == 1:
         cam = S.make_camera(W, H)
-    else:  # same cloud, cameras on a small arc around its centre: statistically equal per-rank work
+    else:
         import math
-        th = math.radians(3.0 * (rank - (world - 1) / 2.0))
+        th = 2.0 * math.pi * (rank % 8) / 8.0
         eye = (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th))
-        cam = S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
+        cam = S.make_camera(W, H) if rank % 8 == 0 else S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
     Gc, Gb = S.make_upstream_grads(H, W, seed=a.seed)
@@ -243,8 +258,10 @@ def main():
             # gradients are still fully reduced, a training loop built that way applies them one step late.
             if pipelined:
                 drain()
-            pending.append(reducer.reduce_flat_async([t.grad for t in leaves]))
+            # the densification side channels first: per-view norms of THIS rank's dL/dmeans2D (train.py:223-227), computed
+            # before anything is summed; dL/dmeans2D itself is not part of the summed range (its sum is never used)
             pending.append(reducer.reduce_densification_stats_async(means2D.grad, radii, observe))
+            pending.append(reducer.reduce_flat_async([t.grad for t in leaves if t is not means2D]))
             if not pipelined:
                 drain()
         info["radii"] = radii

@@ -57,11 +57,6 @@ std::atomic<int> g_reference_binning{0};
 std::atomic<int> g_spin_wait{1};  // forward: poll the pinned num_rendered instead of hipStreamSynchronize
 std::atomic<int> g_debug{0};      // gs2m_set_debug: synchronize + check after every stage
 std::atomic<int> g_markers{0};    // gs2m_set_markers: roctx ranges around the stages
-// blend kernels: 2 (default): per-quadrant lists (quad_lists_kernel + blend_fwd_q.hip + blend_bwd_q.hip);
-// 1: tile lists, forward blend_fwd.hip, backward survivor-per-lane + MFMA (blend_bwd_mfma.hip);
-// 0: tile lists, forward blend_fwd.hip, backward pixel-per-lane + permlane reduction (blend_bwd.hip).
-// A forward and its backward must run under the same setting (the quadrant lists are built by the forward).
-std::atomic<int> g_bwd_impl{2};
 
 const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges+quad_lists",
                                            "blend_fwd", "observe", "blend_bwd", "gaussian_bwd"};
@@ -134,7 +129,7 @@ char* gs2m_prealloc_alloc(size_t bytes, void* user) {
     return p->fallback ? p->fallback(bytes, p->fallback_user) : nullptr;
 }
 
-const char* gs2m_version(void) { return "gs2m_raster 0.2 (gfx950, round 2)"; }
+const char* gs2m_version(void) { return "gs2m_raster 0.3 (gfx950, round 3)"; }
 
 static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
                         void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
@@ -147,8 +142,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream_;
     const int reference_binning = g_reference_binning.load(), spin_wait = g_spin_wait.load();
-    // the list-driven kernels pack a 4-bit quadrant mask above the Gaussian id in the sorted values: P < 2^28 for them
-    const int bwd_impl = (g_bwd_impl.load() == 2 && P >= (1 << GS2M_GID_BITS)) ? 1 : g_bwd_impl.load();
     int failed_stage = 0;  // debug mode: 1 + the first stage whose kernels faulted
     if (P < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geometry_alloc || !binning_alloc || !image_alloc || !out_color || !out_buffer || !background) return GS2M_ERR_INVALID_ARG;
@@ -159,6 +152,8 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (shs_rest && (!shs || M != 16 || (((uintptr_t)shs_rest) & 15))) return GS2M_ERR_UNSUPPORTED;  // split SH: M = 16 only
     if (P > 0 && feature_count > 0 && !features) return GS2M_ERR_INVALID_ARG;
     if (width > 16 * 65535 || height > 16 * 65535) return GS2M_ERR_UNSUPPORTED;
+    // the sorted values carry a 4-bit quadrant mask above the Gaussian id (binning.hip): ids stay below 2^28
+    if (P >= (1 << GS2M_GID_BITS)) return GS2M_ERR_UNSUPPORTED;
 
     const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
@@ -191,7 +186,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, bwd_impl == 2 ? out_observe : nullptr, g,
+                                   tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, out_observe, g,
                                    reference_binning ? 0 : 1, zj, s);
         }
         if (!t_pinned.p) {
@@ -256,12 +251,12 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, g, b, bwd_impl == 2, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, g, b, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);
             // side job (list-driven kernels): the first gradient row of every emit wave, read by the backward
-            const SideScan side = {bwd_impl == 2 ? (P + 63) / 64 : 0, g.wave_rows, g.wave_base};
+            const SideScan side = {(P + 63) / 64, g.wave_rows, g.wave_base};
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
                                           b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, side));
         }
@@ -273,21 +268,13 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
     }
     DEBUG_CHECK();
-    if (bwd_impl == 2) {
-        {
-            StageTimer t(ST_RANGES, s, &failed_stage);  // second binning level: counted with the ranges stage
-            gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
-        }
+    {
+        StageTimer t(ST_RANGES, s, &failed_stage);  // second binning level: counted with the ranges stage
+        gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
+    }
+    {
         StageTimer t(ST_BLEND_FWD, s, &failed_stage);
         gs2m_launch_blend_fwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, out_observe, s);
-    } else {
-        StageTimer t(ST_BLEND_FWD, s, &failed_stage);
-        gs2m_launch_blend_fwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, out_color, out_buffer, s);
-    }
-    DEBUG_CHECK();
-    if (P > 0 && bwd_impl != 2) {  // the list-driven forward adds into out_observe itself
-        StageTimer t(ST_OBSERVE, s, &failed_stage);
-        gs2m_launch_observe(P, g, b, out_observe, s);
     }
     DEBUG_CHECK();
     HIP_TRY(hipGetLastError());
@@ -306,9 +293,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          void* stream_) {
     (void)buffer; (void)features;
     hipStream_t s = (hipStream_t)stream_;
-    const int bwd_impl = (g_bwd_impl.load() == 2 && P >= (1 << GS2M_GID_BITS)) ? 1 : g_bwd_impl.load();
     int failed_stage = 0;
     if (P == 0) return GS2M_OK;
+    if (P >= (1 << GS2M_GID_BITS)) return GS2M_ERR_UNSUPPORTED;
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geom_buffer || !binning_buffer || !image_buffer || !scratch_alloc || !grad_colors || !radii) return GS2M_ERR_INVALID_ARG;
     if (feature_count > 0 && !grad_buffer) return GS2M_ERR_INVALID_ARG;
@@ -323,45 +310,31 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
-    const int rpi = bwd_impl >= 1 ? 4 : 1;  // partial rows per instance: per quadrant or per tile
-    const int rowf = bwd_impl >= 1 ? gs2m_row_floats_mfma(feature_count) : gs2m_row_floats(feature_count);
-    const int rstride = rowf;
-    const size_t rows_bytes = gs2m_align_up(Rn * rpi * (size_t)rstride * sizeof(float));
-    const size_t valid_bytes = gs2m_align_up(Rn * rpi);
-    const size_t sums_bytes = gs2m_align_up((size_t)(P > 0 ? P : 1) * rowf * sizeof(float));  // one reduced row per Gaussian
-    char* sbase = scratch_alloc(rows_bytes + valid_bytes + sums_bytes + 2 * GS2M_ALIGN, scratch_user);
+    // one partial-gradient row per (instance, quadrant) at most, numbered densely (binning.hip), and one reduced row
+    // per Gaussian
+    const int rowf = gs2m_row_floats(feature_count);
+    const size_t rows_bytes = gs2m_align_up(Rn * 4 * (size_t)rowf * sizeof(float));
+    const size_t sums_bytes = gs2m_align_up((size_t)(P > 0 ? P : 1) * rowf * sizeof(float));
+    char* sbase = scratch_alloc(rows_bytes + sums_bytes + 2 * GS2M_ALIGN, scratch_user);
     if (!sbase) return GS2M_ERR_ALLOC;
     char* al = (char*)gs2m_align_up((size_t)(uintptr_t)sbase);
     float* rows = (float*)al;
-    uint8_t* row_valid = (uint8_t*)(al + rows_bytes);
-    float* sums = (float*)(al + rows_bytes + valid_bytes);
+    float* sums = (float*)(al + rows_bytes);
 
-    if (bwd_impl != 2) HIP_TRY(gs2m_zero_async(row_valid, gs2m_align_up(Rn * rpi, 4), s));  // padded: valid_bytes is 256-B aligned
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s, &failed_stage);
-        if (bwd_impl == 2)
-            gs2m_launch_blend_bwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
-                                    grad_buffer, rows, row_valid, s);
-        else if (bwd_impl == 1)
-            gs2m_launch_blend_bwd_mfma(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
-                                       grad_buffer, rows, row_valid, s);
-        else
-            gs2m_launch_blend_bwd(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
-                                  grad_buffer, rows, row_valid, s);
+        gs2m_launch_blend_bwd_q(width, height, tiles_x, tiles_y, feature_count, background, g, b, im, grad_colors,
+                                grad_buffer, rows, s);
     }
     DEBUG_CHECK();
     {
-    StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);
-    if (P > 0 && bwd_impl == 2) {
-        if (R > 0) gs2m_launch_row_reduce_dense(P, g, b, rows, rowf, sums, s);
+        StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);
+        if (R > 0) gs2m_launch_row_reduce_dense(P, g, rows, rowf, sums, s);
         else HIP_TRY(gs2m_zero_async(sums, (size_t)P * rowf * sizeof(float), s));
-    } else if (P > 0) {
-        gs2m_launch_row_reduce(P, g, rows, row_valid, rowf, rstride, rpi, sums, s);
-    }
-    gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                             viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
-                             sums, row_valid, rowf, 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
-                             dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures, s);
+        gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                                 viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
+                                 sums, rowf, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
+                                 dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures, s);
     }
     DEBUG_CHECK();
     HIP_TRY(hipGetLastError());
@@ -454,14 +427,6 @@ int gs2m_set_spin_wait(int on) {
     g_spin_wait = on ? 1 : 0;
     return GS2M_OK;
 }
-
-int gs2m_set_bwd_impl(int impl) {
-    if (impl < 0 || impl > 2) return GS2M_ERR_INVALID_ARG;
-    g_bwd_impl = impl;
-    return GS2M_OK;
-}
-
-int gs2m_get_bwd_impl(void) { return g_bwd_impl.load(); }
 
 int gs2m_profile_mode(int mode) {
     if (mode < 0 || mode > 3) return GS2M_ERR_INVALID_ARG;

@@ -93,14 +93,13 @@ namespace {
 // One wave owns 64 depth-sorted Gaussians whose instances occupy one contiguous slot range;
 // each step the wave writes 64 consecutive slots, each lane locating its source Gaussian by
 // binary search in the wave's prefix sums.  Also stores the emission offset into the record.
-// QUAD (list-driven blend kernels): every instance is also tested against the four 8x8 quadrants of its tile with the
+// Every instance is also tested against the four 8x8 quadrants of its tile with the
 // exact ellipse-vs-rectangle test (common.h) -- here the Gaussian's geometry is loaded once per Gaussian, the second
 // binning level (quad_lists_kernel) then needs no record gather at all -- and the 4-bit hit mask travels through the
 // tile sort above the Gaussian id.  The backward writes one gradient row per set bit; the rows of a wave's 64
 // Gaussians are numbered densely in emission order (instance by instance, quadrant by quadrant): an instance gets its
 // offset inside the wave's range here, the wave's row total goes to wave_rows[] (prefix: wave_base_kernel).  So the
 // rows of every Gaussian are one dense run and the per-Gaussian sum streams them (gaussian_bwd.hip).
-template <bool QUAD>
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint32_t* __restrict__ sorted_gid,
                                                    const uint32_t* __restrict__ sorted_tt,
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
@@ -111,9 +110,9 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
-    __shared__ float4 s_geo[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];   // x, y, A, B
-    __shared__ float2 s_ct[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];    // C, t2
-    __shared__ uint32_t s_rc[QUAD ? 4 : 1][QUAD ? GS2M_WAVE : 1];  // gradient rows per Gaussian
+    __shared__ float4 s_geo[4][GS2M_WAVE];   // x, y, A, B
+    __shared__ float2 s_ct[4][GS2M_WAVE];    // C, t2
+    __shared__ uint32_t s_rc[4][GS2M_WAVE];  // gradient rows per Gaussian
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
@@ -129,11 +128,9 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         rmin = f2u(bin.y);
         rw = f2u(bin.z) & 0xFFFFu;
         reinterpret_cast<uint32_t*>(r)[0] = off;
-        if (QUAD) {
-            s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
-            s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
-            reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = (uint32_t)(i >> 6);  // the emit wave's index
-        }
+        s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
+        s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
+        reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = (uint32_t)(i >> 6);  // the emit wave's index
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
@@ -142,7 +139,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     s_gid[wave][lane] = gid;
     s_rmin[wave][lane] = rmin;
     s_rw[wave][lane] = rw;
-    if (QUAD) s_rc[wave][lane] = 0u;
+    s_rc[wave][lane] = 0u;
     gs2m_sync();
     uint32_t rows_run = 0;  // gradient rows of the wave's instances so far
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
@@ -159,7 +156,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
             const uint32_t rm = s_rmin[wave][lo];
             const uint32_t tx = (rm & 0xFFFFu) + rx, ty = (rm >> 16) + ry;
             uint32_t val = s_gid[wave][lo];
-            if (QUAD) {
+            {
                 const float4 a = s_geo[wave][lo];
                 const float2 ct = s_ct[wave][lo];
                 const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
@@ -173,24 +170,15 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
             }
             keys_out[base + j] = ty * (uint32_t)tiles_x + tx;
             vals_out[base + j] = val;
-            if (!QUAD) inst_obs[base + j] = 0u;  // per-instance observe counts start at 0 (the forward blend only stores non-zero ones)
         }
-        if (QUAD) {
+        {
             const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
             if (j < total) inst_obs[base + j] = rows_run + pin - pc;  // the instance's first row, relative to the wave's range
             rows_run += __shfl(pin, 63, 64);
         }
     }
-    if (QUAD) {
-        if (lane == 0 && (i >> 6) <= ((P - 1) >> 6)) wave_rows[i >> 6] = rows_run;
-        if (i < P) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
-    }
-}
-
-// exclusive prefix of the emit waves' row counts as a kernel of its own (the tile sort's histogram kernel normally does
-// it on the side, radix_sort.hip)
-__global__ void __launch_bounds__(256) wave_base_kernel(int nw, const uint32_t* __restrict__ wave_rows, uint32_t* __restrict__ wave_base) {
-    gs2m_wave_base_scan(nw, wave_rows, wave_base);
+    if (lane == 0 && (i >> 6) <= ((P - 1) >> 6)) wave_rows[i >> 6] = rows_run;
+    if (i < P) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
 }
 
 // identifyTileRanges (rasterizer_impl.cu:108-129) on the sorted tile ids.
@@ -267,31 +255,11 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict
     if (tid < 4) qcount[tile * 4 + tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
 }
 
-// observe[g] = sum of the per-instance counts the forward blend stored in emission order
-// (replaces the per-pixel atomicAdd at forward.cu:348-350).
-__global__ void observe_kernel(int P, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ sorted_tt,
-                               const uint32_t* __restrict__ sorted_off, const uint32_t* __restrict__ inst_obs,
-                               int* __restrict__ observe) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t n = sorted_tt[i], off = sorted_off[i];
-    uint32_t sum = 0;
-    for (uint32_t t = 0; t < n; t++) sum += inst_obs[off + t];
-    observe[sorted_gid[i]] = (int)sum;
-}
-
 }  // namespace
 
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, bool quad_masks, const ZeroJobs& zero, hipStream_t s) {
-    if (quad_masks)
-        emit_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                          b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
-    else
-        emit_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                           b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
-}
-void gs2m_launch_wave_base(int P, const GeomState& g, hipStream_t s) {
-    wave_base_kernel<<<1, 256, 0, s>>>((P + 63) / 64, g.wave_rows, g.wave_base);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
+                                                b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them
@@ -320,7 +288,4 @@ void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomSt
                             const ImageState& im, hipStream_t s) {
     (void)W; (void)H; (void)g;
     quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges, b.point_list, b.qlist, im.qcount);
-}
-void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s) {
-    observe_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, b.inst_obs, out_observe);
 }

@@ -1,19 +1,32 @@
-// Backward of the alpha compositing for gfx950, list-driven matrix-core variant.
+// Backward of the alpha compositing for gfx950.
 //
 // Semantics: renderCUDA (bwd), diff-gaussian-rasterization/cuda_rasterizer/backward.cu:413-598 -- same per-pixel tests,
-// same gradients as blend_bwd_mfma.hip (whose header explains the lane layout: 16 survivors x 4 pixel columns per
-// instruction, DPP scans across survivors, fp32 MFMAs for the sums over pixels, packed fp32 pixel pairs) and the
-// SAME group arithmetic, instruction for instruction.  What changed is how a group gets its 16 survivors: the wave
-// owns one 8x8 quadrant and walks the quadrant's own list (binning.hip:quad_lists_kernel) from the quadrant's last
-// contributor backwards, 16 entries at a time.  Every entry survives the quadrant test by construction, so the
-// batch machinery of blend_bwd_mfma.hip -- staging 32 instances of the TILE list in LDS, testing them against the
-// quadrant, compacting the hits, refilling lanes across batch borders: a third of that kernel's issue slots -- is
-// gone: lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2), the
-// loads for the next group are issued before the current group's epilogue and land behind it.
+// same gradients.  The reference walks a tile's list back to front with one thread per pixel and adds every
+// (pixel, Gaussian) pair's 11 + fc gradient components to global memory with atomicAdd (:551-595).  Here:
+//  * a wave owns one 8x8 quadrant and walks the quadrant's own list (binning.hip: quad_lists_kernel) from the
+//    quadrant's last contributor backwards, 16 entries ("survivors": every entry passed the quadrant test when the list
+//    was built) per group;
+//  * lane = (survivor j = lane & 15, pixel column r = lane >> 4): a group walks the 64 pixels in 8 double-steps, each
+//    lane evaluating its two pixels (r, y) and (r + 4, y) of one image row as ONE packed fp32 pair;
+//  * with w_i = alpha_i T_i the reference's recurrence for the colour behind a survivor (backward.cu:530-550) becomes
+//    dL/dalpha_i = T_i (c_i . g) - S_i / (1 - alpha_i), S_i = sum over the survivors BEHIND i of w_k (c_k . g) + the
+//    background term: ONE scalar recurrence per pixel instead of one per channel.  T_i (a running product of
+//    1 / (1 - alpha)) and S_i (a running sum) across the 16 survivors of a group are Kogge-Stone scans over the 16 lanes
+//    of a DPP row; their values at the group's front are carried to the next group through LDS (s_T2, s_S2);
+//  * the sums over pixels are fp32 MFMAs (v_mfma_f32_16x16x4_f32): dL/dcolour,feature[survivor][channel] =
+//    W[survivor][pixel] x Ggrad[pixel][channel], and the colour . gradient dots (c_i . g)[pixel][survivor] =
+//    Ggrad x C^T in an accumulator layout that needs no transposition (see scB / gA below);
+//  * the geometry gradients (dL/dmean2D with its two |.| channels, dL/dconic, dL/dopacity) come from six moments of
+//    s = opacity dL/dalpha G about the quadrant centre, reduced over the 4 pixel-column lanes of a survivor with
+//    permlane32 / permlane16 swaps;
+//  * lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2); the loads for
+//    the next group are issued before the current group's epilogue and land behind it.
 // One wave per quadrant (64-thread workgroups, no barriers), XCD-aware block ids, one partial-gradient row per
-// (instance, quadrant) in the DENSE numbering emit_kernel<true> prepared (binning.hip): the rows of a Gaussian are one
+// (instance, quadrant) in the DENSE numbering emit_kernel prepared (binning.hip): the rows of a Gaussian are one
 // contiguous run, every row is written (zeros for the entries behind a quadrant's last contributor), and
-// gaussian_bwd.hip streams them.
+// gaussian_bwd.hip streams them.  No float atomics anywhere: gradients are bitwise reproducible.
+// Measured and not kept in round 3: one workgroup per TILE whose four quadrant waves combine an
+// instance's sums in an LDS table before they leave the chip (one row per instance instead of one per quadrant).
 #include "common.h"
 
 namespace {
@@ -285,7 +298,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 row_scan_add2(qv.x, qv.y, Sx, Sy);
                 const v2f Sinc = {Sx, Sy};
                 const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
-                const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of blend_bwd.hip)
+                const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of this file)
                 if (j == 15) {
                     const v2f Sn = S2[h] + Sinc;
                     s_T2[pi] = make_float2(Ti.x, Ti.y);
@@ -386,10 +399,12 @@ int fc_template(int fc) { return fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10)
 
 }  // namespace
 
+int gs2m_row_floats(int fc) { return ((ROW_FEAT + fc_template(fc) + 3) / 4) * 4; }
+
+// every row of the dense numbering is written (zeros behind a quadrant's last contributor)
 void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
-                                const BinningState& b, const ImageState& im, const float* grad_color,
-                                const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s) {
-    (void)row_valid;  // every row of the dense numbering is written (zeros behind a quadrant's last contributor)
+                             const BinningState& b, const ImageState& im, const float* grad_color,
+                             const float* grad_buffer, float* rows, hipStream_t s) {
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
 #define GS2M_BWDQ(FC)                                                                                                      \

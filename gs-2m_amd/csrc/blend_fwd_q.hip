@@ -1,18 +1,17 @@
-// Per-quadrant front-to-back alpha compositing (forward) for gfx950, list-driven variant.
+// Per-quadrant front-to-back alpha compositing (forward) for gfx950.
 //
 // Semantics: renderCUDA, diff-gaussian-rasterization/cuda_rasterizer/forward.cu:246-372 -- the same per-pixel
-// sequence of tests and updates as blend_fwd.hip (which stays in the library as the cross-check,
-// gs2m_set_bwd_impl(1 / 0)), on the per-quadrant lists binning.hip:quad_lists_kernel builds.
+// sequence of tests and updates, on the per-quadrant lists binning.hip:quad_lists_kernel builds.
 //
 // One wave per 8x8 quadrant, pixel per lane, no workgroup barriers: every list entry survives the quadrant test by
 // construction, so the wave walks its list straight down, 16 entries per chunk.  The chunk's blend records are
 // gathered by the wave itself (lane = entry x record quad, full 16-B loads) a whole chunk ahead of their use and
 // parked in LDS; the evaluation reads them back with wave-uniform (broadcast) addresses at constant offsets, so the
-// inner loop is fully unrolled and spends no vector instruction on addressing, ballot walks or quadrant tests
-// (blend_fwd.hip: ~30 scalar + ~8 vector instructions per survivor on those).  Lane predicates live in SGPR pairs
-// as wave masks.  A first version fetched the records with SCALAR loads (s_load_dwordx8 one entry ahead, SGPR
-// operands): it ran at half the speed -- scalar loads return out of order, so the only wait is "all of them", the
-// prefetch distance is one evaluation, and the ~0.45 us load latency was exposed on every entry.
+// inner loop is fully unrolled and spends no vector instruction on addressing, ballot walks or quadrant tests.
+// Lane predicates live in SGPR pairs as wave masks.  A first version fetched the records with SCALAR loads
+// (s_load_dwordx8 one entry ahead, SGPR operands): it ran at half the speed -- scalar loads return out of order, so
+// the only wait is "all of them", the prefetch distance is one evaluation, and the ~0.45 us load latency was exposed
+// on every entry.
 // Two other forms were built and measured: the alpha of two consecutive entries as packed fp32
 // pairs out of a component-wise LDS layout (5 fewer vector instructions per entry, but 76 VGPRs = 6 waves per SIMD
 // and the LDS reads right in front of their use: 0.30 instead of 0.27 ms), and the scalar-load form with the record

@@ -17,15 +17,15 @@
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
 //         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
 //         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
-// q7: x = u32 index of the emit wave (depth rank / 64) that owns the Gaussian's gradient rows (list-driven blend
-//     kernels, binning.hip); y, z, w unused
+// q7: x = u32 index of the emit wave (depth rank / 64) that owns the Gaussian's gradient rows (binning.hip);
+//     y, z, w unused
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
 #define REC_BIN 2
 #define REC_CH 3
 #define REC_AUX 7
-// list-driven blend kernels: the sorted values carry the instance's quadrant-hit mask above the Gaussian id
+// the sorted values carry the instance's quadrant-hit mask above the Gaussian id
 #define GS2M_GID_BITS 28
 #define GS2M_GID_MASK 0x0FFFFFFFu
 
@@ -49,8 +49,8 @@ struct GeomState {
     uint32_t* sorted_off;    // P
     uint8_t* clamped;        // P
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
-    uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order (list-driven kernels)
-    uint32_t* wave_rows;     // ceil(P / 64) + 1: gradient rows of each emit wave's 64 Gaussians (list-driven kernels)
+    uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order
+    uint32_t* wave_rows;     // ceil(P / 64) + 1: gradient rows of each emit wave's 64 Gaussians
     uint32_t* wave_base;     // ceil(P / 64) + 1: exclusive prefix of wave_rows; [nw] = total rows
     char* temp;              // radix sort / scan temporary storage
     size_t temp_bytes;
@@ -63,8 +63,7 @@ struct BinningState {
     uint32_t* sort_valA;     // R
     uint32_t* tile_keys;     // R (sorted)
     uint32_t* point_list;    // R (sorted Gaussian ids)
-    uint32_t* inst_obs;      // R: per-instance observe counts (tile-list kernels) / per-instance row offset inside its
-                             //    emit wave's row range (list-driven kernels)
+    uint32_t* inst_obs;      // R: per-instance row offset inside its emit wave's range of gradient rows
     uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id, position in the tile list};
                              //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
     char* temp;
@@ -247,11 +246,8 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, bool quad_masks, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_wave_base(int P, const GeomState& g, hipStream_t s);
-void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const BinningState& b, const float* rows, int rowf, float* sums, hipStream_t s);
-void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                            int rstride, int rpi, float* sums, hipStream_t s);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
 void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
@@ -262,26 +258,15 @@ void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, con
                              int* out_observe, hipStream_t s);
 void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                              const BinningState& b, const ImageState& im, const float* grad_color,
-                             const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
-void gs2m_launch_blend_fwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
-                           const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
-                           hipStream_t s);
-void gs2m_launch_observe(int P, const GeomState& g, const BinningState& b, int* out_observe, hipStream_t s);
-int gs2m_row_floats(int fc);
-void gs2m_launch_blend_bwd(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
-                           const BinningState& b, const ImageState& im, const float* grad_color,
-                           const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
-int gs2m_row_floats_mfma(int fc);
-void gs2m_launch_blend_bwd_mfma(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
-                                const BinningState& b, const ImageState& im, const float* grad_color,
-                                const float* grad_buffer, float* rows, uint8_t* row_valid, hipStream_t s);
+                             const float* grad_buffer, float* rows, hipStream_t s);
+int gs2m_row_floats(int fc);  // floats per partial-gradient row: 11 + fc, padded to a multiple of 4
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                               const float* colors_precomp,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
-                              int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                              int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              int fc, const GeomState& g, const float* rows, int rowf,
+                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s);
 void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
     const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ rows,
-    const uint8_t* __restrict__ row_valid, int rowf, int rpi, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
+    int rowf, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
@@ -342,125 +342,14 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     }
 }
 
-// Sum of the partial-gradient rows of every Gaussian, ahead of gaussian_bwd_kernel.
-// Threads run in DEPTH-SORTED order (the order the emission slots were assigned in), so the instances of the 64
-// Gaussians of a wave are ONE contiguous range of slots.  The wave walks that range 64 instances at a time:
-// (a) every lane loads the valid flags and the <= RPI rows of ONE instance (predicated, all in flight
-// together) and adds them in quadrant order; (b) the per-instance sums go through LDS; (c) the LDS phase runs
-// with rq lanes per Gaussian -- lane = (group, float4 chunk) -- one LDS read and one float4 add per step, every
-// group walking its own Gaussians in order.  Fixed summation order: bitwise reproducible.
-// What this replaces -- a per-thread walk over the Gaussian's instances with dependent valid -> row loads --
-// left most lanes idle (6.7 iterations per wave for a mean of 2.7 instances).
-template <int RPI>
-__global__ void __launch_bounds__(256) row_reduce_kernel(int P, const uint32_t* __restrict__ sorted_gid,
-                                                         const uint32_t* __restrict__ sorted_tt,
-                                                         const uint32_t* __restrict__ sorted_off,
-                                                         const float* __restrict__ rows,
-                                                         const uint8_t* __restrict__ row_valid, int rowf,
-                                                         float* __restrict__ sums) {
-    constexpr int MAXQ = 6;  // float4 per row at most (11 + 10 features, padded)
-    __shared__ float4 s_inst[4][GS2M_WAVE][MAXQ];
-    __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t cnt = 0, off = 0, gid = 0xFFFFFFFFu;
-    if (i < P) {
-        cnt = sorted_tt[i];
-        off = sorted_off[i];
-        gid = sorted_gid[i];
-    }
-    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64);
-    // first slot of the wave: offsets are exclusive scans in this very order, so instance k of the wave is base + k
-    // (lanes beyond P carry off = 0: take the first lane's, which is in range whenever total > 0)
-    const uint32_t base = __shfl(off, 0, 64);
-    s_excl[wave][lane] = incl - cnt;
-    s_cnt[wave][lane] = cnt;
-    s_gidw[wave][lane] = gid;
-    const int rq = rowf >> 2;
-    // (c) runs with rq lanes per Gaussian -- lane = (group g, float4 chunk c) -- so that one step is ONE LDS read
-    // and one float4 add per lane with all groups busy; group g owns the Gaussians g, g + G, g + 2G, ... of the
-    // wave, in order, and keeps the running sum of its current one in registers across windows.
-    const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
-    const bool worker = g < G;
-    uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;  // this group's current Gaussian (index within the wave)
-    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // The windows of a wave are a serial chain (valid byte -> row -> LDS -> sum) with few waves per CU to hide
-    // it, so the chain is cut: the valid bytes of the first 32 windows are fetched up front (independent loads),
-    // and the rows of window w + 1 are requested before window w is summed.
-    uint32_t vbits = 0;  // RPI valid flags per window, the first 32 / RPI windows
-    constexpr uint32_t PRE = 32 / RPI;
-    const uint32_t nwin = (total + GS2M_WAVE - 1) / GS2M_WAVE;
-    auto valid_flags = [&](uint32_t k) -> uint32_t {  // bit q: row q of instance k of the wave is valid
-        if (k >= total) return 0u;
-        const size_t slot = (size_t)base + k;
-        if (RPI == 4) {
-            const uint32_t w4 = reinterpret_cast<const uint32_t*>(row_valid)[slot];  // the instance's 4 valid bytes
-            return (w4 & 0xFFu ? 1u : 0u) | (w4 & 0xFF00u ? 2u : 0u) | (w4 & 0xFF0000u ? 4u : 0u) | (w4 & 0xFF000000u ? 8u : 0u);
-        }
-        return row_valid[slot] != 0 ? 1u : 0u;
-    };
-    for (uint32_t w = 0; w < min(nwin, PRE); w++) vbits |= valid_flags(w * GS2M_WAVE + lane) << (RPI * w);
-    auto load_window = [&](uint32_t w, float4* a) {
-        const uint32_t k = w * GS2M_WAVE + lane;
-        const size_t slot = (size_t)base + k;
-        uint32_t fl = 0;
-        if (w < nwin) fl = w < PRE ? (vbits >> (RPI * w)) & ((1u << RPI) - 1u) : valid_flags(k);
-        float4 rv[RPI][MAXQ];  // predicated loads, no branches: all rows of the instance are in flight together
-#pragma unroll
-        for (int q = 0; q < RPI; q++) {
-            const bool on = ((fl >> q) & 1u) != 0;
-            const float4* r4 = reinterpret_cast<const float4*>(rows + (slot * RPI + q) * rowf);
-#pragma unroll
-            for (int e = 0; e < MAXQ; e++) rv[q][e] = (on && e < rq) ? r4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int e = 0; e < MAXQ; e++) a[e] = rv[0][e];
-#pragma unroll
-        for (int q = 1; q < RPI; q++)
-#pragma unroll
-            for (int e = 0; e < MAXQ; e++) {
-                a[e].x += rv[q][e].x; a[e].y += rv[q][e].y; a[e].z += rv[q][e].z; a[e].w += rv[q][e].w;
-            }
-    };
-    float4 anext[MAXQ];
-    load_window(0, anext);
-    // one extra pass (w == nwin, empty window) lets every group finish and write its remaining Gaussians
-    for (uint32_t w = 0; w <= nwin; w++) {
-        const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
-        if (w < nwin) {
-#pragma unroll
-            for (int q = 0; q < MAXQ; q++)
-                if (q < rq) s_inst[wave][lane][q] = anext[q];
-            load_window(w + 1, anext);
-        }
-        // LDS operations of one wave execute in order: the reads below see the writes above
-        while (j < GS2M_WAVE) {
-            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
-            if (ex >= k1 && cn > 0) break;  // starts in a later window
-            const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
-            for (uint32_t t = t0; t < t1; t++) {
-                const float4 v = s_inst[wave][t - k0][c];
-                racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
-            }
-            if (ex + cn > k1) break;  // continues in the next window
-            const uint32_t gj = s_gidw[wave][j];
-            if (gj != 0xFFFFFFFFu) reinterpret_cast<float4*>(sums + (size_t)gj * rowf)[c] = racc;
-            racc = make_float4(0.f, 0.f, 0.f, 0.f);
-            j += (uint32_t)G;
-        }
-    }
-}
-
-
-// The same per-Gaussian sum for the list-driven backward (blend_bwd_q.hip), whose rows are numbered DENSELY: emit wave
+// Sum of the partial-gradient rows of every Gaussian, ahead of gaussian_bwd_kernel.  The backward blend
+// (blend_bwd_q.hip) numbers its rows DENSELY: emit wave
 // w (the same 64 depth-sorted Gaussians this kernel's wave w owns) has the rows [wave_base[w], wave_base[w + 1]), Gaussian
 // by Gaussian (sorted_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows
 // per window as five fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked
 // in LDS, then rq lanes per Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance
-// gather (the slot-major layout of the tile-list kernels fetches 1.7x the useful bytes with 20 strided loads per lane).
-// Fixed summation order (the dense numbering: quadrants ascending within an instance, instances in emission order):
-// bitwise reproducible, and the same order as the slot-major kernel's.
+// gather.  Fixed summation order (the dense numbering: quadrants ascending within an instance, instances in emission
+// order): bitwise reproducible.
 __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint32_t* __restrict__ sorted_gid,
                                                                const uint32_t* __restrict__ sorted_rows,
                                                                const uint32_t* __restrict__ wave_base,
@@ -526,17 +415,7 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
 
 }  // namespace
 
-void gs2m_launch_row_reduce(int P, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                            int rstride, int rpi, float* sums, hipStream_t s) {
-    (void)rstride;  // rows are packed at rowf floats
-    if (rpi == 4)
-        row_reduce_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
-    else
-        row_reduce_kernel<1><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_tt, g.sorted_off, rows, row_valid, rowf, sums);
-}
-
-void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const BinningState& b, const float* rows, int rowf, float* sums, hipStream_t s) {
-    (void)b;
+void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s) {
     row_reduce_dense_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.wave_base, rows, rowf, sums);
 }
 
@@ -545,8 +424,8 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
-                              int fc, const GeomState& g, const float* rows, const uint8_t* row_valid, int rowf,
-                              int rows_per_inst, float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
+                              int fc, const GeomState& g, const float* rows, int rowf,
+                              float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
@@ -554,8 +433,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
     gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
         projmatrix,                                                                                                     \
-        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, row_valid, rowf,      \
-        rows_per_inst,                                                                                                  \
+        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, rowf,                 \
         dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales,  \
         dL_drots,                                                                                                       \
         dL_dfeatures)

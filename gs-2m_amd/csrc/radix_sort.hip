@@ -68,32 +68,48 @@ SortPlan make_plan(int total_bits) {
 }
 
 // ---- histogram of every digit of every pass, one read of the keys ----
+// At most RS_HIST_WGS workgroups stride over the 4096-key tiles and keep their counts in LDS until the end, so the
+// global histogram receives at most RS_HIST_WGS x (non-empty bins) atomic adds (one workgroup per tile sent 190 k adds
+// to the 1024 words of the depth sort: same-address atomics serialise at the memory side).  The LDS counters are
+// replicated RS_HIST_REP times (replica = lane & 15): depth keys of a scene share their top byte, and 64 lanes adding
+// to ONE LDS word serialise 64-fold; with the replicas it is 4-fold at worst.  The side sum is kept per thread and
+// reduced across the wave at the end (it used to be an LDS atomic on one word per key).
+#ifndef RS_HIST_WGS_N
+#define RS_HIST_WGS_N 512
+#endif
+constexpr int RS_HIST_WGS = RS_HIST_WGS_N;
+constexpr int RS_HIST_REP = 16;
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npass,
                                                              int4 bits, int4 shift, uint32_t* __restrict__ ghist, int tiles,
-                                                             SideScan side, SideSum sum) {
-    __shared__ uint32_t s_h[RS_MAXPASS][256];
+                                                             int workers, SideScan side, SideSum sum) {
+    __shared__ uint32_t s_h[RS_MAXPASS][256][RS_HIST_REP];
     __shared__ uint32_t s_sum;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_sum = 0;
-    if ((int)blockIdx.x == tiles) {  // the extra workgroup: a small scan that is due at about this point of the stream
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x == workers) {  // the extra workgroup: a small scan that is due at about this point of the stream
         gs2m_wave_base_scan(side.nw, side.wave_rows, side.wave_base);
         return;
     }
-    for (int p = 0; p < RS_MAXPASS; p++) s_h[p][tid] = 0;
+    if (tid == 0) s_sum = 0;
+    for (int i = tid; i < RS_MAXPASS * 256 * RS_HIST_REP; i += RS_THREADS) (&s_h[0][0][0])[i] = 0;
     gs2m_sync();
     const int b[4] = {bits.x, bits.y, bits.z, bits.w}, sh[4] = {shift.x, shift.y, shift.z, shift.w};
-    const uint32_t base = blockIdx.x * RS_TILE;
+    const int rep = lane & (RS_HIST_REP - 1);
+    uint32_t tsum = 0;
+    for (int tile = blockIdx.x; tile < tiles; tile += workers) {
+        const uint32_t base = (uint32_t)tile * RS_TILE;
 #pragma unroll 4
-    for (int k = 0; k < RS_ITEMS; k++) {
-        const uint32_t i = base + k * RS_THREADS + tid;
-        if (i < n) {
-            const uint32_t key = keys[i];
-            for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key >> sh[p]) & ((1u << b[p]) - 1u)], 1u);
-            if (sum.tt) {
-                const uint32_t t = sum.tt[i];
-                if (t) atomicAdd(&s_sum, t);
+        for (int k = 0; k < RS_ITEMS; k++) {
+            const uint32_t i = base + k * RS_THREADS + tid;
+            if (i < n) {
+                const uint32_t key = keys[i];
+                for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key >> sh[p]) & ((1u << b[p]) - 1u)][rep], 1u);
+                if (sum.tt) tsum += sum.tt[i];
             }
         }
+    }
+    if (sum.tt) {
+        tsum = wave_inclusive_scan_u32(tsum, lane);
+        if (lane == 63 && tsum) atomicAdd(&s_sum, tsum);
     }
     gs2m_sync();
     if (sum.tt && tid == 0) {
@@ -103,14 +119,20 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
         __hip_atomic_fetch_add(sum.acc, s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         const uint32_t done = __hip_atomic_fetch_add(sum.acc + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (uint32_t)tiles - 1u) {
+        if (done == (uint32_t)workers - 1u) {
             const uint32_t total = __hip_atomic_exchange(sum.acc, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sum.acc + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sum.landing, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     for (int p = 0; p < npass; p++) {
-        const uint32_t c = s_h[p][tid];
+        const uint4* r4 = reinterpret_cast<const uint4*>(&s_h[p][tid][0]);
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < RS_HIST_REP / 4; q++) {
+            const uint4 v = r4[q];
+            c += v.x + v.y + v.z + v.w;
+        }
         if (c) atomicAdd(&ghist[p * 256 + tid], c);
     }
 }
@@ -296,8 +318,9 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
-    rs_hist_kernel<<<tiles + (side.nw > 0 ? 1 : 0), RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
-                                                                        make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, side, sum);
+    const int workers = tiles < RS_HIST_WGS ? tiles : RS_HIST_WGS;
+    rs_hist_kernel<<<workers + (side.nw > 0 ? 1 : 0), RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
+                                                                          make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, workers, side, sum);
     const uint32_t *ki = kin, *vi = vin;
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;

@@ -20,6 +20,7 @@ import threading
 import torch
 import torch.nn as nn
 
+import gs2m_arena as _arena
 import gs2m_native as _native
 
 NUM_CHANNELS = 3
@@ -110,33 +111,55 @@ class _ScratchCache(_Alloc):
         return super()._alloc(nbytes, _user)
 
 
+class _BinningLease:
+    """Exclusive use of one cache entry's buffer; given back when this object dies.  The autograd Function keeps it on
+    `ctx`, so the buffer is the forward's for exactly as long as its graph node lives: until the backward has run and
+    the outputs are gone, or for good while a retained graph keeps the node."""
+
+    def __init__(self, entry):
+        self.entry = entry
+
+    def __del__(self):
+        e, self.entry = self.entry, None
+        if e is not None:
+            with _BinningCache._lock:
+                e.busy = False
+
+
 class _BinningCache:
     """The binning buffer can only be sized after the forward's host wait for num_rendered, and the GPU idles from that
     wait until the next kernel is launched: a Python allocator callback in that window is pure GPU idle time.  So the
-    autograd path keeps one buffer per device from call to call (25 % larger than the largest request seen) and hands
-    it to the library through its C-level gs2m_prealloc_alloc; Python is only called when it does not fit.
-    The buffer is FREE exactly when nothing but this cache references it: autograd holds a reference from
-    save_for_backward until the backward has released its saved tensors (retain_graph keeps it), so a forward that finds
-    the count above one -- two views rendered before either backward, a retained graph -- allocates as before."""
+    autograd path keeps one buffer per (device, stream) from call to call (25 % larger than the largest request seen)
+    and hands it to the library through its C-level gs2m_prealloc_alloc; Python is only called when it does not fit.
+    Ownership is explicit: a forward takes a _BinningLease on the entry and parks it on its autograd node; a forward
+    that finds the entry leased -- two views rendered before either backward, a retained graph -- allocates as before.
+    Entries are per stream because the buffer bypasses the caching allocator's stream tracking: work queued on one
+    stream is ordered, so the next forward on THAT stream may overwrite what the previous backward has finished with.
+    Retained memory: 1.25 x the largest binning buffer per (device, stream) until release_scratch()."""
     _cache = {}
+    _lock = threading.Lock()
 
     def __init__(self):
         self.tensor = None
-
-    def free(self):
-        return self.tensor is not None and self.tensor._use_count() == 1
+        self.busy = False
 
     @classmethod
-    def get(cls, device):
-        key = torch.device(device).index
-        c = cls._cache.get(key)
-        if c is None:
-            c = cls._cache[key] = cls()
-        return c
+    def acquire(cls, device, stream):
+        """-> (entry, lease); lease is None when the entry is in use."""
+        key = (torch.device(device).index, stream)
+        with cls._lock:
+            e = cls._cache.get(key)
+            if e is None:
+                e = cls._cache[key] = cls()
+            if e.busy:
+                return e, None
+            e.busy = True
+        return e, _BinningLease(e)
 
     @classmethod
     def release(cls):
-        cls._cache.clear()
+        with cls._lock:
+            cls._cache.clear()
 
 
 class _CModule:
@@ -146,7 +169,7 @@ class _CModule:
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                             features, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, featureCount, sh_rest=None, _cached_binning=False):
+                            campos, prefiltered, featureCount, sh_rest=None, _cached_binning=False, _lease_out=None):
         """`sh_rest` (this repository's extension): when given, `sh` is the DC part (P,1,3) and `sh_rest` the other
         coefficients (P,M-1,3), as the reference model stores them -- no concatenation needed (M = 16 only)."""
         if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -173,9 +196,10 @@ class _CModule:
         radii = torch.empty((P,), dtype=torch.int32, device=device)
         observe = torch.empty((P,), dtype=torch.int32, device=device)
         geom, binning, img = _Alloc.three(device)
-        cache = _BinningCache.get(device) if _cached_binning else None  # the autograd path only: `_C` callers own what they get
+        # the autograd path only (`_C` callers own what they get): the cached buffer of this (device, stream), if free
+        cache, lease = _BinningCache.acquire(device, _stream()) if _cached_binning else (None, None)
         pre = None
-        if cache is not None and cache.free():
+        if lease is not None and cache.tensor is not None:
             pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0)
             if _CModule._prealloc_cb is None:
                 _CModule._prealloc_cb = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN)
@@ -194,10 +218,13 @@ class _CModule:
         _native.check(rendered, "gs2m_raster_forward")
         if pre is not None and not pre.used_fallback:
             bin_tensor = cache.tensor
+            if _lease_out is not None:
+                _lease_out.append(lease)  # the caller keeps the buffer leased for as long as it needs it
         else:
             bin_tensor = binning.take()
-            if cache is not None and (cache.tensor is None or cache.free()):  # a buffer 25 % larger than this request for the next call
+            if lease is not None:  # the entry is ours but empty or too small: a buffer 25 % larger than this request for the next call
                 cache.tensor = torch.empty(int(bin_tensor.numel() * 1.25) + 4096, dtype=torch.uint8, device=device)
+        del lease
         return rendered, out_color, radii, observe, out_buffer, geom.take(), bin_tensor, img.take()
 
     @staticmethod
@@ -227,30 +254,25 @@ class _CModule:
         viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
         sh = _f32c(sh, "shs"); campos = _f32c(campos, "campos"); buffer = _f32c(buffer, "buffer")
         radii = radii.contiguous()
-        # Every gradient tensor is a view into ONE buffer (256-B aligned offsets; the kernels write every element, so
-        # no zero fill): data-parallel training sums the whole per-Gaussian gradient of a view with a single
-        # collective over that arena (gs2m_dp.GradReducer.common_arena) instead of one per tensor.
-        shapes = [("means3D", (P, 3)), ("means2D", (P, 4)), ("colors", (P, NUM_CHANNELS)), ("features", (P, NUM_FEATURES)),
-                  ("opacities", (P, 1)), ("cov3D", (P, 6)), ("shs", (P, 1 if split else M, 3)), ("scales", (P, 3)),
-                  ("rotations", (P, 4))]
+        # Every gradient tensor is a view into ONE registered arena (gs2m_arena; the kernels write every element, so no
+        # zero fill).  What a data-parallel step sums across ranks comes first and adjacent -- means3D, opacities, scales,
+        # rotations, features, SH (the SH tensor(s) last, so that a step below the maximal SH degree can sum the rest with
+        # one collective and the active bands separately) -- then what it does not: dL/dmeans2D (its per-view NORMS are
+        # what densification accumulates, train.py:223-227), and the gradients of inputs that are usually absent
+        # (precomputed colours / covariances, scene/gaussian_model.py:230-240 has no such parameter), dL/dconic.
+        entries = [("means3D", (P, 3)), ("opacities", (P, 1)), ("scales", (P, 3)), ("rotations", (P, 4)),
+                   ("features", (P, NUM_FEATURES)), ("shs", (P, 1 if split else M, 3))]
         if split:
-            shapes.append(("shs_rest", (P, M - 1, 3)))
+            entries.append(("shs_rest", (P, M - 1, 3)))
+        entries += [("means2D", (P, 4)), ("colors", (P, NUM_CHANNELS)), ("cov3D", (P, 6))]
         if return_conics:
-            shapes.append(("conics", (P, 2, 2)))
-        offs, total = {}, 0
-        for name, shp in shapes:
-            n = 1
-            for d in shp:
-                n *= d
-            offs[name] = (total, n, shp)
-            total += (n + 63) // 64 * 64
-        arena = (torch.zeros if P == 0 else torch.empty)(max(total, 1), dtype=torch.float32, device=device)
-        view = lambda name: arena[offs[name][0]:offs[name][0] + offs[name][1]].view(offs[name][2])
-        dL_dmeans3D = view("means3D"); dL_dmeans2D = view("means2D"); dL_dcolors = view("colors")
-        dL_dfeatures = view("features"); dL_dopacities = view("opacities"); dL_dcov3D = view("cov3D")
-        dL_dshs = view("shs"); dL_dscales = view("scales"); dL_drotations = view("rotations")
-        dL_dshs_rest = view("shs_rest") if split else None
-        dL_dconics = view("conics") if return_conics else None
+            entries.append(("conics", (P, 2, 2)))
+        arena = _arena.GradArena(device, entries, zero=(P == 0))
+        dL_dmeans3D = arena["means3D"]; dL_dmeans2D = arena["means2D"]; dL_dcolors = arena["colors"]
+        dL_dfeatures = arena["features"]; dL_dopacities = arena["opacities"]; dL_dcov3D = arena["cov3D"]
+        dL_dshs = arena["shs"]; dL_dscales = arena["scales"]; dL_drotations = arena["rotations"]
+        dL_dshs_rest = arena.get("shs_rest")
+        dL_dconics = arena.get("conics")
         scratch = _ScratchCache.get(device, _stream())
         with torch.cuda.device(device):
             bwd = L.gs2m_raster_backward_split_sh if split else L.gs2m_raster_backward
@@ -311,11 +333,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
                 raster_settings.image_height, raster_settings.image_width, shs, raster_settings.sh_degree,
                 raster_settings.campos, raster_settings.prefiltered, raster_settings.feature_count)
+        lease = []
         num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
-            *args, sh_rest=shs_rest, _cached_binning=True)
+            *args, sh_rest=shs_rest, _cached_binning=True, _lease_out=lease)
+        ctx.binning_lease = lease[0] if lease else None  # given back when this graph node dies
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
-        ctx.blend_impl = _native.lib().gs2m_get_bwd_impl()  # the scratch buffers are private to the kernels that wrote them
+        # radii and observe carry no gradient: without this autograd materialises a zero tensor for each of them in front
+        # of every backward (two fill kernels of P elements on the stream)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs,
                               geomBuffer, binningBuffer, imgBuffer, shs_rest)
         ctx.mark_non_differentiable(radii, observe)
@@ -325,10 +351,6 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_out_radii, grad_out_observe, grad_out_buffer):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
-        now = _native.lib().gs2m_get_bwd_impl()
-        if (now == 2) != (ctx.blend_impl == 2):
-            raise RuntimeError(f"gs2m rasterizer: the blend implementation was switched between this forward ({ctx.blend_impl}) and its "
-                               f"backward ({now}): the list-driven kernels (2) and the tile-list kernels (0, 1) keep different private state")
         (buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs, geomBuffer,
          binningBuffer, imgBuffer, shs_rest) = ctx.saved_tensors
         if grad_out_color is None:

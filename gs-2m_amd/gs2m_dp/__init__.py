@@ -8,7 +8,9 @@ exchange inside forward/backward.
 
 Dense gradient payload per Gaussian (param list scene/gaussian_model.py:230-240):
 xyz 3, SH 3*M, opacity 1, scaling 3, rotation 4, material (albedo 3, roughness 1,
-metallic 1) = 64 floats at M = 16.  Side channels used by densification
+metallic 1) = 64 floats at M = 16; below the maximal SH degree only the active bands
+travel (19 / 28 / 43 / 64 floats at degree 0 / 1 / 2 / 3).  The sums run in place over
+registered gradient arenas (gs2m_arena) wherever autograd left the gradients in one.  Side channels used by densification
 (train.py:225-227, scene/gaussian_model.py:569-573) are reduced with the semantics the
 single-GPU loop has: per-view norms of the screen-space gradient are summed, the
 visibility count is summed, radii are max-reduced and `observe` is summed.
@@ -30,7 +32,7 @@ class PendingReduce:
         for h in self.handles:
             h.wait()
         self.handles = []
-        for g, part in self.restore:
+        for g, part in self.restore:  # SH gradients summed as a packed copy of their active bands
             g[:, :part.shape[1]] = part
         self.restore = []
         if self.finish is not None:
@@ -48,10 +50,12 @@ class GradReducer:
     divisible by world size (tensors are padded internally otherwise fall back to allreduce).
     """
 
-    def __init__(self, group=None, mode="allreduce", sh_active_coeffs=None):
+    def __init__(self, group=None, mode="allreduce", sh_active_coeffs=None, always_communicate=False):
         self.group = group
         self.mode = mode
         self.sh_active_coeffs = sh_active_coeffs
+        self.always_communicate = always_communicate  # issue the collectives at world size 1 too (tests of the RCCL path on one GPU)
+        self.last_plan = []
 
     @property
     def world_size(self):
@@ -81,7 +85,7 @@ class GradReducer:
         -- overlaps them; `.wait()` then makes the current stream (gloo: the host) wait and returns the dict.
         The tensors must not be touched before `.wait()`."""
         pend = PendingReduce(grads)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_communicate:
             return pend
         for name, g in grads.items():
             if g is None:
@@ -100,59 +104,75 @@ class GradReducer:
         """grads: dict name -> contiguous tensor (summed in place across ranks). Returns the dict."""
         return self.reduce_grads_async(grads).wait()
 
-    # ---- one collective per step --------------------------------------------------------------------------------
-    @staticmethod
-    def common_arena(tensors):
-        """The flat fp32 tensor over the storage the given tensors all live in, or None.  The rasterizer binding
-        allocates every gradient it returns inside ONE buffer (diff_gaussian_rasterization: _grad_arena), so the
-        nine per-Gaussian gradients of a view can be summed with a single collective and no copy."""
-        ts = [t for t in tensors if t is not None and t.numel() > 0]
-        if not ts or any(t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
-            return None
-        st = ts[0].untyped_storage()
-        if any(t.untyped_storage().data_ptr() != st.data_ptr() for t in ts[1:]):
-            return None
-        covered = sum(t.numel() for t in ts)
-        total = st.nbytes() // 4
-        if covered * 2 < total:  # mostly something else's memory (e.g. slices of a large parameter blob)
-            return None
-        return torch.empty(0, dtype=torch.float32, device=ts[0].device).set_(st, 0, (total,))
-
-    def reduce_flat_async(self, tensors):
-        """Sum of a LIST of gradient tensors across ranks with ONE collective: in place on their common arena when they
-        share one, otherwise through one concatenated copy (the returned tensors are then views of that copy).
+    # ---- arenas: in-place sums over exactly the ranges the caller owns ----------------------------------------------
+    def reduce_flat_async(self, tensors, sh_active=None):
+        """Sum of a LIST of gradient tensors across ranks.  Tensors that are entries of a registered gradient arena
+        (gs2m_arena: the rasterizer binding's backward, the fused activation backward) are summed IN PLACE, one
+        collective per arena, over the smallest range that covers them -- and only if that range holds nothing the
+        caller did not pass (otherwise, and for loose tensors, one concatenated copy is summed and views of it are
+        returned).  Nothing outside the passed tensors is ever modified.
+        `sh_active`: {index into `tensors`: n} for SH gradients (P, M, 3) of which only the first n coefficients can be
+        non-zero on any rank (train.py:81-82: the SH degree is raised every 1000 iterations; bands above it receive no
+        gradient): only those travel, as one packed copy (n = 0: nothing travels); the binding puts the SH gradients at
+        the end of its arena's summed range so that the rest stays one range.
         -> PendingReduce whose .wait() gives the list of reduced tensors (same order; None entries stay None)."""
-        live = [t for t in tensors if t is not None]
+        import gs2m_arena
         pend = PendingReduce(list(tensors))
-        if self.world_size == 1 or not live:
+        live = [(i, t) for i, t in enumerate(tensors) if t is not None and t.numel() > 0]
+        if (self.world_size == 1 and not self.always_communicate) or not live:
             return pend
-        arena = self.common_arena(live)
-        if arena is not None:
-            self._sum(arena, pend.handles)
-            return pend
-        flat = torch.cat([t.reshape(-1) for t in live])
-        pad = (-flat.numel()) % self.world_size
-        if pad:
-            flat = torch.cat([flat, flat.new_zeros(pad)])
-        self._sum(flat, pend.handles)
-        out, off = [], 0
-        for t in tensors:
-            if t is None:
-                out.append(None)
+        trimmed = {}
+        for i, n in (sh_active or {}).items():
+            t = tensors[i]
+            if t is not None and t.dim() == 3 and 0 <= n < t.shape[1]:
+                trimmed[i] = t[:, :n].contiguous()
+        groups, loose = {}, []
+        for i, t in live:
+            if i in trimmed:
+                continue
+            info = gs2m_arena.lookup(t)
+            if info is None:
+                loose.append((i, t))
             else:
-                out.append(flat[off:off + t.numel()].view(t.shape))
+                groups.setdefault(id(info[0]), (info[0], []))[1].append((i, t, info[1], info[2]))
+        self.last_plan = []  # what the call did, for tests: [("arena", numel) | ("copy", numel) | ("sh", numel)]
+        for arena, items in groups.values():
+            rng = gs2m_arena.contiguous_range(arena, [(o, n) for _, _, o, n in items])
+            if rng is None:
+                loose += [(i, t) for i, t, _, _ in items]
+                continue
+            self._sum(arena.flat[rng[0]:rng[1]], pend.handles)
+            self.last_plan.append(("arena", rng[1] - rng[0]))
+        for i, part in trimmed.items():
+            if part.numel():
+                self._sum(part, pend.handles)
+                pend.restore.append((tensors[i], part))
+            self.last_plan.append(("sh", part.numel()))
+        if loose:
+            flat = torch.cat([t.reshape(-1) for _, t in loose])
+            pad = (-flat.numel()) % max(self.world_size, 1)
+            if pad:
+                flat = torch.cat([flat, flat.new_zeros(pad)])
+            self._sum(flat, pend.handles)
+            self.last_plan.append(("copy", flat.numel()))
+            off = 0
+            for i, t in loose:
+                pend.result[i] = flat[off:off + t.numel()].view(t.shape)
                 off += t.numel()
-        pend.result = out
         return pend
 
-    def reduce_flat(self, tensors):
-        return self.reduce_flat_async(tensors).wait()
+    def reduce_flat(self, tensors, sh_active=None):
+        return self.reduce_flat_async(tensors, sh_active).wait()
 
-    def reduce_parameter_grads(self, params):
-        """`p.grad` of every parameter <- sum over ranks, one collective (the parameters keep views of one flat buffer
-        as their .grad, which is what the optimizer then reads)."""
+    def reduce_parameter_grads(self, params, sh_active=None):
+        """`p.grad` of every parameter <- sum over ranks.  Gradients that autograd left inside a registered arena (the SH
+        gradients straight from the rasterizer, the six raw-parameter gradients of the fused activation backward) are
+        summed where they are; the rest (dL/dxyz: a sum of several contributions) through one small concatenated copy
+        whose views become the .grad.  `sh_active`: [(parameter, n)] for SH parameters of which only the first n
+        coefficients have a gradient (band trimming, see reduce_flat_async)."""
         params = [p for p in params if p.grad is not None]
-        red = self.reduce_flat([p.grad for p in params])
+        sh = {k: n for k, p in enumerate(params) for q, n in (sh_active or []) if p is q}
+        red = self.reduce_flat([p.grad for p in params], sh_active=sh)
         for p, g in zip(params, red):
             if g is not p.grad:
                 p.grad = g

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_raster_forward_split_sh", "gs2m_raster_backward_split_sh", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_bwd_impl", "gs2m_get_bwd_impl", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
+           "gs2m_debug_layout", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
@@ -82,10 +82,6 @@ def lib():
     L.gs2m_stage_name.argtypes = [i]
     L.gs2m_set_reference_binning.restype = i
     L.gs2m_set_reference_binning.argtypes = [i]
-    L.gs2m_set_bwd_impl.restype = i
-    L.gs2m_set_bwd_impl.argtypes = [i]
-    L.gs2m_get_bwd_impl.restype = i
-    L.gs2m_get_bwd_impl.argtypes = []
     L.gs2m_set_spin_wait.restype = i
     L.gs2m_set_spin_wait.argtypes = [i]
     L.gs2m_pack_features_forward.restype = i
@@ -185,7 +181,7 @@ def set_markers(on):
 def reset_modes():
     """Every process-wide switch back to its default (tests/conftest.py calls this after each test)."""
     L = lib()
-    L.gs2m_set_bwd_impl(2); L.gs2m_set_reference_binning(0); L.gs2m_set_spin_wait(1); L.gs2m_set_debug(0)
+    L.gs2m_set_reference_binning(0); L.gs2m_set_spin_wait(1); L.gs2m_set_debug(0)
     L.gs2m_set_markers(0); L.gs2m_profile_mode(0)
 
 
@@ -218,10 +214,3 @@ def set_reference_binning(on):
     """True: emit exactly the reference's tile rectangles (bit-identical sorted lists, for the parity tests
     of the integer artefacts); False (default): drop tiles the alpha >= 1/255 ellipse cannot reach."""
     check(lib().gs2m_set_reference_binning(1 if on else 0), "gs2m_set_reference_binning")
-
-
-def set_bwd_impl(impl):
-    """Blend kernels, forward and backward (include/gs2m_raster.h): 2 (default) per-quadrant lists; 1 tile lists
-    with the survivor-per-lane MFMA backward; 0 tile lists with the pixel-per-lane backward.  Must not change
-    between a forward and its backward."""
-    check(lib().gs2m_set_bwd_impl(int(impl)), "gs2m_set_bwd_impl")

@@ -6,6 +6,7 @@ post-processing (:126-141).  Same values, same gradients as the PyTorch ops they
 HIP tensors only -- there is no CPU path, the callers keep the reference's PyTorch formulation for that."""
 import torch
 
+import gs2m_arena as _arena
 import gs2m_native as _native
 
 
@@ -153,7 +154,11 @@ class _Activate(torch.autograd.Function):
         need = [g is not None and ctx.needs_input_grad[k] for k, g in enumerate(grads)]
         g = [_f32c(t, "grad") if n else None for t, n in zip(grads, need)]
         like = (scales, rotation, opac, alb, rgh, met)
-        d = [torch.empty_like(t) if n else None for t, n in zip(like, need)]
+        # the raw-parameter gradients side by side in one registered arena (gs2m_arena): data-parallel training sums them
+        # in place with one collective (they become the parameters' .grad as they are)
+        names = ("scaling", "rotation", "opacity", "albedo", "roughness", "metallic")
+        arena = _arena.GradArena(rotation.device, [(nm, t.shape) for nm, t, n in zip(names, like, need) if n])
+        d = [arena[nm] if n else None for nm, n in zip(names, need)]
         with torch.cuda.device(rotation.device):
             _native.check(_native.lib().gs2m_activate_backward(
                 P, _ptr(rotation), _ptr(scales), _ptr(opac), _ptr(alb), _ptr(rgh), _ptr(met), *[_ptr(t) for t in g],

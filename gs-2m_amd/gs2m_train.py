@@ -278,8 +278,12 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             # ---- train.py:219-254, in the reference's order: densification statistics and densify / prune, the
             # multi-view observe trim, THEN the opacity reduce / reset (a trim that ran after a reset would count
             # `observe` with every opacity at 0.01) ----
-            if dp:  # the sum of the ranks' parameter gradients, one blocking collective (gs2m_dp)
-                reducer.reduce_parameter_grads([g["params"][0] for g in gaussians.optimizer.param_groups])
+            if dp:  # the sum of the ranks' parameter gradients (gs2m_dp): in place where autograd left them in a gradient arena
+                # (SH straight from the rasterizer, the six raw-parameter gradients of the fused activation backward), only
+                # the active SH bands below the maximal degree (train.py:81-82)
+                n_act = (gaussians.active_sh_degree + 1) ** 2
+                sh_act = [(gaussians._features_rest, n_act - 1)] if gaussians.active_sh_degree < gaussians.max_sh_degree else None
+                reducer.reduce_parameter_grads([g["params"][0] for g in gaussians.optimizer.param_groups], sh_active=sh_act)
                 if lighting is not None and material_stage:
                     reducer.reduce_parameter_grads(list(lighting.cubemap.parameters()))
             if it <= opt.densify_until_iter:

@@ -265,18 +265,6 @@ int gs2m_activate_backward(int P, const float* rotation, const float* scales, co
  * (falls back to a stream synchronize after 2 s); 0: hipStreamSynchronize.  Same results. */
 int gs2m_set_spin_wait(int on);
 
-/* Blend implementation, forward AND backward (same results within fp32 rounding, every variant runs through the
- * parity tests).  A forward and its backward must run under the same setting.
- *   2 (default) per-quadrant lists: a second binning level splits every 16x16 tile list into four 8x8 quadrant
- *     lists; one wave per quadrant walks its own list -- forward with scalar loads and SGPR operands, backward
- *     in the survivor-per-lane / DPP-scan / fp32-MFMA layout        csrc/blend_fwd_q.hip, csrc/blend_bwd_q.hip
- *   1 tile lists; forward: one workgroup per tile, quadrant test + ballot walk (csrc/blend_fwd.hip); backward:
- *     survivor-per-lane layout on batches of the tile list                    csrc/blend_bwd_mfma.hip
- *   0 tile lists; same forward; backward pixel-per-lane, permlane/DPP reductions, one row per instance
- *                                                                             csrc/blend_bwd.hip */
-int gs2m_set_bwd_impl(int impl);
-int gs2m_get_bwd_impl(void);
-
 /* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)
  * allocated AHEAD of that wait: pass gs2m_prealloc_alloc as the callback and a gs2m_prealloc as its user pointer.  A
  * request that fits `capacity` returns `ptr` without leaving the library -- the GPU idles between the wait and the next

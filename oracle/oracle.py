@@ -43,12 +43,29 @@ def build(force=False):
     return _LIB_PATH
 
 
-def lib():
+def use_native_build():
+    """bench.py's cpu_baseline leg only: compile the same source at -O3 -march=native ON THIS MACHINE
+    (oracle/Makefile: libgs2m_oracle_native.so) and route this module's calls to it.  Returns the flags used, or None
+    when the build is not possible (the -O2 checker build is then timed instead).  Never used by the parity tests: the
+    checker stays the portable -O2 build."""
+    global _lib
+    path = os.path.join(_HERE, "libgs2m_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgs2m_oracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = None
+        lib(path)
+        return "-O3 -march=native -fopenmp"
+    except Exception:
+        _lib = None
+        return None
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if path is None and not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(path or _LIB_PATH)
         _lib.gs2m_oracle_forward.restype = C.POINTER(_State)
         _lib.gs2m_oracle_free.argtypes = [C.POINTER(_State)]
         _lib.gs2m_oracle_higher_msb.restype = C.c_uint32

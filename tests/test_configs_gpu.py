@@ -1,13 +1,18 @@
-"""Every BASELINE.json configuration at its stated size (tensor sizes table):
-  C1  10k Gaussians, 256x256, feature_count 10        HIP vs the oracle, everything (the oracle itself is checked against
-                                                      CPU autograd at this size in tests/test_oracle.py)
-  C2  500k Gaussians, 1920x1080, feature_count 5      size-independent properties + a 50k sub-problem vs the oracle
-  C3  1M Gaussians, 1080p, feature_count 9            tests/test_fullsize_gpu.py; here its "deferred pbr.shade" leg: the
-                                                      fused shading on the 1080p G-buffer of that render vs the op-by-op form
-  C5  2M Gaussians, 1080p, feature_count 9            the per-GPU shape of the 8-GPU configuration, on one GPU: properties
-                                                      (the 8-GPU leg itself needs the driver's node; tests/test_dp.py covers the
-                                                      sharding logic on two gloo ranks)
-C4 (train.py loop on a COLMAP-format scene) is tests/test_train_gpu.py."""
+"""Every BASELINE.json configuration at its stated size (tensor sizes table), the HIP path against the
+CPU oracle on the WHOLE workload (the oracle does one 1M / 1080p view, forward + backward, in about five seconds on the
+GPU box's host cores):
+  C1  10k Gaussians, 256x256, feature_count 10        (the oracle itself is checked against CPU autograd at this size in
+                                                      tests/test_oracle.py)
+  C2  500k Gaussians, 1920x1080, feature_count 5
+  C3  1M Gaussians, 1080p, feature_count 9            the bench workload; also its "deferred pbr.shade" leg: the fused
+                                                      shading on the 1080p G-buffer of that render vs the op-by-op form
+  C5  2M Gaussians, 1080p, feature_count 9            the per-GPU shape of the 8-GPU configuration, on one GPU (the 8-GPU leg
+                                                      itself needs the driver's node; tests/test_dp.py covers the sharding
+                                                      logic on two gloo ranks)
+each in BOTH binning modes: radii exact, observe and images with the threshold-event proof, gradients element-wise, the
+backward in its two halves (helpers.assert_two_stage); in reference-binning mode also the sorted instance list, the tile
+ranges and n_contrib against the oracle's, bit for bit.  Plus size-independent properties (compositing identities,
+reproducibility).  C4 (train.py loop on a COLMAP-format scene) is tests/test_train_gpu.py."""
 import numpy as np
 import pytest
 import torch
@@ -49,45 +54,93 @@ def _properties(sc, P, fc):
     assert float(np.abs(g1["means3D"]).max()) > 0
 
 
-def _subproblem(oracle, sc, n):
-    sub = dict(sc)
-    sub["g"] = {k: v[:n].contiguous() for k, v in sc["g"].items()}
-    f, gr = Hh.run_oracle(oracle, sub)
-    out, g = Hh.run_hip(sub)
+_ORACLE_CACHE = {}
+
+
+def _oracle_for(oracle, key, sc):
+    """one oracle forward + backward per configuration, shared by the two binning modes"""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE.clear()  # one configuration at a time: an OracleForward of the 2M scene holds ~1 GB
+        _ORACLE_CACHE[key] = Hh.run_oracle(oracle, sc)
+    return _ORACLE_CACHE[key]
+
+
+def _against_oracle(oracle, key, sc, reference_binning):
+    import gs2m_native
+    import diff_gaussian_rasterization as dgr
+    f, gr = _oracle_for(oracle, key, sc)
+    gs2m_native.set_reference_binning(reference_binning)
+    out, g = Hh.run_hip(sc)
     assert np.array_equal(out["radii"], f.radii)
-    dobs = np.abs(out["observe"].astype(np.int64) - f.observe.astype(np.int64))
-    assert int((dobs != 0).sum()) <= n // 2000 and dobs.max(initial=0) <= 2
+    Hh.assert_observe_close(out["observe"], f)
     Hh.assert_image_close("color", out["color"], f.color, oracle_fwd=f)
     for ch in range(10):
         scale = max(1.0, float(np.abs(f.buffer[ch]).max()))
         Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], f.buffer[ch], scale=scale, oracle_fwd=f)
+    assert np.all(out["buffer"][sc["fc"]:] == 0)
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations", "features"):
         Hh.assert_grad_close(k, g[k], gr[k])
-    Hh.assert_two_stage(oracle, f, gr, Hh.run_hip_sums(sub))
+    sums = Hh.run_hip_sums(sc)
+    Hh.assert_chain_exceptions_conditioned(f, g, gr, sums)  # the end-to-end exceptions of dL/dscale, dL/drot are ill-conditioned Gaussians
+    del out, g
+    Hh.assert_two_stage(oracle, f, gr, sums)
+    if reference_binning:  # the integer artefacts of the benched workload itself, bit for bit
+        P, W, H = f.P, sc["W"], sc["H"]
+        gd = {k: v.cuda() for k, v in sc["g"].items()}
+        st = Hh.settings_for(sc, "cuda")
+        e = torch.Tensor([])
+        R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
+            st.bg, gd["means3D"], e, gd["opacities"], gd["scales"], gd["rotations"], 1.0, e, gd["features"], st.viewmatrix,
+            st.projmatrix, st.tanfovx, st.tanfovy, H, W, gd["shs"], 3, st.campos, False, sc["fc"])
+        torch.cuda.synchronize()
+        assert R == f.num_rendered
+        lay = gs2m_native.debug_layout(P, R, W, H)
+        al = lambda t: (-t.data_ptr()) % 256
+        view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
+        assert np.array_equal(view(geomB, lay.tiles_touched, P, np.uint32), f.tiles_touched)
+        assert np.array_equal(view(binB, lay.point_list, R, np.uint32) & np.uint32(0x0FFFFFFF), f.vals_sorted), "sorted Gaussian ids"
+        assert np.array_equal(view(binB, lay.tile_keys, R, np.uint32), (f.keys_sorted >> np.uint64(32)).astype(np.uint32)), "sorted tile ids"
+        Tn = f.tiles_x * f.tiles_y
+        assert np.array_equal(view(imgB, lay.ranges, 2 * Tn, np.uint32).reshape(Tn, 2), f.ranges)
+        nc = view(imgB, lay.n_contrib, W * H, np.uint32).reshape(H, W)
+        assert (nc != f.n_contrib).mean() <= 1e-4
+    gs2m_native.set_reference_binning(False)
+    dgr.release_scratch()
 
 
 def test_config_c1(oracle_lib):
     """10k random Gaussians, 1 camera, 256x256, feature_count 10: the same scene tests/test_oracle.py checks the oracle
     on against CPU autograd"""
     sc = Hh.make_scene(10_000, 256, 256, seed=1, fc=10)
-    _subproblem(oracle_lib, sc, 10_000)
+    for refbin in (False, True):
+        _against_oracle(oracle_lib, "c1", sc, refbin)
 
 
-def test_config_c2(oracle_lib):
-    """500k synthetic Gaussians, 1920x1080, colour + depth + normal buffers (feature_count 5)"""
-    P = 500_000
-    sc = Hh.make_scene(P, 1920, 1080, seed=0, fc=5)
-    _properties(sc, P, 5)
-    _subproblem(oracle_lib, sc, 50_000)
+@pytest.mark.parametrize("reference_binning", [False, True], ids=["default_binning", "reference_binning"])
+def test_config_c2_full_size_against_oracle(oracle_lib, reference_binning):
+    """500k synthetic Gaussians, 1920x1080, colour + depth + normal buffers (feature_count 5): the whole view vs the oracle"""
+    sc = Hh.make_scene(500_000, 1920, 1080, seed=0, fc=5)
+    if not reference_binning:
+        _properties(sc, 500_000, 5)
+    _against_oracle(oracle_lib, "c2", sc, reference_binning)
 
 
-def test_config_c5_per_gpu_shape():
-    """2M Gaussians, 1920x1080, feature_count 9 on ONE GPU (every rank of the 8-GPU configuration holds this)"""
+@pytest.mark.parametrize("reference_binning", [False, True], ids=["default_binning", "reference_binning"])
+def test_config_c3_full_size_against_oracle(oracle_lib, reference_binning):
+    """1M Gaussians, 1920x1080, feature_count 9 -- the bench workload itself (bench.py --config c3) vs the oracle"""
+    sc = Hh.make_scene(1_000_000, 1920, 1080, seed=0, fc=9)
+    _against_oracle(oracle_lib, "c3", sc, reference_binning)
+
+
+@pytest.mark.parametrize("reference_binning", [False, True], ids=["default_binning", "reference_binning"])
+def test_config_c5_per_gpu_shape_full_size_against_oracle(oracle_lib, reference_binning):
+    """2M Gaussians, 1920x1080, feature_count 9 on ONE GPU (every rank of the 8-GPU configuration holds this): the whole
+    view vs the oracle"""
     P = 2_000_000
     sc = Hh.make_scene(P, 1920, 1080, seed=0, fc=9)
-    _properties(sc, P, 9)
-    import diff_gaussian_rasterization as dgr
-    dgr.release_scratch()
+    if not reference_binning:
+        _properties(sc, P, 9)
+    _against_oracle(oracle_lib, "c5", sc, reference_binning)
 
 
 def test_config_c3_deferred_shading_leg():

@@ -181,12 +181,15 @@ def _flat_worker(rank, world, port, mode, q):
     from gs2m_dp import GradReducer
     g = torch.Generator().manual_seed(100 + rank)
     red = GradReducer(mode=mode)
-    # (a) views of ONE buffer at aligned offsets, as the rasterizer binding returns its gradients
-    arena = torch.zeros(128 + 512)
-    views = [arena[0:30].view(10, 3), arena[64:104].view(10, 4), arena[128:608].view(10, 16, 3)]
-    for v in views:
-        v.copy_(torch.randn(v.shape, generator=g))
-    assert GradReducer.common_arena(views) is not None
+    # (a) entries of ONE registered arena, as the rasterizer binding returns its gradients; the summed ones first and
+    # adjacent, then two the caller does not pass (they must come back untouched)
+    import gs2m_arena
+    ar = gs2m_arena.GradArena("cpu", [("a", (10, 3)), ("b", (10, 4)), ("sh", (10, 16, 3)), ("x", (10, 4)), ("y", (10, 6))], zero=True)
+    views = [ar["a"], ar["b"], ar["sh"]]
+    for name in ("a", "b", "sh", "x", "y"):
+        ar[name].copy_(torch.randn(ar[name].shape, generator=g))
+    keep_x, keep_y = ar["x"].clone(), ar["y"].clone()
+    assert gs2m_arena.lookup(views[0])[0] is ar and gs2m_arena.lookup(ar["sh"][:, :4]) is None
     calls = {"n": 0}
     orig_ar, orig_rs = dist.all_reduce, dist.reduce_scatter_tensor
 
@@ -203,12 +206,22 @@ def _flat_worker(rank, world, port, mode, q):
     # (b) unrelated tensors (and a None): one concatenated copy
     calls["n"] = 0
     loose = [torch.randn(7, 3, generator=g), None, torch.randn(5, generator=g), torch.randn(2, 2, 2, generator=g)]
-    assert GradReducer.common_arena([t for t in loose if t is not None]) is None
     out_b = red.reduce_flat(loose)
     n_b = calls["n"]
+    # (c) only part of an arena's summed entries, with a foreign entry in between: no in-place sum, one copy; (d) SH bands
+    calls["n"] = 0
+    ar2 = gs2m_arena.GradArena("cpu", [("a", (6, 3)), ("mid", (6, 2)), ("b", (6, 4)), ("sh", (6, 16, 3))], zero=True)
+    for name in ("a", "mid", "b", "sh"):
+        ar2[name].copy_(torch.randn(ar2[name].shape, generator=g))
+    ar2["sh"][:, 4:] = 0.0  # degree 1: bands above it have no gradient on any rank
+    mid = ar2["mid"].clone()
+    red_sh = GradReducer(mode=mode, sh_active_coeffs=None)
+    out_c = red_sh.reduce_flat([ar2["a"], ar2["b"], ar2["sh"]], sh_active={2: 4})
+    plan_c = list(red_sh.last_plan)
+    untouched = torch.equal(ar2["mid"], mid) and torch.equal(ar["x"], keep_x) and torch.equal(ar["y"], keep_y)
     dist.all_reduce, dist.reduce_scatter_tensor = orig_ar, orig_rs
     q.put((rank, [t.clone().numpy() for t in out_a], [None if t is None else t.clone().numpy() for t in out_b], n_a, n_b,
-           all(o is v for o, v in zip(out_a, views))))
+           all(o is v for o, v in zip(out_a, views)), [t.clone().numpy() for t in out_c], plan_c, untouched))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -235,17 +248,28 @@ def test_one_collective_per_step(mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    exp_a, exp_b = None, None
+    exp_a, exp_b, exp_c = None, None, None
     for rank in range(2):
         g = torch.Generator().manual_seed(100 + rank)
         a = [torch.randn(s, generator=g) for s in ((10, 3), (10, 4), (10, 16, 3))]
+        torch.randn((10, 4), generator=g); torch.randn((10, 6), generator=g)  # the two entries the caller keeps to itself
         b = [torch.randn(7, 3, generator=g), None, torch.randn(5, generator=g), torch.randn(2, 2, 2, generator=g)]
+        c = [torch.randn(s, generator=g) for s in ((6, 3), (6, 2), (6, 4), (6, 16, 3))]
+        c[3][:, 4:] = 0.0
+        c = [c[0], c[2], c[3]]
         exp_a = a if exp_a is None else [x + y for x, y in zip(exp_a, a)]
         exp_b = b if exp_b is None else [None if x is None else x + y for x, y in zip(exp_b, b)]
-    for rank, out_a, out_b, n_a, n_b, in_place in res:
+        exp_c = c if exp_c is None else [x + y for x, y in zip(exp_c, c)]
+    for rank, out_a, out_b, n_a, n_b, in_place, out_c, plan_c, untouched in res:
         assert n_a == 1 and n_b == 1, "one collective each"
         assert in_place, "arena tensors are reduced in place"
+        assert untouched, "entries of an arena that were not passed must not be modified"
+        # (c): `a` and `b` have the foreign entry `mid` between them -> one concatenated copy; the SH tensor travels as its
+        # 4 active coefficients
+        assert sorted(k for k, _ in plan_c) == ["copy", "sh"] and dict(plan_c)["sh"] == 6 * 4 * 3, plan_c
         for got, want in zip(out_a, exp_a):
             assert np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)
         for got, want in zip(out_b, exp_b):
             assert (got is None) == (want is None) and (got is None or np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-6))
+        for got, want in zip(out_c, exp_c):
+            assert np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)

@@ -1,5 +1,7 @@
 """Host-side model logic on the CPU: the schedule / conversions against vectors generated from the
-reference's own helpers (tests/golden/make_golden.py), the PLY layout, the optimizer surgery bookkeeping."""
+reference's own helpers (tests/golden/make_golden.py), the PLY layout, the optimizer surgery bookkeeping.  The
+densification / PLY / COLMAP parity tests run on the CPU (`-m "not gpu"`) AND on the device (`-m gpu`: the model's tensors,
+the fused Adam's state and the split's torch.normal draws then live on the GPU, as in training)."""
 import os
 
 import numpy as np
@@ -7,6 +9,7 @@ import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_model.npz")
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
 
 
 def test_lr_schedule_and_conversions_match_reference_vectors():
@@ -101,7 +104,8 @@ def test_prune_and_cat_keep_parameters_and_adam_state_aligned():
     assert (m.get_opacity <= 0.01 + 1e-6).all() and not m.optimizer.state[m._opacity]["exp_avg"].any()
 
 
-def test_colmap_reader_matches_the_reference_reader(tmp_path):
+@pytest.mark.parametrize("device", DEVICES)
+def test_colmap_reader_matches_the_reference_reader(tmp_path, device):
     """tests/golden/colmap_small/*.bin parsed by gs2m_colmap against what the reference's own reader returned for the
     same files (tests/golden/colmap_small.npz, generated by make_golden.py), plus a write -> read round trip."""
     import gs2m_colmap as C
@@ -133,6 +137,18 @@ def test_colmap_reader_matches_the_reference_reader(tmp_path):
         assert open(os.path.join(folder, name), "rb").read() == open(os.path.join(str(tmp_path), name), "rb").read()
     for im in imgs.values():
         np.testing.assert_allclose(C.rotmat2qvec(C.qvec2rotmat(im.qvec)), im.qvec, atol=1e-12)
+    # the cameras the training loop builds from these records (gs2m_train.load_colmap_dataset), on `device`: W2C rotation and
+    # translation are the file's (scene/dataset_readers.py:81-82 stores R transposed), the centre is -R^T t
+    import gs2m_synth as S
+    from gs2m_scene import Camera
+    for info, iid in zip(infos, imgs):
+        cam = Camera(S.make_camera(info.width, info.height, fx=info.Fx, fy=info.Fy, R=info.R, T=info.T), device)
+        assert cam.world_view_transform.device.type == device and cam.full_proj_transform.device.type == device
+        w2c = cam.world_view_transform.t().cpu().numpy()
+        Rw2c = np.transpose(d[f"img{iid}_R"])
+        np.testing.assert_allclose(w2c[:3, :3], Rw2c, atol=1e-6)
+        np.testing.assert_allclose(w2c[:3, 3], d[f"img{iid}_tvec"], atol=1e-5)
+        np.testing.assert_allclose(cam.camera_center.cpu().numpy(), -Rw2c.T @ d[f"img{iid}_tvec"], atol=1e-4)
 
 
 def test_hyperparameter_defaults_match_the_reference():
@@ -191,7 +207,7 @@ def test_blender_dataset_reader(tmp_path):
 def _restated_build_rotation(r):  # utils/general_utils.py:76-98
     q = r / torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])[:, None]
     w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    R = torch.zeros((q.size(0), 3, 3))
+    R = torch.zeros((q.size(0), 3, 3), device=r.device)
     R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
     R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
     R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
@@ -207,18 +223,21 @@ class _RestatedModel:
         self.p = {k: v.clone() for k, v in params.items()}
         self.m = {k: (a.clone(), b.clone()) for k, (a, b) in moments.items()}
         self.percent_dense = percent_dense
+        self.dev = params["xyz"].device
         n = self.p["xyz"].shape[0]
-        self.accum, self.accum_abs, self.denom = torch.zeros(n, 1), torch.zeros(n, 1), torch.zeros(n, 1)
-        self.max_radii = torch.zeros(n)
+        self._reset(n)
+
+    def _reset(self, n):
+        z = lambda *sh: torch.zeros(*sh, device=self.dev)
+        self.accum, self.accum_abs, self.denom = z(n, 1), z(n, 1), z(n, 1)
+        self.max_radii = z(n)
 
     def _append(self, new):  # cat_tensors_to_optimizer GM:430-455 + densification_postfix GM:459-492
         for k in self.NAMES:
             self.p[k] = torch.cat((self.p[k], new[k]), dim=0)
             a, b = self.m[k]
             self.m[k] = (torch.cat((a, torch.zeros_like(new[k])), dim=0), torch.cat((b, torch.zeros_like(new[k])), dim=0))
-        n = self.p["xyz"].shape[0]
-        self.accum, self.accum_abs, self.denom = torch.zeros(n, 1), torch.zeros(n, 1), torch.zeros(n, 1)
-        self.max_radii = torch.zeros(n)
+        self._reset(self.p["xyz"].shape[0])
 
     def _prune(self, mask):  # prune_points GM:396-415 (+ _prune_optimizer GM:378-394)
         keep = ~mask
@@ -240,18 +259,18 @@ class _RestatedModel:
         # densify_and_split GM:489-514, N = 2
         N = 2
         n = self.p["xyz"].shape[0]
-        padded = torch.zeros(n)
+        padded = torch.zeros(n, device=self.dev)
         padded[:grads_abs.shape[0]] = grads_abs.squeeze()
         act = torch.exp(self.p["scaling"])
         sel = (padded >= max_grad_abs) & (torch.max(act, dim=1).values > self.percent_dense * extent)
         stds = act[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros((stds.size(0), 3)), std=stds)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=self.dev), std=stds)
         rots = _restated_build_rotation(self.p["rotation"][sel]).repeat(N, 1, 1)
         new = {k: self.p[k][sel].repeat(N, *([1] * (self.p[k].dim() - 1))) for k in self.NAMES}
         new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.p["xyz"][sel].repeat(N, 1)
         new["scaling"] = torch.log(act[sel].repeat(N, 1) / (0.8 * N))
         self._append(new)
-        self._prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool))))
+        self._prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool, device=self.dev))))
         # transparent / large GM:549-558 (max_radii2D was just reset by the postfix, as in the reference)
         prune = (torch.sigmoid(self.p["opacity"]) < min_opacity).squeeze()
         if max_screen_size:
@@ -265,9 +284,11 @@ class _RestatedModel:
         self.m["opacity"] = (torch.zeros_like(self.p["opacity"]), torch.zeros_like(self.p["opacity"]))
 
 
-def test_densify_prune_reset_match_the_restated_reference():
+@pytest.mark.parametrize("device", DEVICES)
+def test_densify_prune_reset_match_the_restated_reference(device):
     """clone + split (torch.normal under a fixed generator) + prune with the Adam-moment surgery, then an opacity reset
-    and a second round with max_screen_size: GaussianModel on the CPU vs the restatement above, bit for bit."""
+    and a second round with max_screen_size: GaussianModel vs the restatement above on the same device, bit for bit.
+    On the GPU the optimizer is the product's fused Adam (gs2m_optim.Adam), whose state the surgery edits in training."""
     from gs2m_model import GaussianModel, OptimizationParams
     g = torch.Generator().manual_seed(11)
     n, extent = 400, 4.0
@@ -275,17 +296,17 @@ def test_densify_prune_reset_match_the_restated_reference():
                opacity=torch.randn(n, 1, generator=g) * 2.5, scaling=torch.randn(n, 3, generator=g) * 0.8 - 3.0,
                rotation=torch.randn(n, 4, generator=g), albedo=torch.randn(n, 3, generator=g), roughness=torch.randn(n, 1, generator=g),
                metallic=torch.randn(n, 1, generator=g))
-    model = GaussianModel(3, "cpu")
+    model = GaussianModel(3, device)
     model.parameterize([prm[k].clone() for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
 
     class Opt(OptimizationParams):
         prune_init_points = False
         percent_dense = 0.01
-    model.training_setup(Opt, optimizer_cls=torch.optim.Adam)
+    model.training_setup(Opt, optimizer_cls=torch.optim.Adam if device == "cpu" else None)
     # one optimizer step so that every parameter has non-trivial Adam moments
     for grp in model.optimizer.param_groups:
         p = grp["params"][0]
-        p.grad = torch.randn(p.shape, generator=g)
+        p.grad = torch.randn(p.shape, generator=g).to(device)
     model.optimizer.step()
     model.optimizer.zero_grad(set_to_none=True)
     params = {grp["name"]: grp["params"][0].detach().clone() for grp in model.optimizer.param_groups}
@@ -304,10 +325,10 @@ def test_densify_prune_reset_match_the_restated_reference():
 
     for rnd, screen in ((0, None), (1, 20)):
         m = model.get_xyz.shape[0]
-        acc = torch.rand(m, 1, generator=g) * 6e-4
-        acc_abs = torch.rand(m, 1, generator=g) * 2.4e-3
-        den = (torch.rand(m, 1, generator=g) > 0.1).float() * 3  # some Gaussians never seen: 0 / 0 -> NaN -> 0
-        rad = torch.rand(m, generator=g) * 40
+        acc = (torch.rand(m, 1, generator=g) * 6e-4).to(device)
+        acc_abs = (torch.rand(m, 1, generator=g) * 2.4e-3).to(device)
+        den = ((torch.rand(m, 1, generator=g) > 0.1).float() * 3).to(device)  # some Gaussians never seen: 0 / 0 -> NaN -> 0
+        rad = (torch.rand(m, generator=g) * 40).to(device)
         model.xyz_gradient_accum, model.xyz_gradient_accum_abs, model.denom, model.max_radii2D = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
         ref.accum, ref.accum_abs, ref.denom, ref.max_radii = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
         torch.manual_seed(500 + rnd)
@@ -322,20 +343,22 @@ def test_densify_prune_reset_match_the_restated_reference():
             check("reset")
 
 
-def test_ply_bytes_match_the_reference_layout(tmp_path):
+@pytest.mark.parametrize("device", DEVICES)
+def test_ply_bytes_match_the_reference_layout(tmp_path, device):
     """tests/golden/model_small.ply was assembled byte by byte in the layout GaussianModel.save_ply of the reference
     produces (tests/golden/make_ply_golden.py): our writer must produce the same bytes from the same tensors, and our
     reader must recover the tensors from it."""
     from gs2m_model import GaussianModel
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     z = np.load(os.path.join(here, "model_small.npz"))
-    model = GaussianModel(3, "cpu")
+    model = GaussianModel(3, device)
     model.parameterize([torch.tensor(z[k]) for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
     out = tmp_path / "out.ply"
     model.save_ply(str(out))
     assert out.read_bytes() == open(os.path.join(here, "model_small.ply"), "rb").read()
-    back = GaussianModel(3, "cpu")
+    back = GaussianModel(3, device)
     back.load_ply(os.path.join(here, "model_small.ply"))
+    assert back._xyz.device.type == device
     for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("scaling", "_scaling"),
                     ("rotation", "_rotation"), ("albedo", "_albedo"), ("roughness", "_roughness"), ("metallic", "_metallic")):
-        assert np.array_equal(getattr(back, attr).detach().numpy(), z[k]), k
+        assert np.array_equal(getattr(back, attr).detach().cpu().numpy(), z[k]), k

@@ -11,17 +11,6 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 1, 0], ids=["quad_lists", "bwd_mfma", "bwd_permlane"])
-def bwd_impl(request):
-    """every test runs against all three blend implementations (include/gs2m_raster.h: gs2m_set_bwd_impl)"""
-    import gs2m_native
-    if torch.cuda.is_available():
-        gs2m_native.set_bwd_impl(request.param)
-    yield request.param
-    if torch.cuda.is_available():
-        gs2m_native.set_bwd_impl(2)
-
-
 def _require_gpu():
     assert torch.cuda.is_available(), "these tests need a HIP device"
     import gs2m_native
@@ -32,11 +21,7 @@ def _check(oracle, sc, grads=True, tol=Hh.ABS_TOL_BUFFERS, **kw):
     f, gr = Hh.run_oracle(oracle, sc, backward=grads, **kw)
     out, g = Hh.run_hip(sc, backward=grads, **kw)
     assert np.array_equal(out["radii"], f.radii), "radii"
-    # observe counts depend on exp() only through T > 0.5 / alpha thresholds: a vanishing number of Gaussians may
-    # differ, each by the one or two pixels that sit on a threshold
-    dobs = np.abs(out["observe"].astype(np.int64) - f.observe.astype(np.int64))
-    assert int((dobs != 0).sum()) <= max(1, f.P // 2000), f"observe mismatches {int((dobs != 0).sum())}"
-    assert dobs.max(initial=0) <= 2, f"observe differs by {dobs.max()} pixels on one Gaussian"
+    Hh.assert_observe_close(out["observe"], f)
     Hh.assert_image_close("color", out["color"], f.color, tol=tol, oracle_fwd=f)
     for ch in range(10):
         scale = max(1.0, float(np.abs(f.buffer[ch]).max()))
@@ -387,18 +372,3 @@ def test_two_forwards_before_their_backwards_and_a_retained_graph():
     assert np.array_equal(first.cpu().numpy(), ga["means3D"]) and torch.equal(pa["means3D"].grad, first)
     assert np.array_equal(pb["means3D"].grad.cpu().numpy(), gb["means3D"])
     assert np.array_equal(pc["means3D"].grad.cpu().numpy(), gb["means3D"])
-
-
-def test_switching_the_blend_implementation_between_forward_and_backward_is_refused():
-    _require_gpu()
-    import gs2m_native
-    from diff_gaussian_rasterization import GaussianRasterizer
-    sc = Hh.make_scene(500, 64, 48, seed=61, fc=9)
-    g = {k: v.cuda().requires_grad_(True) for k, v in sc["g"].items()}
-    m2 = torch.zeros(500, 4, device="cuda", requires_grad=True)
-    gs2m_native.set_bwd_impl(2)
-    color, _, _, buffer = GaussianRasterizer(Hh.settings_for(sc, "cuda"))(g["means3D"], m2, g["opacities"], shs=g["shs"], scales=g["scales"],
-                                                                      rotations=g["rotations"], features=g["features"])
-    gs2m_native.set_bwd_impl(1)
-    with pytest.raises(RuntimeError, match="switched between this forward"):
-        (color.sum() + buffer.sum()).backward()

@@ -1,12 +1,12 @@
+"""Three forward + backward runs of the same scene: every output and gradient must be bitwise equal (fixed summation
+orders everywhere; `observe` uses integer atomics).  usage: python tools/gpu_determinism.py [P]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gs-2m_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np, torch
-import helpers as Hh, gs2m_native
+import helpers as Hh
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-impl = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-gs2m_native.set_bwd_impl(impl)
 sc = Hh.make_scene(P, 1920, 1080, seed=0, fc=9)
 outs = []
 for i in range(3):
@@ -22,4 +22,4 @@ for i in (1, 2):
         if d.any():
             idx = np.argwhere(d)
             print("run", i, "grad", k, "mismatch elems", int(d.sum()), "rows", len(np.unique(idx[:, 0])), "first", idx[:3].tolist(), a[d][:3], b[d][:3])
-print("done P", P, "impl", impl)
+print("done P", P)

@@ -21,12 +21,10 @@ scenes = {
     "thin_large": dict(P=1500, W=160, H=128, seed=5, fc=10, scale_lo=0.0005, scale_hi=0.6, bg=(0.2, 0.2, 0.2)),
     "c1": dict(P=10000, W=256, H=256, seed=1, fc=10),
 }
-impls = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2,1").split(",")]
 for name, kw in scenes.items():
     sc = Hh.make_scene(**kw)
     f, gr = Hh.run_oracle(oracle, sc)
-    for impl in impls:
-        gs2m_native.set_bwd_impl(impl)
+    for impl in ("hip",):
         out, g = Hh.run_hip(sc)
         print(f"== {name} impl {impl}: color max {np.abs(out['color'] - f.color).max():.2e}  buffer max {np.abs(out['buffer'] - f.buffer).max():.2e}"
               f"  observe mism {(out['observe'] != f.observe).sum()}")
