@@ -181,10 +181,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--ring-position", type=int, default=None,
+                    help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
+                         "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # watchdog: a rank that hangs (a peer died inside a collective, a stuck kernel) dumps every thread's stack and exits
+    # instead of holding the GPU until the caller's limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("GS2M_BENCH_WATCHDOG_S", "900")), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -214,13 +221,14 @@ def main():
     # the N-GPU workload renders cameras on a circle of radius 6 around the cloud centre (0, 0, 6), looking at
     # it, 8 positions 45 degrees apart; rank r takes position r (position 0 is the single-GPU camera at the origin).  The
     # views differ in work (instances per view): the step time is the slowest rank's.
-    if world == 1:
+    ring = rank if world > 1 else (a.ring_position or 0)
+    if ring % 8 == 0:
         cam = S.make_camera(W, H)
     else:
         import math
-        th = 2.0 * math.pi * (rank % 8) / 8.0
+        th = 2.0 * math.pi * (ring % 8) / 8.0
         eye = (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th))
-        cam = S.make_camera(W, H) if rank % 8 == 0 else S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
+        cam = S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
     Gc, Gb = S.make_upstream_grads(H, W, seed=a.seed)
@@ -344,7 +352,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
                                    + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
-                                   + ("" if world == 1 else ", blocking RCCL sum of the view's gradients (one collective) at step end"),
+                                   + ("" if world == 1 else ", cameras on the 8-position ring of SURVEY.md 8(d) (rank r: position r), blocking RCCL sum of "
+                                      "the view's gradients (one in-place collective over the gradient arena) at step end")
+                                   + (f" [ring position {a.ring_position}: NOT the metric's camera]" if world == 1 and a.ring_position else ""),
                        "gaussians": P, "visible": V, "num_rendered": R, "width": W, "height": H, "feature_count": fc,
                        "parallelism": f"view-parallel x{world}"},
             "roofline": roof,

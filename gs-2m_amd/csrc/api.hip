@@ -179,7 +179,20 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         const size_t sort_temp_bytes = gs2m_align_up(gs2m_radix_temp_bytes((size_t)P, 32));
         char* scan_temp = g.temp + sort_temp_bytes;
         const size_t scan_temp_bytes = g.temp_bytes - sort_temp_bytes;
-        ZeroJobs zj = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
+        if (!t_pinned.p) {
+            HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
+        }
+        int dev_id = 0;
+        HIP_TRY(hipGetDevice(&dev_id));
+        uint32_t* acc = nullptr;  // per device: the words the side sum of the histogram kernel works in
+        if (dev_id >= 0 && dev_id < 16) {
+            if (!t_pinned.acc[dev_id]) HIP_TRY(hipMalloc((void**)&t_pinned.acc[dev_id], 64));
+            acc = t_pinned.acc[dev_id];
+        }
+        // zeroed by the preprocess kernel, on this stream, ahead of every use: the depth sort's scratch, the scan's, and the
+        // side sum's accumulator (so a call that died half way cannot leave a count behind for the next one)
+        ZeroJobs zj = {{nullptr, nullptr, acc}, {0, 0, acc ? (size_t)4 : (size_t)0}};
         gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
         gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
         {
@@ -188,20 +201,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                                    tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, out_observe, g,
                                    reference_binning ? 0 : 1, zj, s);
-        }
-        if (!t_pinned.p) {
-            HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
-        }
-        int dev_id = 0;
-        HIP_TRY(hipGetDevice(&dev_id));
-        uint32_t* acc = nullptr;
-        if (dev_id >= 0 && dev_id < 16) {
-            if (!t_pinned.acc[dev_id]) {
-                HIP_TRY(hipMalloc((void**)&t_pinned.acc[dev_id], 64));
-                HIP_TRY(hipMemset(t_pinned.acc[dev_id], 0, 64));
-            }
-            acc = t_pinned.acc[dev_id];
         }
         // The reference waits for num_rendered after its scan (rasterizer_impl.cu:269-270) and the GPU idles until the
         // host has seen the value, sized the binning buffer and launched the next kernel.  Here the value -- the plain sum
@@ -236,6 +235,12 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         if (land[0] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
         if (land[0] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // the look-back status words carry 30 value bits
         R = (int)land[0];
+        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: the side sum against the scan's own total
+            uint32_t total = 0;
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(&total, g.counters, sizeof(total), hipMemcpyDeviceToHost));
+            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_SCAN);
+        }
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);

@@ -222,8 +222,9 @@ struct SideScan {
     uint32_t* wave_base;
 };
 // second side job of a histogram kernel: sum of an n-element u32 array (the same indices the kernel reads keys at),
-// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = two words that
-// are zero before the launch and are left zero by the kernel (accumulator, finished-workgroup count).
+// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = four 8-byte
+// aligned words that are zero before the launch (the caller zeroes them on the stream ahead of every call) and are left
+// zero by the kernel: a 64-bit accumulator, the finished-workgroup count, one spare.
 struct SideSum {
     const uint32_t* tt;
     uint32_t* acc;

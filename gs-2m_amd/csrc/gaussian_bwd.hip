@@ -64,38 +64,35 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     // (P,16,3) tensors is a coalesced stream (see preprocess.hip); row stride 49 floats.
     __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx < P;
+    const int li = in_range ? idx : 0;
+    // The thread's own inputs and its reduced gradient row are requested BEFORE the block stages its SH rows (the staging
+    // ends in a barrier: loads issued behind it would cost a second exposed memory round trip).
+    const bool visible = in_range && radii[li] > 0;
+    const float mx = means3D[3 * li], my = means3D[3 * li + 1], mz = means3D[3 * li + 2];
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s_in[3] = {0.f, 0.f, 0.f};
+    if (scales != nullptr) {
+        q_in = reinterpret_cast<const float4*>(rotations)[li];
+        s_in[0] = scales[3 * li]; s_in[1] = scales[3 * li + 1]; s_in[2] = scales[3 * li + 2];
+    }
+    float acc[24];
+    {   // `rows` holds one reduced row per Gaussian (row_reduce_dense_kernel below): P x rowf floats
+        const int rq = rowf >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(rows + (size_t)li * rowf);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 v = q < rq ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+        }
+    }
     if (SH_LDS) {
         gs2m_stage_sh(shs, shs_rest, P, s_sh);
         gs2m_sync();
     }
-    const bool in_range = idx < P;
-    const bool visible = in_range && radii[idx] > 0;
     if (!SH_LDS && !in_range) return;
     if (in_range) {
 
-    // the per-Gaussian inputs (the reduced gradient row follows)
-    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
-    float s_in[3] = {0.f, 0.f, 0.f};
-    if (scales != nullptr) {
-        q_in = reinterpret_cast<const float4*>(rotations)[idx];
-        s_in[0] = scales[3 * idx]; s_in[1] = scales[3 * idx + 1]; s_in[2] = scales[3 * idx + 2];
-    }
-
-    float acc[24];
-#pragma unroll
-    for (int k = 0; k < 24; k++) acc[k] = 0.f;
-    {
-        const int rq = rowf >> 2;
-        {   // `rows` holds one reduced row per Gaussian (row_reduce_kernel below): P x rowf floats
-            const float4* s4 = reinterpret_cast<const float4*>(rows + (size_t)idx * rowf);
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                const float4 v = q < rq ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
-            }
-        }
-    }
     // ---- gradients that are plain sums of the rows ----
     reinterpret_cast<float4*>(dL_dmeans2D)[idx] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     if (dL_dconics) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(acc[4], acc[5], 0.f, acc[6]);
@@ -385,17 +382,15 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
             a[e] = (e < rq && q < nq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    float4 anext[MAXQ];
-    load_window(0, anext);
-    for (uint32_t w = 0; w <= nwin; w++) {
+    // One window: park the loaded rows in LDS, then every group adds the rows of its Gaussians that lie in the window.
+    // LDS operations of one wave execute in order: the reads see the writes above them.
+    auto consume = [&](uint32_t w, const float4* a) {
         const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
         if (w < nwin) {
 #pragma unroll
             for (int e = 0; e < MAXQ; e++)
-                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = anext[e];
-            load_window(w + 1, anext);
+                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = a[e];
         }
-        // LDS operations of one wave execute in order: the reads below see the writes above
         while (j < GS2M_WAVE) {
             const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
             if (ex >= k1 && cn > 0) break;  // starts in a later window
@@ -410,6 +405,22 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
             racc = make_float4(0.f, 0.f, 0.f, 0.f);
             j += (uint32_t)G;
         }
+    };
+    // THREE windows in flight: the windows of a wave are a serial chain (load -> LDS -> sum), and the nearest Gaussians
+    // (the first waves in depth order) own tens of instances each -- up to 36 windows in one wave on the bench scene; with
+    // one window in flight every one of them cost a full memory round trip.  One extra pass (w == nwin, an empty window)
+    // lets every group finish and write its remaining Gaussians.
+    float4 a0[MAXQ], a1[MAXQ], a2[MAXQ];
+    load_window(0, a0);
+    load_window(1, a1);
+    load_window(2, a2);
+    for (uint32_t w = 0; w <= nwin; w += 3) {
+        consume(w, a0);
+        load_window(w + 3, a0);
+        if (w + 1 <= nwin) consume(w + 1, a1);
+        load_window(w + 4, a1);
+        if (w + 2 <= nwin) consume(w + 2, a2);
+        load_window(w + 5, a2);
     }
 }
 

@@ -63,6 +63,22 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
+    // issued behind it would cost a second exposed memory round trip (the kernel is latency bound at 12 waves per CU).
+    const bool inr = idx < P;
+    const int li = inr ? idx : 0;
+    const float px = means3D[3 * li], py = means3D[3 * li + 1], pz = means3D[3 * li + 2];
+    float in_s[3] = {0.f, 0.f, 0.f};
+    float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cov3D_precomp == nullptr) {
+        in_s[0] = scales[3 * li]; in_s[1] = scales[3 * li + 1]; in_s[2] = scales[3 * li + 2];
+        in_q = reinterpret_cast<const float4*>(rotations)[li];
+    }
+    const float in_op = opacities[li];
+    float2 in_f[GS2M_NUM_FEATURES / 2];
+#pragma unroll
+    for (int k = 0; k < GS2M_NUM_FEATURES / 2; k++)
+        in_f[k] = features != nullptr ? reinterpret_cast<const float2*>(features + (size_t)li * GS2M_NUM_FEATURES)[k] : make_float2(0.f, 0.f);
     if (SH_LDS) {
         gs2m_stage_sh(shs, shs_rest, P, s_sh);
         gs2m_sync();
@@ -74,7 +90,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t out_tt = 0;
     uint32_t out_key = 0xFFFFFFFFu;
 
-    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
     // view-space point (transformPoint4x3), near-plane cull at 0.2
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
     const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
@@ -91,9 +106,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
             for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
         } else {
-            const float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1],
-                        sz = scale_modifier * scales[3 * idx + 2];
-            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            const float sx = scale_modifier * in_s[0], sy = scale_modifier * in_s[1], sz = scale_modifier * in_s[2];
+            const float4 q = in_q;
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             M3 S = m3_cols(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
             M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
@@ -178,7 +192,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 // used by the blend kernels to skip 8x8 pixel blocks.  Must never under-estimate:
                 // evaluated in double from the very conic the blend kernels use, inflated, and
                 // switched off (infinite) for ill-conditioned or indefinite conics.
-                const float op = opacities[idx];
+                const float op = in_op;
                 float ex, ey;
                 float tau2f = __builtin_inff();  // bound on A dx^2 + 2B dx dy + C dy^2 inside the ellipse
                 if (op < 1.0f / 255.0f) {
@@ -224,13 +238,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 float f[GS2M_NUM_FEATURES];
 #pragma unroll
                 for (int k = 0; k < GS2M_NUM_FEATURES; k++) f[k] = 0.f;
-                if (features != nullptr) {
-                    const float2* f2 = reinterpret_cast<const float2*>(features + (size_t)idx * GS2M_NUM_FEATURES);
 #pragma unroll
-                    for (int k = 0; k < GS2M_NUM_FEATURES / 2; k++) {
-                        const float2 t = f2[k];
-                        f[2 * k] = t.x; f[2 * k + 1] = t.y;
-                    }
+                for (int k = 0; k < GS2M_NUM_FEATURES / 2; k++) {
+                    f[2 * k] = in_f[k].x; f[2 * k + 1] = in_f[k].y;
                 }
                 r4[REC_CH + 0] = make_float4(cr, cg, cb, f[0]);
                 r4[REC_CH + 1] = make_float4(f[1], f[2], f[3], f[4]);

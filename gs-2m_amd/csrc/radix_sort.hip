@@ -116,13 +116,16 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
         // the total of `tt` (num_rendered) leaves for the host as soon as the LAST workgroup has added its share: long
         // before the sort and the scan behind this kernel are done (api.hip).  Relaxed agent-scope atomics on one word
         // each; the finishing workgroup puts both words back to zero for the next call.
-        __hip_atomic_fetch_add(sum.acc, s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the running total is kept in 64 bits (acc[0..1]) and published saturated, so a count beyond 2^32 cannot wrap past
+        // the caller's range check; acc[2] counts the finished workgroups
+        unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(sum.acc);
+        __hip_atomic_fetch_add(acc64, (unsigned long long)s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        const uint32_t done = __hip_atomic_fetch_add(sum.acc + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t done = __hip_atomic_fetch_add(sum.acc + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (uint32_t)workers - 1u) {
-            const uint32_t total = __hip_atomic_exchange(sum.acc, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sum.acc + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sum.landing, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long total = __hip_atomic_exchange(acc64, 0ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sum.acc + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sum.landing, total > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     for (int p = 0; p < npass; p++) {

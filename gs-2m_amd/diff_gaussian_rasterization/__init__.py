@@ -267,7 +267,7 @@ class _CModule:
         entries += [("means2D", (P, 4)), ("colors", (P, NUM_CHANNELS)), ("cov3D", (P, 6))]
         if return_conics:
             entries.append(("conics", (P, 2, 2)))
-        arena = _arena.GradArena(device, entries, zero=(P == 0))
+        arena = _arena.GradArena(device, entries, zero=(P == 0), key="rasterizer")
         dL_dmeans3D = arena["means3D"]; dL_dmeans2D = arena["means2D"]; dL_dcolors = arena["colors"]
         dL_dfeatures = arena["features"]; dL_dopacities = arena["opacities"]; dL_dcov3D = arena["cov3D"]
         dL_dshs = arena["shs"]; dL_dscales = arena["scales"]; dL_drotations = arena["rotations"]
@@ -314,6 +314,7 @@ def release_scratch():
     """Free the backward's cached row scratch (~0.9 GB at 1M Gaussians / 1080p, kept per device and stream between calls)."""
     _ScratchCache.release()
     _BinningCache.release()
+    _arena.release()
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,

@@ -6,21 +6,27 @@ occupy -- no concatenated copy.  The registry is what makes that safe: the reduc
 every entry it was handed (gs2m_dp.GradReducer.reduce_flat), never "whatever else lives in that storage".
 Producers: the rasterizer binding's backward (diff_gaussian_rasterization) and the fused activation backward
 (gs2m_render_ops._Activate)."""
+import collections
 import threading
-import weakref
 
 import torch
 
 _ALIGN = 4  # floats: entries start on 16-B boundaries (the kernels stream SH rows as float4)
+_KEEP = 2   # arenas kept registered (and thereby alive) per producer and device
 _lock = threading.Lock()
-_registry = {}  # storage data_ptr -> weakref to the GradArena that owns it
+_registry = {}  # (producer key, device index) -> deque of the producer's latest GradArenas
 
 
 class GradArena:
-    """entries: list of (name, shape).  `self[name]` is the view; `self.layout` = [(name, offset, numel)] in floats, in
-    the order given -- callers put what a data-parallel step sums FIRST / ADJACENT so that it forms one contiguous range."""
+    """entries: list of (name, shape).  `self[name]` is the view; `self.layout` = [(name, offset, numel, shape)] in floats, in
+    the order given -- callers put what a data-parallel step sums FIRST / ADJACENT so that it forms one contiguous range.
+    The registry holds the `_KEEP` latest arenas of every producer (`key`) per device: a registered arena's buffer is
+    alive, so a tensor whose storage starts where the arena's does IS one of its views (an address cannot have been
+    reused).  Older arenas drop out -- their gradients are then summed through a copy -- and gs2m_arena.release() (also
+    called by diff_gaussian_rasterization.release_scratch) lets go of all of them.  Retained memory: at most `_KEEP`
+    arenas per producer beyond the gradients' own lifetime (the rasterizer's: 82 floats per Gaussian)."""
 
-    def __init__(self, device, entries, zero=False):
+    def __init__(self, device, entries, zero=False, key="default"):
         self.layout, total = [], 0
         for name, shape in entries:
             n = 1
@@ -29,27 +35,35 @@ class GradArena:
             self.layout.append((name, total, n, tuple(int(d) for d in shape)))
             total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
         self.flat = (torch.zeros if zero else torch.empty)(max(total, 1), dtype=torch.float32, device=device)
-        self._views = {name: self.flat[off:off + n].view(shape) for name, off, n, shape in self.layout}
+        # no view is kept here: autograd takes a gradient over as a leaf's .grad WITHOUT a copy only while nothing else
+        # references the tensor (AccumulateGrad checks its use count) -- a registry that held the views made every
+        # backward clone all of its gradients
+        self._index = {name: (off, n, shape) for name, off, n, shape in self.layout}
+        self.ptr = self.flat.untyped_storage().data_ptr()
         with _lock:
-            for k in [k for k, r in _registry.items() if r() is None]:
-                del _registry[k]
-            _registry[self.flat.untyped_storage().data_ptr()] = weakref.ref(self)
+            _registry.setdefault((key, self.flat.device.index), collections.deque(maxlen=_KEEP)).append(self)
 
     def __getitem__(self, name):
-        return self._views[name]
+        off, n, shape = self._index[name]
+        return self.flat[off:off + n].view(shape)
 
     def get(self, name):
-        return self._views.get(name)
+        return self[name] if name in self._index else None
+
+
+def release():
+    with _lock:
+        _registry.clear()
 
 
 def lookup(t):
-    """-> (arena, offset, numel) when `t` is exactly one registered entry of a live arena, else None."""
+    """-> (arena, offset, numel) when `t` is exactly one entry of a registered arena, else None."""
     if t is None or t.dtype != torch.float32 or not t.is_contiguous():
         return None
+    ptr = t.untyped_storage().data_ptr()
     with _lock:
-        ref = _registry.get(t.untyped_storage().data_ptr())
-    arena = ref() if ref is not None else None
-    if arena is None or arena.flat.untyped_storage().data_ptr() != t.untyped_storage().data_ptr():
+        arena = next((a for dq in _registry.values() for a in dq if a.ptr == ptr), None)
+    if arena is None:
         return None
     off = t.storage_offset()
     for name, o, n, shape in arena.layout:

@@ -157,7 +157,7 @@ class _Activate(torch.autograd.Function):
         # the raw-parameter gradients side by side in one registered arena (gs2m_arena): data-parallel training sums them
         # in place with one collective (they become the parameters' .grad as they are)
         names = ("scaling", "rotation", "opacity", "albedo", "roughness", "metallic")
-        arena = _arena.GradArena(rotation.device, [(nm, t.shape) for nm, t, n in zip(names, like, need) if n])
+        arena = _arena.GradArena(rotation.device, [(nm, t.shape) for nm, t, n in zip(names, like, need) if n], key="activate")
         d = [arena[nm] if n else None for nm, n in zip(names, need)]
         with torch.cuda.device(rotation.device):
             _native.check(_native.lib().gs2m_activate_backward(
