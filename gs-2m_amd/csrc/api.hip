@@ -215,7 +215,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
             const SideSum sum = {acc ? g.tiles_touched : nullptr, acc, t_pinned.dev};
             HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
-                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, SideScan{0, nullptr, nullptr}, sum));
+                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, sum));
         }
         {   // 2. emission offsets in that order (publishes the count itself when the side sum is not available)
             StageTimer t(ST_SCAN, s, &failed_stage);
@@ -260,10 +260,8 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);
-            // side job (list-driven kernels): the first gradient row of every emit wave, read by the backward
-            const SideScan side = {(P + 63) / 64, g.wave_rows, g.wave_base};
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
-                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, side));
+                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s));
         }
         {
             StageTimer t(ST_RANGES, s, &failed_stage);

@@ -33,8 +33,6 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     g.clamped = (uint8_t*)take(P);
     g.counters = (uint32_t*)take(64 * 4);
     g.sorted_rows = (uint32_t*)take(P * 4);
-    g.wave_rows = (uint32_t*)take(((P + 63) / 64 + 2) * 4);
-    g.wave_base = (uint32_t*)take(((P + 63) / 64 + 2) * 4);
     g.temp = take(temp_bytes);
     g.temp_bytes = temp_bytes;
     g.total_bytes = off + GS2M_ALIGN;
@@ -98,13 +96,15 @@ namespace {
 // binning level (quad_lists_kernel) then needs no record gather at all -- and the 4-bit hit mask travels through the
 // tile sort above the Gaussian id.  The backward writes one gradient row per set bit; the rows of a wave's 64
 // Gaussians are numbered densely in emission order (instance by instance, quadrant by quadrant): an instance gets its
-// offset inside the wave's range here, the wave's row total goes to wave_rows[] (prefix: wave_base_kernel).  So the
-// rows of every Gaussian are one dense run and the per-Gaussian sum streams them (gaussian_bwd.hip).
+// offset inside the wave's range here; the range of wave w starts at row 4 x (emission offset of its first Gaussian)
+// -- a wave with n instances owns at most 4 n rows, so the ranges cannot overlap and need no prefix sum over the waves
+// (the row scratch is sized for 4 R rows anyway).  So the rows of every Gaussian are one dense run and the
+// per-Gaussian sum streams them (gaussian_bwd.hip).
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint32_t* __restrict__ sorted_gid,
                                                    const uint32_t* __restrict__ sorted_tt,
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                   uint32_t* __restrict__ inst_obs, uint32_t* __restrict__ wave_rows,
+                                                   uint32_t* __restrict__ inst_obs,
                                                    uint32_t* __restrict__ sorted_rows, ZeroJobs zero) {
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         cnt = sorted_tt[i];
         off = sorted_off[i];
     }
+    const uint32_t base = __shfl(off, 0, 64);  // first emission slot of the wave (lane 0 is in range whenever the wave has work)
     if (cnt > 0) {
         float4* r = rec + (size_t)gid * REC_Q + REC_BIN;
         const float4 bin = *r;
@@ -130,11 +131,10 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         reinterpret_cast<uint32_t*>(r)[0] = off;
         s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
         s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
-        reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = (uint32_t)(i >> 6);  // the emit wave's index
+        reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = 4u * base;  // first gradient row of the wave's range
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
-    const uint32_t base = __shfl(off, 0, 64);
     s_pref[wave][lane] = incl - cnt;
     s_gid[wave][lane] = gid;
     s_rmin[wave][lane] = rmin;
@@ -177,7 +177,6 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
             rows_run += __shfl(pin, 63, 64);
         }
     }
-    if (lane == 0 && (i >> 6) <= ((P - 1) >> 6)) wave_rows[i >> 6] = rows_run;
     if (i < P) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
 }
 
@@ -259,7 +258,7 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict
 
 void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, b.inst_obs, g.wave_rows, g.sorted_rows, zero);
+                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

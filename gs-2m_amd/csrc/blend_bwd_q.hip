@@ -83,7 +83,7 @@ __device__ __forceinline__ void row_scan_add2(const float x, const float y, floa
 template <int FC>
 __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qlast,
-    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row, const uint32_t* __restrict__ wave_base,
+    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
@@ -180,17 +180,17 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         float2 g1;       // C, opacity
         float ch[KK];
         float4 bin;      // emission offset, rect min, rect w|h, (t2)
-        uint32_t wave;   // emit wave that owns the Gaussian's gradient rows (record quad REC_AUX)
+        uint32_t wave;   // first gradient row of the emit wave that owns the Gaussian's rows (record quad REC_AUX)
         uint32_t pos1;   // position in the tile list + 1
         uint32_t below;  // this instance's rows in the quadrants before this one
     };
     // Gradient-row index of (instance, quadrant): the rows of an emit wave's 64 Gaussians are numbered densely in
-    // emission order (binning.hip: emit_kernel<true>): wave_base[wave] + the instance's offset inside the wave's range
+    // emission order (binning.hip: emit_kernel): the first row of the wave's range + the instance's offset inside the range
     // + the number of its quadrants before this one.
     auto row_of = [&](const float4 bin, uint32_t wave, uint32_t below) {
         const uint32_t off = f2u(bin.x), rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
         const uint32_t slot = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
-        return wave_base[wave] + inst_row[slot] + below;
+        return wave + inst_row[slot] + below;
     };
     // list entry of survivor j in group g.  Lanes past the front of the list (the last group may be partial) take
     // entry 0 with position ~0 = behind every pixel's last contributor: real, finite record data that no pixel accepts.
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;
-            row_cur = row_of(f.bin, f.wave, f.below);  // two dependent gathers, in flight while the group's steps run
+            row_cur = row_of(f.bin, f.wave, f.below);  // one gather (the instance's offset inside its wave's range), in flight while the group's steps run
             process_group(min(16, np - 16 * g_cur));
         }
     }
@@ -408,7 +408,7 @@ void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, con
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
 #define GS2M_BWDQ(FC)                                                                                                      \
-    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.wave_base, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
+    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
                                                   im.n_contrib, grad_color, grad_buffer, rows)
     switch (fc_template(fc)) {
         case 1: GS2M_BWDQ(1); break;

@@ -17,8 +17,8 @@
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
 //         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
 //         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
-// q7: x = u32 index of the emit wave (depth rank / 64) that owns the Gaussian's gradient rows (binning.hip);
-//     y, z, w unused
+// q7: x = u32 first gradient row of the range of the emit wave (depth rank / 64) that owns the Gaussian's rows
+//     (binning.hip); y, z, w unused
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
@@ -50,8 +50,6 @@ struct GeomState {
     uint8_t* clamped;        // P
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
     uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order
-    uint32_t* wave_rows;     // ceil(P / 64) + 1: gradient rows of each emit wave's 64 Gaussians
-    uint32_t* wave_base;     // ceil(P / 64) + 1: exclusive prefix of wave_rows; [nw] = total rows
     char* temp;              // radix sort / scan temporary storage
     size_t temp_bytes;
     size_t total_bytes;      // including alignment slack
@@ -215,16 +213,10 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 size_t gs2m_geom_temp_bytes(size_t P);
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
-// side job of a sort's histogram kernel: one extra workgroup runs gs2m_wave_base_scan (nw == 0: none)
-struct SideScan {
-    int nw;
-    const uint32_t* wave_rows;
-    uint32_t* wave_base;
-};
-// second side job of a histogram kernel: sum of an n-element u32 array (the same indices the kernel reads keys at),
-// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = four 8-byte
-// aligned words that are zero before the launch (the caller zeroes them on the stream ahead of every call) and are left
-// zero by the kernel: a 64-bit accumulator, the finished-workgroup count, one spare.
+// side job of a sort's histogram kernel: sum of an n-element u32 array (the same indices the kernel reads keys at),
+// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = an 8-byte
+// aligned 64-bit word that is zero before the launch (the caller zeroes it on the stream ahead of every call): total and
+// finished-workgroup count in one.
 struct SideSum {
     const uint32_t* tt;
     uint32_t* acc;
@@ -232,7 +224,7 @@ struct SideSum {
 };
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideScan side = SideScan{0, nullptr, nullptr}, SideSum sum = SideSum{nullptr, nullptr, nullptr});
+                                 SideSum sum = SideSum{nullptr, nullptr, nullptr});
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
@@ -329,49 +321,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane
         if (lane >= d) v += t;
     }
     return v;
-}
-
-// Exclusive prefix of the emit waves' gradient-row counts by ONE 256-thread workgroup (ceil(P / 64) values):
-// wave_base[w] = first row of wave w, wave_base[nw] = total.  Run as a side job by one extra workgroup of the tile
-// sort's histogram kernel, so it costs no launch and no time on the forward's critical path.
-__device__ __forceinline__ void gs2m_wave_base_scan(int nw, const uint32_t* __restrict__ wave_rows, uint32_t* __restrict__ wave_base) {
-    constexpr int MAXI = 32, T = 256;
-    __shared__ uint32_t s_wbw[4];
-    __shared__ uint32_t s_wbrun;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_wbrun = 0;
-    for (int b0 = 0; b0 < nw; b0 += MAXI * T) {
-        const int n = min(nw - b0, MAXI * T);
-        const int per = (n + T - 1) / T;  // consecutive items per thread
-        const int i0 = b0 + tid * per;
-        uint32_t v[MAXI], sum = 0;
-#pragma unroll
-        for (int k = 0; k < MAXI; k++) {
-            v[k] = (k < per && i0 + k < b0 + n) ? wave_rows[i0 + k] : 0u;
-            sum += v[k];
-        }
-        const uint32_t incl = wave_inclusive_scan_u32(sum, lane);
-        gs2m_sync();  // s_wbrun of the previous pass is final, s_wbw free
-        if (lane == 63) s_wbw[wave] = incl;
-        gs2m_sync();
-        uint32_t wb = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w < wave) wb += s_wbw[w];
-            tot += s_wbw[w];
-        }
-        uint32_t run = s_wbrun + wb + incl - sum;
-#pragma unroll
-        for (int k = 0; k < MAXI; k++)
-            if (k < per && i0 + k < b0 + n) {
-                wave_base[i0 + k] = run;
-                run += v[k];
-            }
-        gs2m_sync();
-        if (tid == 0) s_wbrun += tot;
-    }
-    gs2m_sync();
-    if (tid == 0) wave_base[nw] = s_wbrun;
 }
 
 // alpha evaluation shared bit-for-bit by the forward and backward blend kernels:

@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 
 // Sum of the partial-gradient rows of every Gaussian, ahead of gaussian_bwd_kernel.  The backward blend
 // (blend_bwd_q.hip) numbers its rows DENSELY: emit wave
-// w (the same 64 depth-sorted Gaussians this kernel's wave w owns) has the rows [wave_base[w], wave_base[w + 1]), Gaussian
+// w (the same 64 depth-sorted Gaussians this kernel's wave w owns) has its rows from 4 x its first emission offset on, Gaussian
 // by Gaussian (sorted_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows
 // per window as five fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked
 // in LDS, then rq lanes per Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 // order): bitwise reproducible.
 __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint32_t* __restrict__ sorted_gid,
                                                                const uint32_t* __restrict__ sorted_rows,
-                                                               const uint32_t* __restrict__ wave_base,
+                                                               const uint32_t* __restrict__ sorted_off,
                                                                const float* __restrict__ rows, int rowf, float* __restrict__ sums) {
     constexpr int MAXQ = 6;
     __shared__ float4 s_row[4][GS2M_WAVE * MAXQ];  // one window: 64 rows x rq float4, row-major
@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's Gaussians
-    const uint32_t wb = (i >> 6) <= ((P - 1) >> 6) ? wave_base[i >> 6] : 0u;
+    // the wave's rows start at 4 x the emission offset of its first Gaussian (binning.hip: emit_kernel)
+    const uint32_t wb = (i >> 6) <= ((P - 1) >> 6) ? 4u * sorted_off[(i >> 6) << 6] : 0u;
     s_excl[wave][lane] = incl - cnt;
     s_cnt[wave][lane] = cnt;
     s_gidw[wave][lane] = gid;
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
 }  // namespace
 
 void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s) {
-    row_reduce_dense_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.wave_base, rows, rowf, sums);
+    row_reduce_dense_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums);
 }
 
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,

@@ -81,14 +81,10 @@ constexpr int RS_HIST_WGS = RS_HIST_WGS_N;
 constexpr int RS_HIST_REP = 16;
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npass,
                                                              int4 bits, int4 shift, uint32_t* __restrict__ ghist, int tiles,
-                                                             int workers, SideScan side, SideSum sum) {
+                                                             int workers, SideSum sum) {
     __shared__ uint32_t s_h[RS_MAXPASS][256][RS_HIST_REP];
     __shared__ uint32_t s_sum;
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x == workers) {  // the extra workgroup: a small scan that is due at about this point of the stream
-        gs2m_wave_base_scan(side.nw, side.wave_rows, side.wave_base);
-        return;
-    }
     if (tid == 0) s_sum = 0;
     for (int i = tid; i < RS_MAXPASS * 256 * RS_HIST_REP; i += RS_THREADS) (&s_h[0][0][0])[i] = 0;
     gs2m_sync();
@@ -97,13 +93,21 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
     uint32_t tsum = 0;
     for (int tile = blockIdx.x; tile < tiles; tile += workers) {
         const uint32_t base = (uint32_t)tile * RS_TILE;
-#pragma unroll 4
+        // all 16 keys (and side-sum terms) of the thread are requested before the first is used: one memory round trip per
+        // tile instead of four (the kernel is a single short pass over the keys: latency is all it costs)
+        uint32_t key[RS_ITEMS], tv[RS_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; k++) {
+            const uint32_t i = base + k * RS_THREADS + tid;
+            key[k] = i < n ? keys[i] : 0u;
+            tv[k] = (sum.tt && i < n) ? sum.tt[i] : 0u;
+        }
+#pragma unroll
         for (int k = 0; k < RS_ITEMS; k++) {
             const uint32_t i = base + k * RS_THREADS + tid;
             if (i < n) {
-                const uint32_t key = keys[i];
-                for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key >> sh[p]) & ((1u << b[p]) - 1u)][rep], 1u);
-                if (sum.tt) tsum += sum.tt[i];
+                for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(key[k] >> sh[p]) & ((1u << b[p]) - 1u)][rep], 1u);
+                tsum += tv[k];
             }
         }
     }
@@ -114,17 +118,16 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
     gs2m_sync();
     if (sum.tt && tid == 0) {
         // the total of `tt` (num_rendered) leaves for the host as soon as the LAST workgroup has added its share: long
-        // before the sort and the scan behind this kernel are done (api.hip).  Relaxed agent-scope atomics on one word
-        // each; the finishing workgroup puts both words back to zero for the next call.
-        // the running total is kept in 64 bits (acc[0..1]) and published saturated, so a count beyond 2^32 cannot wrap past
-        // the caller's range check; acc[2] counts the finished workgroups
+        // before the sort and the scan behind this kernel are done (api.hip).
+        // ONE 64-bit returning atomic carries both the running total (low 44 bits: every partial sum is below 2^32 and at most
+        // 512 workgroups add one) and the number of workgroups that have added theirs (bits 44 and up): the workgroup whose
+        // add returns workers - 1 in the count field is the last one and holds the grand total -- no fence, no second
+        // counter.  Published saturated, so a count beyond 2^32 cannot wrap past the caller's range check.  The words are
+        // zeroed on the stream ahead of every call (api.hip: the preprocess kernel's zero jobs).
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(sum.acc);
-        __hip_atomic_fetch_add(acc64, (unsigned long long)s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const uint32_t done = __hip_atomic_fetch_add(sum.acc + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (uint32_t)workers - 1u) {
-            const unsigned long long total = __hip_atomic_exchange(acc64, 0ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sum.acc + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(acc64, (1ull << 44) | (unsigned long long)s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(old >> 44) == (uint32_t)workers - 1u) {
+            const unsigned long long total = (old & ((1ull << 44) - 1ull)) + (unsigned long long)s_sum;
             __hip_atomic_store(sum.landing, total > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -309,7 +312,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideScan side, SideSum sum) {
+                                 SideSum sum) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -322,8 +325,8 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     const int workers = tiles < RS_HIST_WGS ? tiles : RS_HIST_WGS;
-    rs_hist_kernel<<<workers + (side.nw > 0 ? 1 : 0), RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
-                                                                          make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, workers, side, sum);
+    rs_hist_kernel<<<workers, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
+                                                                          make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, workers, sum);
     const uint32_t *ki = kin, *vi = vin;
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;
