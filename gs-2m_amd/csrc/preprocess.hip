@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, ZeroJobs zero) {
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
-    __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
+    // (the block's blend records are parked in the same LDS afterwards: 256 x 36 floats)
+    __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 36];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
     // issued behind it would cost a second exposed memory round trip (the kernel is latency bound at 12 waves per CU).
@@ -84,8 +85,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         gs2m_sync();
     }
     gs2m_zero_jobs(zero, (size_t)idx, (size_t)gridDim.x * blockDim.x);  // the sort / scan scratch of the stages that follow
-    if (idx >= P) return;
-
     int out_radius = 0;
     uint32_t out_tt = 0;
     uint32_t out_key = 0xFFFFFFFFu;
@@ -94,7 +93,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
     const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
     const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
-    if (vz > 0.2f) {
+    float4 rq[REC_Q];  // the blend record (zeros for a Gaussian that emits nothing: its record is never read)
+#pragma unroll
+    for (int k = 0; k < REC_Q; k++) rq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inr && vz > 0.2f) {
         const float hx_ = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
         const float hy_ = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
         const float hw_ = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                     }
                 }
                 const uint32_t ew = (uint32_t)(ex1 - ex0), eh = (uint32_t)(ey1 - ey0);
-                float4* r4 = rec + (size_t)idx * REC_Q;
+                float4* r4 = rq;
                 r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
                 r4[REC_GEO1] = make_float4(cC, op, ex, ey);
                 r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), tau2f);
@@ -252,10 +254,26 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             }
         }
     }
-    radii[idx] = out_radius;
-    if (observe_zero) observe_zero[idx] = 0;  // the list-driven forward adds its counts with integer atomics
-    tiles_touched[idx] = out_tt;
-    depth_key[idx] = out_key;
+    if (inr) {
+        radii[idx] = out_radius;
+        if (observe_zero) observe_zero[idx] = 0;  // the forward adds its counts with integer atomics
+        tiles_touched[idx] = out_tt;
+        depth_key[idx] = out_key;
+    }
+    // The block's 256 records are one contiguous 32-KB run of `rec`: they leave through LDS (row stride 36 floats:
+    // conflict-free 16-B writes) as fully coalesced float4 stores -- a thread storing its own record writes seven 16-B
+    // pieces into a line of its own, 64 lines per store instruction.
+    gs2m_sync();  // every thread is done with its SH row
+    float4* s_rec = reinterpret_cast<float4*>(s_sh);
+#pragma unroll
+    for (int k = 0; k < REC_Q; k++) s_rec[threadIdx.x * 9 + k] = rq[k];
+    gs2m_sync();
+    const size_t lim4 = (size_t)P * REC_Q, base4 = (size_t)blockIdx.x * 256 * REC_Q;
+#pragma unroll
+    for (int k = 0; k < REC_Q; k++) {
+        const int e = k * 256 + threadIdx.x;
+        if (base4 + e < lim4) rec[base4 + e] = s_rec[(e >> 3) * 9 + (e & 7)];
+    }
 }
 
 // markVisible / checkFrustum (rasterizer_impl.cu:48-59, 132-143)

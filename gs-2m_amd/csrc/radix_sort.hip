@@ -391,43 +391,41 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
         if (w < wave) wbase += s_w[w];
         total += s_w[w];
     }
-    if (tid == 0) {
+    if (wave == 0) {
+        // look-back by a whole wave: lane l reads the status of tile - 1 - l, so one round trip covers 64 predecessors (a
+        // single thread walking 4 per round trip needed ~11 round trips of ~1 us for the 245 tiles of 1M Gaussians)
         uint32_t excl = 0;
         if (tile == 0) {
-            __hip_atomic_store(status, FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status, FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(status + tile, FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int p = (int)tile - 1;
+            if (lane == 0) __hip_atomic_store(status + tile, FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int p = (int)tile - 1;  // nearest predecessor not yet accounted for
             bool found = false;
-            while (!found) {  // windowed look-back as in rs_onesweep_kernel
-                uint32_t w[LB_WIN];
-#pragma unroll
-                for (int k = 0; k < LB_WIN; k++)
-                    w[k] = p - k >= 0 ? __hip_atomic_load(status + (p - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_PFX;
-                bool stalled = false;
-#pragma unroll
-                for (int k = 0; k < LB_WIN; k++) {
-                    const uint32_t f = w[k] & ~VAL_MASK;
-                    if (!found && !stalled) {
-                        if (f == 0u) {
-                            stalled = true;
-                        } else {
-                            excl += w[k] & VAL_MASK;
-                            p--;
-                            found = f == FLAG_PFX;
-                        }
-                    }
-                }
-                if (stalled) __builtin_amdgcn_s_sleep(1);
+            while (!found) {
+                const int q = p - lane;
+                // in front of tile 0: prefix 0
+                const uint32_t w = q >= 0 ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_PFX;
+                const uint32_t f = w & ~VAL_MASK;
+                const unsigned long long mp = __builtin_amdgcn_ballot_w64(f == FLAG_PFX), mz = __builtin_amdgcn_ballot_w64(f == 0u);
+                const int fp = mp ? (int)__builtin_ctzll(mp) : 64, fz = mz ? (int)__builtin_ctzll(mz) : 64;
+                const int take = fz < fp ? fz : (fp < 64 ? fp + 1 : 64);  // lanes [0, take) are summed
+                uint32_t v = lane < take ? (w & VAL_MASK) : 0u;
+                v = wave_inclusive_scan_u32(v, lane);
+                excl += __shfl(v, 63, 64);
+                p -= take;
+                found = fp < fz;  // a prefix was reached with every nearer tile published
+                if (!found && fz < 64) __builtin_amdgcn_s_sleep(1);  // an unpublished tile: poll again from there
             }
-            __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_base = excl;
-        if ((tile + 1) * (256 * SC_ITEMS) >= n) {  // last tile: num_rendered
-            counters[0] = excl + total;
-            // ... and straight to the host: ONE aligned 32-bit store at system scope into the mapped pinned word the host
-            // polls (a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen, api.hip)
-            if (landing) __hip_atomic_store(landing, excl + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) {
+            s_base = excl;
+            if ((tile + 1) * (256 * SC_ITEMS) >= n) {  // last tile: num_rendered
+                counters[0] = excl + total;
+                // ... and straight to the host: ONE aligned 32-bit store at system scope into the mapped pinned word the host
+                // polls (a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen, api.hip)
+                if (landing) __hip_atomic_store(landing, excl + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     gs2m_sync();
