@@ -220,12 +220,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
             __hip_atomic_store(my, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // look-back, LB_WIN predecessors per round trip: the loads of one window are independent, so a chain
             // of k not-yet-prefixed tiles costs k / LB_WIN memory latencies instead of k
-#ifndef RS_LB_REPS
-#define RS_LB_REPS 1
-#endif
             int p = (int)tile - 1;
             bool found = false;
-            for (int lbrep = 0; lbrep < RS_LB_REPS; lbrep++) { p = (int)tile - 1; found = false; excl = 0;
             while (!found) {
                 uint32_t w[LB_WIN];
 #pragma unroll
@@ -247,7 +243,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
                     }
                 }
                 if (stalled) __builtin_amdgcn_s_sleep(1);
-            }
             }
             __hip_atomic_store(my, FLAG_PFX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
