@@ -92,6 +92,7 @@ def cpu_baseline(P, W, H, fc, seed):
         # autograd rasterizer BASELINE.json configs[0] names
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from torch_ref import rasterize_dense
+        torch.set_num_threads(min(8, cores))  # hundreds of threads on ops this small only contend (13 minutes instead of half of one)
         d = {k: v.double().requires_grad_(True) for k, v in g.items()}
         t0 = time.time()
         color, buf, _, _ = rasterize_dense(d["means3D"], d["opacities"], d["shs"], None, d["scales"], d["rotations"], None, d["features"],
