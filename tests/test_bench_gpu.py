@@ -33,7 +33,8 @@ def test_bench_line_has_the_contract_fields():
 def test_bench_two_ranks_share_one_gpu_over_gloo():
     """The N > 1 path of bench.py (launch contract, one collective per step over the gradient arena, blocking and
     pipelined timings, max over ranks) run functionally: two ranks on the one GPU of the box, gloo instead of RCCL."""
-    env = dict(os.environ, GS2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", GS2M_BENCH_WATCHDOG_S="240")
+    # two processes share the one GPU here: the radix sort must not assume it has the device to itself (INTEGRATION.md)
+    env = dict(os.environ, GS2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", GS2M_BENCH_WATCHDOG_S="240", GS2M_SORT_TICKETS="1")
     port = 29700 + os.getpid() % 200
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
