@@ -275,6 +275,18 @@ def assert_image_close(name, got, ref, tol=ABS_TOL_BUFFERS, scale=None, max_outl
                                 f"not at a threshold (closest event {ev:.3e} > {band:g})")
 
 
+def assert_n_contrib_close(nc, f, band=1e-4, max_frac=1e-4, max_proofs=64):
+    """n_contrib (the position of a pixel's last contributor, CR/forward.cu:352-357) is an integer: equal except on a
+    vanishing number of pixels (<= 1e-4 of them), each of which must be shown -- from the oracle's own state, as for image
+    outliers -- to sit on a threshold of the blend (an entry with alpha within `band` of 1/255, power within 1e-6 of 0 or
+    test_T within `band` of 1e-4), where two correct fp32 implementations may take different branches."""
+    bad = np.argwhere(np.asarray(nc) != f.n_contrib)
+    assert len(bad) <= max_frac * f.n_contrib.size, f"n_contrib differs on {len(bad)} pixels"
+    for y, x in bad[:max_proofs]:
+        ev = pixel_threshold_events(f, int(x), int(y), band)
+        assert ev <= band, f"n_contrib differs at pixel ({x},{y}) ({nc[y, x]} vs {f.n_contrib[y, x]}) but the pixel is not at a threshold (closest event {ev:.3e})"
+
+
 def grad_stats(got, ref, rel=REL_TOL_GRADS, floor_frac=1e-5):
     """Element-wise comparison: an element passes when |a-b| <= rel*|b| + floor, floor = floor_frac * rms(b) over
     b's non-zero elements (the absolute error an fp32 sum of that tensor's typical terms carries; the oracle

@@ -104,6 +104,7 @@ def _against_oracle(oracle, key, sc, reference_binning):
         assert np.array_equal(view(imgB, lay.ranges, 2 * Tn, np.uint32).reshape(Tn, 2), f.ranges)
         nc = view(imgB, lay.n_contrib, W * H, np.uint32).reshape(H, W)
         assert (nc != f.n_contrib).mean() <= 1e-4
+        Hh.assert_n_contrib_close(nc, f)  # every pixel whose last contributor differs sits on a threshold of the blend
     gs2m_native.set_reference_binning(False)
     dgr.release_scratch()
 

@@ -209,6 +209,7 @@ def _binning_bit_exact(oracle_lib, gs2m_native, dgr):
     assert np.array_equal(view(imgB, lay.ranges, 2 * Tn, np.uint32).reshape(Tn, 2), f.ranges)
     nc = view(imgB, lay.n_contrib, W * H, np.uint32).reshape(H, W)
     assert (nc != f.n_contrib).mean() <= 1e-4
+    Hh.assert_n_contrib_close(nc, f)  # every pixel whose last contributor differs sits on a threshold of the blend
     assert np.all(nc <= (f.ranges[:, 1] - f.ranges[:, 0]).reshape(f.tiles_y, f.tiles_x).repeat(16, 0).repeat(16, 1)[:H, :W])
 
 
