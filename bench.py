@@ -112,9 +112,9 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
     L1 + D-SSIM + plane + depth-normal losses, backward, densification statistics, fused Adam step."""
     import gs2m_optim
     import gs2m_synth as S
-    from fused_ssim import fused_ssim
+    from fused_ssim import dssim_loss
     from gaussian_renderer import render
-    from gs2m_losses import depth_normal_loss, l1_loss, plane_loss
+    from gs2m_losses import densification_stats, edge_gradient, fused_plane_loss, geometry_image_loss
     from gs2m_scene import Camera, GaussianParams, PipelineParams
     cam0 = S.make_camera(W, H)
     g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=seed).items()}
@@ -141,17 +141,13 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
     def train_step():
         out = render(cam, pc, pipe, bg, geometry_stage=False, material_stage=False, sobel_normal=True)
         vis, radii = out["visibility_filter"], out["radii"]
-        rgb = out["render"].clamp(0, 1)
-        loss = 0.8 * l1_loss(rgb, gt) + 0.2 * (1.0 - fused_ssim(rgb.unsqueeze(0), gt.unsqueeze(0))) + 0.01 * plane_loss(vis, pc)
-        loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+        # clamp + L1 + edge-weighted depth-normal term in one pass (the edge strength of the ground truth recomputed per
+        # iteration, as the reference does), plane term and densification statistics as one launch each (csrc/loss_ops.hip)
+        rgb, Limg, _ = geometry_image_loss(out["render"], gt, out["normal_map"], out["sobel_map"], edge=edge_gradient(gt), w_l1=0.8, w_dn=0.015)
+        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * fused_plane_loss(vis, pc)
         loss.backward()
-        with torch.no_grad():  # train.py:223-227, GM:569-573 in gs2m_model's masked form
-            mask = (out["observe"] > 0) & vis
-            state["max_radii"] = torch.where(mask, torch.max(state["max_radii"], radii), state["max_radii"])
-            vg, f = out["viewspace_points"].grad, vis[:, None]
-            accum.add_(torch.where(f, torch.norm(vg[:, :2], dim=-1, keepdim=True), 0.0))
-            accum_abs.add_(torch.where(f, torch.norm(vg[:, 2:], dim=-1, keepdim=True), 0.0))
-            denom.add_(f)
+        with torch.no_grad():  # train.py:223-227, GM:569-573
+            densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, state["max_radii"])
             opt.step()
             opt.zero_grad(set_to_none=True)
 

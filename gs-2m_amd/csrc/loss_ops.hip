@@ -1,0 +1,357 @@
+// The per-iteration loss tail of the reference's training loop as fused kernels for gfx950 (SURVEY.md 8(f) row N1:
+// "optimizer-side elementwise work"; C ABI in include/gs2m_loss.h).
+//
+// Around the rasterizer and the D-SSIM term the reference's geometry stage runs ~90 small PyTorch kernels per iteration
+// (train.py:94-130, 223-227; utils/loss_utils.py:27-28, 72-79, 113-135; scene/gaussian_model.py:569-573): the clamp of
+// the render, its L1 distance to the ground truth, the edge-aware depth-normal term (with the image-gradient weight
+// recomputed from the ground truth every iteration), the plane (flattening) term and the densification statistics --
+// 0.74 ms of a 2.8 ms iteration at 1M Gaussians / 1080p, every one a full pass over 6-25 MB.  Here:
+//   edge_gradient     ground truth -> raw edge strength per pixel + its min / max over the interior     (1 launch)
+//   image_loss fwd    render, ground truth, normal / Sobel-normal maps, edge strength -> clamped render (for the
+//                     D-SSIM term) + the weighted sum  w_l1 mean|rgb - gt| + w_dn mean(edge weight * |sobel - normal|_1)
+//   image_loss bwd    d loss, d rgb (from D-SSIM) -> d render, d normal map, d Sobel map                  (1 launch)
+//   plane_loss        activated scales + visibility -> mean smallest scale of the visible Gaussians, and its backward
+//   densification_stats   viewspace gradient norms, counts and the screen-radius maximum, in place            (1 launch)
+// All of it is HBM bound: one read of every input, one write of every output.
+// Sums are formed deterministically: a fixed grid, one partial per workgroup, and the last workgroup to finish (atomic
+// ticket) adds the partials in index order in double precision and leaves the ticket at 0 for the next call.
+#include "common.h"
+#include "../../include/gs2m_loss.h"
+
+namespace {
+
+constexpr int LB = 256;     // threads per workgroup of the elementwise launches
+// Reducing launches: one 1024-thread workgroup per CU (16 waves: the loads of a full CU in flight) and a fixed grid, so the
+// partial sums do not depend on the problem size and the ticket (a same-address atomic, ~10 ns each) is taken 256 times.
+constexpr int RB = 1024;
+constexpr int LG = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Workgroup partials -> ws[k * LG + block], then a ticket; returns true in the LAST workgroup once every partial is visible.
+template <int K>
+__device__ __forceinline__ bool publish_partials(const float (&v)[K], float* __restrict__ ws, uint32_t* __restrict__ ticket,
+                                                 int op /* 0 sum, 1: v[0] min, v[1] max */) {
+    __shared__ float s_p[K][RB / 64];
+    __shared__ bool s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float r = op == 0 ? wave_sum(v[k]) : (k == 0 ? wave_min(v[k]) : wave_max(v[k]));
+        if (lane == 0) s_p[k][wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            float r = s_p[k][0];
+#pragma unroll
+            for (int w = 1; w < RB / 64; w++) r = op == 0 ? r + s_p[k][w] : (k == 0 ? fminf(r, s_p[k][w]) : fmaxf(r, s_p[k][w]));
+            __hip_atomic_store(&ws[k * LG + blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last;
+}
+// In the last workgroup: the sum of partial k over the grid, in a fixed order, double precision.  Valid in thread 0.
+__device__ __forceinline__ double final_sum(const float* __restrict__ ws, int k) {
+    __shared__ double s_d[RB];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += RB)
+        a += (double)__hip_atomic_load(&ws[k * LG + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_d[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = RB / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_d[threadIdx.x] += s_d[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = s_d[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float final_minmax(const float* __restrict__ ws, int k) {
+    __shared__ float s_f[RB];
+    float a = k == 0 ? INFINITY : -INFINITY;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += RB) {
+        const float v = __hip_atomic_load(&ws[k * LG + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = k == 0 ? fminf(a, v) : fmaxf(a, v);
+    }
+    s_f[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = RB / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_f[threadIdx.x] = k == 0 ? fminf(s_f[threadIdx.x], s_f[threadIdx.x + s]) : fmaxf(s_f[threadIdx.x], s_f[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const float r = s_f[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float clamp01(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }  // NaN passes, as torch.clamp
+__device__ __forceinline__ float sgn(float d) { return (float)(d > 0.f) - (float)(d < 0.f); }          // torch.sgn: 0 at 0
+
+// _get_img_grad_weight, utils/loss_utils.py:122-135, without the normalisation: per interior pixel the larger of the
+// mean absolute central differences along x and along y; 0 on the one-pixel border (the reference pads).
+__global__ void __launch_bounds__(RB) edge_gradient_kernel(int W, int H, const float* __restrict__ gt, float* __restrict__ g,
+                                                           float* __restrict__ minmax, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    const size_t HW = (size_t)H * W;
+    float v[2] = {INFINITY, -INFINITY};
+    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        float e = 0.f;
+        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+            float ax[3], ay[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float* q = gt + c * HW + p;
+                ax[c] = fabsf(q[1] - q[-1]);
+                ay[c] = fabsf(q[-W] - q[W]);
+            }
+            const float gx = ((ax[0] + ax[1]) + ax[2]) / 3.0f, gy = ((ay[0] + ay[1]) + ay[2]) / 3.0f;
+            e = fmaxf(gx, gy);
+            v[0] = fminf(v[0], e);
+            v[1] = fmaxf(v[1], e);
+        }
+        g[p] = e;
+    }
+    if (publish_partials<2>(v, ws, ticket, 1)) {
+        const float mn = final_minmax(ws, 0), mx = final_minmax(ws, 1);
+        if (threadIdx.x == 0) { minmax[0] = mn; minmax[1] = mx; }
+    }
+}
+
+// (1 - normalised edge strength) clamped to [0, 1], squared (utils/loss_utils.py:117-118); 1 on the border
+__device__ __forceinline__ float edge_weight(float e, float mn, float mx, bool interior) {
+    const float gn = interior ? (e - mn) / (mx - mn) : 0.f;
+    const float w = clamp01(1.0f - gn);
+    return w * w;
+}
+
+struct ImageLossArgs {
+    int W, H;
+    const float *image, *gt, *normal, *sobel, *edge, *edge_minmax, *weight_map;
+    float w_l1, w_dn;
+};
+
+__global__ void __launch_bounds__(RB) image_loss_fwd_kernel(ImageLossArgs a, float* __restrict__ rgb, float* __restrict__ out,
+                                                            float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    const size_t HW = (size_t)a.H * a.W;
+    const bool dn = a.normal != nullptr;
+    float mn = 0.f, mx = 1.f;
+    if (dn && a.edge) { mn = a.edge_minmax[0]; mx = a.edge_minmax[1]; }
+    float v[2] = {0.f, 0.f};
+    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float r = clamp01(a.image[c * HW + p]);
+            rgb[c * HW + p] = r;
+            v[0] += fabsf(r - a.gt[c * HW + p]);
+        }
+        if (dn) {
+            const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
+            float w = a.edge ? edge_weight(a.edge[p], mn, mx, x > 0 && x < a.W - 1 && y > 0 && y < a.H - 1) : 1.0f;
+            if (a.weight_map) w *= a.weight_map[p];
+            const float d0 = fabsf(a.sobel[p] - a.normal[p]), d1 = fabsf(a.sobel[HW + p] - a.normal[HW + p]),
+                        d2 = fabsf(a.sobel[2 * HW + p] - a.normal[2 * HW + p]);
+            v[1] += w * ((d0 + d1) + d2);
+        }
+    }
+    if (publish_partials<2>(v, ws, ticket, 0)) {
+        const double s0 = final_sum(ws, 0), s1 = final_sum(ws, 1);
+        if (threadIdx.x == 0) {
+            const float l1 = (float)(s0 / (3.0 * (double)HW)), dnl = (float)(s1 / (double)HW);
+            out[0] = a.w_l1 * l1 + a.w_dn * dnl;
+            out[1] = l1;
+            out[2] = dnl;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, const float* __restrict__ g_loss,
+                                                            const float* __restrict__ g_rgb, float* __restrict__ d_image,
+                                                            float* __restrict__ d_normal, float* __restrict__ d_sobel) {
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t p = (size_t)blockIdx.x * LB + threadIdx.x;
+    if (p >= HW) return;
+    const float g = g_loss ? g_loss[0] : 0.f;
+    const float k1 = g * a.w_l1 / (3.0f * (float)HW);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float x = a.image[c * HW + p];
+        const float up = (g_rgb ? g_rgb[c * HW + p] : 0.f) + k1 * sgn(clamp01(x) - a.gt[c * HW + p]);
+        d_image[c * HW + p] = (x >= 0.f && x <= 1.f) ? up : 0.f;  // clamp's backward: the gradient passes inside [min, max]
+    }
+    if (a.normal != nullptr) {
+        const int y = (int)(p / a.W), xx = (int)(p - (size_t)y * a.W);
+        float w = a.edge ? edge_weight(a.edge[p], a.edge_minmax[0], a.edge_minmax[1], xx > 0 && xx < a.W - 1 && y > 0 && y < a.H - 1) : 1.0f;
+        if (a.weight_map) w *= a.weight_map[p];
+        const float k2 = g * a.w_dn / (float)HW * w;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float s = k2 * sgn(a.sobel[c * HW + p] - a.normal[c * HW + p]);
+            d_sobel[c * HW + p] = s;
+            d_normal[c * HW + p] = -s;
+        }
+    }
+}
+
+// plane_loss, utils/loss_utils.py:72-79: the mean over the visible Gaussians of their smallest scale
+// (raw: `scaling` holds the log-scales, scene/gaussian_model.py:113-114 -- exp is monotone, so min exp(s) = exp(min s))
+__global__ void __launch_bounds__(RB) plane_loss_fwd_kernel(int P, const float* __restrict__ scaling, int raw, const uint8_t* __restrict__ vis,
+                                                            float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    float v[2] = {0.f, 0.f};
+    for (int i = blockIdx.x * RB + threadIdx.x; i < P; i += LG * RB) {
+        if (vis[i]) {
+            const float m = fminf(fminf(scaling[3 * i], scaling[3 * i + 1]), scaling[3 * i + 2]);
+            v[0] += raw ? expf(m) : m;
+            v[1] += 1.0f;
+        }
+    }
+    if (publish_partials<2>(v, ws, ticket, 0)) {
+        const double s = final_sum(ws, 0), n = final_sum(ws, 1);
+        if (threadIdx.x == 0) {
+            out[0] = (float)(s / (n > 1.0 ? n : 1.0));
+            out[1] = (float)n;
+        }
+    }
+}
+__global__ void __launch_bounds__(LB) plane_loss_bwd_kernel(int P, const float* __restrict__ scaling, int raw, const uint8_t* __restrict__ vis,
+                                                            const float* __restrict__ out, const float* __restrict__ g,
+                                                            float* __restrict__ d_scaling) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= P) return;
+    const float n = out[1];
+    float k = vis[i] ? g[0] / (n > 1.0f ? n : 1.0f) : 0.f;
+    const float s0 = scaling[3 * i], s1 = scaling[3 * i + 1], s2 = scaling[3 * i + 2];
+    int m = 0;  // the first index of the minimum takes the gradient
+    float sm = s0;
+    if (s1 < sm) { sm = s1; m = 1; }
+    if (s2 < sm) { sm = s2; m = 2; }
+    if (raw) k *= expf(sm);  // d exp(s) / d s
+    d_scaling[3 * i] = m == 0 ? k : 0.f;
+    d_scaling[3 * i + 1] = m == 1 ? k : 0.f;
+    d_scaling[3 * i + 2] = m == 2 ? k : 0.f;
+}
+
+// add_densification_stats, scene/gaussian_model.py:569-573, and the max_radii2D update of train.py:223-225
+__global__ void __launch_bounds__(LB) densification_stats_kernel(int P, const float4* __restrict__ vg, const uint8_t* __restrict__ vis,
+                                                                 const int* __restrict__ observe, const int* __restrict__ radii,
+                                                                 float* __restrict__ accum, float* __restrict__ accum_abs,
+                                                                 float* __restrict__ denom, float* __restrict__ max_radii) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= P || !vis[i]) return;
+    const float4 g = vg[i];
+    accum[i] += sqrtf(g.x * g.x + g.y * g.y);
+    accum_abs[i] += sqrtf(g.z * g.z + g.w * g.w);
+    denom[i] += 1.0f;
+    if (max_radii != nullptr && observe[i] > 0) max_radii[i] = fmaxf(max_radii[i], (float)radii[i]);
+}
+
+// out[0] = a + b * mean(x): the mean of a map as a loss term (fused_ssim's `.mean()`, the D-SSIM term lambda (1 - mean))
+__global__ void __launch_bounds__(RB) affine_mean_kernel(size_t n, const float* __restrict__ x, float a, float b, float* __restrict__ out,
+                                                         float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    float v[1] = {0.f};
+    const size_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < n4; i += (size_t)LG * RB) {
+        const float4 q = x4[i];
+        v[0] += (q.x + q.y) + (q.z + q.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) v[0] += x[(n4 << 2) + threadIdx.x];
+    if (publish_partials<1>(v, ws, ticket, 0)) {
+        const double s = final_sum(ws, 0);
+        if (threadIdx.x == 0) out[0] = a + b * (float)(s / (double)n);
+    }
+}
+
+inline int launched() { return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP; }
+
+}  // namespace
+
+extern "C" {
+
+int gs2m_loss_workspace_bytes(void) { return (int)(2 * LG * sizeof(float) + 64); }
+
+int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_minmax, void* workspace, void* stream) {
+    if (W < 3 || H < 3 || !gt || !edge || !edge_minmax || !workspace) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    edge_gradient_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(W, H, gt, edge, edge_minmax, ws, (uint32_t*)(ws + 2 * LG));
+    return launched();
+}
+
+int gs2m_image_loss_forward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+                            const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
+                            float* rgb, float* out, void* workspace, void* stream) {
+    if (W < 1 || H < 1 || !image || !gt || !rgb || !out || !workspace) return GS2M_ERR_INVALID_ARG;
+    if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge_minmax, weight_map, w_l1, w_dn};
+    image_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, rgb, out, ws, (uint32_t*)(ws + 2 * LG));
+    return launched();
+}
+
+int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+                             const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
+                             const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
+                             void* stream) {
+    if (W < 1 || H < 1 || !image || !gt || !d_image) return GS2M_ERR_INVALID_ARG;
+    if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
+    if (normal_map && (!d_normal_map || !d_sobel_map)) return GS2M_ERR_INVALID_ARG;
+    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge_minmax, weight_map, w_l1, w_dn};
+    const size_t HW = (size_t)W * H;
+    image_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, g_rgb, d_image, d_normal_map, d_sobel_map);
+    return launched();
+}
+
+int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream) {
+    if (n <= 0 || !x || !out || !workspace || ((uintptr_t)x & 15)) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    affine_mean_kernel<<<LG, RB, 0, (hipStream_t)stream>>>((size_t)n, x, a, b, out, ws, (uint32_t*)(ws + 2 * LG));
+    return launched();
+}
+
+int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float* out, void* workspace, void* stream) {
+    if (P < 0 || !out || !workspace || (P > 0 && (!scaling || !visible))) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    plane_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, out, ws, (uint32_t*)(ws + 2 * LG));
+    return launched();
+}
+
+int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, const float* out, const float* g_loss,
+                             float* d_scaling, void* stream) {
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if (P == 0) return GS2M_OK;
+    if (!scaling || !visible || !out || !g_loss || !d_scaling) return GS2M_ERR_INVALID_ARG;
+    plane_loss_bwd_kernel<<<(P + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, out, g_loss, d_scaling);
+    return launched();
+}
+
+int gs2m_densification_stats(int P, const float* viewspace_grad, const unsigned char* visible, const int* observe, const int* radii,
+                             float* grad_accum, float* grad_accum_abs, float* denom, float* max_radii, void* stream) {
+    if (P < 0) return GS2M_ERR_INVALID_ARG;
+    if (P == 0) return GS2M_OK;
+    if (!viewspace_grad || !visible || !grad_accum || !grad_accum_abs || !denom) return GS2M_ERR_INVALID_ARG;
+    if (max_radii && (!observe || !radii)) return GS2M_ERR_INVALID_ARG;
+    densification_stats_kernel<<<(P + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(
+        P, (const float4*)viewspace_grad, visible, observe, radii, grad_accum, grad_accum_abs, denom, max_radii);
+    return launched();
+}
+
+}  // extern "C"

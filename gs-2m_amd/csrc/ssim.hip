@@ -139,8 +139,11 @@ __global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, fl
 __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
                                                       const float* __restrict__ img2, const float* __restrict__ dL_dmap,
                                                       const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
-                                                      const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+                                                      const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1,
+                                                      const float* __restrict__ dL_dvalue, float mul, float div) {
     __shared__ float s_x[2][3][SSIM_LDSW];
+    // dL_dmap == nullptr: the map's gradient is the same at every element, dL_dvalue[0] * mul / div (the mean's backward)
+    const float gu = dL_dmap == nullptr ? (dL_dvalue[0] * mul) / div : 0.f;
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * SSIM_ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -153,11 +156,11 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
         const bool row = y >= 0 && y < H;
         const size_t o = plane + (size_t)(row ? y : 0) * W;
         const bool m0 = row && ina, m1 = row && inb;
-        v[0] = m0 ? dL_dmap[o + xa] : 0.f;
+        v[0] = m0 ? (dL_dmap ? dL_dmap[o + xa] : gu) : 0.f;
         v[1] = m0 ? dm_dmu1[o + xa] : 0.f;
         v[2] = m0 ? dm_dsigma1_sq[o + xa] : 0.f;
         v[3] = m0 ? dm_dsigma12[o + xa] : 0.f;
-        v[4] = m1 ? dL_dmap[o + xb] : 0.f;
+        v[4] = m1 ? (dL_dmap ? dL_dmap[o + xb] : gu) : 0.f;
         v[5] = m1 ? dm_dmu1[o + xb] : 0.f;
         v[6] = m1 ? dm_dsigma1_sq[o + xb] : 0.f;
         v[7] = m1 ? dm_dsigma12[o + xb] : 0.f;
@@ -242,6 +245,19 @@ extern "C" int gs2m_ssim_backward(int B, int CH, int H, int W, const float* img1
     if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
     dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
     ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                                                         dL_dimg1);
+                                                         dL_dimg1, nullptr, 0.f, 1.f);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+extern "C" int gs2m_ssim_backward_uniform(int B, int CH, int H, int W, const float* img1, const float* img2, const float* dL_dvalue,
+                                          float mul, float div, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                                          const float* dm_dsigma12, float* dL_dimg1, void* stream) {
+    if (B == 0 || CH == 0 || H == 0 || W == 0) return GS2M_OK;
+    if (B < 0 || CH < 0 || H < 0 || W < 0 || !img1 || !img2 || !dL_dvalue || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1 || div == 0.f)
+        return GS2M_ERR_INVALID_ARG;
+    if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
+    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
+    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, img1, img2, nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                                                         dL_dimg1, dL_dvalue, mul, div);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }

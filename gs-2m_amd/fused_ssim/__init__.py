@@ -87,8 +87,46 @@ class FusedSSIMMap(torch.autograd.Function):
         return None, None, grad, None, None, None
 
 
+class _FusedSSIMAffineMean(torch.autograd.Function):
+    """a + b * mean(ssim_map) as ONE autograd node ("same" padding): the mean is a fixed-order reduction kernel
+    (gs2m_affine_mean) and the backward hands the scalar upstream gradient straight to the SSIM backward kernel
+    (gs2m_ssim_backward_uniform) -- the map's gradient (a constant) is never materialised."""
+
+    @staticmethod
+    def forward(ctx, C1, C2, img1, img2, a, b):
+        import gs2m_losses
+        ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = fusedssim(C1, C2, img1, img2, True)
+        out = torch.empty(1, dtype=torch.float32, device=img1.device)
+        with torch.cuda.device(img1.device):
+            _native.check(_native.lib().gs2m_affine_mean(ssim_map.numel(), _ptr(ssim_map), float(a), float(b), _ptr(out),
+                                                         _ptr(gs2m_losses._workspace(img1.device)),
+                                                         C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_affine_mean")
+        ctx.save_for_backward(img1.detach().contiguous(), img2.contiguous(), dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
+        ctx.b = float(b)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = ctx.saved_tensors
+        B, CH, H, W = img1.shape
+        grad = torch.empty_like(img1)
+        with torch.cuda.device(img1.device):
+            _native.check(_native.lib().gs2m_ssim_backward_uniform(
+                B, CH, H, W, _ptr(img1), _ptr(img2), _ptr(g.contiguous()), ctx.b, float(img1.numel()), _ptr(dm_dmu1), _ptr(dm_dsigma1_sq),
+                _ptr(dm_dsigma12), _ptr(grad), C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_ssim_backward_uniform")
+        return None, None, grad, None, None, None
+
+
 def fused_ssim(img1, img2, padding="same", train=True):
     C1 = 0.01 ** 2
     C2 = 0.03 ** 2
     assert padding in allowed_padding
+    if padding == "same" and train and torch.is_grad_enabled() and isinstance(img1, torch.Tensor) and img1.requires_grad:
+        return _FusedSSIMAffineMean.apply(C1, C2, _check(img1, "img1"), _check(img2, "img2", img1), 0.0, 1.0)
     return FusedSSIMMap.apply(C1, C2, img1, img2, padding, train).mean()
+
+
+def dssim_loss(img1, img2, weight=1.0):
+    """The D-SSIM term of train.py:103 / :136, weight * (1 - fused_ssim(img1, img2)), as one autograd node (no scalar
+    arithmetic kernels around the mean, no materialised map gradient)."""
+    return _FusedSSIMAffineMean.apply(0.01 ** 2, 0.03 ** 2, _check(img1, "img1"), _check(img2, "img2", img1), float(weight), -float(weight))

@@ -19,18 +19,36 @@ import gs2m_render_ops
 from gs2m_scene import eval_sh, normal_from_depth_image
 
 
+_zero_points_cache = {}
+
+
+def _zero_points(P, dtype, device):
+    key = (P, dtype, device)
+    z = _zero_points_cache.get(key)
+    if z is None:
+        _zero_points_cache.clear()  # one size at a time (densification changes P)
+        z = _zero_points_cache[key] = torch.zeros((P, 4), dtype=dtype, device=device)
+    return z
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=False, material_stage=False,
            sobel_normal=False, blend_metallic=False):
     """Render the scene.  Background tensor (bg_color) must be on the GPU."""
     device = pc.get_xyz.device
     # zero tensor whose gradient carries the 2D (screen-space) mean gradients: the first two columns as
     # in 3DGS, the last two accumulate absolute values (GR:38-43)
-    screenspace_points = torch.zeros((pc.get_xyz.shape[0], 4), dtype=pc.get_xyz.dtype, requires_grad=True,
-                                     device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if device.type == "cuda" and bool(getattr(pipe, "fused_render_ops", True)):
+        # A fresh LEAF over a cached block of zeros: the rasterizer never reads the values (only the gradient matters), so no
+        # fill, no `+ 0`, and after backward `.grad` IS the rasterizer's dL/dmeans2D buffer (autograd takes it over; the
+        # reference's non-leaf + retain_grad idiom costs a fill, an add and two (P,4) copies per view)
+        screenspace_points = _zero_points(pc.get_xyz.shape[0], pc.get_xyz.dtype, device).detach().requires_grad_(True)
+    else:
+        screenspace_points = torch.zeros((pc.get_xyz.shape[0], 4), dtype=pc.get_xyz.dtype, requires_grad=True,
+                                         device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

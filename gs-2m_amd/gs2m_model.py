@@ -344,6 +344,19 @@ class GaussianModel(GaussianParams):
         mask = (observe > 0) & visibility_filter
         self.max_radii2D = torch.where(mask, torch.max(self.max_radii2D, radii), self.max_radii2D)
 
+    def accumulate_view_stats(self, viewspace_points, visibility_filter, observe, radii, fused=None):
+        """train.py:223-227 for one view: `update_max_radii` + `add_densification_stats`.  On the GPU one HIP launch
+        (gs2m_losses.densification_stats) instead of ~14 framework kernels; `fused=False` keeps the PyTorch expressions."""
+        if fused is None:
+            fused = self._xyz.is_cuda
+        if fused and observe.dtype == torch.int32 and radii.dtype == torch.int32:
+            from gs2m_losses import densification_stats
+            densification_stats(viewspace_points.grad, visibility_filter, self.xyz_gradient_accum, self.xyz_gradient_accum_abs, self.denom,
+                                observe, radii, self.max_radii2D)
+        else:
+            self.update_max_radii(observe, visibility_filter, radii)
+            self.add_densification_stats(viewspace_points, visibility_filter)
+
     def reset_opacity(self, ceiling=0.01):  # GM:362-365 (ceiling 0.8: reduce_opacity, GM:367-370)
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * ceiling))
         self._rebind(self.replace_tensor_to_optimizer(new, "opacity"))

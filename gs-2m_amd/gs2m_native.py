@@ -149,6 +149,24 @@ def lib():
     L.gs2m_ssim_backward.restype = i
     L.gs2m_ssim_backward.argtypes = [i, i, i, i, p, p, p, p, p, p, p, p]
     L.gs2m_profile_mode.restype = i
+    L.gs2m_loss_workspace_bytes.argtypes = []
+    L.gs2m_loss_workspace_bytes.restype = i
+    L.gs2m_edge_gradient.argtypes = [i, i, p, p, p, p, p]
+    L.gs2m_edge_gradient.restype = i
+    L.gs2m_image_loss_forward.argtypes = [i, i, p, p, p, p, p, p, p, f, f, p, p, p, p]
+    L.gs2m_image_loss_forward.restype = i
+    L.gs2m_image_loss_backward.argtypes = [i, i, p, p, p, p, p, p, p, f, f, p, p, p, p, p, p]
+    L.gs2m_image_loss_backward.restype = i
+    L.gs2m_affine_mean.argtypes = [C.c_longlong, p, f, f, p, p, p]
+    L.gs2m_affine_mean.restype = i
+    L.gs2m_ssim_backward_uniform.argtypes = [i, i, i, i, p, p, p, f, f, p, p, p, p, p]
+    L.gs2m_ssim_backward_uniform.restype = i
+    L.gs2m_plane_loss_forward.argtypes = [i, p, i, p, p, p, p]
+    L.gs2m_plane_loss_forward.restype = i
+    L.gs2m_plane_loss_backward.argtypes = [i, p, i, p, p, p, p, p]
+    L.gs2m_plane_loss_backward.restype = i
+    L.gs2m_densification_stats.argtypes = [i, p, p, p, p, p, p, p, p, p]
+    L.gs2m_densification_stats.restype = i
     L.gs2m_profile_mode.argtypes = [i]
     L.gs2m_profile_collect.restype = i
     L.gs2m_profile_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), i]

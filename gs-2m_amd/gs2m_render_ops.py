@@ -70,7 +70,7 @@ class _GBufferPost(torch.autograd.Function):
         buffer, view = _f32c(buffer, "buffer"), _f32c(view, "world_view_transform")
         rays = None if rays is None else _f32c(rays, "rays")
         _, H, W = buffer.shape
-        mask = torch.empty((1, H, W), dtype=torch.uint8, device=buffer.device)
+        mask = torch.empty((1, H, W), dtype=torch.bool, device=buffer.device)  # one byte per pixel, the kernel writes 0 / 1
         local_normal = torch.empty((3, H, W), dtype=torch.float32, device=buffer.device)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=buffer.device)
         with torch.cuda.device(buffer.device):
@@ -79,7 +79,6 @@ class _GBufferPost(torch.autograd.Function):
                 _stream()), "gs2m_gbuffer_post_forward")
         ctx.save_for_backward(buffer, rays, view)
         ctx.z_depth = int(bool(z_depth))
-        mask = mask.bool()
         ctx.mark_non_differentiable(mask)
         return mask, local_normal, depth
 
@@ -110,6 +109,7 @@ class _GBufferMaps(torch.autograd.Function):
     def forward(ctx, buffer, rays, view, z_depth):
         b = _f32c(buffer, "buffer")
         mask, local_normal, depth = _GBufferPost.forward(ctx, b, rays, view, z_depth)
+        ctx.set_materialize_grads(False)  # maps the loss never touches arrive as None (the kernel takes NULL), not as zero-filled frames
         return b[0:1], b[1:2], b[2:5], b[5:8], b[8:9], b[9:10], mask, local_normal, depth
 
     @staticmethod

@@ -26,9 +26,10 @@ if _HERE not in sys.path:
 import torch
 
 import gs2m_synth as S
-from fused_ssim import fused_ssim
+from fused_ssim import dssim_loss, fused_ssim
 from gaussian_renderer import render
-from gs2m_losses import depth_normal_loss, edge_weights, l1_loss, plane_loss, tv_loss
+from gs2m_losses import (depth_normal_loss, edge_gradient, edge_weights, fused_plane_loss, geometry_image_loss, l1_loss, plane_loss,
+                         tv_loss)
 from gs2m_model import GaussianModel, OptimizationParams
 from gs2m_scene import Camera, GaussianParams, PipelineParams, inverse_sigmoid
 
@@ -216,7 +217,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         import gs2m_mvs
         mv_opt = mv_opt or gs2m_mvs.MultiViewParams()
         mv_scene = gs2m_mvs.MultiViewScene(cams, gts, gaussians, mv_opt)
-    lighting, rays, dn_weights = None, {}, {}
+    lighting, rays, dn_weights, dn_edges = None, {}, {}, {}
     if material_from_iter < iterations:
         from pbr import pbr_render
         import torch.nn.functional as F
@@ -245,17 +246,31 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         material_stage = it > material_from_iter
         out = render(cam, gaussians, pipe, bg, geometry_stage, material_stage, sobel_normal=geometry_stage)
         vis, radii = out["visibility_filter"], out["radii"]
-        rgb = out["render"].clamp(0, 1)
-        loss = opt.lambda_plane * plane_loss(vis, gaussians)
+        # the loss tail as fused kernels (gs2m_losses, csrc/loss_ops.hip) on the GPU; the PyTorch expressions otherwise
+        fused_tail = out["render"].is_cuda and getattr(pipe, "fused_loss_tail", True)
+        fused_image = fused_tail and not material_stage
+        rgb = None if fused_image else out["render"].clamp(0, 1)
+        loss = opt.lambda_plane * (fused_plane_loss if fused_tail else plane_loss)(vis, gaussians)
         if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
             loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
-        if not material_stage:  # train.py:101-115
+        if fused_image:  # train.py:101-120 in one pass: clamp, L1 and the edge-weighted depth-normal term
+            if geometry_stage and k not in dn_edges:  # a function of the ground-truth image only (the reference recomputes it every iteration)
+                dn_edges[k] = edge_gradient(gt)
+            rgb, Limg, _ = geometry_image_loss(out["render"], gt, out["normal_map"] if geometry_stage else None,
+                                               out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
+                                               w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0)
+            if ssim_fn is None:  # lambda (1 - ssim) as one node
+                loss = loss + Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+            else:
+                loss = loss + Limg + opt.lambda_ssim * (1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0)))
+        elif not material_stage:  # train.py:101-115
             Lssim = 1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
-            if k not in dn_weights:  # a function of the ground-truth image only (the reference recomputes it every iteration)
-                dn_weights[k] = edge_weights(gt)
-            loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
+            if not fused_image:
+                if k not in dn_weights:
+                    dn_weights[k] = edge_weights(gt)
+                loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
             if mv_scene is not None and lambda_multi_view > 0:
                 Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render,
                                                fused=os.environ.get("GS2M_MV_OP_BY_OP") is None)  # debugging aid: the op-by-op formulation
@@ -294,8 +309,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                     gaussians.xyz_gradient_accum_abs += ga
                     gaussians.denom += cnt
                 else:
-                    gaussians.update_max_radii(out["observe"], vis, radii)
-                    gaussians.add_densification_stats(out["viewspace_points"], vis)
+                    gaussians.accumulate_view_stats(out["viewspace_points"], vis, out["observe"], radii, fused=fused_tail)
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                     thr = opt.radii2D_threshold if it > opt.opacity_reset_interval else None
                     gaussians.densify_and_prune(opt.densify_grad_threshold, opt.densify_grad_abs_threshold, opt.opacity_prune_threshold, extent, thr)

@@ -1,0 +1,65 @@
+/* gs2m_loss.h -- C ABI of the fused loss tail of one training iteration ("optimizer-side
+ * elementwise work"), part of libgs2m_raster.so.
+ *
+ * The reference computes these terms with plain PyTorch ops (there is no native interface to replace); each entry
+ * point below cites the Python it restates.  The Python mirror is gs-2m_amd/gs2m_losses.py (`geometry_image_loss`,
+ * `fused_plane_loss`, `edge_gradient`) and GaussianModel.add_densification_stats / update_max_radii.
+ *
+ * All pointers are DEVICE pointers to contiguous arrays (fp32 unless stated); images are planar (C, H, W).  Scalars that
+ * the training loop produces on the device (upstream gradients, min / max) are passed as device pointers so that no
+ * call synchronises.  `workspace`: gs2m_loss_workspace_bytes() bytes of device memory, ZERO when first used and owned
+ * by one stream at a time (the reducing kernels leave it zeroed).  Calls are asynchronous on `stream`; return GS2M_OK (0)
+ * or a negative GS2M_ERR_* code (gs2m_raster.h).  Sums are formed in a fixed order: results are bitwise reproducible. */
+#ifndef GS2M_LOSS_H
+#define GS2M_LOSS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gs2m_loss_workspace_bytes(void);
+
+/* _get_img_grad_weight, utils/loss_utils.py:122-135, up to its min-max normalisation: edge[y][x] = max over the two axes
+ * of the channel-mean absolute central difference of gt (3, H, W) for interior pixels, 0 on the one-pixel border;
+ * edge_minmax[0..1] = min and max of edge over the interior.  Depends on the ground truth only. */
+int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_minmax, void* workspace, void* stream);
+
+/* train.py:101-104, 113-120 in one pass:  rgb = clamp(image, 0, 1)  (written: the D-SSIM term reads it),
+ *   l1 = mean |rgb - gt|                                            (l1_loss, utils/loss_utils.py:27-28)
+ *   dn = mean_pixels( w * sum_c |sobel_map - normal_map| ),  w = clamp(1 - (edge - min) / (max - min), 0, 1)^2 inside,
+ *        1 on the border, times weight_map when given               (depth_normal_loss, utils/loss_utils.py:113-120)
+ * out[0] = w_l1 * l1 + w_dn * dn, out[1] = l1, out[2] = dn.  normal_map / sobel_map both NULL: no dn term;
+ * edge / edge_minmax both NULL: w = 1; weight_map may be NULL. */
+int gs2m_image_loss_forward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+                            const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
+                            float* rgb, float* out, void* workspace, void* stream);
+
+/* Backward of the above: g_loss[0] = d L / d out[0] (NULL: 0), g_rgb = d L / d rgb from the D-SSIM term (NULL: 0).
+ * Writes d_image (through the clamp: 0 outside [0, 1]) and, when the dn term is present, d_normal_map and d_sobel_map. */
+int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+                             const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
+                             const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
+                             void* stream);
+
+/* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
+ * fused_ssim/__init__.py:40-41) and the D-SSIM term lambda * (1 - ssim) of train.py:103 (a = lambda, b = -lambda). */
+int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream);
+
+/* plane_loss, utils/loss_utils.py:72-79: out[0] = mean over the visible Gaussians of the smallest of their three
+ * scales, 0 when none is visible; out[1] = the number of visible Gaussians (kept for the backward).  scaling (P, 3): the
+ * activated scales (raw = 0, `get_scaling`) or the log-scales the model stores (raw = 1, `_scaling`: the exp of
+ * scene/gaussian_model.py:113-114 and its derivative are applied here).  visible: P bytes (torch.bool). */
+int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float* out, void* workspace, void* stream);
+int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, const float* out, const float* g_loss,
+                             float* d_scaling, void* stream);
+
+/* add_densification_stats, scene/gaussian_model.py:569-573, in place: for visible Gaussians grad_accum += |grad[:, :2]|,
+ * grad_accum_abs += |grad[:, 2:]|, denom += 1 (viewspace_grad: (P, 4)).  With max_radii non-NULL also train.py:223-225:
+ * max_radii = max(max_radii, radii) where visible and observe > 0 (observe, radii: int32). */
+int gs2m_densification_stats(int P, const float* viewspace_grad, const unsigned char* visible, const int* observe, const int* radii,
+                             float* grad_accum, float* grad_accum_abs, float* denom, float* max_radii, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

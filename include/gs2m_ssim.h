@@ -26,6 +26,13 @@ int gs2m_ssim_backward(int B, int CH, int H, int W, const float* img1, const flo
                        const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                        void* stream);
 
+/* The same with a map gradient that is uniform: dL/dmap = dL_dvalue[0] * mul / div at every element (dL_dvalue: a
+ * DEVICE scalar).  This is the backward of `ssim_map.mean()` (mul = 1, div = element count: fused_ssim/__init__.py:40-41)
+ * and of the D-SSIM loss term lambda * (1 - mean) (mul = -lambda; train.py:103) without materialising the map's gradient. */
+int gs2m_ssim_backward_uniform(int B, int CH, int H, int W, const float* img1, const float* img2, const float* dL_dvalue,
+                               float mul, float div, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                               const float* dm_dsigma12, float* dL_dimg1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

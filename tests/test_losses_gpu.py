@@ -1,0 +1,154 @@
+"""The fused loss tail (csrc/loss_ops.hip, include/gs2m_loss.h) against the PyTorch expressions of the
+reference it replaces (gs2m_losses: l1_loss, depth_normal_loss + edge_weights, plane_loss; GaussianModel's statistics),
+values and gradients, on the device."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-2m_amd"))
+pytestmark = pytest.mark.gpu
+
+
+def _frames(H, W, seed, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    image = (torch.randn(3, H, W, generator=g) * 0.45 + 0.5)          # a good share outside [0, 1]: the clamp's mask matters
+    gt = torch.rand(3, H, W, generator=g)
+    normal = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    sobel = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    R = torch.randn(3, H, W, generator=g)                             # a second consumer of rgb (stands in for D-SSIM)
+    wm = torch.rand(1, H, W, generator=g)
+    return [t.to(dev) for t in (image, gt, normal, sobel, R, wm)]
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (77, 333), (5, 4)])
+@pytest.mark.parametrize("mode", ["l1+dn", "l1+dn+weight_map", "l1", "dn unweighted"])
+def test_geometry_image_loss_equals_the_pytorch_expressions(H, W, mode):
+    import gs2m_losses as L
+    image, gt, normal, sobel, R, wm = _frames(H, W, seed=H + W)
+    w_l1, w_dn = 0.8, 0.015
+    # --- PyTorch formulation (train.py:101-120)
+    i0, n0, s0 = (t.clone().requires_grad_(True) for t in (image, normal, sobel))
+    rgb0 = i0.clamp(0, 1)
+    ref = w_l1 * L.l1_loss(rgb0, gt) + (rgb0 * R).sum() * 1e-3
+    if mode != "l1":
+        if mode == "dn unweighted":
+            ref = ref + w_dn * (s0 - n0).abs().sum(dim=0).mean()
+        else:
+            ref = ref + w_dn * L.depth_normal_loss(n0, s0, gt, weight_map=wm if "weight_map" in mode else None)
+    ref.backward()
+    # --- fused
+    i1, n1, s1 = (t.clone().requires_grad_(True) for t in (image, normal, sobel))
+    dn = mode != "l1"
+    rgb1, loss, terms = L.geometry_image_loss(i1, gt, n1 if dn else None, s1 if dn else None,
+                                              edge=L.edge_gradient(gt) if dn and mode != "dn unweighted" else None,
+                                              weight_map=wm if "weight_map" in mode else None, w_l1=w_l1, w_dn=w_dn if dn else 0.0)
+    got = loss + (rgb1 * R).sum() * 1e-3
+    got.backward()
+    assert torch.equal(rgb1, rgb0.detach())
+    assert abs(float(got) - float(ref)) <= 2e-5 * abs(float(ref)) + 1e-6
+    assert abs(float(terms[0]) - float(L.l1_loss(rgb0, gt))) <= 1e-5
+    # gradients: identical expressions element by element, up to the order of two roundings
+    assert torch.allclose(i1.grad, i0.grad, rtol=1e-5, atol=1e-10)
+    if dn:
+        assert torch.allclose(n1.grad, n0.grad, rtol=2e-5, atol=1e-12) and torch.allclose(s1.grad, s0.grad, rtol=2e-5, atol=1e-12)
+        assert float(n1.grad.abs().sum()) > 0
+    else:
+        assert n1.grad is None and s1.grad is None
+
+
+def test_edge_gradient_is_the_reference_image_gradient_weight():
+    import gs2m_losses as L
+    gt = _frames(270, 480, seed=5)[1]
+    edge, mm = L.edge_gradient(gt)
+    gx = (gt[:, 1:-1, 2:] - gt[:, 1:-1, :-2]).abs().mean(0)
+    gy = (gt[:, :-2, 1:-1] - gt[:, 2:, 1:-1]).abs().mean(0)
+    g = torch.maximum(gx, gy)
+    assert torch.allclose(edge[1:-1, 1:-1], g, rtol=1e-6, atol=1e-8)
+    assert float(edge[0].abs().sum() + edge[-1].abs().sum() + edge[:, 0].abs().sum() + edge[:, -1].abs().sum()) == 0.0
+    assert abs(float(mm[0]) - float(g.min())) <= 1e-7 and abs(float(mm[1]) - float(g.max())) <= 1e-7
+    w = (1.0 - (edge - mm[0]) / (mm[1] - mm[0])).clamp(0, 1) ** 2
+    assert torch.allclose(w[1:-1, 1:-1], L.edge_weights(gt)[1:-1, 1:-1], rtol=1e-5, atol=1e-6)
+
+
+def test_reductions_are_bitwise_reproducible_and_leave_the_workspace_clean():
+    import gs2m_losses as L
+    image, gt, normal, sobel, _, _ = _frames(1080, 1920, seed=1)
+    edge = L.edge_gradient(gt)
+    a = [L.geometry_image_loss(image, gt, normal, sobel, edge=edge, w_l1=0.8, w_dn=0.015)[1].clone() for _ in range(3)]
+    assert torch.equal(a[0], a[1]) and torch.equal(a[1], a[2])
+    e2 = L.edge_gradient(gt)
+    assert torch.equal(edge[1], e2[1]) and torch.equal(edge[0], e2[0])
+    torch.cuda.synchronize()
+    assert all(float(ws[-16:].abs().sum()) == 0.0 for ws in L._workspaces.values()), "the ticket word (behind the partial sums) is back at 0"
+
+
+class _Scales:
+    def __init__(self, s):
+        self._s = s
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._s)
+
+
+class _RawScales(_Scales):  # the reference model's attribute name: the fused form reads the log-scales directly
+    @property
+    def _scaling(self):
+        return self._s
+
+
+@pytest.mark.parametrize("model", [_Scales, _RawScales])
+@pytest.mark.parametrize("P,frac", [(1_000_000, 0.85), (1000, 0.5), (257, 0.0), (0, 0.0)])
+def test_fused_plane_loss_equals_plane_loss(P, frac, model):
+    import gs2m_losses as L
+    g = torch.Generator().manual_seed(P + 1)
+    raw = (torch.randn(P, 3, generator=g) - 4.0).cuda()
+    vis = (torch.rand(P, generator=g) < frac).cuda()
+    r0, r1 = raw.clone().requires_grad_(True), raw.clone().requires_grad_(True)
+    a = L.plane_loss(vis, _Scales(r0))
+    b = L.fused_plane_loss(vis, model(r1))
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a)) + 1e-12
+    (a * 3.0).backward()
+    (b * 3.0).backward()
+    assert torch.allclose(r1.grad, r0.grad, rtol=1e-5, atol=1e-14)
+    if frac == 0.0 and P:
+        assert float(b) == 0.0 and float(r1.grad.abs().sum()) == 0.0
+
+
+def test_densification_stats_equal_the_model_expressions():
+    import gs2m_losses as L
+    P = 300_001
+    g = torch.Generator().manual_seed(3)
+    vg = torch.randn(P, 4, generator=g).cuda()
+    vis = (torch.rand(P, generator=g) < 0.8).cuda()
+    observe = torch.randint(0, 3, (P,), generator=g, dtype=torch.int32).cuda()
+    radii = torch.randint(0, 200, (P,), generator=g, dtype=torch.int32).cuda()
+    acc, acc_abs, den = (torch.rand(P, 1, generator=g).cuda() for _ in range(3))
+    mr = (torch.rand(P, generator=g) * 100).cuda()
+    f = vis[:, None]
+    ref_acc = acc + torch.where(f, torch.norm(vg[:, :2], dim=-1, keepdim=True), 0.0)
+    ref_abs = acc_abs + torch.where(f, torch.norm(vg[:, 2:], dim=-1, keepdim=True), 0.0)
+    ref_den = den + f
+    mask = (observe > 0) & vis
+    ref_mr = torch.where(mask, torch.max(mr, radii), mr)
+    L.densification_stats(vg, vis, acc, acc_abs, den, observe, radii, mr)
+    assert torch.equal(den, ref_den) and torch.equal(mr, ref_mr)
+    assert torch.allclose(acc, ref_acc, rtol=3e-7, atol=0) and torch.allclose(acc_abs, ref_abs, rtol=3e-7, atol=0)
+    # without the radius update
+    acc2, abs2, den2 = ref_acc.clone(), ref_abs.clone(), ref_den.clone()
+    L.densification_stats(vg, vis, acc2, abs2, den2)
+    assert torch.equal(den2, ref_den + f)
+
+
+def test_the_fused_forms_refuse_cpu_tensors():
+    import gs2m_losses as L
+    x = torch.rand(3, 8, 8)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        L.geometry_image_loss(x, x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        L.edge_gradient(x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        L.fused_plane_loss(torch.ones(4, dtype=torch.bool), _Scales(torch.zeros(4, 3)))

@@ -95,3 +95,21 @@ def test_fused_ssim_fullsize_properties():
     assert abs(s.item() - 1.0) < 1e-5
     s.backward()
     assert a.grad.abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 1080, 1920), (2, 3, 45, 67), (1, 1, 7, 9)])
+def test_dssim_loss_is_weight_times_one_minus_mean_ssim(shape):
+    """train.py:103's term as one node: the value, and the gradient against the map formulation with the same kernels."""
+    from fused_ssim import dssim_loss, FusedSSIMMap
+    gen = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(shape, generator=gen).cuda().requires_grad_(True)
+    b = torch.rand(shape, generator=gen).cuda()
+    ref = 0.2 * (1.0 - FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, a, b, "same", True).mean())
+    (ref * 1.7).backward()
+    g_ref = a.grad.clone()
+    a.grad = None
+    got = dssim_loss(a, b, 0.2)
+    (got * 1.7).backward()
+    assert torch.isclose(got, ref.detach(), rtol=2e-6, atol=1e-7)
+    assert torch.allclose(a.grad, g_ref, rtol=1e-5, atol=1e-12), (a.grad - g_ref).abs().max()
+    assert torch.equal(dssim_loss(a.detach().requires_grad_(True), b, 0.2), got), "fixed-order reduction: bitwise reproducible"

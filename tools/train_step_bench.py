@@ -14,9 +14,10 @@ from gs2m_scene import GaussianParams, PipelineParams, Camera
 from gs2m_losses import l1_loss, plane_loss, depth_normal_loss
 import gs2m_losses
 from gaussian_renderer import render
-from fused_ssim import fused_ssim
+from fused_ssim import dssim_loss, fused_ssim
 
 REF = "--reference-formulation" in sys.argv
+TORCH_TAIL = REF or "--torch-loss-tail" in sys.argv  # the losses / statistics around the fused pieces as PyTorch expressions
 MV = "--multi-view" in sys.argv   # + multi_view_loss against a second, nearby camera (fused path only)
 P, W, H = 1_000_000, 1920, 1080
 dev = "cuda"
@@ -75,10 +76,14 @@ def step():
     global max_radii
     out = render(cam, pc, pipe, bg, geometry_stage=MV, material_stage=False, sobel_normal=True)
     image, vis, radii = out["render"], out["visibility_filter"], out["radii"]
-    rgb = image.clamp(0, 1)
-    Lssim = 1.0 - ssim_fn(rgb.unsqueeze(0), gt.unsqueeze(0))
-    loss = 0.8 * l1_loss(rgb, gt) + 0.2 * Lssim + 0.01 * plane_loss(vis, pc)
-    loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+    if TORCH_TAIL:
+        rgb = image.clamp(0, 1)
+        Lssim = 1.0 - ssim_fn(rgb.unsqueeze(0), gt.unsqueeze(0))
+        loss = 0.8 * l1_loss(rgb, gt) + 0.2 * Lssim + 0.01 * plane_loss(vis, pc)
+        loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
+    else:  # the loss tail as fused kernels (csrc/loss_ops.hip)
+        rgb, Limg, _ = gs2m_losses.geometry_image_loss(image, gt, out["normal_map"], out["sobel_map"], edge=gs2m_losses.edge_gradient(gt), w_l1=0.8, w_dn=0.015)
+        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * gs2m_losses.fused_plane_loss(vis, pc)
     if MV:
         loss = loss + gs2m_mvs.multi_view_loss(mvs, cam, mvp, out, pipe, bg, False, render, rng=rng)
     loss.backward()
@@ -90,6 +95,8 @@ def step():
             accum[vis] += torch.norm(vg[vis, :2], dim=-1, keepdim=True)
             accum_abs[vis] += torch.norm(vg[vis, 2:], dim=-1, keepdim=True)
             denom[vis] += 1
+        elif not TORCH_TAIL:
+            gs2m_losses.densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, max_radii)
         else:  # gs2m_model.GaussianModel's masked forms
             mask = (out["observe"] > 0) & vis
             max_radii = torch.where(mask, torch.max(max_radii, radii), max_radii)
@@ -118,3 +125,12 @@ if "--profile" in sys.argv:
             step()
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+if "--profile-ops" in sys.argv:  # which framework ops (with shapes) the non-HIP time belongs to
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+    for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:60]:
+        print("%-28s n %3d  self device %8.1f us/step  %s" % (e.key, e.count // 3, e.self_device_time_total / 3, str(e.input_shapes)[:110]))
