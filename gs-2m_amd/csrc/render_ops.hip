@@ -320,11 +320,12 @@ __global__ void __launch_bounds__(256) sobel_normal_kernel(int W, int H, const f
 // gradients of the stencil at (u, v) with respect to a and b, given the upstream gradient of its normal
 __device__ __forceinline__ void stencil_grads(const CamInv& C, const float* __restrict__ depth,
                                               const float* __restrict__ alpha, const float* __restrict__ g, int W, int H,
-                                              int u, int v, float da[3], float db[3]) {
-    da[0] = da[1] = da[2] = db[0] = db[1] = db[2] = 0.f;
+                                              int u, int v, float da[3], float db[3], float n[3]) {
+    da[0] = da[1] = da[2] = db[0] = db[1] = db[2] = n[0] = n[1] = n[2] = 0.f;
     if (!(u > 0 && u < W - 1 && v > 0 && v < H - 1)) return;
     const size_t N = (size_t)W * H, q = (size_t)v * W + u;
     const Stencil s = eval_stencil(C, depth, W, u, v);
+    n[0] = s.n[0]; n[1] = s.n[1]; n[2] = s.n[2];
     const float al = alpha[q];
     const float dn[3] = {g[q] * al, g[N + q] * al, g[2 * N + q] * al};
     float dm[3];
@@ -342,29 +343,42 @@ __device__ __forceinline__ void stencil_grads(const CamInv& C, const float* __re
 }
 
 // gather form: pixel p is the right neighbour of (u-1, v), the left of (u+1, v), the top of (u, v+1), the bottom of
-// (u, v-1); no atomics, bitwise reproducible
-__global__ void __launch_bounds__(256) sobel_normal_bwd_kernel(int W, int H, const float* __restrict__ depth,
-                                                               const float* __restrict__ alpha,
-                                                               const float* __restrict__ bg, const float* __restrict__ view,
-                                                               float fx, float fy, float cx, float cy,
-                                                               const float* __restrict__ g, float* __restrict__ d_depth,
-                                                               float* __restrict__ d_alpha) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= W * H) return;
-    const int u = p % W, v = p / W;
-    const size_t N = (size_t)W * H;
+// (u, v-1); no atomics, bitwise reproducible.  A 16x16-pixel workgroup evaluates the stencil gradients of its tile plus a
+// one-pixel halo ONCE into LDS (324 stencils for 256 pixels; every stencil costs ~15 divisions and a square root, and a
+// thread that evaluated its four neighbours itself paid for five) and every pixel gathers its four terms from there.
+constexpr int SOB_T = 16, SOB_H = SOB_T + 2;
+__global__ void __launch_bounds__(SOB_T* SOB_T) sobel_normal_bwd_kernel(int W, int H, const float* __restrict__ depth,
+                                                                       const float* __restrict__ alpha,
+                                                                       const float* __restrict__ bg, const float* __restrict__ view,
+                                                                       float fx, float fy, float cx, float cy,
+                                                                       const float* __restrict__ g, float* __restrict__ d_depth,
+                                                                       float* __restrict__ d_alpha) {
+    __shared__ float s_da[3][SOB_H * SOB_H], s_db[3][SOB_H * SOB_H], s_n[3][SOB_H * SOB_H];
+    const int x0 = blockIdx.x * SOB_T, y0 = blockIdx.y * SOB_T;
     const CamInv C = load_cam_inv(view, fx, fy, cx, cy);
-    float n[3] = {0.f, 0.f, 0.f};
-    if (u > 0 && u < W - 1 && v > 0 && v < H - 1) {
-        const Stencil s = eval_stencil(C, depth, W, u, v);
-        n[0] = s.n[0]; n[1] = s.n[1]; n[2] = s.n[2];
+    for (int h = threadIdx.x; h < SOB_H * SOB_H; h += SOB_T * SOB_T) {
+        const int hu = x0 - 1 + h % SOB_H, hv = y0 - 1 + h / SOB_H;
+        float da[3] = {0.f, 0.f, 0.f}, db[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f};
+        if (hu >= 0 && hu < W && hv >= 0 && hv < H) stencil_grads(C, depth, alpha, g, W, H, hu, hv, da, db, n);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_da[k][h] = da[k]; s_db[k][h] = db[k]; s_n[k][h] = n[k]; }
     }
-    d_alpha[p] = g[p] * (n[0] - bg[0]) + g[N + p] * (n[1] - bg[1]) + g[2 * N + p] * (n[2] - bg[2]);
-    float acc[3] = {0.f, 0.f, 0.f}, da[3], db[3];
-    if (u > 0) { stencil_grads(C, depth, alpha, g, W, H, u - 1, v, da, db); acc[0] += da[0]; acc[1] += da[1]; acc[2] += da[2]; }
-    if (u < W - 1) { stencil_grads(C, depth, alpha, g, W, H, u + 1, v, da, db); acc[0] -= da[0]; acc[1] -= da[1]; acc[2] -= da[2]; }
-    if (v < H - 1) { stencil_grads(C, depth, alpha, g, W, H, u, v + 1, da, db); acc[0] += db[0]; acc[1] += db[1]; acc[2] += db[2]; }
-    if (v > 0) { stencil_grads(C, depth, alpha, g, W, H, u, v - 1, da, db); acc[0] -= db[0]; acc[1] -= db[1]; acc[2] -= db[2]; }
+    __syncthreads();
+    const int lx = threadIdx.x % SOB_T, ly = threadIdx.x / SOB_T;
+    const int u = x0 + lx, v = y0 + ly;
+    if (u >= W || v >= H) return;
+    const size_t N = (size_t)W * H, p = (size_t)v * W + u;
+    const int hc = (ly + 1) * SOB_H + lx + 1;  // this pixel in the halo grid
+    d_alpha[p] = g[p] * (s_n[0][hc] - bg[0]) + g[N + p] * (s_n[1][hc] - bg[1]) + g[2 * N + p] * (s_n[2][hc] - bg[2]);
+    float acc[3] = {0.f, 0.f, 0.f};
+    // positions outside the image hold zeros: adding them changes nothing
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (u > 0) acc[k] += s_da[k][hc - 1];
+        if (u < W - 1) acc[k] -= s_da[k][hc + 1];
+        if (v < H - 1) acc[k] += s_db[k][hc + SOB_H];
+        if (v > 0) acc[k] -= s_db[k][hc - SOB_H];
+    }
     float r[3];
     world_ray(C, u, v, r);
     d_depth[p] = r[0] * acc[0] + r[1] * acc[1] + r[2] * acc[2];
@@ -526,9 +540,9 @@ int gs2m_sobel_normal_backward(int width, int height, const float* depth, const 
     if (width <= 0 || height <= 0 || !depth || !alpha || !bg || !view || !dL_dsobel || !dL_ddepth || !dL_dalpha || fx == 0.f ||
         fy == 0.f)
         return GS2M_ERR_INVALID_ARG;
-    const int N = width * height;
-    sobel_normal_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx,
-                                                                             cy, dL_dsobel, dL_ddepth, dL_dalpha);
+    const dim3 grid((width + SOB_T - 1) / SOB_T, (height + SOB_T - 1) / SOB_T);
+    sobel_normal_bwd_kernel<<<grid, SOB_T * SOB_T, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx,
+                                                                            cy, dL_dsobel, dL_ddepth, dL_dalpha);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

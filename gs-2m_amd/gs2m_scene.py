@@ -142,6 +142,7 @@ class PipelineParams:
     split_sh = True          # this repository's addition: hand _features_dc / _features_rest to the rasterizer unconcatenated
     fused_render_ops = True  # this repository's addition: fused HIP pre/post-processing in render() (gs2m_render_ops)
     fused_activations = True  # ... and the model's activation getters as one launch (needs fused_render_ops)
+    fused_loss_tail = True   # ... and, in gs2m_train, the loss terms + densification statistics around D-SSIM as HIP kernels (gs2m_losses)
 
 
 class Camera:

@@ -225,16 +225,17 @@ def test_render_fused_equals_unfused(material_stage, blend_metallic):
             _close("grad " + n, a, b, 1e-3)  # the depth division amplifies fp32 rounding; 1e-3 is the gradient bar of the path
 
 
-def test_sobel_normal_matches_torch():
+@pytest.mark.parametrize("H,W", [(45, 61), (16, 16), (33, 17), (3, 3), (64, 130)])
+def test_sobel_normal_matches_torch(H, W):
     """depth -> world points -> cross product normals -> alpha blend with the background: fused kernel (forward and the
-    gather-form backward) against utils/normal_utils.py as restated in gs2m_scene.normal_from_depth_image."""
+    gather-form backward, 16x16 tiles with a halo: sizes on, below and across the tile edges) against utils/normal_utils.py
+    as restated in gs2m_scene.normal_from_depth_image."""
     assert torch.cuda.is_available()
     import gs2m_render_ops as R
     import gs2m_synth as S
     from gs2m_scene import Camera
     from gaussian_renderer import render_normal_from_depth_map
     dev = "cuda"
-    H, W = 45, 61
     cam = Camera(S.look_at_camera(W, H, (1.0, -0.7, 0.5), (0.2, 0.1, 6.0)), dev)
     gen = torch.Generator().manual_seed(8)
     depth = (torch.rand(H, W, generator=gen) * 3.0 + 2.0).to(dev).requires_grad_(True)
