@@ -264,6 +264,73 @@ __global__ void __launch_bounds__(LB) densification_stats_kernel(int P, const fl
     if (max_radii != nullptr && observe[i] > 0) max_radii[i] = fmaxf(max_radii[i], (float)radii[i]);
 }
 
+// tv_loss, utils/loss_utils.py:536-557: edge-aware total variation of pred (C, H, W).  Neighbour differences along y and
+// along x (absolute, or squared with norm1 = 0), damped by exp(-channel-mean |difference of the ground truth|) and, with a
+// weight map, by the mean of the two pixels' weights; the mean over all vertical pairs plus the mean over all horizontal pairs.
+struct TvArgs {
+    int W, H, C, norm1;
+    const float *gt, *pred, *wm;
+};
+// damping and weight of the pair (p, p + stride): stride = W (vertical) or 1 (horizontal)
+__device__ __forceinline__ float tv_pair_weight(const TvArgs& a, size_t HW, size_t p, size_t stride) {
+    const float e0 = fabsf(a.gt[p + stride] - a.gt[p]), e1 = fabsf(a.gt[HW + p + stride] - a.gt[HW + p]),
+                e2 = fabsf(a.gt[2 * HW + p + stride] - a.gt[2 * HW + p]);
+    float w = expf(-(((e0 + e1) + e2) / 3.0f));
+    if (a.wm) w *= (a.wm[p + stride] + a.wm[p]) / 2.0f;
+    return w;
+}
+__global__ void __launch_bounds__(RB) tv_loss_fwd_kernel(TvArgs a, float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    const size_t HW = (size_t)a.H * a.W;
+    float v[2] = {0.f, 0.f};
+    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
+        const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
+        if (y < a.H - 1) {
+            const float w = tv_pair_weight(a, HW, p, a.W);
+            for (int c = 0; c < a.C; c++) {
+                const float d = a.pred[c * HW + p + a.W] - a.pred[c * HW + p];
+                v[0] += (a.norm1 ? fabsf(d) : d * d) * w;
+            }
+        }
+        if (x < a.W - 1) {
+            const float w = tv_pair_weight(a, HW, p, 1);
+            for (int c = 0; c < a.C; c++) {
+                const float d = a.pred[c * HW + p + 1] - a.pred[c * HW + p];
+                v[1] += (a.norm1 ? fabsf(d) : d * d) * w;
+            }
+        }
+    }
+    if (publish_partials<2>(v, ws, ticket, 0)) {
+        const double sh = final_sum(ws, 0), sw = final_sum(ws, 1);
+        if (threadIdx.x == 0)
+            out[0] = (float)(sh / ((double)a.C * (a.H - 1) * a.W)) + (float)(sw / ((double)a.C * a.H * (a.W - 1)));
+    }
+}
+// gather form: pixel p is the lower end of its own vertical / horizontal pair and the upper end of the pairs that start
+// one row up / one column left
+__global__ void __launch_bounds__(LB) tv_loss_bwd_kernel(TvArgs a, const float* __restrict__ g_loss, float* __restrict__ d_pred) {
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t p = (size_t)blockIdx.x * LB + threadIdx.x;
+    if (p >= HW) return;
+    const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
+    const float g = g_loss[0];
+    const float kh = g / (float)((double)a.C * (a.H - 1) * a.W), kw = g / (float)((double)a.C * a.H * (a.W - 1));
+    const float wd = y < a.H - 1 ? kh * tv_pair_weight(a, HW, p, a.W) : 0.f;       // pair (p, p + W)
+    const float wu = y > 0 ? kh * tv_pair_weight(a, HW, p - a.W, a.W) : 0.f;      // pair (p - W, p)
+    const float wr = x < a.W - 1 ? kw * tv_pair_weight(a, HW, p, 1) : 0.f;         // pair (p, p + 1)
+    const float wl = x > 0 ? kw * tv_pair_weight(a, HW, p - 1, 1) : 0.f;           // pair (p - 1, p)
+    for (int c = 0; c < a.C; c++) {
+        const float* q = a.pred + c * HW + p;
+        const float v0 = q[0];
+        auto dd = [&](float d) { return a.norm1 ? sgn(d) : 2.0f * d; };
+        float r = 0.f;
+        if (y < a.H - 1) r -= wd * dd(q[a.W] - v0);
+        if (y > 0) r += wu * dd(v0 - q[-a.W]);
+        if (x < a.W - 1) r -= wr * dd(q[1] - v0);
+        if (x > 0) r += wl * dd(v0 - q[-1]);
+        d_pred[c * HW + p] = r;
+    }
+}
+
 // out[0] = a + b * mean(x): the mean of a map as a loss term (fused_ssim's `.mean()`, the D-SSIM term lambda (1 - mean))
 __global__ void __launch_bounds__(RB) affine_mean_kernel(size_t n, const float* __restrict__ x, float a, float b, float* __restrict__ out,
                                                          float* __restrict__ ws, uint32_t* __restrict__ ticket) {
@@ -317,6 +384,24 @@ int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, 
     const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge_minmax, weight_map, w_l1, w_dn};
     const size_t HW = (size_t)W * H;
     image_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, g_rgb, d_image, d_normal_map, d_sobel_map);
+    return launched();
+}
+
+int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float* out,
+                         void* workspace, void* stream) {
+    if (W < 2 || H < 2 || C < 1 || !gt || !pred || !out || !workspace) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map};
+    tv_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, ws, (uint32_t*)(ws + 2 * LG));
+    return launched();
+}
+
+int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1,
+                          const float* g_loss, float* d_pred, void* stream) {
+    if (W < 2 || H < 2 || C < 1 || !gt || !pred || !g_loss || !d_pred) return GS2M_ERR_INVALID_ARG;
+    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map};
+    const size_t HW = (size_t)W * H;
+    tv_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, d_pred);
     return launched();
 }
 

@@ -211,6 +211,43 @@ def fused_plane_loss(visibility_filter, gaussians):
     return _PlaneLoss.apply(gaussians.get_scaling, visibility_filter, False)
 
 
+class _TvLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, pred, weight_map, norm1):
+        pred = _cuda_f32(pred, "pred")
+        C, H, W = pred.shape
+        gt = _cuda_f32(gt, "gt_image", (3, H, W))
+        if weight_map is not None:
+            weight_map = _cuda_f32(weight_map.reshape(H, W), "weight_map")
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _native().check(_native().lib().gs2m_tv_loss_forward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), int(bool(norm1)), _ptr(out),
+                                                                 _ptr(_workspace(pred.device)), C_void(_stream(pred.device))), "gs2m_tv_loss_forward")
+        ctx.save_for_backward(gt, pred, weight_map)
+        ctx.norm1 = int(bool(norm1))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gt, pred, weight_map = ctx.saved_tensors
+        C, H, W = pred.shape
+        d = torch.empty_like(pred)
+        with torch.cuda.device(pred.device):
+            _native().check(_native().lib().gs2m_tv_loss_backward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), ctx.norm1, _ptr(g.contiguous()),
+                                                                  _ptr(d), C_void(_stream(pred.device))), "gs2m_tv_loss_backward")
+        return None, d, None, None
+
+
+def C_void(stream):
+    return C.c_void_p(stream.cuda_stream)
+
+
+def fused_tv_loss(gt_image, pred, norm1=True, weight_map=None):
+    """`tv_loss` (same arguments) as one launch each way; the gradient goes to `pred` only (the loop passes a detached
+    weight map and the ground truth)."""
+    return _TvLoss.apply(gt_image, pred, weight_map, norm1)
+
+
 def densification_stats(viewspace_grad, visibility_filter, grad_accum, grad_accum_abs, denom, observe=None, radii=None, max_radii=None):
     """scene/gaussian_model.py:569-573 (+ train.py:223-225 when observe / radii / max_radii are given) in place, one launch."""
     vg = _cuda_f32(viewspace_grad, "viewspace_grad")

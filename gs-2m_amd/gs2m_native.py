@@ -157,6 +157,10 @@ def lib():
     L.gs2m_image_loss_forward.restype = i
     L.gs2m_image_loss_backward.argtypes = [i, i, p, p, p, p, p, p, p, f, f, p, p, p, p, p, p]
     L.gs2m_image_loss_backward.restype = i
+    L.gs2m_tv_loss_forward.argtypes = [i, i, i, p, p, p, i, p, p, p]
+    L.gs2m_tv_loss_forward.restype = i
+    L.gs2m_tv_loss_backward.argtypes = [i, i, i, p, p, p, i, p, p, p]
+    L.gs2m_tv_loss_backward.restype = i
     L.gs2m_affine_mean.argtypes = [C.c_longlong, p, f, f, p, p, p]
     L.gs2m_affine_mean.restype = i
     L.gs2m_ssim_backward_uniform.argtypes = [i, i, i, i, p, p, p, f, f, p, p, p, p, p]

@@ -28,8 +28,8 @@ import torch
 import gs2m_synth as S
 from fused_ssim import dssim_loss, fused_ssim
 from gaussian_renderer import render
-from gs2m_losses import (depth_normal_loss, edge_gradient, edge_weights, fused_plane_loss, geometry_image_loss, l1_loss, plane_loss,
-                         tv_loss)
+from gs2m_losses import (depth_normal_loss, edge_gradient, edge_weights, fused_plane_loss, fused_tv_loss, geometry_image_loss, l1_loss,
+                         plane_loss, tv_loss)
 from gs2m_model import GaussianModel, OptimizationParams
 from gs2m_scene import Camera, GaussianParams, PipelineParams, inverse_sigmoid
 
@@ -281,10 +281,15 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
             pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
             pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
-            Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
-            Lsm = lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
+            tv = fused_tv_loss if fused_tail else tv_loss
+            if fused_tail and ssim_fn is None:  # L1 on the shaded image (already inside [0, 1]: the clamp is the identity) + D-SSIM, one node each
+                pbr, Lpbr1, _ = geometry_image_loss(pbr, gt, w_l1=1.0 - opt.lambda_ssim)
+                Lpbr = Lpbr1 + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+            else:
+                Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+            Lsm = lambda_smooth * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
             wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
-            loss = loss + Lpbr + Lsm + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn)
+            loss = loss + Lpbr + Lsm + lambda_normal * tv(gt, out["normal_map"], weight_map=wn)
             if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
                 loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
             stats["pbr_loss"].append(Lpbr.item())

@@ -41,6 +41,16 @@ int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, 
                              const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
                              void* stream);
 
+/* tv_loss, utils/loss_utils.py:536-557 (the smoothness terms of the material stage, train.py:160-175): edge-aware total
+ * variation of pred (C, H, W) against the ground truth gt (3, H, W): neighbour differences along both image axes, absolute
+ * (norm1 != 0) or squared, each damped by exp(-channel-mean |gt difference|) of the same pixel pair and, when weight_map
+ * (H, W) is given, by the mean of the pair's two weights; out[0] = mean over the vertical pairs + mean over the horizontal
+ * pairs.  The backward writes d_pred = g_loss[0] * d out / d pred (gt and weight_map get no gradient, as in the loop). */
+int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float* out,
+                         void* workspace, void* stream);
+int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1,
+                          const float* g_loss, float* d_pred, void* stream);
+
 /* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
  * fused_ssim/__init__.py:40-41) and the D-SSIM term lambda * (1 - ssim) of train.py:103 (a = lambda, b = -lambda). */
 int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream);

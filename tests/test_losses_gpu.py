@@ -152,3 +152,22 @@ def test_the_fused_forms_refuse_cpu_tensors():
         L.edge_gradient(x)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         L.fused_plane_loss(torch.ones(4, dtype=torch.bool), _Scales(torch.zeros(4, 3)))
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (7, 9), (2, 2)])
+@pytest.mark.parametrize("C,norm1,weighted", [(1, False, False), (3, True, False), (3, True, True), (2, False, True)])
+def test_fused_tv_loss_equals_tv_loss(H, W, C, norm1, weighted):
+    """The smoothness terms of the material stage (train.py:160-175; utils/loss_utils.py:536-557)."""
+    import gs2m_losses as L
+    g = torch.Generator().manual_seed(H * 7 + W + C)
+    gt = torch.rand(3, H, W, generator=g).cuda()
+    pred = torch.rand(C, H, W, generator=g).cuda()
+    wm = torch.rand(1, H, W, generator=g).cuda() if weighted else None
+    p0, p1 = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    a = L.tv_loss(gt, p0, norm1=norm1, weight_map=wm)
+    b = L.fused_tv_loss(gt, p1, norm1=norm1, weight_map=wm)
+    assert abs(float(a.detach()) - float(b.detach())) <= 2e-5 * abs(float(a.detach())) + 1e-9
+    (a * 0.7).backward()
+    (b * 0.7).backward()
+    assert torch.allclose(p1.grad, p0.grad, rtol=2e-5, atol=1e-12), (p1.grad - p0.grad).abs().max()
+    assert torch.equal(L.fused_tv_loss(gt, pred, norm1=norm1, weight_map=wm), b.detach()), "bitwise reproducible"

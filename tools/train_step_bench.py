@@ -18,6 +18,7 @@ from fused_ssim import dssim_loss, fused_ssim
 
 REF = "--reference-formulation" in sys.argv
 TORCH_TAIL = REF or "--torch-loss-tail" in sys.argv  # the losses / statistics around the fused pieces as PyTorch expressions
+MAT = "--material" in sys.argv  # the material stage (train.py:132-196): deferred PBR shading under a learnable 512^2 environment light
 MV = "--multi-view" in sys.argv   # + multi_view_loss against a second, nearby camera (fused path only)
 P, W, H = 1_000_000, 1920, 1080
 dev = "cuda"
@@ -72,8 +73,51 @@ if MV:
     rng = random.Random(0)
 
 
+if MAT:
+    import torch.nn.functional as F
+    from pbr import CubemapLight, get_brdf_lut, pbr_render
+    from gs2m_losses import tv_loss
+
+    class Lighting:
+        cubemap = CubemapLight(base_res=512, device=dev)
+        brdf_lut = get_brdf_lut().to(dev)
+    light_opt = gs2m_optim.Adam([{"name": "cubemap", "params": list(Lighting.cubemap.parameters()), "lr": 0.05}], lr=0.05)
+    rays = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
+    TORCH_TV = "--torch-tv" in sys.argv
+
+
+def material_step():
+    """gs2m_train's material-stage iteration (train.py:132-196 without the multi-view roughness term)."""
+    global max_radii
+    out = render(cam, pc, pipe, bg, geometry_stage=True, material_stage=True, sobel_normal=True)
+    vis, radii = out["visibility_filter"], out["radii"]
+    loss = 0.01 * gs2m_losses.fused_plane_loss(vis, pc)
+    loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=DNW)
+    pkg = pbr_render(Lighting, cam, rays, out, metallic=False)
+    pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
+    tv = tv_loss if TORCH_TV else gs2m_losses.fused_tv_loss
+    if TORCH_TV:
+        Lpbr = 0.8 * l1_loss(pbr, gt) + 0.2 * (1.0 - fused_ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+    else:
+        pbr, Lpbr1, _ = gs2m_losses.geometry_image_loss(pbr, gt, w_l1=0.8)
+        Lpbr = Lpbr1 + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2)
+    Lsm = 0.002 * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
+    wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
+    loss = loss + Lpbr + Lsm + 0.01 * tv(gt, out["normal_map"], weight_map=wn)
+    loss.backward()
+    with torch.no_grad():
+        gs2m_losses.densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, max_radii)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        light_opt.step()
+        light_opt.zero_grad(set_to_none=True)
+        Lighting.cubemap.clamp_(min=0.0)
+
+
 def step():
     global max_radii
+    if MAT:
+        return material_step()
     out = render(cam, pc, pipe, bg, geometry_stage=MV, material_stage=False, sobel_normal=True)
     image, vis, radii = out["render"], out["visibility_filter"], out["radii"]
     if TORCH_TAIL:
@@ -109,6 +153,8 @@ def step():
         opt.zero_grad(set_to_none=True)
 
 
+if MAT:
+    DNW = gs2m_losses.edge_weights(gt)
 for _ in range(5):
     step()
 torch.cuda.synchronize()
@@ -117,7 +163,7 @@ t0 = time.perf_counter()
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print("training iteration (%s): %.3f ms" % ("reference formulation on the drop-in rasterizer" if REF else "fused", (time.perf_counter() - t0) / n * 1e3))
+print("%s iteration (%s): %.3f ms" % ("material-stage" if MAT else "training", "reference formulation on the drop-in rasterizer" if REF else "fused", (time.perf_counter() - t0) / n * 1e3))
 if "--profile" in sys.argv:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
