@@ -148,7 +148,11 @@ struct ImageLossArgs {
     int W, H;
     const float *image, *gt, *normal, *sobel, *edge, *edge_minmax, *weight_map;
     float w_l1, w_dn;
+    int hwc;              // image (and its gradient) are (H, W, 3) -- the shading's layout -- instead of (3, H, W)
+    const uint8_t* mask;  // (H, W): pixels outside take the background colour (train.py:141-142); NULL: every pixel
+    const float* bg;      // (3)
 };
+__device__ __forceinline__ size_t image_index(const ImageLossArgs& a, size_t HW, size_t p, int c) { return a.hwc ? 3 * p + c : c * HW + p; }
 
 __global__ void __launch_bounds__(RB) image_loss_fwd_kernel(ImageLossArgs a, float* __restrict__ rgb, float* __restrict__ out,
                                                             float* __restrict__ ws, uint32_t* __restrict__ ticket) {
@@ -158,9 +162,10 @@ __global__ void __launch_bounds__(RB) image_loss_fwd_kernel(ImageLossArgs a, flo
     if (dn && a.edge) { mn = a.edge_minmax[0]; mx = a.edge_minmax[1]; }
     float v[2] = {0.f, 0.f};
     for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
+        const bool inside = a.mask == nullptr || a.mask[p] != 0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float r = clamp01(a.image[c * HW + p]);
+            const float r = inside ? clamp01(a.image[image_index(a, HW, p, c)]) : a.bg[c];
             rgb[c * HW + p] = r;
             v[0] += fabsf(r - a.gt[c * HW + p]);
         }
@@ -184,19 +189,21 @@ __global__ void __launch_bounds__(RB) image_loss_fwd_kernel(ImageLossArgs a, flo
     }
 }
 
-__global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, const float* __restrict__ g_loss,
+__global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, const float* __restrict__ g_loss, bool has_g,
                                                             const float* __restrict__ g_rgb, float* __restrict__ d_image,
                                                             float* __restrict__ d_normal, float* __restrict__ d_sobel) {
     const size_t HW = (size_t)a.H * a.W;
     const size_t p = (size_t)blockIdx.x * LB + threadIdx.x;
     if (p >= HW) return;
-    const float g = g_loss ? g_loss[0] : 0.f;
+    const float g = has_g ? g_loss[0] : 0.f;
     const float k1 = g * a.w_l1 / (3.0f * (float)HW);
+    const bool inside = a.mask == nullptr || a.mask[p] != 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float x = a.image[c * HW + p];
+        const float x = a.image[image_index(a, HW, p, c)];
         const float up = (g_rgb ? g_rgb[c * HW + p] : 0.f) + k1 * sgn(clamp01(x) - a.gt[c * HW + p]);
-        d_image[c * HW + p] = (x >= 0.f && x <= 1.f) ? up : 0.f;  // clamp's backward: the gradient passes inside [min, max]
+        // clamp's backward: the gradient passes inside [min, max]; masked-out pixels show the background: no gradient
+        d_image[image_index(a, HW, p, c)] = (inside && x >= 0.f && x <= 1.f) ? up : 0.f;
     }
     if (a.normal != nullptr) {
         const int y = (int)(p / a.W), xx = (int)(p - (size_t)y * a.W);
@@ -363,27 +370,32 @@ int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_m
     return launched();
 }
 
-int gs2m_image_loss_forward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+int gs2m_image_loss_forward(int W, int H, const float* image, int image_hwc, const unsigned char* mask, const float* background,
+                            const float* gt, const float* normal_map, const float* sobel_map,
                             const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
                             float* rgb, float* out, void* workspace, void* stream) {
-    if (W < 1 || H < 1 || !image || !gt || !rgb || !out || !workspace) return GS2M_ERR_INVALID_ARG;
+    if (W < 1 || H < 1 || !image || !gt || !rgb || !out || !workspace || (mask && !background)) return GS2M_ERR_INVALID_ARG;
     if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge_minmax, weight_map, w_l1, w_dn};
+    // (no NULL for the wave-uniform scalars: the compiler hoists scalar loads such as bg[c] above the test that guards them;
+    // gt is valid memory and the values are not used)
+    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge ? edge_minmax : gt, weight_map, w_l1, w_dn, image_hwc, mask, background ? background : gt};
     image_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, rgb, out, ws, (uint32_t*)(ws + 2 * LG));
     return launched();
 }
 
-int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, const unsigned char* mask, const float* gt,
+                             const float* normal_map, const float* sobel_map,
                              const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
                              const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
                              void* stream) {
     if (W < 1 || H < 1 || !image || !gt || !d_image) return GS2M_ERR_INVALID_ARG;
     if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
     if (normal_map && (!d_normal_map || !d_sobel_map)) return GS2M_ERR_INVALID_ARG;
-    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge_minmax, weight_map, w_l1, w_dn};
+    const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge ? edge_minmax : gt, weight_map, w_l1, w_dn, image_hwc, mask, gt};
     const size_t HW = (size_t)W * H;
-    image_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, g_rgb, d_image, d_normal_map, d_sobel_map);
+    image_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss ? g_loss : gt, g_loss != nullptr, g_rgb, d_image,
+                                                                                          d_normal_map, d_sobel_map);
     return launched();
 }
 

@@ -121,10 +121,21 @@ def edge_gradient(gt_image):
 
 class _GeometryImageLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, gt, normal_map, sobel_map, edge, minmax, weight_map, w_l1, w_dn):
+    def forward(ctx, image, gt, normal_map, sobel_map, edge, minmax, weight_map, w_l1, w_dn, mask, background):
         image = _cuda_f32(image, "image")
-        _, H, W = image.shape
-        gt = _cuda_f32(gt, "gt", image.shape)
+        gt = _cuda_f32(gt, "gt")
+        _, H, W = gt.shape
+        if tuple(image.shape) == (3, H, W):
+            hwc = 0
+        elif tuple(image.shape) == (H, W, 3):
+            hwc = 1
+        else:
+            raise RuntimeError(f"gs2m_losses: image must be (3, {H}, {W}) or ({H}, {W}, 3), got {tuple(image.shape)}")
+        if mask is not None:
+            if mask.dtype != torch.bool or mask.numel() != H * W or mask.device != image.device:
+                raise RuntimeError("gs2m_losses: mask must be a bool tensor of H x W elements on the image's device")
+            mask = mask.contiguous()
+            background = _cuda_f32(background, "background", (3,))
         dn = normal_map is not None
         if dn:
             normal_map, sobel_map = _cuda_f32(normal_map, "normal_map", (3, H, W)), _cuda_f32(sobel_map, "sobel_map", (3, H, W))
@@ -132,15 +143,16 @@ class _GeometryImageLoss(torch.autograd.Function):
             edge, minmax = _cuda_f32(edge, "edge", (H, W)), _cuda_f32(minmax, "minmax", (2,))
         if weight_map is not None:
             weight_map = _cuda_f32(weight_map.reshape(H, W), "weight_map")
-        rgb = torch.empty_like(image)
+        rgb = torch.empty_like(gt)
         out = torch.empty(3, dtype=torch.float32, device=image.device)
         with torch.cuda.device(image.device):
             _native().check(_native().lib().gs2m_image_loss_forward(
-                W, H, _ptr(image), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
+                W, H, _ptr(image), hwc, _ptr(mask), _ptr(background if mask is not None else None), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
                 float(w_l1), float(w_dn), _ptr(rgb), _ptr(out), _ptr(_workspace(image.device)),
                 C.c_void_p(_stream(image.device).cuda_stream)), "gs2m_image_loss_forward")
-        ctx.save_for_backward(image, gt, normal_map, sobel_map, edge, minmax, weight_map)
+        ctx.save_for_backward(image, gt, normal_map, sobel_map, edge, minmax, weight_map, mask)
         ctx.w = (float(w_l1), float(w_dn))
+        ctx.hwc = hwc
         terms = out[1:]
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)  # an unused rgb / loss arrives as None (NULL for the kernel), not as a zero frame
@@ -148,8 +160,8 @@ class _GeometryImageLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_loss, _g_terms):
-        image, gt, normal_map, sobel_map, edge, minmax, weight_map = ctx.saved_tensors
-        _, H, W = image.shape
+        image, gt, normal_map, sobel_map, edge, minmax, weight_map, mask = ctx.saved_tensors
+        _, H, W = gt.shape
         if g_rgb is not None:
             g_rgb = g_rgb.contiguous()
         if g_loss is not None:
@@ -159,20 +171,23 @@ class _GeometryImageLoss(torch.autograd.Function):
         d_sobel = torch.empty_like(sobel_map) if sobel_map is not None else None
         with torch.cuda.device(image.device):
             _native().check(_native().lib().gs2m_image_loss_backward(
-                W, H, _ptr(image), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
+                W, H, _ptr(image), ctx.hwc, _ptr(mask), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
                 ctx.w[0], ctx.w[1], _ptr(g_loss), _ptr(g_rgb), _ptr(d_image), _ptr(d_normal), _ptr(d_sobel),
                 C.c_void_p(_stream(image.device).cuda_stream)), "gs2m_image_loss_backward")
-        return d_image, None, d_normal, d_sobel, None, None, None, None, None
+        return d_image, None, d_normal, d_sobel, None, None, None, None, None, None, None
 
 
-def geometry_image_loss(image, gt, normal_map=None, sobel_map=None, edge=None, weight_map=None, w_l1=1.0, w_dn=0.0):
+def geometry_image_loss(image, gt, normal_map=None, sobel_map=None, edge=None, weight_map=None, w_l1=1.0, w_dn=0.0, mask=None,
+                        background=None):
     """train.py:101-104 and :113-120 in one pass over the frame: clamps the rendered `image` (3,H,W) to [0, 1] and returns
     `(rgb, loss, terms)` with rgb the clamped image (input of the D-SSIM term), loss = w_l1 * l1_loss(rgb, gt) +
     w_dn * depth_normal_loss(normal_map, sobel_map, ...) as a 0-dim tensor and terms = (l1, dn) detached, for logging.
     `edge` = `edge_gradient(gt)` (None: unweighted), `weight_map` (1,H,W) or (H,W) an extra per-pixel factor.  Gradients
-    flow to image (through the clamp, including what arrives at rgb), normal_map and sobel_map."""
+    flow to image (through the clamp, including what arrives at rgb), normal_map and sobel_map.
+    The material stage's shaded image (train.py:141-146) goes in as pbr_shading returns it: `image` (H,W,3) with
+    `mask` = normal_mask and `background`: rgb = where(mask, clamp(image^T, 0, 1), background)."""
     e, mm = edge if edge is not None else (None, None)
-    return _GeometryImageLoss.apply(image, gt, normal_map, sobel_map, e, mm, weight_map, w_l1, w_dn)
+    return _GeometryImageLoss.apply(image, gt, normal_map, sobel_map, e, mm, weight_map, w_l1, w_dn, mask, background)
 
 
 class _PlaneLoss(torch.autograd.Function):

@@ -153,9 +153,9 @@ def lib():
     L.gs2m_loss_workspace_bytes.restype = i
     L.gs2m_edge_gradient.argtypes = [i, i, p, p, p, p, p]
     L.gs2m_edge_gradient.restype = i
-    L.gs2m_image_loss_forward.argtypes = [i, i, p, p, p, p, p, p, p, f, f, p, p, p, p]
+    L.gs2m_image_loss_forward.argtypes = [i, i, p, i, p, p, p, p, p, p, p, p, f, f, p, p, p, p]
     L.gs2m_image_loss_forward.restype = i
-    L.gs2m_image_loss_backward.argtypes = [i, i, p, p, p, p, p, p, p, f, f, p, p, p, p, p, p]
+    L.gs2m_image_loss_backward.argtypes = [i, i, p, i, p, p, p, p, p, p, p, f, f, p, p, p, p, p, p]
     L.gs2m_image_loss_backward.restype = i
     L.gs2m_tv_loss_forward.argtypes = [i, i, i, p, p, p, i, p, p, p]
     L.gs2m_tv_loss_forward.restype = i

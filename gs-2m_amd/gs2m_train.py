@@ -267,7 +267,9 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             Lssim = 1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
             loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
         if geometry_stage:
-            if not fused_image:
+            if fused_tail and material_stage and ssim_fn is None:
+                pass  # rides along with the shaded image's L1 below (one pass over the frame)
+            elif not fused_image:
                 if k not in dn_weights:
                     dn_weights[k] = edge_weights(gt)
                 loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
@@ -280,19 +282,29 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             if k not in rays:
                 rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
             pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
-            pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
             tv = fused_tv_loss if fused_tail else tv_loss
-            if fused_tail and ssim_fn is None:  # L1 on the shaded image (already inside [0, 1]: the clamp is the identity) + D-SSIM, one node each
-                pbr, Lpbr1, _ = geometry_image_loss(pbr, gt, w_l1=1.0 - opt.lambda_ssim)
-                Lpbr = Lpbr1 + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+            if fused_tail and ssim_fn is None:
+                # where(normal_mask, clamp(render_rgb^T, 0, 1), bg), its L1 to the ground truth and (geometry stage) the
+                # depth-normal term in ONE pass -- the shading's (H,W,3) output goes in as it is -- and D-SSIM as one node
+                if geometry_stage and k not in dn_edges:
+                    dn_edges[k] = edge_gradient(gt)
+                pbr, Limg, terms = geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"] if geometry_stage else None,
+                                                       out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
+                                                       w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0,
+                                                       mask=out["normal_mask"], background=bg)
+                Lds = dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+                Lpbr = Limg + Lds                                               # in the graph (carries the depth-normal term too)
+                Lpbr_log = (1.0 - opt.lambda_ssim) * terms[0] + Lds.detach()    # the reference's Lpbr, for the statistics
             else:
+                pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
                 Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+                Lpbr_log = Lpbr
             Lsm = lambda_smooth * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
             wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
             loss = loss + Lpbr + Lsm + lambda_normal * tv(gt, out["normal_map"], weight_map=wn)
             if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
                 loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
-            stats["pbr_loss"].append(Lpbr.item())
+            stats["pbr_loss"].append(Lpbr_log.item())
         loss.backward()
         with torch.no_grad():
             # ---- train.py:219-254, in the reference's order: densification statistics and densify / prune, the

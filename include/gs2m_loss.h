@@ -24,19 +24,24 @@ int gs2m_loss_workspace_bytes(void);
  * edge_minmax[0..1] = min and max of edge over the interior.  Depends on the ground truth only. */
 int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_minmax, void* workspace, void* stream);
 
-/* train.py:101-104, 113-120 in one pass:  rgb = clamp(image, 0, 1)  (written: the D-SSIM term reads it),
+/* train.py:101-104, 113-120 (and :141-146 for the shaded image of the material stage) in one pass:
+ *   rgb = clamp(image, 0, 1), or `background` (3) where mask (H, W bytes, torch.bool) is 0   (written, (3, H, W): the
+ *         D-SSIM term reads it); image is (3, H, W), or (H, W, 3) with image_hwc != 0 (the layout pbr_shading returns),
  *   l1 = mean |rgb - gt|                                            (l1_loss, utils/loss_utils.py:27-28)
  *   dn = mean_pixels( w * sum_c |sobel_map - normal_map| ),  w = clamp(1 - (edge - min) / (max - min), 0, 1)^2 inside,
  *        1 on the border, times weight_map when given               (depth_normal_loss, utils/loss_utils.py:113-120)
  * out[0] = w_l1 * l1 + w_dn * dn, out[1] = l1, out[2] = dn.  normal_map / sobel_map both NULL: no dn term;
  * edge / edge_minmax both NULL: w = 1; weight_map may be NULL. */
-int gs2m_image_loss_forward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+int gs2m_image_loss_forward(int W, int H, const float* image, int image_hwc, const unsigned char* mask, const float* background,
+                            const float* gt, const float* normal_map, const float* sobel_map,
                             const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
                             float* rgb, float* out, void* workspace, void* stream);
 
 /* Backward of the above: g_loss[0] = d L / d out[0] (NULL: 0), g_rgb = d L / d rgb from the D-SSIM term (NULL: 0).
- * Writes d_image (through the clamp: 0 outside [0, 1]) and, when the dn term is present, d_normal_map and d_sobel_map. */
-int gs2m_image_loss_backward(int W, int H, const float* image, const float* gt, const float* normal_map, const float* sobel_map,
+ * Writes d_image (in the image's layout; through the clamp and the mask: 0 outside [0, 1] and where mask is 0) and, when the
+ * dn term is present, d_normal_map and d_sobel_map. */
+int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, const unsigned char* mask, const float* gt,
+                             const float* normal_map, const float* sobel_map,
                              const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
                              const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
                              void* stream);

@@ -171,3 +171,26 @@ def test_fused_tv_loss_equals_tv_loss(H, W, C, norm1, weighted):
     (b * 0.7).backward()
     assert torch.allclose(p1.grad, p0.grad, rtol=2e-5, atol=1e-12), (p1.grad - p0.grad).abs().max()
     assert torch.equal(L.fused_tv_loss(gt, pred, norm1=norm1, weight_map=wm), b.detach()), "bitwise reproducible"
+
+
+@pytest.mark.parametrize("H,W", [(540, 960), (33, 17)])
+def test_geometry_image_loss_on_the_shaded_image_of_the_material_stage(H, W):
+    """train.py:141-146: where(normal_mask, clamp(render_rgb^T, 0, 1), bg) -> L1 (+ the depth-normal term), with the shading's
+    (H,W,3) output handed over as it is."""
+    import gs2m_losses as L
+    image, gt, normal, sobel, R, _ = _frames(H, W, seed=H - W)
+    hwc = image.permute(1, 2, 0).contiguous()
+    mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(3)) < 0.7).cuda()
+    bg = torch.tensor([0.2, 1.0, 0.0], device="cuda")
+    x0, n0, s0 = hwc.clone().requires_grad_(True), normal.clone().requires_grad_(True), sobel.clone().requires_grad_(True)
+    pbr0 = torch.where(mask, x0.permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
+    ref = 0.8 * L.l1_loss(pbr0, gt) + 0.015 * L.depth_normal_loss(n0, s0, gt) + (pbr0 * R).sum() * 1e-3
+    ref.backward()
+    x1, n1, s1 = hwc.clone().requires_grad_(True), normal.clone().requires_grad_(True), sobel.clone().requires_grad_(True)
+    pbr1, loss, _ = L.geometry_image_loss(x1, gt, n1, s1, edge=L.edge_gradient(gt), w_l1=0.8, w_dn=0.015, mask=mask, background=bg)
+    (loss + (pbr1 * R).sum() * 1e-3).backward()
+    assert torch.equal(pbr1, pbr0.detach())
+    assert abs(float(loss.detach()) + float(((pbr1 * R).sum() * 1e-3).detach()) - float(ref.detach())) <= 2e-5 * abs(float(ref.detach()))
+    assert x1.grad.shape == (H, W, 3) and torch.allclose(x1.grad, x0.grad, rtol=1e-5, atol=1e-10)
+    assert torch.allclose(n1.grad, n0.grad, rtol=2e-5, atol=1e-12) and torch.allclose(s1.grad, s0.grad, rtol=2e-5, atol=1e-12)
+    assert float(x1.grad[~mask[0]].abs().sum()) == 0.0

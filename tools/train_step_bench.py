@@ -92,15 +92,16 @@ def material_step():
     out = render(cam, pc, pipe, bg, geometry_stage=True, material_stage=True, sobel_normal=True)
     vis, radii = out["visibility_filter"], out["radii"]
     loss = 0.01 * gs2m_losses.fused_plane_loss(vis, pc)
-    loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=DNW)
     pkg = pbr_render(Lighting, cam, rays, out, metallic=False)
-    pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
     tv = tv_loss if TORCH_TV else gs2m_losses.fused_tv_loss
     if TORCH_TV:
+        loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=DNW)
+        pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
         Lpbr = 0.8 * l1_loss(pbr, gt) + 0.2 * (1.0 - fused_ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
     else:
-        pbr, Lpbr1, _ = gs2m_losses.geometry_image_loss(pbr, gt, w_l1=0.8)
-        Lpbr = Lpbr1 + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2)
+        pbr, Limg, _ = gs2m_losses.geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"], out["sobel_map"], edge=DNE, w_l1=0.8, w_dn=0.015,
+                                                       mask=out["normal_mask"], background=bg)
+        Lpbr = Limg + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2)
     Lsm = 0.002 * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
     wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
     loss = loss + Lpbr + Lsm + 0.01 * tv(gt, out["normal_map"], weight_map=wn)
@@ -154,7 +155,7 @@ def step():
 
 
 if MAT:
-    DNW = gs2m_losses.edge_weights(gt)
+    DNW, DNE = gs2m_losses.edge_weights(gt), gs2m_losses.edge_gradient(gt)
 for _ in range(5):
     step()
 torch.cuda.synchronize()
