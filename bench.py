@@ -13,8 +13,9 @@ step k overlapping step k + 1) is timed as well and reported beside it.  Prints 
   --config c2            configs[1]: 500k Gaussians, 1080p, feature_count 5 (colour + depth + normal)
   --config c5            configs[4]'s per-GPU shape: 2M Gaussians, 1080p, feature_count 9
   --config c1            configs[0]: 10k Gaussians, 256x256, feature_count 10 (the CPU-runnable case)
-At N = 1 the line also carries `cpu_baseline` (the oracle timed on this box's host cores), `render_level_ms` and
-`train_step_ms` (render() and a full geometry-stage training iteration around the same op).
+At N = 1 the line also carries `cpu_baseline` (the oracle timed on this box's host cores), `render_level_ms`,
+`train_step_ms` and `material_step_ms` (render(), a full geometry-stage and a full material-stage training iteration around
+the same op).
 """
 import argparse
 import glob
@@ -109,13 +110,18 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
     """the same op one and two levels up.  render_level_ms: gaussian_renderer.render(material stage)
     forward + backward of a weighted sum of its maps.  train_step_ms: one geometry-stage training iteration
     (train.py:94-130, 223-227, 258-259 without the multi-view term): render with the Sobel normal, clamp,
-    L1 + D-SSIM + plane + depth-normal losses, backward, densification statistics, fused Adam step."""
+    L1 + D-SSIM + plane + depth-normal losses, backward, densification statistics, fused Adam step.
+    material_step_ms: one material-stage iteration (train.py:132-196 without the multi-view roughness term, config C3's
+    "+ deferred pbr.shade"): render, prefilter of a learnable 512^2 environment light, deferred split-sum shading, L1 + D-SSIM
+    on the shaded image, depth-normal, plane and the three edge-aware smoothness terms, backward to Gaussians and light,
+    statistics, both Adam steps."""
     import gs2m_optim
     import gs2m_synth as S
     from fused_ssim import dssim_loss
     from gaussian_renderer import render
-    from gs2m_losses import densification_stats, edge_gradient, fused_plane_loss, geometry_image_loss
+    from gs2m_losses import densification_stats, edge_gradient, fused_plane_loss, fused_tv_loss, geometry_image_loss
     from gs2m_scene import Camera, GaussianParams, PipelineParams
+    from pbr import CubemapLight, get_brdf_lut, pbr_render
     cam0 = S.make_camera(W, H)
     g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=seed).items()}
     u = lambda c: torch.rand(P, c, device=dev) * 0.8 + 0.1
@@ -151,8 +157,34 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
             opt.step()
             opt.zero_grad(set_to_none=True)
 
+    class Lighting:  # what pbr_render needs of the reference's Scene (scene/__init__.py:44-46, 144-148)
+        cubemap = CubemapLight(base_res=512, device=dev)
+        brdf_lut = get_brdf_lut().to(dev)
+    light_opt = gs2m_optim.Adam([{"name": "cubemap", "params": list(Lighting.cubemap.parameters()), "lr": 0.05}], lr=0.05)
+    rays = torch.nn.functional.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
+    edge = edge_gradient(gt)  # per view, as gs2m_train keeps it
+
+    def material_step():
+        out = render(cam, pc, pipe, bg, geometry_stage=True, material_stage=True, sobel_normal=True)
+        vis, radii = out["visibility_filter"], out["radii"]
+        pkg = pbr_render(Lighting, cam, rays, out, metallic=False)
+        pbr, Limg, _ = geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"], out["sobel_map"], edge=edge, w_l1=0.8, w_dn=0.015,
+                                           mask=out["normal_mask"], background=bg)
+        wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
+        loss = (Limg + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * fused_plane_loss(vis, pc)
+                + 0.002 * fused_tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * fused_tv_loss(gt, out["albedo_map"])
+                + 0.01 * fused_tv_loss(gt, out["normal_map"], weight_map=wn))
+        loss.backward()
+        with torch.no_grad():
+            densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, state["max_radii"])
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            light_opt.step()
+            light_opt.zero_grad(set_to_none=True)
+            Lighting.cubemap.clamp_(min=0.0)
+
     res = {}
-    for key, fn in (("render_level_ms", render_step), ("train_step_ms", train_step)):
+    for key, fn in (("render_level_ms", render_step), ("train_step_ms", train_step), ("material_step_ms", material_step)):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
@@ -176,7 +208,7 @@ def main():
     ap.add_argument("--fc", type=int, default=None, help="feature_count (9 = --material stage)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms")
+    ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms / material_step_ms")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "

@@ -267,6 +267,136 @@ __global__ void __launch_bounds__(256) specular_kernel(int N, float roughness, f
     }
 }
 
+// Mid-size lobes (tens to a couple of thousand pairs per output: the 256^2 and 128^2 levels of a 512^2 light, 80 % of the
+// prefilter's time): ONE WAVE PER 8x8 TILE OF OUTPUTS, lane = output.  The cones of neighbouring outputs overlap almost
+// completely, so the wave walks the UNION of its 64 boxes on every face it reaches -- a wave-uniform loop -- and every
+// texel's data (colour, fx, 1/|P_t|, area) is loaded and derived ONCE per wave by the lane that owns its column and
+// broadcast through LDS (v_readlane was tried first: 6 per texel with their SGPR hazards ran 3x slower than the arithmetic):
+// per (output, texel) pair 5 operations for L . V from the lane's own constants plus the cone test, and inside the
+// cone the 13 of the weight and the sums.  The 16-lanes-per-output form above spends three times
+// that: addressing and conversions per pair, a 16-lane group that covers a 27-texel row in two steps, row and face
+// set-up repeated by every group, and a shuffle reduction per output.  L . V is formed by the same expression from the
+// same numbers (bit-identical, so forward and backward accept the same pairs); only the order of each output's sum differs
+// (row-major over the union box, one lane).
+// SPLIT waves share a tile when the level has too few tiles to fill the chip (128^2: 1536): wave k takes every SPLIT-th row
+// of the union box and the partial sums are added in wave order at the end.
+template <bool BWD, int SPLIT>
+__global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float roughness, float cos_cut, const float* __restrict__ ax,
+                                                                   const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles = N >> 3;
+    const int os = blockIdx.x / (tiles * tiles), tt = blockIdx.x - os * tiles * tiles;
+    const int ox = (tt % tiles) * 8 + (lane & 7), oy = (tt / tiles) * 8 + (lane >> 3);
+    const int o = (os * N + oy) * N + ox;
+    const V3 Vo = texel_dir(ox, oy, os, N);
+    const float alpha = roughness * roughness, alpha_sqr = alpha * alpha;
+    const float sin_t = sqrtf(fmaxf(1.f - cos_cut * cos_cut, 0.f));
+    constexpr int IC = BWD ? 4 : 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
+    const float pi_inv_a2 = alpha_sqr / 3.14159265358979323846f, a2m1h = 0.5f * (alpha_sqr - 1.f);
+    const float step = 2.0f / (float)N, org = 1.0f / (float)N - 1.0f;
+    const float fxo = org + step * (float)ox, fyo = org + step * (float)oy;
+    const V3 Po = face_point(os, fxo, fyo);
+    const float ro = __builtin_amdgcn_rsqf((fxo * fxo + fyo * fyo) + 1.f);
+    __shared__ float4 s_geo_[SPLIT][64], s_col_[SPLIT][64];
+    float4* const s_geo = s_geo_[wv];
+    float4* const s_col = s_col_[wv];
+    // LDS operations of one wave execute in order: what orders a wave's parking writes and broadcast reads is only the
+    // compiler (the waves of a split tile run different trip counts: no workgroup barrier inside the loops)
+    auto wave_fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    for (int s = 0; s < 6; s++) {
+        // this lane's box on face s, exactly as specular_kernel finds it (empty: x0 > x1)
+        const V3 c = to_face_frame(s, Vo);
+        int x0 = N, x1 = -1, y0 = N, y1 = -1;
+        if (cos_cut <= 0.70710678f) { x0 = 0; x1 = N - 1; y0 = 0; y1 = N - 1; }
+        else if (c.z > -sin_t && !(fmaxf(fabsf(c.x), fabsf(c.y)) - c.z > 1.41421356f * sin_t + 2e-3f)) {
+            cone_range(c.x, c.z, sin_t, N, x0, x1);
+            cone_range(c.y, c.z, sin_t, N, y0, y1);
+            if (x0 > x1 || y0 > y1) { x0 = N; x1 = -1; y0 = N; y1 = -1; }
+        }
+        if (__builtin_amdgcn_ballot_w64(x0 <= x1) == 0ull) continue;  // no output of the tile reaches this face
+        // the union of the 64 boxes (wave-uniform)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            x0 = min(x0, __shfl_xor(x0, d)); y0 = min(y0, __shfl_xor(y0, d));
+            x1 = max(x1, __shfl_xor(x1, d)); y1 = max(y1, __shfl_xor(y1, d));
+        }
+        const int X0 = __builtin_amdgcn_readfirstlane(x0), X1 = __builtin_amdgcn_readfirstlane(x1);
+        const int Y0 = __builtin_amdgcn_readfirstlane(y0), Y1 = __builtin_amdgcn_readfirstlane(y1);
+        float dc, bk, br, ek, er;  // P_o . P_t = (dc fx + (bk + br fy)) + (ek + er fy), see specular_kernel
+        switch (s) {
+            case 0: dc = -Po.z; bk = Po.x; br = -Po.y; ek = 0.f; er = 0.f; break;
+            case 1: dc = Po.z; bk = -Po.x; br = -Po.y; ek = 0.f; er = 0.f; break;
+            case 2: dc = Po.x; bk = Po.y; br = 0.f; ek = 0.f; er = Po.z; break;
+            case 3: dc = Po.x; bk = -Po.y; br = 0.f; ek = 0.f; er = -Po.z; break;
+            case 4: dc = Po.x; bk = 0.f; br = -Po.y; ek = Po.z; er = 0.f; break;
+            default: dc = -Po.x; bk = 0.f; br = -Po.y; ek = -Po.z; er = 0.f; break;
+        }
+        // The union box in segments of up to 64 texels of one row.  The lane that owns a texel's column loads its colour
+        // (one segment ahead of its use), derives fx, 1 / |P_t| and the area factor, and parks the eight floats in LDS; the
+        // evaluation reads them back with wave-uniform addresses (broadcasts).  One wave per workgroup, LDS in order.
+        int y = Y0 + wv, xb = X0;
+        if (y > Y1) continue;
+        auto fetch = [&](int yy, int xx, float& q0, float& q1, float& q2) {
+            const int xt = min(xx + lane, X1);  // lanes past the end re-read the last texel; never evaluated
+            const float* p = in + (uint32_t)(N * N * s + N * yy + xt) * (uint32_t)IC;
+            q0 = p[0]; q1 = p[1]; q2 = p[2];
+        };
+        float q0, q1, q2;
+        fetch(y, xb, q0, q1, q2);
+        while (true) {
+            const float fy = org + step * (float)y;
+            {
+                const int xt = min(xb + lane, X1);
+                const float fxt = org + step * (float)xt;
+                const float rt = __builtin_amdgcn_rsqf((fxt * fxt + fy * fy) + 1.f);
+                const float at = BWD ? 0.f : ax[xt] * (0.25f * ax[y]);
+                s_geo[lane] = make_float4(fxt, rt, at, 0.f);
+                s_col[lane] = make_float4(q0, q1, q2, 0.f);
+            }
+            wave_fence();
+            int yn = y, xn = xb + 64;
+            if (xn > X1) { xn = X0; yn = y + SPLIT; }
+            const bool more = yn <= Y1;
+            if (more) fetch(yn, xn, q0, q1, q2);
+            const float b = bk + br * fy, e = ek + er * fy;
+            const int w = min(64, X1 - xb + 1);
+            for (int l = 0; l < w; l++) {
+                const float4 g = s_geo[l];
+                const float d = ((dc * g.x + b) + e) * (ro * g.y);
+                if (d >= cos_cut) {
+                    const float4 cl = s_col[l];
+                    const float den = __builtin_fmaf(1.f + d, a2m1h, 1.f);
+                    const float k = fmaxf(d, 0.f) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
+                    const float wgt = BWD ? k : k * g.z;
+                    a0 = __builtin_fmaf(wgt, cl.x, a0); a1 = __builtin_fmaf(wgt, cl.y, a1); a2 = __builtin_fmaf(wgt, cl.z, a2);
+                    ws += wgt;
+                }
+            }
+            wave_fence();
+            if (!more) break;
+            y = yn; xb = xn;
+        }
+    }
+    if (SPLIT > 1) {  // partial sums of waves 1 .. SPLIT - 1, added in wave order
+        __shared__ float4 s_part[SPLIT][64];
+        s_part[wv][lane] = make_float4(a0, a1, a2, ws);
+        gs2m_sync();
+        if (wv != 0) return;
+#pragma unroll
+        for (int k = 1; k < SPLIT; k++) {
+            const float4 q = s_part[k][lane];
+            a0 += q.x; a1 += q.y; a2 += q.z; ws += q.w;
+        }
+    }
+    if (BWD) {
+        const float k = ax[ox] * ax[oy] * 0.25f;
+        out[3 * (size_t)o] = a0 * k; out[3 * (size_t)o + 1] = a1 * k; out[3 * (size_t)o + 2] = a2 * k;
+    } else {
+        reinterpret_cast<float4*>(out)[o] = make_float4(a0, a1, a2, ws);
+    }
+}
+
 // the division by the weight sum (render_utils/ops.py:403) and its backward as part of the operator: in PyTorch the slice /
 // divide and their autograd nodes are ~13 launches per level, six levels per view
 __global__ void __launch_bounds__(256) specular_normalize_kernel(int n, const float4* __restrict__ raw, float* __restrict__ out3) {
@@ -290,7 +420,11 @@ int launch_specular(int res, float roughness, float cos_cut, const float* tab, c
     const double pairs = 0.5 * (1.0 - (double)cos_cut) * (double)total;
     // one output per wave for wide lobes and for small levels (few outputs: 16 lanes each would leave the chip empty);
     // measured: 64 lanes per output LOSE on the 256^2 / 128^2 levels (1.37 vs 0.88 ms, 0.55 vs 0.41 ms)
-    if (pairs >= 2048.0 || (pairs >= 48.0 && total <= 8192)) specular_kernel<BWD, 64><<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(res, roughness, cos_cut, tab, in, out);
+    if (pairs >= 48.0 && pairs < 4096.0 && res >= 64 && res % 8 == 0 && ((uintptr_t)out & 15) == 0) {
+        const int tiles = 6 * (res / 8) * (res / 8);
+        if (tiles >= 1024) specular_tile_kernel<BWD, 4><<<tiles, 256, 0, s>>>(res, roughness, cos_cut, tab, in, out);
+        else specular_tile_kernel<BWD, 8><<<tiles, 512, 0, s>>>(res, roughness, cos_cut, tab, in, out);
+    } else if (pairs >= 2048.0 || (pairs >= 48.0 && total <= 8192)) specular_kernel<BWD, 64><<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(res, roughness, cos_cut, tab, in, out);
     else if (pairs >= 48.0) specular_kernel<BWD, 16><<<(unsigned)((total * 16 + 255) / 256), 256, 0, s>>>(res, roughness, cos_cut, tab, in, out);
     else specular_kernel<BWD, 1><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(res, roughness, cos_cut, tab, in, out);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;

@@ -31,13 +31,16 @@ def diffuse_matrix(N):
     return np.clip(d @ d.T, 0.0, 0.999) * texel_areas(N)[None, :] / 3.141592
 
 
-def specular_matrix(N, roughness, cos_cut, dot_dtype=np.float64):
+def specular_matrix(N, roughness, cos_cut, dot_dtype=np.float64, rows=None):
+    """Dense weights W[o, t]; `rows`: only these output texels (a (len(rows), 6 N^2) slice, for resolutions whose full
+    matrix does not fit)."""
     d = texel_dirs(N)
-    dots = (d.astype(dot_dtype) @ d.astype(dot_dtype).T).astype(np.float64)
+    do = d if rows is None else d[np.asarray(rows)]
+    dots = (do.astype(dot_dtype) @ d.astype(dot_dtype).T).astype(np.float64)
     inside = dots >= cos_cut
-    H = d[:, None, :] + d[None, :, :]
+    H = do[:, None, :] + d[None, :, :]
     H /= np.maximum(np.linalg.norm(H, axis=-1, keepdims=True), 1e-300)
-    vh = np.clip(np.einsum("oc,otc->ot", d, H), 0.0, 1.0)
+    vh = np.clip(np.einsum("oc,otc->ot", do, H), 0.0, 1.0)
     a2 = roughness ** 4
     den = (vh * a2 - vh) * vh + 1.0
     W = np.maximum(dots, 0.0) * (a2 / (den * den * np.pi)) * texel_areas(N)[None, :] / 4.0

@@ -26,6 +26,7 @@ def test_bench_line_has_the_contract_fields():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
     assert rf["kernel"] == "blend_bwd" and rf["measured"] == "timed region", "the contract workload: live bracket of the backward blend"
     assert d["render_level_ms"] > d["ms_per_step"] * 0.9 and d["train_step_ms"] > d["ms_per_step"] * 0.9  # the callers
+    assert d["material_step_ms"] > d["train_step_ms"], "the material stage adds the light's prefilter and the deferred shading"
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
 
