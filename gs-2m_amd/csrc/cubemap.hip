@@ -298,9 +298,10 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
     const float fxo = org + step * (float)ox, fyo = org + step * (float)oy;
     const V3 Po = face_point(os, fxo, fyo);
     const float ro = __builtin_amdgcn_rsqf((fxo * fxo + fyo * fyo) + 1.f);
-    __shared__ float4 s_geo_[SPLIT][64], s_col_[SPLIT][64];
+    __shared__ float4 s_geo_[SPLIT][64];  // per texel of the segment: fx, 1 / |P_t|, area / 4, colour.x
+    __shared__ float2 s_col_[SPLIT][64];  // colour.y, colour.z
     float4* const s_geo = s_geo_[wv];
-    float4* const s_col = s_col_[wv];
+    float2* const s_col = s_col_[wv];
     // LDS operations of one wave execute in order: what orders a wave's parking writes and broadcast reads is only the
     // compiler (the waves of a split tile run different trip counts: no workgroup barrier inside the loops)
     auto wave_fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -351,8 +352,8 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
                 const float fxt = org + step * (float)xt;
                 const float rt = __builtin_amdgcn_rsqf((fxt * fxt + fy * fy) + 1.f);
                 const float at = BWD ? 0.f : ax[xt] * (0.25f * ax[y]);
-                s_geo[lane] = make_float4(fxt, rt, at, 0.f);
-                s_col[lane] = make_float4(q0, q1, q2, 0.f);
+                s_geo[lane] = make_float4(fxt, rt, at, q0);
+                s_col[lane] = make_float2(q1, q2);
             }
             wave_fence();
             int yn = y, xn = xb + 64;
@@ -360,19 +361,29 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
             const bool more = yn <= Y1;
             if (more) fetch(yn, xn, q0, q1, q2);
             const float b = bk + br * fy, e = ek + er * fy;
-            const int w = min(64, X1 - xb + 1);
-            for (int l = 0; l < w; l++) {
-                const float4 g = s_geo[l];
+            const int w = __builtin_amdgcn_readfirstlane(min(64, X1 - xb + 1));
+            auto pair = [&](const float4 g, const float2 cl) {
                 const float d = ((dc * g.x + b) + e) * (ro * g.y);
                 if (d >= cos_cut) {
-                    const float4 cl = s_col[l];
                     const float den = __builtin_fmaf(1.f + d, a2m1h, 1.f);
                     const float k = fmaxf(d, 0.f) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
                     const float wgt = BWD ? k : k * g.z;
-                    a0 = __builtin_fmaf(wgt, cl.x, a0); a1 = __builtin_fmaf(wgt, cl.y, a1); a2 = __builtin_fmaf(wgt, cl.z, a2);
+                    a0 = __builtin_fmaf(wgt, g.w, a0); a1 = __builtin_fmaf(wgt, cl.x, a1); a2 = __builtin_fmaf(wgt, cl.y, a2);
                     ws += wgt;
                 }
+            };
+            // four texels per step, all eight broadcast reads in front of the arithmetic: a read issued inside the cone
+            // test's branch waits out the LDS latency there
+            int l = 0;
+            for (; l + 3 < w; l += 4) {
+                const float4 g0 = s_geo[l], g1 = s_geo[l + 1], g2 = s_geo[l + 2], g3 = s_geo[l + 3];
+                const float2 c0 = s_col[l], c1 = s_col[l + 1], c2 = s_col[l + 2], c3 = s_col[l + 3];
+                pair(g0, c0);
+                pair(g1, c1);
+                pair(g2, c2);
+                pair(g3, c3);
             }
+            for (; l < w; l++) pair(s_geo[l], s_col[l]);
             wave_fence();
             if (!more) break;
             y = yn; xb = xn;
