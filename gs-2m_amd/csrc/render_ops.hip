@@ -384,6 +384,49 @@ __global__ void __launch_bounds__(SOB_T* SOB_T) sobel_normal_bwd_kernel(int W, i
     d_depth[p] = r[0] * acc[0] + r[1] * acc[1] + r[2] * acc[2];
 }
 
+// ---------------------------------------------------------------- shading inputs of the material stage
+// pbr_render, pbr/__init__.py:25-43, turns the planar G-buffer maps into the pixel-major arrays pbr_shading wants: the
+// normal map re-normalised where it is non-zero, the albedo clamped to [0, 1], the roughness remapped to [rmin, rmax], the
+// metallic map estimated as alpha * clamp(1 - roughness, 0, 1) when the model does not learn one, and four
+// permute(1, 2, 0) copies -- ~20 framework kernels forward, ~10 backward.  One launch each way; only the albedo carries a
+// gradient (through its clamp), as in the reference (normals, roughness and the estimate are detached there).
+__global__ void __launch_bounds__(256) pbr_inputs_kernel(int N, const float* __restrict__ normal_map, const float* __restrict__ albedo_map,
+                                                         const float* __restrict__ roughness_map, const float* __restrict__ alpha_map,
+                                                         const float* __restrict__ metallic_map, float rmin, float rmax,
+                                                         float* __restrict__ normals, float* __restrict__ albedo,
+                                                         float* __restrict__ roughness, float* __restrict__ metallic) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const size_t n = (size_t)N;
+    float n0 = normal_map[p], n1 = normal_map[n + p], n2 = normal_map[2 * n + p];
+    const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);  // torch.norm(dim=0); F.normalize divides by max(norm, 1e-12)
+    if (len > 0.f) { const float dn = fmaxf(len, 1e-12f); n0 /= dn; n1 /= dn; n2 /= dn; }
+    normals[3 * (size_t)p] = n0; normals[3 * (size_t)p + 1] = n1; normals[3 * (size_t)p + 2] = n2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = albedo_map[c * n + p];
+        albedo[3 * (size_t)p + c] = a < 0.f ? 0.f : (a > 1.f ? 1.f : a);
+    }
+    const float r = roughness_map[p];
+    if (metallic_map != nullptr) metallic[p] = metallic_map[p];
+    else {
+        const float q = 1.0f - r;
+        metallic[p] = alpha_map[p] * (q < 0.f ? 0.f : (q > 1.f ? 1.f : q));
+    }
+    roughness[p] = r * (rmax - rmin) + rmin;
+}
+__global__ void __launch_bounds__(256) pbr_inputs_bwd_kernel(int N, const float* __restrict__ albedo_map, const float* __restrict__ d_albedo,
+                                                             float* __restrict__ d_albedo_map) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const size_t n = (size_t)N;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = albedo_map[c * n + p];
+        d_albedo_map[c * n + p] = (a >= 0.f && a <= 1.f) ? d_albedo[3 * (size_t)p + c] : 0.f;  // clamp's backward
+    }
+}
+
 // ---------------------------------------------------------------- parameter activations (GM:113-144 getters)
 // scales = exp(_scaling), rotations = _rotation / max(|_rotation|, 1e-12), opacity / albedo / roughness / metallic =
 // sigmoid(raw): six getters, ~9 PyTorch launches forward and ~14 backward per view; one launch each way here.
@@ -543,6 +586,25 @@ int gs2m_sobel_normal_backward(int width, int height, const float* depth, const 
     const dim3 grid((width + SOB_T - 1) / SOB_T, (height + SOB_T - 1) / SOB_T);
     sobel_normal_bwd_kernel<<<grid, SOB_T * SOB_T, 0, (hipStream_t)stream>>>(width, height, depth, alpha, bg, view, fx, fy, cx,
                                                                             cy, dL_dsobel, dL_ddepth, dL_dalpha);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_pbr_inputs_forward(int width, int height, const float* normal_map, const float* albedo_map, const float* roughness_map,
+                            const float* alpha_map, const float* metallic_map, float min_roughness, float max_roughness,
+                            float* normals, float* albedo, float* roughness, float* metallic, void* stream) {
+    if (width <= 0 || height <= 0 || !normal_map || !albedo_map || !roughness_map || (!metallic_map && !alpha_map) || !normals || !albedo ||
+        !roughness || !metallic)
+        return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    pbr_inputs_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, normal_map, albedo_map, roughness_map, alpha_map, metallic_map,
+                                                                       min_roughness, max_roughness, normals, albedo, roughness, metallic);
+    return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
+}
+
+int gs2m_pbr_inputs_backward(int width, int height, const float* albedo_map, const float* dL_dalbedo, float* dL_dalbedo_map, void* stream) {
+    if (width <= 0 || height <= 0 || !albedo_map || !dL_dalbedo || !dL_dalbedo_map) return GS2M_ERR_INVALID_ARG;
+    const int N = width * height;
+    pbr_inputs_bwd_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, albedo_map, dL_dalbedo, dL_dalbedo_map);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

@@ -157,6 +157,10 @@ def lib():
     L.gs2m_image_loss_forward.restype = i
     L.gs2m_image_loss_backward.argtypes = [i, i, p, i, p, p, p, p, p, p, p, f, f, p, p, p, p, p, p]
     L.gs2m_image_loss_backward.restype = i
+    L.gs2m_pbr_inputs_forward.argtypes = [i, i, p, p, p, p, p, f, f, p, p, p, p, p]
+    L.gs2m_pbr_inputs_forward.restype = i
+    L.gs2m_pbr_inputs_backward.argtypes = [i, i, p, p, p, p]
+    L.gs2m_pbr_inputs_backward.restype = i
     L.gs2m_tv_loss_forward.argtypes = [i, i, i, p, p, p, i, p, p, p]
     L.gs2m_tv_loss_forward.restype = i
     L.gs2m_tv_loss_backward.argtypes = [i, i, i, p, p, p, i, p, p, p]

@@ -4,7 +4,7 @@ import torch
 import torch.nn.functional as F
 
 from .light import CubemapLight
-from .shade import get_brdf_lut, pbr_shading, pbr_shading_fused, saturate_dot, linear_to_srgb, srgb_to_linear
+from .shade import get_brdf_lut, pbr_shading, pbr_shading_fused, shading_inputs_fused, saturate_dot, linear_to_srgb, srgb_to_linear
 
 __all__ = ["CubemapLight", "get_brdf_lut", "pbr_shading", "pbr_shading_fused", "saturate_dot", "linear_to_srgb", "srgb_to_linear", "pbr_render"]
 
@@ -27,6 +27,13 @@ def pbr_render(scene, viewpoint_cam, canonical_rays, render_pkg, metallic, gamma
     else:
         view_dirs = cache[1]
 
+    if fused and render_pkg["normal_map"].is_cuda:  # the preparation below as one kernel each way, then the fused shading
+        H_, W_ = render_pkg["normal_map"].shape[-2:]
+        normals, albedo, rough, metal = shading_inputs_fused(render_pkg["normal_map"], render_pkg["albedo_map"], render_pkg["roughness_map"],
+                                                             render_pkg["alpha_map"], render_pkg["metallic_map"] if metallic else None, 0.04, 1.0)
+        pkg = pbr_shading_fused(scene.cubemap, normals, view_dirs, albedo, rough, metallic=metal, brdf_lut=scene.brdf_lut, gamma=gamma)
+        pkg.update({"roughness_map": rough.reshape(1, H_, W_), "metallic_map": metal.reshape(1, H_, W_)})
+        return pkg
     normal_map = render_pkg["normal_map"].detach()
     normal_map = torch.where(torch.norm(normal_map, dim=0, keepdim=True) > 0, F.normalize(normal_map, dim=0, p=2), normal_map)
     albedo_map = render_pkg["albedo_map"].clamp(0, 1)

@@ -32,6 +32,16 @@ int gs2m_pbr_shade_backward(int n, const float* normals, const float* view_dirs,
                             float max_roughness, const float* dL_drender_rgb, float* dL_dalbedo, float* dL_dmetallic,
                             float* dL_ddiffuse, float* const* dL_dspecular, int image_width, void* stream);
 
+/* The shading inputs from the planar G-buffer maps (pbr_render, pbr/__init__.py:25-43), one launch: normals (H, W, 3) =
+ * normal_map (3, H, W) re-normalised where non-zero; albedo (H, W, 3) = clamp(albedo_map, 0, 1); roughness (H, W) =
+ * roughness_map * (max - min) + min; metallic (H, W) = metallic_map, or alpha_map * clamp(1 - roughness_map, 0, 1) when
+ * metallic_map is NULL.  Backward: only the albedo carries a gradient (through the clamp; the reference detaches the rest,
+ * and a learnt metallic map passes its gradient through unchanged): dL_dalbedo (H, W, 3) -> dL_dalbedo_map (3, H, W). */
+int gs2m_pbr_inputs_forward(int width, int height, const float* normal_map, const float* albedo_map, const float* roughness_map,
+                            const float* alpha_map, const float* metallic_map, float min_roughness, float max_roughness,
+                            float* normals, float* albedo, float* roughness, float* metallic, void* stream);
+int gs2m_pbr_inputs_backward(int width, int height, const float* albedo_map, const float* dL_dalbedo, float* dL_dalbedo_map, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,39 @@ def test_fused_shading_equals_the_op_by_op_form(with_metallic):
         assert res[True][2] is None and res[False][2] is None
     gb0, gb1 = res[False][3], res[True][3]
     assert (gb1 - gb0).abs().max().item() < 2e-4 * max(1.0, gb0.abs().max().item())
+
+
+@pytest.mark.parametrize("with_metallic", [True, False])
+def test_pbr_render_fused_inputs_equal_the_op_by_op_preparation(with_metallic):
+    """pbr_render end to end (pbr/__init__.py:9-56): the fused preparation of the shading inputs + fused shading against the
+    PyTorch preparation + op-by-op shading, from the same planar G-buffer maps: image, returned maps and the gradients that
+    reach the albedo map (through its clamp), a learnt metallic map and the light."""
+    import types
+    from pbr import get_brdf_lut, pbr_render
+    H, W = 37, 52
+    g = torch.Generator().manual_seed(5)
+    maps = {"normal_map": torch.randn(3, H, W, generator=g) * 0.7, "albedo_map": torch.rand(3, H, W, generator=g) * 1.4 - 0.2,
+            "roughness_map": torch.rand(1, H, W, generator=g) * 1.2 - 0.1, "alpha_map": torch.rand(1, H, W, generator=g),
+            "metallic_map": torch.rand(1, H, W, generator=g)}
+    maps["normal_map"][:, :2] = 0.0   # background rows: zero normals stay zero
+    rays = torch.nn.functional.normalize(torch.randn(H * W, 3, generator=g), dim=-1).cuda()
+    cam = types.SimpleNamespace(image_height=H, image_width=W, world_view_transform=torch.eye(4).cuda())
+    Gw = torch.randn(H, W, 3, generator=g).cuda()
+    res = {}
+    for fused in (False, True):
+        scene = types.SimpleNamespace(cubemap=_light(64, seed=9), brdf_lut=get_brdf_lut().cuda())
+        pkg_in = {k: v.clone().cuda().requires_grad_(k in ("albedo_map", "metallic_map", "roughness_map")) for k, v in maps.items()}
+        pkg = pbr_render(scene, cam, rays, pkg_in, metallic=with_metallic, fused=fused)
+        (pkg["render_rgb"].reshape(H, W, 3) * Gw).sum().backward()
+        res[fused] = (pkg, pkg_in["albedo_map"].grad, pkg_in["metallic_map"].grad, scene.cubemap.base.grad, pkg_in["roughness_map"].grad)
+    a, b = res[False], res[True]
+    assert (a[0]["render_rgb"].reshape(H, W, 3) - b[0]["render_rgb"].reshape(H, W, 3)).abs().max().item() < 3e-5
+    for k in ("roughness_map", "metallic_map"):
+        assert a[0][k].shape == b[0][k].shape == (1, H, W) and torch.allclose(a[0][k], b[0][k], atol=1e-7), k
+    assert torch.allclose(b[1], a[1], rtol=1e-4, atol=1e-6) and float((a[1] == 0).float().mean()) > 0.1, "the clamp gates the albedo gradient"
+    if with_metallic:
+        assert torch.allclose(b[2], a[2], rtol=1e-4, atol=1e-6)
+    else:
+        assert a[2] is None and b[2] is None
+    assert b[4] is None and a[4] is None, "the roughness is detached"
+    assert (b[3] - a[3]).abs().max().item() < 2e-4 * max(1.0, a[3].abs().max().item())
