@@ -48,8 +48,8 @@ def test_geometry_image_loss_equals_the_pytorch_expressions(H, W, mode):
     got = loss + (rgb1 * R).sum() * 1e-3
     got.backward()
     assert torch.equal(rgb1, rgb0.detach())
-    assert abs(float(got) - float(ref)) <= 2e-5 * abs(float(ref)) + 1e-6
-    assert abs(float(terms[0]) - float(L.l1_loss(rgb0, gt))) <= 1e-5
+    assert abs(float(got.detach()) - float(ref.detach())) <= 2e-5 * abs(float(ref.detach())) + 1e-6
+    assert abs(float(terms[0]) - float(L.l1_loss(rgb0, gt).detach())) <= 1e-5
     # gradients: identical expressions element by element, up to the order of two roundings
     assert torch.allclose(i1.grad, i0.grad, rtol=1e-5, atol=1e-10)
     if dn:
