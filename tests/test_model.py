@@ -161,7 +161,7 @@ def test_hyperparameter_defaults_match_the_reference():
     for cls, ref in ((gs2m_model.OptimizationParams, gold["OptimizationParams"]), (gs2m_mvs.MultiViewParams, gold["OptimizationParams"]),
                      (gs2m_scene.PipelineParams, gold["PipelineParams"])):
         for k, v in vars(cls).items():
-            if k.startswith("_") or k in ("split_sh", "fused_render_ops", "fused_activations"):   # this repository's additions
+            if k.startswith("_") or k in ("split_sh", "fused_render_ops", "fused_activations", "fused_loss_tail"):   # this repository's additions
                 continue
             assert k in ref, f"{cls.__name__}.{k} is not a reference parameter"
             assert ref[k] == v, f"{cls.__name__}.{k} = {v}, reference {ref[k]}"
