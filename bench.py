@@ -184,7 +184,11 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
             Lighting.cubemap.clamp_(min=0.0)
 
     res = {}
+    start = [t.detach().clone() for t in params]
     for key, fn in (("render_level_ms", render_step), ("train_step_ms", train_step), ("material_step_ms", material_step)):
+        with torch.no_grad():  # every level starts from the same scene: the Adam steps of the previous one have moved it
+            for t, t0 in zip(params, start):
+                t.copy_(t0)
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
