@@ -61,11 +61,12 @@ def test_specular_cubemap_matches_oracle(N, roughness, cutoff):
         assert np.abs(out.detach().cpu().numpy().reshape(-1, 3) - col / ws).max() < 1e-4
 
 
-@pytest.mark.parametrize("N,roughness", [(256, 0.155), (128, 0.27), (64, 0.385)])
+@pytest.mark.parametrize("N,roughness", [(256, 0.155), (128, 0.27), (64, 0.385), (1024, 0.12)])
 def test_specular_tile_kernels_match_oracle_on_sampled_texels(N, roughness):
     """The levels of a 512^2 light that run the one-wave-per-8x8-tile kernels (csrc/cubemap.hip: specular_tile_kernel), at
     their own resolution and roughness: forward and backward against the restatement's weights for sampled texels (face
-    centres, edges, corners and random ones) -- the full matrix has (6 N^2)^2 entries."""
+    centres, edges, corners and random ones) -- the full matrix has (6 N^2)^2 entries.  (1024, 0.12): a union box wider than one
+    64-texel segment."""
     assert torch.cuda.is_available()
     import render_utils as RU
     from oracle import cubemap_oracle as O
@@ -77,19 +78,20 @@ def test_specular_tile_kernels_match_oracle_on_sampled_texels(N, roughness):
     (gx,) = torch.autograd.grad(raw, x, G)
     T = 6 * N * N
     special = [0, N - 1, N * N - 1, (N // 2) * N + N // 2, 3 * N * N + 5, 5 * N * N + (N - 1) * N, 2 * N * N + 7 * N + N - 1, T - 1]
-    rows = np.unique(np.concatenate([special, torch.randint(0, T, (40,), generator=g).numpy()]))
+    rows = np.unique(np.concatenate([special, torch.randint(0, T, (40 if N < 512 else 8,), generator=g).numpy()]))
+    chunk = 8 if N < 512 else 2   # (chunk, 6 N^2, 3) doubles for the half vectors
     xs = x.detach().cpu().double().numpy().reshape(-1, 3)
     Gn = G.cpu().double().numpy().reshape(-1, 4)[:, :3]
     got = raw.detach().cpu().double().numpy().reshape(-1, 4)[rows]
     ggot = gx.cpu().double().numpy().reshape(-1, 3)[rows]
     areas = O.texel_areas(N)
     checked = 0
-    for k in range(0, len(rows), 8):
-        r = rows[k:k + 8]
+    for k in range(0, len(rows), chunk):
+        r = rows[k:k + chunk]
         Wlo, Whi = O.specular_matrix(N, roughness, cos_cut + 2e-6, rows=r), O.specular_matrix(N, roughness, cos_cut - 2e-6, rows=r)
         lo = np.concatenate([Wlo @ xs, Wlo.sum(1, keepdims=True)], axis=1)
         hi = np.concatenate([Whi @ xs, Whi.sum(1, keepdims=True)], axis=1)
-        gk = got[k:k + 8]
+        gk = got[k:k + chunk]
         assert (gk[:, 3] >= lo[:, 3] * (1 - 1e-3) - 1e-5).all() and (gk[:, 3] <= hi[:, 3] * (1 + 1e-3) + 1e-5).all()
         ratio, rlo, rhi = gk[:, :3] / gk[:, 3:], lo[:, :3] / lo[:, 3:], hi[:, :3] / hi[:, 3:]
         assert (ratio >= np.minimum(rlo, rhi) - 2e-4).all() and (ratio <= np.maximum(rlo, rhi) + 2e-4).all()
@@ -101,7 +103,9 @@ def test_specular_tile_kernels_match_oracle_on_sampled_texels(N, roughness):
             assert np.abs(ggot[k + j] - want[j]).max() < 2e-4 * max(1.0, np.abs(want[j]).max()), (N, r[j])
             assert np.abs(gk[j] - lo[j]).max() < 2e-4 * max(1.0, np.abs(lo[j]).max()), (N, r[j])
             checked += 1
-    assert checked >= len(rows) // 3, "most sampled texels have no pair exactly on the cone boundary"
+    # (at 1024^2 a 3700-pair cone has ~200 texels on its rim and nearly every row has one inside the +-2e-6 band: there the
+    # forward is checked by the bounds above and the backward by the adjoint identity of the next test)
+    assert checked >= (len(rows) // 3 if N < 512 else 1), "most sampled texels have no pair exactly on the cone boundary"
 
 
 def test_specular_cubemap_backward_is_the_adjoint_at_full_size():
@@ -110,7 +114,7 @@ def test_specular_cubemap_backward_is_the_adjoint_at_full_size():
     assert torch.cuda.is_available()
     import render_utils as RU
     gen = torch.Generator().manual_seed(3)
-    for N, r in ((512, 0.04), (64, 0.385), (128, 0.27)):
+    for N, r in ((512, 0.04), (64, 0.385), (128, 0.27), (256, 0.155), (1024, 0.12)):
         x = torch.rand(6, N, N, 3, generator=gen).cuda().requires_grad_(True)
         G = torch.randn(6, N, N, 4, generator=gen).cuda()
         raw = RU._specular_cubemap.apply(x, r, RU.ndf_cutoff(r, 0.99))
