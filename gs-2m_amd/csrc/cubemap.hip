@@ -305,7 +305,11 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
     // LDS operations of one wave execute in order: what orders a wave's parking writes and broadcast reads is only the
     // compiler (the waves of a split tile run different trip counts: no workgroup barrier inside the loops)
     auto wave_fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    for (int s = 0; s < 6; s++) {
+    const bool pos_cut = cos_cut > 0.f;
+    // The union of the tile's 64 cone boxes on every face, found ONCE per workgroup: the waves of the tile share the faces
+    // (a box costs two cone_range calls: atan2 / asin / tan, ~700 instructions -- as much as 35 texels of the walk).
+    __shared__ int s_box[6][4];
+    for (int s = wv; s < 6; s += SPLIT) {
         // this lane's box on face s, exactly as specular_kernel finds it (empty: x0 > x1)
         const V3 c = to_face_frame(s, Vo);
         int x0 = N, x1 = -1, y0 = N, y1 = -1;
@@ -315,15 +319,20 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
             cone_range(c.y, c.z, sin_t, N, y0, y1);
             if (x0 > x1 || y0 > y1) { x0 = N; x1 = -1; y0 = N; y1 = -1; }
         }
-        if (__builtin_amdgcn_ballot_w64(x0 <= x1) == 0ull) continue;  // no output of the tile reaches this face
-        // the union of the 64 boxes (wave-uniform)
+        if (__builtin_amdgcn_ballot_w64(x0 <= x1) != 0ull) {  // some output of the tile reaches this face
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            x0 = min(x0, __shfl_xor(x0, d)); y0 = min(y0, __shfl_xor(y0, d));
-            x1 = max(x1, __shfl_xor(x1, d)); y1 = max(y1, __shfl_xor(y1, d));
+            for (int d = 32; d >= 1; d >>= 1) {
+                x0 = min(x0, __shfl_xor(x0, d)); y0 = min(y0, __shfl_xor(y0, d));
+                x1 = max(x1, __shfl_xor(x1, d)); y1 = max(y1, __shfl_xor(y1, d));
+            }
         }
-        const int X0 = __builtin_amdgcn_readfirstlane(x0), X1 = __builtin_amdgcn_readfirstlane(x1);
-        const int Y0 = __builtin_amdgcn_readfirstlane(y0), Y1 = __builtin_amdgcn_readfirstlane(y1);
+        if (lane == 0) { s_box[s][0] = x0; s_box[s][1] = x1; s_box[s][2] = y0; s_box[s][3] = y1; }
+    }
+    gs2m_sync();
+    for (int s = 0; s < 6; s++) {
+        const int X0 = __builtin_amdgcn_readfirstlane(s_box[s][0]), X1 = __builtin_amdgcn_readfirstlane(s_box[s][1]);
+        const int Y0 = __builtin_amdgcn_readfirstlane(s_box[s][2]), Y1 = __builtin_amdgcn_readfirstlane(s_box[s][3]);
+        if (X0 > X1 || Y0 > Y1) continue;
         float dc, bk, br, ek, er;  // P_o . P_t = (dc fx + (bk + br fy)) + (ek + er fy), see specular_kernel
         switch (s) {
             case 0: dc = -Po.z; bk = Po.x; br = -Po.y; ek = 0.f; er = 0.f; break;
@@ -366,7 +375,8 @@ __global__ void __launch_bounds__(64 * SPLIT) specular_tile_kernel(int N, float 
                 const float d = ((dc * g.x + b) + e) * (ro * g.y);
                 if (d >= cos_cut) {
                     const float den = __builtin_fmaf(1.f + d, a2m1h, 1.f);
-                    const float k = fmaxf(d, 0.f) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
+                    // inside the cone d >= cos_cut; for a positive cutoff (every lobe narrower than a hemisphere) max(d, 0) = d
+                    const float k = (pos_cut ? d : fmaxf(d, 0.f)) * pi_inv_a2 * __builtin_amdgcn_rcpf(den * den);
                     const float wgt = BWD ? k : k * g.z;
                     a0 = __builtin_fmaf(wgt, g.w, a0); a1 = __builtin_fmaf(wgt, cl.x, a1); a2 = __builtin_fmaf(wgt, cl.y, a2);
                     ws += wgt;
