@@ -150,7 +150,7 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
         # clamp + L1 + edge-weighted depth-normal term in one pass (the edge strength of the ground truth recomputed per
         # iteration, as the reference does), plane term and densification statistics as one launch each (csrc/loss_ops.hip)
         rgb, Limg, _ = geometry_image_loss(out["render"], gt, out["normal_map"], out["sobel_map"], edge=edge_gradient(gt), w_l1=0.8, w_dn=0.015)
-        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * fused_plane_loss(vis, pc)
+        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + fused_plane_loss(vis, pc, weight=0.01)
         loss.backward()
         with torch.no_grad():  # train.py:223-227, GM:569-573
             densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, state["max_radii"])
@@ -171,9 +171,9 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
         pbr, Limg, _ = geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"], out["sobel_map"], edge=edge, w_l1=0.8, w_dn=0.015,
                                            mask=out["normal_mask"], background=bg)
         wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
-        loss = (Limg + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * fused_plane_loss(vis, pc)
-                + 0.002 * fused_tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * fused_tv_loss(gt, out["albedo_map"])
-                + 0.01 * fused_tv_loss(gt, out["normal_map"], weight_map=wn))
+        loss = (Limg + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2) + fused_plane_loss(vis, pc, weight=0.01)
+                + fused_tv_loss(gt, out["roughness_map"], norm1=False, weight=0.002) + fused_tv_loss(gt, out["albedo_map"], weight=0.01)
+                + fused_tv_loss(gt, out["normal_map"], weight_map=wn, weight=0.01))
         loss.backward()
         with torch.no_grad():
             densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, state["max_radii"])

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, con
 // plane_loss, utils/loss_utils.py:72-79: the mean over the visible Gaussians of their smallest scale
 // (raw: `scaling` holds the log-scales, scene/gaussian_model.py:113-114 -- exp is monotone, so min exp(s) = exp(min s))
 __global__ void __launch_bounds__(RB) plane_loss_fwd_kernel(int P, const float* __restrict__ scaling, int raw, const uint8_t* __restrict__ vis,
-                                                            float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+                                                            float weight, float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
     float v[2] = {0.f, 0.f};
     for (int i = blockIdx.x * RB + threadIdx.x; i < P; i += LG * RB) {
         if (vis[i]) {
@@ -234,18 +234,18 @@ __global__ void __launch_bounds__(RB) plane_loss_fwd_kernel(int P, const float* 
     if (publish_partials<2>(v, ws, ticket, 0)) {
         const double s = final_sum(ws, 0), n = final_sum(ws, 1);
         if (threadIdx.x == 0) {
-            out[0] = (float)(s / (n > 1.0 ? n : 1.0));
+            out[0] = weight * (float)(s / (n > 1.0 ? n : 1.0));
             out[1] = (float)n;
         }
     }
 }
 __global__ void __launch_bounds__(LB) plane_loss_bwd_kernel(int P, const float* __restrict__ scaling, int raw, const uint8_t* __restrict__ vis,
-                                                            const float* __restrict__ out, const float* __restrict__ g,
+                                                            float weight, const float* __restrict__ out, const float* __restrict__ g,
                                                             float* __restrict__ d_scaling) {
     const int i = blockIdx.x * LB + threadIdx.x;
     if (i >= P) return;
     const float n = out[1];
-    float k = vis[i] ? g[0] / (n > 1.0f ? n : 1.0f) : 0.f;
+    float k = vis[i] ? (g[0] * weight) / (n > 1.0f ? n : 1.0f) : 0.f;
     const float s0 = scaling[3 * i], s1 = scaling[3 * i + 1], s2 = scaling[3 * i + 2];
     int m = 0;  // the first index of the minimum takes the gradient
     float sm = s0;
@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(LB) densification_stats_kernel(int P, const fl
 struct TvArgs {
     int W, H, C, norm1;
     const float *gt, *pred, *wm;
+    float weight;  // the term's multiplier in the loss (lambda): out = weight * tv, the backward scales by it
 };
 // damping and weight of the pair (p, p + stride): stride = W (vertical) or 1 (horizontal)
 __device__ __forceinline__ float tv_pair_weight(const TvArgs& a, size_t HW, size_t p, size_t stride) {
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(RB) tv_loss_fwd_kernel(TvArgs a, float* __rest
     if (publish_partials<2>(v, ws, ticket, 0)) {
         const double sh = final_sum(ws, 0), sw = final_sum(ws, 1);
         if (threadIdx.x == 0)
-            out[0] = (float)(sh / ((double)a.C * (a.H - 1) * a.W)) + (float)(sw / ((double)a.C * a.H * (a.W - 1)));
+            out[0] = a.weight * ((float)(sh / ((double)a.C * (a.H - 1) * a.W)) + (float)(sw / ((double)a.C * a.H * (a.W - 1))));
     }
 }
 // gather form: pixel p is the lower end of its own vertical / horizontal pair and the upper end of the pairs that start
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(LB) tv_loss_bwd_kernel(TvArgs a, const float* 
     const size_t p = (size_t)blockIdx.x * LB + threadIdx.x;
     if (p >= HW) return;
     const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
-    const float g = g_loss[0];
+    const float g = g_loss[0] * a.weight;
     const float kh = g / (float)((double)a.C * (a.H - 1) * a.W), kw = g / (float)((double)a.C * a.H * (a.W - 1));
     const float wd = y < a.H - 1 ? kh * tv_pair_weight(a, HW, p, a.W) : 0.f;       // pair (p, p + W)
     const float wu = y > 0 ? kh * tv_pair_weight(a, HW, p - a.W, a.W) : 0.f;      // pair (p - W, p)
@@ -399,19 +400,19 @@ int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, co
     return launched();
 }
 
-int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float* out,
-                         void* workspace, void* stream) {
+int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
+                         float* out, void* workspace, void* stream) {
     if (W < 2 || H < 2 || C < 1 || !gt || !pred || !out || !workspace) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map};
+    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map, weight};
     tv_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, ws, (uint32_t*)(ws + 2 * LG));
     return launched();
 }
 
-int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1,
+int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
                           const float* g_loss, float* d_pred, void* stream) {
     if (W < 2 || H < 2 || C < 1 || !gt || !pred || !g_loss || !d_pred) return GS2M_ERR_INVALID_ARG;
-    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map};
+    const TvArgs a = {W, H, C, norm1, gt, pred, weight_map, weight};
     const size_t HW = (size_t)W * H;
     tv_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, d_pred);
     return launched();
@@ -424,19 +425,20 @@ int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, 
     return launched();
 }
 
-int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float* out, void* workspace, void* stream) {
+int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float weight, float* out, void* workspace,
+                            void* stream) {
     if (P < 0 || !out || !workspace || (P > 0 && (!scaling || !visible))) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    plane_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, out, ws, (uint32_t*)(ws + 2 * LG));
+    plane_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, weight, out, ws, (uint32_t*)(ws + 2 * LG));
     return launched();
 }
 
-int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, const float* out, const float* g_loss,
+int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, float weight, const float* out, const float* g_loss,
                              float* d_scaling, void* stream) {
     if (P < 0) return GS2M_ERR_INVALID_ARG;
     if (P == 0) return GS2M_OK;
     if (!scaling || !visible || !out || !g_loss || !d_scaling) return GS2M_ERR_INVALID_ARG;
-    plane_loss_bwd_kernel<<<(P + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, out, g_loss, d_scaling);
+    plane_loss_bwd_kernel<<<(P + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, weight, out, g_loss, d_scaling);
     return launched();
 }
 

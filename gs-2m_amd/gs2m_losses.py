@@ -192,7 +192,7 @@ def geometry_image_loss(image, gt, normal_map=None, sobel_map=None, edge=None, w
 
 class _PlaneLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaling, visible, raw):
+    def forward(ctx, scaling, visible, raw, weight):
         scaling = _cuda_f32(scaling, "scaling")
         P = scaling.shape[0]
         if scaling.dim() != 2 or scaling.shape[1] != 3 or visible.dtype != torch.bool or visible.shape != (P,) or visible.device != scaling.device:
@@ -200,10 +200,10 @@ class _PlaneLoss(torch.autograd.Function):
         visible = visible.contiguous()
         out = torch.empty(2, dtype=torch.float32, device=scaling.device)
         with torch.cuda.device(scaling.device):
-            _native().check(_native().lib().gs2m_plane_loss_forward(P, _ptr(scaling), int(raw), _ptr(visible), _ptr(out), _ptr(_workspace(scaling.device)),
+            _native().check(_native().lib().gs2m_plane_loss_forward(P, _ptr(scaling), int(raw), _ptr(visible), float(weight), _ptr(out), _ptr(_workspace(scaling.device)),
                                                                     C.c_void_p(_stream(scaling.device).cuda_stream)), "gs2m_plane_loss_forward")
         ctx.save_for_backward(scaling, visible, out)
-        ctx.raw = int(raw)
+        ctx.raw, ctx.weight = int(raw), float(weight)
         return out[0]
 
     @staticmethod
@@ -211,24 +211,24 @@ class _PlaneLoss(torch.autograd.Function):
         scaling, visible, out = ctx.saved_tensors
         d = torch.empty_like(scaling)
         with torch.cuda.device(scaling.device):
-            _native().check(_native().lib().gs2m_plane_loss_backward(scaling.shape[0], _ptr(scaling), ctx.raw, _ptr(visible), _ptr(out), _ptr(g.contiguous()),
+            _native().check(_native().lib().gs2m_plane_loss_backward(scaling.shape[0], _ptr(scaling), ctx.raw, _ptr(visible), ctx.weight, _ptr(out), _ptr(g.contiguous()),
                                                                      _ptr(d), C.c_void_p(_stream(scaling.device).cuda_stream)), "gs2m_plane_loss_backward")
-        return d, None, None
+        return d, None, None, None
 
 
-def fused_plane_loss(visibility_filter, gaussians):
-    """`plane_loss` as one launch each way (same arguments).  A model that stores log-scales under the reference's name
+def fused_plane_loss(visibility_filter, gaussians, weight=1.0):
+    """`weight * plane_loss(...)` as one launch each way (same arguments; `weight` = lambda_plane folded into the node).  A model that stores log-scales under the reference's name
     `_scaling` (scene/gaussian_model.py:113-114: get_scaling = exp(_scaling)) is read there directly: the exp and its
     derivative happen inside the two kernels instead of as framework ops around them."""
     raw = getattr(gaussians, "_scaling", None)
     if torch.is_tensor(raw) and getattr(gaussians, "scaling_activation", torch.exp) is torch.exp:
-        return _PlaneLoss.apply(raw, visibility_filter, True)
-    return _PlaneLoss.apply(gaussians.get_scaling, visibility_filter, False)
+        return _PlaneLoss.apply(raw, visibility_filter, True, weight)
+    return _PlaneLoss.apply(gaussians.get_scaling, visibility_filter, False, weight)
 
 
 class _TvLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gt, pred, weight_map, norm1):
+    def forward(ctx, gt, pred, weight_map, norm1, weight):
         pred = _cuda_f32(pred, "pred")
         C, H, W = pred.shape
         gt = _cuda_f32(gt, "gt_image", (3, H, W))
@@ -236,10 +236,10 @@ class _TvLoss(torch.autograd.Function):
             weight_map = _cuda_f32(weight_map.reshape(H, W), "weight_map")
         out = torch.empty(1, dtype=torch.float32, device=pred.device)
         with torch.cuda.device(pred.device):
-            _native().check(_native().lib().gs2m_tv_loss_forward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), int(bool(norm1)), _ptr(out),
+            _native().check(_native().lib().gs2m_tv_loss_forward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), int(bool(norm1)), float(weight), _ptr(out),
                                                                  _ptr(_workspace(pred.device)), C_void(_stream(pred.device))), "gs2m_tv_loss_forward")
         ctx.save_for_backward(gt, pred, weight_map)
-        ctx.norm1 = int(bool(norm1))
+        ctx.norm1, ctx.weight = int(bool(norm1)), float(weight)
         return out[0]
 
     @staticmethod
@@ -248,19 +248,19 @@ class _TvLoss(torch.autograd.Function):
         C, H, W = pred.shape
         d = torch.empty_like(pred)
         with torch.cuda.device(pred.device):
-            _native().check(_native().lib().gs2m_tv_loss_backward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), ctx.norm1, _ptr(g.contiguous()),
+            _native().check(_native().lib().gs2m_tv_loss_backward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), ctx.norm1, ctx.weight, _ptr(g.contiguous()),
                                                                   _ptr(d), C_void(_stream(pred.device))), "gs2m_tv_loss_backward")
-        return None, d, None, None
+        return None, d, None, None, None
 
 
 def C_void(stream):
     return C.c_void_p(stream.cuda_stream)
 
 
-def fused_tv_loss(gt_image, pred, norm1=True, weight_map=None):
-    """`tv_loss` (same arguments) as one launch each way; the gradient goes to `pred` only (the loop passes a detached
-    weight map and the ground truth)."""
-    return _TvLoss.apply(gt_image, pred, weight_map, norm1)
+def fused_tv_loss(gt_image, pred, norm1=True, weight_map=None, weight=1.0):
+    """`weight * tv_loss(...)` (same arguments; `weight` = the term's lambda folded into the node) as one launch each way; the
+    gradient goes to `pred` only (the loop passes a detached weight map and the ground truth)."""
+    return _TvLoss.apply(gt_image, pred, weight_map, norm1, weight)
 
 
 def densification_stats(viewspace_grad, visibility_filter, grad_accum, grad_accum_abs, denom, observe=None, radii=None, max_radii=None):

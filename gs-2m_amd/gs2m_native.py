@@ -161,17 +161,17 @@ def lib():
     L.gs2m_pbr_inputs_forward.restype = i
     L.gs2m_pbr_inputs_backward.argtypes = [i, i, p, p, p, p]
     L.gs2m_pbr_inputs_backward.restype = i
-    L.gs2m_tv_loss_forward.argtypes = [i, i, i, p, p, p, i, p, p, p]
+    L.gs2m_tv_loss_forward.argtypes = [i, i, i, p, p, p, i, f, p, p, p]
     L.gs2m_tv_loss_forward.restype = i
-    L.gs2m_tv_loss_backward.argtypes = [i, i, i, p, p, p, i, p, p, p]
+    L.gs2m_tv_loss_backward.argtypes = [i, i, i, p, p, p, i, f, p, p, p]
     L.gs2m_tv_loss_backward.restype = i
     L.gs2m_affine_mean.argtypes = [C.c_longlong, p, f, f, p, p, p]
     L.gs2m_affine_mean.restype = i
     L.gs2m_ssim_backward_uniform.argtypes = [i, i, i, i, p, p, p, f, f, p, p, p, p, p]
     L.gs2m_ssim_backward_uniform.restype = i
-    L.gs2m_plane_loss_forward.argtypes = [i, p, i, p, p, p, p]
+    L.gs2m_plane_loss_forward.argtypes = [i, p, i, p, f, p, p, p]
     L.gs2m_plane_loss_forward.restype = i
-    L.gs2m_plane_loss_backward.argtypes = [i, p, i, p, p, p, p, p]
+    L.gs2m_plane_loss_backward.argtypes = [i, p, i, p, f, p, p, p, p]
     L.gs2m_plane_loss_backward.restype = i
     L.gs2m_densification_stats.argtypes = [i, p, p, p, p, p, p, p, p, p]
     L.gs2m_densification_stats.restype = i

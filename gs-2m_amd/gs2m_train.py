@@ -250,7 +250,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         fused_tail = out["render"].is_cuda and getattr(pipe, "fused_loss_tail", True)
         fused_image = fused_tail and not material_stage
         rgb = None if fused_image else out["render"].clamp(0, 1)
-        loss = opt.lambda_plane * (fused_plane_loss if fused_tail else plane_loss)(vis, gaussians)
+        loss = fused_plane_loss(vis, gaussians, weight=opt.lambda_plane) if fused_tail else opt.lambda_plane * plane_loss(vis, gaussians)
         if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
             loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
         if fused_image:  # train.py:101-120 in one pass: clamp, L1 and the edge-weighted depth-normal term
@@ -282,7 +282,6 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             if k not in rays:
                 rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
             pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
-            tv = fused_tv_loss if fused_tail else tv_loss
             if fused_tail and ssim_fn is None:
                 # where(normal_mask, clamp(render_rgb^T, 0, 1), bg), its L1 to the ground truth and (geometry stage) the
                 # depth-normal term in ONE pass -- the shading's (H,W,3) output goes in as it is -- and D-SSIM as one node
@@ -299,9 +298,14 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
                 Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
                 Lpbr_log = Lpbr
-            Lsm = lambda_smooth * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
             wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
-            loss = loss + Lpbr + Lsm + lambda_normal * tv(gt, out["normal_map"], weight_map=wn)
+            if fused_tail:  # the lambdas folded into the nodes
+                Lsm = (fused_tv_loss(gt, out["roughness_map"], norm1=False, weight=lambda_smooth) + fused_tv_loss(gt, out["albedo_map"], weight=0.01)
+                       + fused_tv_loss(gt, out["normal_map"], weight_map=wn, weight=lambda_normal))
+            else:
+                Lsm = (lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
+                       + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn))
+            loss = loss + Lpbr + Lsm
             if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
                 loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
             stats["pbr_loss"].append(Lpbr_log.item())

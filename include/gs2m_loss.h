@@ -50,10 +50,11 @@ int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, co
  * variation of pred (C, H, W) against the ground truth gt (3, H, W): neighbour differences along both image axes, absolute
  * (norm1 != 0) or squared, each damped by exp(-channel-mean |gt difference|) of the same pixel pair and, when weight_map
  * (H, W) is given, by the mean of the pair's two weights; out[0] = mean over the vertical pairs + mean over the horizontal
- * pairs.  The backward writes d_pred = g_loss[0] * d out / d pred (gt and weight_map get no gradient, as in the loop). */
-int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float* out,
-                         void* workspace, void* stream);
-int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1,
+ * pairs, times `weight` (the term's lambda in the loss: no one-element multiply kernels around the node).  The backward
+ * writes d_pred = g_loss[0] * d out / d pred (gt and weight_map get no gradient, as in the loop). */
+int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
+                         float* out, void* workspace, void* stream);
+int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
                           const float* g_loss, float* d_pred, void* stream);
 
 /* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
@@ -63,10 +64,12 @@ int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, 
 /* plane_loss, utils/loss_utils.py:72-79: out[0] = mean over the visible Gaussians of the smallest of their three
  * scales, 0 when none is visible; out[1] = the number of visible Gaussians (kept for the backward).  scaling (P, 3): the
  * activated scales (raw = 0, `get_scaling`) or the log-scales the model stores (raw = 1, `_scaling`: the exp of
- * scene/gaussian_model.py:113-114 and its derivative are applied here).  visible: P bytes (torch.bool). */
-int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float* out, void* workspace, void* stream);
-int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, const float* out, const float* g_loss,
-                             float* d_scaling, void* stream);
+ * scene/gaussian_model.py:113-114 and its derivative are applied here).  visible: P bytes (torch.bool).  out[0] is
+ * multiplied by `weight` (lambda_plane). */
+int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned char* visible, float weight, float* out, void* workspace,
+                            void* stream);
+int gs2m_plane_loss_backward(int P, const float* scaling, int raw, const unsigned char* visible, float weight, const float* out,
+                             const float* g_loss, float* d_scaling, void* stream);
 
 /* add_densification_stats, scene/gaussian_model.py:569-573, in place: for visible Gaussians grad_accum += |grad[:, :2]|,
  * grad_accum_abs += |grad[:, 2:]|, denom += 1 (viewspace_grad: (P, 4)).  With max_radii non-NULL also train.py:223-225:

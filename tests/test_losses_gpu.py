@@ -108,8 +108,9 @@ def test_fused_plane_loss_equals_plane_loss(P, frac, model):
     raw = (torch.randn(P, 3, generator=g) - 4.0).cuda()
     vis = (torch.rand(P, generator=g) < frac).cuda()
     r0, r1 = raw.clone().requires_grad_(True), raw.clone().requires_grad_(True)
-    a = L.plane_loss(vis, _Scales(r0))
-    b = L.fused_plane_loss(vis, model(r1))
+    lam = 0.01 if P == 1000 else 1.0
+    a = lam * L.plane_loss(vis, _Scales(r0))
+    b = L.fused_plane_loss(vis, model(r1), weight=lam)
     assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a)) + 1e-12
     (a * 3.0).backward()
     (b * 3.0).backward()
@@ -164,13 +165,14 @@ def test_fused_tv_loss_equals_tv_loss(H, W, C, norm1, weighted):
     pred = torch.rand(C, H, W, generator=g).cuda()
     wm = torch.rand(1, H, W, generator=g).cuda() if weighted else None
     p0, p1 = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
-    a = L.tv_loss(gt, p0, norm1=norm1, weight_map=wm)
-    b = L.fused_tv_loss(gt, p1, norm1=norm1, weight_map=wm)
+    lam = 0.37 if weighted else 1.0   # the term's multiplier folded into the node
+    a = lam * L.tv_loss(gt, p0, norm1=norm1, weight_map=wm)
+    b = L.fused_tv_loss(gt, p1, norm1=norm1, weight_map=wm, weight=lam)
     assert abs(float(a.detach()) - float(b.detach())) <= 2e-5 * abs(float(a.detach())) + 1e-9
     (a * 0.7).backward()
     (b * 0.7).backward()
     assert torch.allclose(p1.grad, p0.grad, rtol=2e-5, atol=1e-12), (p1.grad - p0.grad).abs().max()
-    assert torch.equal(L.fused_tv_loss(gt, pred, norm1=norm1, weight_map=wm), b.detach()), "bitwise reproducible"
+    assert torch.equal(L.fused_tv_loss(gt, pred, norm1=norm1, weight_map=wm, weight=lam), b.detach()), "bitwise reproducible"
 
 
 @pytest.mark.parametrize("H,W", [(540, 960), (33, 17)])

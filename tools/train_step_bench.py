@@ -91,9 +91,8 @@ def material_step():
     global max_radii
     out = render(cam, pc, pipe, bg, geometry_stage=True, material_stage=True, sobel_normal=True)
     vis, radii = out["visibility_filter"], out["radii"]
-    loss = 0.01 * gs2m_losses.fused_plane_loss(vis, pc)
+    loss = gs2m_losses.fused_plane_loss(vis, pc, weight=0.01)
     pkg = pbr_render(Lighting, cam, rays, out, metallic=False)
-    tv = tv_loss if TORCH_TV else gs2m_losses.fused_tv_loss
     if TORCH_TV:
         loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=DNW)
         pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
@@ -102,9 +101,13 @@ def material_step():
         pbr, Limg, _ = gs2m_losses.geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"], out["sobel_map"], edge=DNE, w_l1=0.8, w_dn=0.015,
                                                        mask=out["normal_mask"], background=bg)
         Lpbr = Limg + dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), 0.2)
-    Lsm = 0.002 * tv(gt, out["roughness_map"], norm1=False) + 0.01 * tv(gt, out["albedo_map"])
     wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
-    loss = loss + Lpbr + Lsm + 0.01 * tv(gt, out["normal_map"], weight_map=wn)
+    if TORCH_TV:
+        Lsm = 0.002 * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"]) + 0.01 * tv_loss(gt, out["normal_map"], weight_map=wn)
+    else:
+        F_ = gs2m_losses.fused_tv_loss
+        Lsm = F_(gt, out["roughness_map"], norm1=False, weight=0.002) + F_(gt, out["albedo_map"], weight=0.01) + F_(gt, out["normal_map"], weight_map=wn, weight=0.01)
+    loss = loss + Lpbr + Lsm
     loss.backward()
     with torch.no_grad():
         gs2m_losses.densification_stats(out["viewspace_points"].grad, vis, accum, accum_abs, denom, out["observe"], radii, max_radii)
@@ -128,7 +131,7 @@ def step():
         loss = loss + 0.015 * depth_normal_loss(out["normal_map"], out["sobel_map"], gt)
     else:  # the loss tail as fused kernels (csrc/loss_ops.hip)
         rgb, Limg, _ = gs2m_losses.geometry_image_loss(image, gt, out["normal_map"], out["sobel_map"], edge=gs2m_losses.edge_gradient(gt), w_l1=0.8, w_dn=0.015)
-        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + 0.01 * gs2m_losses.fused_plane_loss(vis, pc)
+        loss = Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), 0.2) + gs2m_losses.fused_plane_loss(vis, pc, weight=0.01)
     if MV:
         loss = loss + gs2m_mvs.multi_view_loss(mvs, cam, mvp, out, pipe, bg, False, render, rng=rng)
     loss.backward()
