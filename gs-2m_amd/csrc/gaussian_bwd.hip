@@ -385,8 +385,48 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
     };
     // One window: park the loaded rows in LDS, then every group adds the rows of its Gaussians that lie in the window.
     // LDS operations of one wave execute in order: the reads see the writes above them.
+    // A Gaussian that covers WHOLE windows (a splat over hundreds of tiles owns thousands of rows: a close-up, a background
+    // blob): its group alone would add 64 rows per window from LDS, window after window, while the rest of the wave
+    // waits -- six such splats in a view tripled this kernel's time.  Such windows never go through LDS: float4 number
+    // e * 64 + lane of every window belongs to channel quad (e * 64 + lane) mod rq whatever the window, so every lane adds
+    // the windows into rq accumulators of its own, and when the run of covered windows ends the owner's lanes add the
+    // 64 rq accumulators of their channel in index order -- a fixed order as well.
+    float4 hacc[MAXQ];
+#pragma unroll
+    for (int e = 0; e < MAXQ; e++) hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int heavy_owner = -1;  // group whose Gaussian the accumulators belong to (wave-uniform); -1: none
     auto consume = [&](uint32_t w, const float4* a) {
         const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
+        bool mine = false;
+        if (w < nwin && j < GS2M_WAVE) {
+            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
+            mine = ex <= k0 && ex + cn >= k1;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine && c == 0);
+        const int cover = m != 0ull ? (__ffsll((long long)m) - 1) / rq : -1;  // group whose Gaussian owns the whole window (wave-uniform)
+        if (heavy_owner >= 0 && cover != heavy_owner) {  // the run of covered windows has ended: hand the accumulators to their owner
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++) {
+                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = hacc[e];
+                hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (worker && g == heavy_owner) {
+                for (int q = c; q < GS2M_WAVE * rq; q += rq) {
+                    const float4 v = s_row[wave][q];
+                    racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            heavy_owner = -1;
+        }
+        if (cover >= 0) {  // registers only; the owner writes its sum once a later window takes the ordinary path
+            heavy_owner = cover;
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++)
+                if (e < rq) { hacc[e].x += a[e].x; hacc[e].y += a[e].y; hacc[e].z += a[e].z; hacc[e].w += a[e].w; }
+            return;
+        }
         if (w < nwin) {
 #pragma unroll
             for (int e = 0; e < MAXQ; e++)
@@ -395,6 +435,7 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
         while (j < GS2M_WAVE) {
             const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
             if (ex >= k1 && cn > 0) break;  // starts in a later window
+            // rows of this Gaussian inside the window; those of windows it covered entirely are in racc already
             const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
             for (uint32_t t = t0; t < t1; t++) {
                 const float4 v = s_row[wave][(t - k0) * rq + c];

@@ -122,7 +122,7 @@ def step():
     global max_radii
     if MAT:
         return material_step()
-    out = render(cam, pc, pipe, bg, geometry_stage=MV, material_stage=False, sobel_normal=True)
+    out = render(cam, pc, pipe, bg, geometry_stage=MV or "--geometry" in sys.argv, material_stage=False, sobel_normal=True)
     image, vis, radii = out["render"], out["visibility_filter"], out["radii"]
     if TORCH_TAIL:
         rgb = image.clamp(0, 1)
