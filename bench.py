@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
                          "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
+    ap.add_argument("--heavy-tail", default=None, metavar="F:K",
+                    help="not the metric's workload: a fraction F of the Gaussians K times larger (splats over hundreds of tiles, as "
+                         "close-ups and background blobs of real scenes have them) -- how the stages hold up off the uniform scene")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +267,11 @@ def main():
         cam = S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
+    if a.heavy_tail:
+        frac, factor = (float(x) for x in a.heavy_tail.split(":"))
+        big = torch.rand(P, generator=torch.Generator().manual_seed(a.seed + 1)) < frac
+        g["scales"] = torch.where(big[:, None], g["scales"] * factor, g["scales"])
+        preset = False
     Gc, Gb = S.make_upstream_grads(H, W, seed=a.seed)
     Gc, Gb = Gc.to(dev), Gb.to(dev)
     prm = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
