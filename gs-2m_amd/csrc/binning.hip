@@ -96,7 +96,7 @@ namespace {
 // binning level (quad_lists_kernel) then needs no record gather at all -- and the 4-bit hit mask travels through the
 // tile sort above the Gaussian id.  The backward writes one gradient row per set bit; the rows of a wave's 64
 // Gaussians are numbered densely in emission order (instance by instance, quadrant by quadrant): an instance gets its
-// offset inside the wave's range here; the range of wave w starts at row 4 x (emission offset of its first Gaussian)
+// first row here; the range of wave w starts at row 4 x (emission offset of its first Gaussian)
 // -- a wave with n instances owns at most 4 n rows, so the ranges cannot overlap and need no prefix sum over the waves
 // (the row scratch is sized for 4 R rows anyway).  So the rows of every Gaussian are one dense run and the
 // per-Gaussian sum streams them (gaussian_bwd.hip).
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                    uint32_t* __restrict__ inst_obs,
-                                                   uint32_t* __restrict__ sorted_rows, ZeroJobs zero) {
+                                                   uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ slot_by_gid, ZeroJobs zero) {
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
@@ -124,14 +124,15 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     }
     const uint32_t base = __shfl(off, 0, 64);  // first emission slot of the wave (lane 0 is in range whenever the wave has work)
     if (cnt > 0) {
-        float4* r = rec + (size_t)gid * REC_Q + REC_BIN;
-        const float4 bin = *r;
+        const float4 bin = rec[(size_t)gid * REC_Q + REC_BIN];
         rmin = f2u(bin.y);
         rw = f2u(bin.z) & 0xFFFFu;
-        reinterpret_cast<uint32_t*>(r)[0] = off;
+        // the Gaussian's first emission slot, for the backward's row lookup: into a compact by-id array (4 MB at 1M
+        // Gaussians: the scattered words combine in L2) -- as a word of the 128-byte record this store was a 32-byte
+        // read-modify-write in HBM per Gaussian
+        slot_by_gid[gid] = off;
         s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
         s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
-        reinterpret_cast<uint32_t*>(rec + (size_t)gid * REC_Q + REC_AUX)[0] = 4u * base;  // first gradient row of the wave's range
     }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
@@ -173,7 +174,8 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         }
         {
             const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
-            if (j < total) inst_obs[base + j] = rows_run + pin - pc;  // the instance's first row, relative to the wave's range
+            // the instance's first gradient row: the wave's range starts at row 4 x (its first emission slot)
+            if (j < total) inst_obs[base + j] = 4u * base + rows_run + pin - pc;
             rows_run += __shfl(pin, 63, 64);
         }
     }
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict
 
 void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, zero);
+                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, g.sort_keyA, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

@@ -17,8 +17,8 @@
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
 //         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
 //         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
-// q7: x = u32 first gradient row of the range of the emit wave (depth rank / 64) that owns the Gaussian's rows
-//     (binning.hip); y, z, w unused
+// q7: unused (rounds 2-3 kept the first gradient row of the Gaussian's emit wave here; the per-slot row index in
+//     BinningState::inst_obs is absolute now: one scattered 4-byte store per Gaussian less in emit_kernel)
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
@@ -41,7 +41,7 @@ struct GeomState {
     float4* rec;             // P * 8
     uint32_t* tiles_touched; // P (by Gaussian id)
     uint32_t* depth_key;     // P
-    uint32_t* sort_keyA;     // P (radix sort ping buffer)
+    uint32_t* sort_keyA;     // P (radix sort ping buffer; after the depth sort: each Gaussian's first emission slot, BY ID -- emit_kernel)
     uint32_t* sort_valA;     // P
     uint32_t* depth_key_sorted; // P
     uint32_t* sorted_gid;    // P
@@ -61,7 +61,7 @@ struct BinningState {
     uint32_t* sort_valA;     // R
     uint32_t* tile_keys;     // R (sorted)
     uint32_t* point_list;    // R (sorted Gaussian ids)
-    uint32_t* inst_obs;      // R: per-instance row offset inside its emit wave's range of gradient rows
+    uint32_t* inst_obs;      // R: per emission slot, the instance's first gradient row (dense numbering, binning.hip: emit_kernel)
     uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id, position in the tile list};
                              //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
     char* temp;
