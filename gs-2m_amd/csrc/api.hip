@@ -302,7 +302,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || feature_count < 0 || feature_count > GS2M_NUM_FEATURES) return GS2M_ERR_INVALID_ARG;
     if (!geom_buffer || !binning_buffer || !image_buffer || !scratch_alloc || !grad_colors || !radii) return GS2M_ERR_INVALID_ARG;
     if (feature_count > 0 && !grad_buffer) return GS2M_ERR_INVALID_ARG;
-    if (!dL_dmeans2D || !dL_dopacities || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drots || !dL_dfeatures) return GS2M_ERR_INVALID_ARG;
+    if (!dL_dmeans2D || !dL_dopacities || !dL_dmeans3D || !dL_dscales || !dL_drots || !dL_dfeatures) return GS2M_ERR_INVALID_ARG;
+    // dL_dcolors / dL_dcov3D may be NULL when the corresponding input was not given (nobody reads them then)
+    if ((colors_precomp && !dL_dcolors) || (cov3D_precomp && !dL_dcov3D)) return GS2M_ERR_INVALID_ARG;
     if (shs && M > 0 && !dL_dshs) return GS2M_ERR_INVALID_ARG;
     if (shs_rest && (M != 16 || !dL_dshs_rest || ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15))) return GS2M_ERR_UNSUPPORTED;
 

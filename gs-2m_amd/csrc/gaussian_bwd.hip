@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     reinterpret_cast<float4*>(dL_dmeans2D)[idx] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     if (dL_dconics) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(acc[4], acc[5], 0.f, acc[6]);
     dL_dopacities[idx] = acc[7];
-    dL_dcolors[3 * idx] = acc[ROW_COL]; dL_dcolors[3 * idx + 1] = acc[ROW_COL + 1]; dL_dcolors[3 * idx + 2] = acc[ROW_COL + 2];
+    if (dL_dcolors) {  // wanted only when the colours came in precomputed (the SH chain below uses the row itself)
+        dL_dcolors[3 * idx] = acc[ROW_COL]; dL_dcolors[3 * idx + 1] = acc[ROW_COL + 1]; dL_dcolors[3 * idx + 2] = acc[ROW_COL + 2];
+    }
 #pragma unroll
     for (int ch = 0; ch < GS2M_NUM_FEATURES; ch++)
         dL_dfeatures[(size_t)idx * GS2M_NUM_FEATURES + ch] = ch < fc ? acc[ROW_FEAT + ch] : 0.f;
@@ -328,8 +330,10 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     }
 
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
+    if (dL_dcov3D) {  // wanted only when the covariances came in precomputed
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+    }
     dL_dscales[3 * idx] = dscale[0]; dL_dscales[3 * idx + 1] = dscale[1]; dL_dscales[3 * idx + 2] = dscale[2];
     reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     }  // in_range

@@ -231,7 +231,10 @@ class _CModule:
     def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, features, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_colors,
                                      grad_buffer, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                     featureCount, return_conics=False, sh_rest=None):
+                                     featureCount, return_conics=False, sh_rest=None, unused_input_grads=True):
+        """`unused_input_grads=False`: dL/dcolors_precomp and dL/dcov3D_precomp are not computed (None in the result) when
+        those inputs were not given -- the reference's extension writes them regardless and its autograd Function drops
+        them (diff_gaussian_rasterization/__init__.py:127-139); the Function below asks for this form."""
         L = _native.lib()
         device = means3D.device
         means3D = _f32c(means3D, "means3D")
@@ -264,12 +267,14 @@ class _CModule:
                    ("features", (P, NUM_FEATURES)), ("shs", (P, 1 if split else M, 3))]
         if split:
             entries.append(("shs_rest", (P, M - 1, 3)))
-        entries += [("means2D", (P, 4)), ("colors", (P, NUM_CHANNELS)), ("cov3D", (P, 6))]
+        want_colors = unused_input_grads or (colors is not None and colors.numel() != 0)
+        want_cov3D = unused_input_grads or (cov3D_precomp is not None and cov3D_precomp.numel() != 0)
+        entries += [("means2D", (P, 4))] + ([("colors", (P, NUM_CHANNELS))] if want_colors else []) + ([("cov3D", (P, 6))] if want_cov3D else [])
         if return_conics:
             entries.append(("conics", (P, 2, 2)))
         arena = _arena.GradArena(device, entries, zero=(P == 0), key="rasterizer")
-        dL_dmeans3D = arena["means3D"]; dL_dmeans2D = arena["means2D"]; dL_dcolors = arena["colors"]
-        dL_dfeatures = arena["features"]; dL_dopacities = arena["opacities"]; dL_dcov3D = arena["cov3D"]
+        dL_dmeans3D = arena["means3D"]; dL_dmeans2D = arena["means2D"]; dL_dcolors = arena.get("colors")
+        dL_dfeatures = arena["features"]; dL_dopacities = arena["opacities"]; dL_dcov3D = arena.get("cov3D")
         dL_dshs = arena["shs"]; dL_dscales = arena["scales"]; dL_drotations = arena["rotations"]
         dL_dshs_rest = arena.get("shs_rest")
         dL_dconics = arena.get("conics")
@@ -363,7 +368,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
                 grad_out_buffer, shs, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
                 binningBuffer, imgBuffer, raster_settings.feature_count)
-        res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest)
+        res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest, unused_input_grads=False)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_features) = res[:9]
         grad_sh_rest = res[9] if len(res) > 9 else None

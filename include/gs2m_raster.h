@@ -91,7 +91,9 @@ int gs2m_raster_forward(
     void* stream);
 
 /* Returns GS2M_OK or a negative error.  dL_dconics may be NULL (it is an internal
- * temporary in the reference, rasterize_points.cu:154). */
+ * temporary in the reference, rasterize_points.cu:154); dL_dcolors may be NULL when colors_precomp is NULL and dL_dcov3D
+ * when cov3D_precomp is NULL (the reference writes them regardless and its Python side drops them: 36 bytes per Gaussian
+ * of HBM writes nobody reads). */
 int gs2m_raster_backward(
     int P, int D, int M, int R,
     const float* background,
@@ -119,9 +121,9 @@ int gs2m_raster_backward(
     float* dL_dmeans2D,   /* (P,4) */
     float* dL_dconics,    /* (P,2,2) or NULL */
     float* dL_dopacities, /* (P,1) */
-    float* dL_dcolors,    /* (P,3) */
+    float* dL_dcolors,    /* (P,3), or NULL without colors_precomp */
     float* dL_dmeans3D,   /* (P,3) */
-    float* dL_dcov3D,     /* (P,6) */
+    float* dL_dcov3D,     /* (P,6), or NULL without cov3D_precomp */
     float* dL_dshs,       /* (P,M,3) */
     float* dL_dscales,    /* (P,3) */
     float* dL_drots,      /* (P,4) */
