@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                    uint32_t* __restrict__ inst_obs,
-                                                   uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ slot_by_gid, ZeroJobs zero) {
+                                                   uint32_t* __restrict__ sorted_rows, ZeroJobs zero) {
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
@@ -124,13 +124,14 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     }
     const uint32_t base = __shfl(off, 0, 64);  // first emission slot of the wave (lane 0 is in range whenever the wave has work)
     if (cnt > 0) {
-        const float4 bin = rec[(size_t)gid * REC_Q + REC_BIN];
+        float4* r = rec + (size_t)gid * REC_Q + REC_BIN;
+        const float4 bin = *r;
         rmin = f2u(bin.y);
         rw = f2u(bin.z) & 0xFFFFu;
-        // the Gaussian's first emission slot, for the backward's row lookup: into a compact by-id array (4 MB at 1M
-        // Gaussians: the scattered words combine in L2) -- as a word of the 128-byte record this store was a 32-byte
-        // read-modify-write in HBM per Gaussian
-        slot_by_gid[gid] = off;
+        // the Gaussian's first emission slot, for the backward's row lookup: the ONE scattered word this kernel writes into
+        // the records (a compact by-id array instead saved 1.6 us here and cost the backward blend 0.25 GB of sector
+        // traffic for its gathers; the second word rounds 2-3 wrote, the wave's first row, is folded into inst_obs below)
+        reinterpret_cast<uint32_t*>(r)[0] = off;
         s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
         s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
     }
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict
 
 void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, g.sort_keyA, zero);
+                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

@@ -83,7 +83,7 @@ __device__ __forceinline__ void row_scan_add2(const float x, const float y, floa
 template <int FC>
 __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qlast,
-    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row, const uint32_t* __restrict__ slot_by_gid,
+    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
@@ -179,16 +179,15 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         float4 g0;       // x, y, A, B
         float2 g1;       // C, opacity
         float ch[KK];
-        float4 bin;      // (unused), rect min, rect w|h, (t2)
-        uint32_t off;    // the Gaussian's first emission slot (binning.hip: emit_kernel)
+        float4 bin;      // emission offset, rect min, rect w|h, (t2)
         uint32_t pos1;   // position in the tile list + 1
         uint32_t below;  // this instance's rows in the quadrants before this one
     };
     // Gradient-row index of (instance, quadrant): the rows of an emit wave's 64 Gaussians are numbered densely in
     // emission order (binning.hip: emit_kernel): the instance's first row (per emission slot) + the number of its
     // quadrants before this one.
-    auto row_of = [&](const float4 bin, uint32_t off, uint32_t below) {
-        const uint32_t rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
+    auto row_of = [&](const float4 bin, uint32_t below) {
+        const uint32_t off = f2u(bin.x), rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
         const uint32_t slot = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
         return inst_row[slot] + below;
     };
@@ -206,7 +205,6 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         f.g0 = p[REC_GEO0];
         f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
         f.bin = p[REC_BIN];
-        f.off = slot_by_gid[e.x & GS2M_GID_MASK];
 #pragma unroll
         for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
         f.pos1 = e.y;
@@ -373,7 +371,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         for (int i = np + lane; i < n; i += GS2M_WAVE) {
             const uint2 e = list[i];
             const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
-            const uint32_t row = row_of(p[REC_BIN], slot_by_gid[e.x & GS2M_GID_MASK], (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u)));
+            const uint32_t row = row_of(p[REC_BIN], (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u)));
             float4* o4 = reinterpret_cast<float4*>(row_ptr(row));
 #pragma unroll
             for (int q4 = 0; q4 < ROWF / 4; q4++) o4[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -388,7 +386,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;
-            row_cur = row_of(f.bin, f.off, f.below);  // one gather (the instance's offset inside its wave's range), in flight while the group's steps run
+            row_cur = row_of(f.bin, f.below);  // one gather (the instance's offset inside its wave's range), in flight while the group's steps run
             process_group(min(16, np - 16 * g_cur));
         }
     }
@@ -407,7 +405,7 @@ void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, con
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
 #define GS2M_BWDQ(FC)                                                                                                      \
-    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.sort_keyA, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
+    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
                                                   im.n_contrib, grad_color, grad_buffer, rows)
     switch (fc_template(fc)) {
         case 1: GS2M_BWDQ(1); break;

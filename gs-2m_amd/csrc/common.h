@@ -41,7 +41,7 @@ struct GeomState {
     float4* rec;             // P * 8
     uint32_t* tiles_touched; // P (by Gaussian id)
     uint32_t* depth_key;     // P
-    uint32_t* sort_keyA;     // P (radix sort ping buffer; after the depth sort: each Gaussian's first emission slot, BY ID -- emit_kernel)
+    uint32_t* sort_keyA;     // P (radix sort ping buffer)
     uint32_t* sort_valA;     // P
     uint32_t* depth_key_sorted; // P
     uint32_t* sorted_gid;    // P
