@@ -23,7 +23,7 @@ def short(name):
 
 def find(sub, pat):
     fs = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None  # gpurun merges into the directory: earlier runs' files stay
 
 
 lines = [f"# rocprofv3 summary ({tag}) -- `python bench.py` default workload (1M Gaussians, 1080p, fc=9)", ""]
