@@ -351,11 +351,12 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 // in LDS, then rq lanes per Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance
 // gather.  Fixed summation order (the dense numbering: quadrants ascending within an instance, instances in emission
 // order): bitwise reproducible.
+template <int RQ>  // float4 per row (rowf / 4: 3, 4, 5 or 6): sizes the three window register sets and the covered-run accumulators
 __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint32_t* __restrict__ sorted_gid,
                                                                const uint32_t* __restrict__ sorted_rows,
                                                                const uint32_t* __restrict__ sorted_off,
                                                                const float* __restrict__ rows, int rowf, float* __restrict__ sums) {
-    constexpr int MAXQ = 6;
+    constexpr int MAXQ = RQ;
     __shared__ float4 s_row[4][GS2M_WAVE * MAXQ];  // one window: 64 rows x rq float4, row-major
     __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
     s_excl[wave][lane] = incl - cnt;
     s_cnt[wave][lane] = cnt;
     s_gidw[wave][lane] = gid;
-    const int rq = rowf >> 2;
+    constexpr int rq = RQ;
     const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
     const bool worker = g < G;
     uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
@@ -473,7 +474,12 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
 }  // namespace
 
 void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s) {
-    row_reduce_dense_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums);
+    switch (rowf >> 2) {
+        case 3: row_reduce_dense_kernel<3><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
+        case 4: row_reduce_dense_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
+        case 5: row_reduce_dense_kernel<5><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
+        default: row_reduce_dense_kernel<6><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
+    }
 }
 
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
