@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     // (the block's blend records are parked in the same LDS afterwards: 256 x 36 floats)
     __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 36];
+    __shared__ uint8_t s_seen[256];  // the thread's Gaussian has a radius: its record is stored
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
     // issued behind it would cost a second exposed memory round trip (the kernel is latency bound at 12 waves per CU).
@@ -262,17 +263,20 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     }
     // The block's 256 records are one contiguous 32-KB run of `rec`: they leave through LDS (row stride 36 floats:
     // conflict-free 16-B writes) as fully coalesced float4 stores -- a thread storing its own record writes seven 16-B
-    // pieces into a line of its own, 64 lines per store instruction.
+    // pieces into a line of its own, 64 lines per store instruction.  Records of Gaussians without a radius (culled,
+    // behind the near plane, degenerate) are not stored: nothing downstream reads them (emit_kernel and the blend lists
+    // only reach Gaussians with tiles) -- 128 bytes per unseen Gaussian, most of the scene in a typical training view.
     gs2m_sync();  // every thread is done with its SH row
     float4* s_rec = reinterpret_cast<float4*>(s_sh);
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) s_rec[threadIdx.x * 9 + k] = rq[k];
+    s_seen[threadIdx.x] = out_radius > 0 ? 1 : 0;
     gs2m_sync();
     const size_t lim4 = (size_t)P * REC_Q, base4 = (size_t)blockIdx.x * 256 * REC_Q;
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) {
         const int e = k * 256 + threadIdx.x;
-        if (base4 + e < lim4) rec[base4 + e] = s_rec[(e >> 3) * 9 + (e & 7)];
+        if (base4 + e < lim4 && s_seen[e >> 3]) rec[base4 + e] = s_rec[(e >> 3) * 9 + (e & 7)];
     }
 }
 
