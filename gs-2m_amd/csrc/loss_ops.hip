@@ -25,6 +25,7 @@ constexpr int LB = 256;     // threads per workgroup of the elementwise launches
 // partial sums do not depend on the problem size and the ticket (a same-address atomic, ~10 ns each) is taken 256 times.
 constexpr int RB = 1024;
 constexpr int LG = 256;
+constexpr int WS_K = 4;     // partial sums per workgroup the workspace holds (the ticket word sits behind them)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -339,6 +340,54 @@ __global__ void __launch_bounds__(LB) tv_loss_bwd_kernel(TvArgs a, const float* 
     }
 }
 
+// The geometric part of multi_view_loss, utils/loss_utils.py:277-291, from the per-pixel quantities of mv_geo (csrc/mvs.hip):
+//   pixel_valid = valid & (noise < 1),  angle_valid = valid & (angle < angle_threshold),  geo_w = exp(-decay noise) on
+//   pixel_valid (detached),  loss = weight (sum geo_w noise / #pixel_valid + sum geo_w factor angle [angle_valid] / #angle_valid)
+// plus what the photometric part samples from: the mask itself and w_ncc = exp(-noise) on it.  ~40 framework kernels over
+// 2 M pixels (0.3 ms) become one launch each way.
+struct MvGeoArgs {
+    int N;
+    const float *noise, *angle;
+    const uint8_t* valid;
+    float angle_threshold, decay, factor, weight;
+};
+__global__ void __launch_bounds__(RB) mv_geo_loss_fwd_kernel(MvGeoArgs a, float* __restrict__ out, uint8_t* __restrict__ pixel_valid,
+                                                             float* __restrict__ w_ncc, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * RB + threadIdx.x; i < a.N; i += LG * RB) {
+        const float nz = a.noise[i], an = a.angle[i];
+        const bool ok = a.valid[i] != 0;
+        const bool pv = ok && nz < 1.0f, av = ok && an < a.angle_threshold;
+        const float gw = pv ? expf(-nz * a.decay) : 0.f;
+        v[0] += gw * nz;
+        v[1] += pv ? 1.0f : 0.f;
+        v[2] += av ? gw * (a.factor * an) : 0.f;
+        v[3] += av ? 1.0f : 0.f;
+        pixel_valid[i] = pv ? 1 : 0;
+        w_ncc[i] = pv ? expf(-nz) : 0.f;
+    }
+    if (publish_partials<4>(v, ws, ticket, 0)) {
+        const double s0 = final_sum(ws, 0), n0 = final_sum(ws, 1), s1 = final_sum(ws, 2), n1 = final_sum(ws, 3);
+        if (threadIdx.x == 0) {
+            out[0] = a.weight * ((float)(s0 / (n0 > 1.0 ? n0 : 1.0)) + (float)(s1 / (n1 > 1.0 ? n1 : 1.0)));
+            out[1] = (float)n0;
+            out[2] = (float)n1;
+        }
+    }
+}
+__global__ void __launch_bounds__(LB) mv_geo_loss_bwd_kernel(MvGeoArgs a, const float* __restrict__ out, const float* __restrict__ g_loss,
+                                                             float* __restrict__ d_noise, float* __restrict__ d_angle) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= a.N) return;
+    const float nz = a.noise[i], an = a.angle[i];
+    const bool ok = a.valid[i] != 0;
+    const bool pv = ok && nz < 1.0f, av = ok && an < a.angle_threshold;
+    const float gw = pv ? expf(-nz * a.decay) : 0.f;  // detached in the loss: a weight, not a function of the noise
+    const float g = g_loss[0] * a.weight, n0 = out[1], n1 = out[2];
+    d_noise[i] = g * gw / (n0 > 1.0f ? n0 : 1.0f);
+    d_angle[i] = av ? g * gw * a.factor / (n1 > 1.0f ? n1 : 1.0f) : 0.f;
+}
+
 // out[0] = a + b * mean(x): the mean of a map as a loss term (fused_ssim's `.mean()`, the D-SSIM term lambda (1 - mean))
 __global__ void __launch_bounds__(RB) affine_mean_kernel(size_t n, const float* __restrict__ x, float a, float b, float* __restrict__ out,
                                                          float* __restrict__ ws, uint32_t* __restrict__ ticket) {
@@ -362,12 +411,12 @@ inline int launched() { return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_
 
 extern "C" {
 
-int gs2m_loss_workspace_bytes(void) { return (int)(2 * LG * sizeof(float) + 64); }
+int gs2m_loss_workspace_bytes(void) { return (int)(WS_K * LG * sizeof(float) + 64); }
 
 int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_minmax, void* workspace, void* stream) {
     if (W < 3 || H < 3 || !gt || !edge || !edge_minmax || !workspace) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    edge_gradient_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(W, H, gt, edge, edge_minmax, ws, (uint32_t*)(ws + 2 * LG));
+    edge_gradient_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(W, H, gt, edge, edge_minmax, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
 }
 
@@ -381,7 +430,7 @@ int gs2m_image_loss_forward(int W, int H, const float* image, int image_hwc, con
     // (no NULL for the wave-uniform scalars: the compiler hoists scalar loads such as bg[c] above the test that guards them;
     // gt is valid memory and the values are not used)
     const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge ? edge_minmax : gt, weight_map, w_l1, w_dn, image_hwc, mask, background ? background : gt};
-    image_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, rgb, out, ws, (uint32_t*)(ws + 2 * LG));
+    image_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, rgb, out, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
 }
 
@@ -405,7 +454,7 @@ int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred
     if (W < 2 || H < 2 || C < 1 || !gt || !pred || !out || !workspace) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
     const TvArgs a = {W, H, C, norm1, gt, pred, weight_map, weight};
-    tv_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, ws, (uint32_t*)(ws + 2 * LG));
+    tv_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
 }
 
@@ -418,10 +467,28 @@ int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pre
     return launched();
 }
 
+int gs2m_mv_geo_loss_forward(int n, const float* noise, const float* angle, const unsigned char* valid, float angle_threshold, float decay,
+                             float factor, float weight, float* out, unsigned char* pixel_valid, float* w_ncc, void* workspace, void* stream) {
+    if (n < 1 || !noise || !angle || !valid || !out || !pixel_valid || !w_ncc || !workspace) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    const MvGeoArgs a = {n, noise, angle, valid, angle_threshold, decay, factor, weight};
+    mv_geo_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, pixel_valid, w_ncc, ws, (uint32_t*)(ws + WS_K * LG));
+    return launched();
+}
+
+int gs2m_mv_geo_loss_backward(int n, const float* noise, const float* angle, const unsigned char* valid, float angle_threshold, float decay,
+                              float factor, float weight, const float* out, const float* g_loss, float* d_noise, float* d_angle,
+                              void* stream) {
+    if (n < 1 || !noise || !angle || !valid || !out || !g_loss || !d_noise || !d_angle) return GS2M_ERR_INVALID_ARG;
+    const MvGeoArgs a = {n, noise, angle, valid, angle_threshold, decay, factor, weight};
+    mv_geo_loss_bwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(a, out, g_loss, d_noise, d_angle);
+    return launched();
+}
+
 int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream) {
     if (n <= 0 || !x || !out || !workspace || ((uintptr_t)x & 15)) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    affine_mean_kernel<<<LG, RB, 0, (hipStream_t)stream>>>((size_t)n, x, a, b, out, ws, (uint32_t*)(ws + 2 * LG));
+    affine_mean_kernel<<<LG, RB, 0, (hipStream_t)stream>>>((size_t)n, x, a, b, out, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
 }
 
@@ -429,7 +496,7 @@ int gs2m_plane_loss_forward(int P, const float* scaling, int raw, const unsigned
                             void* stream) {
     if (P < 0 || !out || !workspace || (P > 0 && (!scaling || !visible))) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
-    plane_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, weight, out, ws, (uint32_t*)(ws + 2 * LG));
+    plane_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(P, scaling, raw, visible, weight, out, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
 }
 

@@ -9,6 +9,7 @@ op as the reference writes it (batched 3x3 matmuls, einsum, grid_sample, "ones" 
 is tested against.  The geometric part (reprojection error, normal agreement) stays PyTorch here.
 """
 import ctypes as C
+import math
 import os
 import random
 
@@ -173,6 +174,46 @@ class _MVGeo(torch.autograd.Function):
 def mv_geo(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion):
     """-> pixel_noise (H W), angle (H W) [rad], valid (H W) bool; gradients to the four maps."""
     return _MVGeo.apply(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion)
+
+
+class _MVGeoLoss(torch.autograd.Function):
+    """utils/loss_utils.py:277-291 from mv_geo's per-pixel outputs as one launch each way (include/gs2m_loss.h:
+    gs2m_mv_geo_loss_*): -> (weight * geo_loss, pixel_valid (bool), w_ncc = exp(-noise) on pixel_valid)."""
+
+    @staticmethod
+    def forward(ctx, noise, angle, valid, angle_threshold, decay, factor, weight):
+        import gs2m_losses
+        noise, angle, valid = noise.contiguous().float(), angle.contiguous().float(), valid.contiguous()
+        n = noise.numel()
+        dev = noise.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        pixel_valid = torch.empty(noise.shape, dtype=torch.bool, device=dev)
+        w_ncc = torch.empty_like(noise)
+        args = (float(angle_threshold), float(decay), float(factor), float(weight))
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().gs2m_mv_geo_loss_forward(
+                n, noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), *args, out.data_ptr(), pixel_valid.data_ptr(), w_ncc.data_ptr(),
+                gs2m_losses._workspace(dev).data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gs2m_mv_geo_loss_forward")
+        ctx.save_for_backward(noise, angle, valid, out)
+        ctx.args = args
+        ctx.mark_non_differentiable(pixel_valid, w_ncc)
+        return out[0], pixel_valid, w_ncc
+
+    @staticmethod
+    def backward(ctx, g, _gv, _gw):
+        noise, angle, valid, out = ctx.saved_tensors
+        d_noise, d_angle = torch.empty_like(noise), torch.empty_like(angle)
+        with torch.cuda.device(noise.device):
+            _native.check(_native.lib().gs2m_mv_geo_loss_backward(
+                noise.numel(), noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), *ctx.args, out.data_ptr(), g.contiguous().data_ptr(),
+                d_noise.data_ptr(), d_angle.data_ptr(), C.c_void_p(torch.cuda.current_stream(noise.device).cuda_stream)), "gs2m_mv_geo_loss_backward")
+        return d_noise, d_angle, None, None, None, None, None
+
+
+def mv_geo_loss(pixel_noise, angle, valid, opt):
+    """-> (multi_view_geo_weight * geo_loss, pixel_valid, w_ncc): the fused form of the masked means below."""
+    return _MVGeoLoss.apply(pixel_noise, angle, valid, opt.mv_angle_threshold * math.pi / 180.0, opt.mv_geo_weight_decay, opt.mv_angle_factor,
+                            opt.multi_view_geo_weight)
 
 
 def mv_geo_torch(depth, normal, depth_n, normal_n, ref_cam, near_cam, occlusion, pixels):
@@ -399,22 +440,27 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
     else:
         pixel_noise, angle, valid = mv_geo_torch(render_pkg["depth_map"], render_pkg["normal_map"], near_pkg["depth_map"], near_pkg["normal_map"],
                                                  viewpoint_cam, near, opt.mv_occlusion_threshold, scene.pixels)
-    angle_valid = valid & (angle < opt.mv_angle_threshold * torch.pi / 180.0)
-    pixel_valid = valid & (pixel_noise < 1.0)
-    geo_w = torch.where(pixel_valid, torch.exp(-pixel_noise * opt.mv_geo_weight_decay), 0.0).detach()
-    # masked means instead of boolean-mask gathers (same values up to the summation order; no nonzero / host sync)
-    pixel_loss = (geo_w * pixel_noise * pixel_valid).sum() / pixel_valid.sum().clamp(min=1)
-    angle_loss = (geo_w * (opt.mv_angle_factor * angle) * angle_valid).sum() / angle_valid.sum().clamp(min=1)
-    geo_loss = pixel_loss + angle_loss
+    fused_geo = fused and pixel_noise.is_cuda and os.environ.get("GS2M_MV_GEO_TORCH") is None
+    if fused_geo:  # the masked means, the masks and the NCC weights in one pass over the frame (gs2m_mv_geo_loss_*)
+        w_geo_loss, pixel_valid, w_ncc_map = mv_geo_loss(pixel_noise, angle, valid, opt)
+    else:
+        angle_valid = valid & (angle < opt.mv_angle_threshold * torch.pi / 180.0)
+        pixel_valid = valid & (pixel_noise < 1.0)
+        geo_w = torch.where(pixel_valid, torch.exp(-pixel_noise * opt.mv_geo_weight_decay), 0.0).detach()
+        # masked means instead of boolean-mask gathers (same values up to the summation order; no nonzero / host sync)
+        pixel_loss = (geo_w * pixel_noise * pixel_valid).sum() / pixel_valid.sum().clamp(min=1)
+        angle_loss = (geo_w * (opt.mv_angle_factor * angle) * angle_valid).sum() / angle_valid.sum().clamp(min=1)
+        w_geo_loss = opt.multi_view_geo_weight * (pixel_loss + angle_loss)
+        w_ncc_map = None
     if pipe.z_depth:
-        return opt.multi_view_geo_weight * geo_loss
+        return w_geo_loss
     with torch.no_grad():
         idx = torch.nonzero(pixel_valid.reshape(-1)).squeeze(1)
         if idx.numel() > opt.multi_view_sample_num:
             idx = idx[torch.randperm(idx.numel(), device=idx.device)[:opt.multi_view_sample_num]]
         if idx.numel() == 0:
-            return opt.multi_view_geo_weight * geo_loss
-        w_ncc = torch.where(pixel_valid, torch.exp(-pixel_noise), 0.0).reshape(-1)[idx]
+            return w_geo_loss
+        w_ncc = (w_ncc_map if w_ncc_map is not None else torch.where(pixel_valid, torch.exp(-pixel_noise), 0.0)).reshape(-1)[idx]
         if material_stage:
             w_ncc = w_ncc * (render_pkg["roughness_map"].squeeze().clamp(0, 1) ** 2.0).reshape(-1)[idx]
         pixels = scene.pixels.reshape(-1, 2)[idx]
@@ -423,7 +469,7 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
     ncc, mask = (patch_ncc if fused else patch_ncc_torch)(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size)
     m = mask.reshape(-1)
     ncc_loss = (ncc.reshape(-1) * w_ncc * m).sum() / m.sum().clamp(min=1)
-    return opt.multi_view_geo_weight * geo_loss + opt.multi_view_ncc_weight * ncc_loss
+    return w_geo_loss + opt.multi_view_ncc_weight * ncc_loss
 
 
 def roughness_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, render_fn, fused=True, rng=random):

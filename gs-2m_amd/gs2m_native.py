@@ -165,6 +165,10 @@ def lib():
     L.gs2m_tv_loss_forward.restype = i
     L.gs2m_tv_loss_backward.argtypes = [i, i, i, p, p, p, i, f, p, p, p]
     L.gs2m_tv_loss_backward.restype = i
+    L.gs2m_mv_geo_loss_forward.argtypes = [i, p, p, p, f, f, f, f, p, p, p, p, p]
+    L.gs2m_mv_geo_loss_forward.restype = i
+    L.gs2m_mv_geo_loss_backward.argtypes = [i, p, p, p, f, f, f, f, p, p, p, p, p]
+    L.gs2m_mv_geo_loss_backward.restype = i
     L.gs2m_affine_mean.argtypes = [C.c_longlong, p, f, f, p, p, p]
     L.gs2m_affine_mean.restype = i
     L.gs2m_ssim_backward_uniform.argtypes = [i, i, i, i, p, p, p, f, f, p, p, p, p, p]

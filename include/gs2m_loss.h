@@ -57,6 +57,17 @@ int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred
 int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
                           const float* g_loss, float* d_pred, void* stream);
 
+/* The geometric part of multi_view_loss, utils/loss_utils.py:277-291, from the per-pixel outputs of gs2m_mv_geo_forward
+ * (gs2m_mvs.h): pixel_valid = valid & (noise < 1) and w_ncc = exp(-noise) on it (both written: the photometric part samples
+ * from them), angle_valid = valid & (angle < angle_threshold), geo_w = exp(-decay * noise) on pixel_valid (a detached weight),
+ * out[0] = weight * (sum geo_w noise / #pixel_valid + sum geo_w factor angle over angle_valid / #angle_valid) (empty sets
+ * count 1), out[1..2] = the two counts.  valid / pixel_valid: bytes (torch.bool).  The backward writes d_noise, d_angle. */
+int gs2m_mv_geo_loss_forward(int n, const float* noise, const float* angle, const unsigned char* valid, float angle_threshold, float decay,
+                             float factor, float weight, float* out, unsigned char* pixel_valid, float* w_ncc, void* workspace, void* stream);
+int gs2m_mv_geo_loss_backward(int n, const float* noise, const float* angle, const unsigned char* valid, float angle_threshold, float decay,
+                              float factor, float weight, const float* out, const float* g_loss, float* d_noise, float* d_angle,
+                              void* stream);
+
 /* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
  * fused_ssim/__init__.py:40-41) and the D-SSIM term lambda * (1 - ssim) of train.py:103 (a = lambda, b = -lambda). */
 int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream);

@@ -203,3 +203,30 @@ def test_mv_geo_matches_op_by_op():
     # the occlusion test and the image border switch pixels off
     a2 = MV.mv_geo(depth, normal, depth_n, normal_n, ref, near, 5e-4)
     assert a2[2].float().mean().item() < a[2].float().mean().item()
+
+
+@pytest.mark.parametrize("N", [1920 * 1080, 1000, 7])
+def test_fused_geo_loss_equals_the_masked_means(N):
+    """utils/loss_utils.py:277-291: the fused reduction (include/gs2m_loss.h: gs2m_mv_geo_loss_*) against the PyTorch
+    expressions multi_view_loss uses otherwise -- value, both masks' by-products and the gradients to noise and angle."""
+    import gs2m_mvs as M
+    opt = M.MultiViewParams()
+    g = torch.Generator().manual_seed(N)
+    noise = (torch.rand(N, generator=g) * 1.6).cuda()
+    angle = (torch.rand(N, generator=g) * 1.2).cuda()
+    valid = (torch.rand(N, generator=g) < 0.8).cuda()
+    n0, a0 = noise.clone().requires_grad_(True), angle.clone().requires_grad_(True)
+    angle_valid = valid & (a0 < opt.mv_angle_threshold * torch.pi / 180.0)
+    pixel_valid = valid & (n0 < 1.0)
+    geo_w = torch.where(pixel_valid, torch.exp(-n0 * opt.mv_geo_weight_decay), 0.0).detach()
+    ref = opt.multi_view_geo_weight * ((geo_w * n0 * pixel_valid).sum() / pixel_valid.sum().clamp(min=1)
+                                       + (geo_w * (opt.mv_angle_factor * a0) * angle_valid).sum() / angle_valid.sum().clamp(min=1))
+    (ref * 3.0).backward()
+    n1, a1 = noise.clone().requires_grad_(True), angle.clone().requires_grad_(True)
+    got, pv, w_ncc = M.mv_geo_loss(n1, a1, valid, opt)
+    (got * 3.0).backward()
+    assert torch.equal(pv, pixel_valid)
+    assert torch.allclose(w_ncc, torch.where(pixel_valid, torch.exp(-noise), 0.0), rtol=1e-6, atol=1e-7)
+    assert abs(float(got.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) + 1e-12
+    assert torch.allclose(n1.grad, n0.grad, rtol=1e-5, atol=1e-14) and torch.allclose(a1.grad, a0.grad, rtol=1e-5, atol=1e-14)
+    assert torch.equal(M.mv_geo_loss(noise, angle, valid, opt)[0], got.detach()), "fixed-order reduction"
