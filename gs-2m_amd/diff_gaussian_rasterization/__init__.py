@@ -80,7 +80,7 @@ class _Alloc:
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _native.stream_ptr()
 
 
 class _ScratchCache(_Alloc):
@@ -206,7 +206,7 @@ class _CModule:
             bin_cb, bin_user = _CModule._prealloc_cb, C.byref(pre)
         else:
             bin_cb, bin_user = binning.cb, None
-        with torch.cuda.device(device):
+        with _native.device_guard(device):
             fwd = L.gs2m_raster_forward_split_sh if split else L.gs2m_raster_forward
             sh_args = (_ptr(sh), _ptr(sh_rest)) if split else (_ptr(sh),)
             rendered = fwd(
@@ -279,7 +279,7 @@ class _CModule:
         dL_dshs_rest = arena.get("shs_rest")
         dL_dconics = arena.get("conics")
         scratch = _ScratchCache.get(device, _stream())
-        with torch.cuda.device(device):
+        with _native.device_guard(device):
             bwd = L.gs2m_raster_backward_split_sh if split else L.gs2m_raster_backward
             sh_args = (_ptr(sh), _ptr(sh_rest)) if split else (_ptr(sh),)
             dsh_args = (_ptr(dL_dshs), _ptr(dL_dshs_rest)) if split else (_ptr(dL_dshs),)
@@ -305,7 +305,7 @@ class _CModule:
         P = means3D.size(0)
         present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
         if P != 0:
-            with torch.cuda.device(means3D.device):
+            with _native.device_guard(means3D.device):
                 rc = L.gs2m_raster_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
                                                 _ptr(_f32c(projmatrix, "projmatrix")), present.data_ptr(), _stream())
             _native.check(rc, "gs2m_raster_mark_visible")

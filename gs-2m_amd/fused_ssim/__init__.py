@@ -41,11 +41,11 @@ def fusedssim(C1, C2, img1, img2, train):
         dm = (d[0], d[1], d[2])
     else:
         dm = tuple(torch.empty(0, dtype=torch.float32, device=img1.device) for _ in range(3))
-    with torch.cuda.device(img1.device):
+    with _native.device_guard(img1.device):
         _native.check(_native.lib().gs2m_ssim_forward(
             B, CH, H, W, float(C1), float(C2), _ptr(img1), _ptr(img2), _ptr(ssim_map),
             *( [_ptr(t) for t in dm] if train else [None, None, None]),
-            C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_ssim_forward")
+            C.c_void_p(_native.stream_ptr(img1.device))), "gs2m_ssim_forward")
     return (ssim_map,) + dm
 
 
@@ -57,10 +57,10 @@ def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_d
     maps = [_check(t, n, img1) for t, n in ((dm_dmu1, "dm_dmu1"), (dm_dsigma1_sq, "dm_dsigma1_sq"), (dm_dsigma12, "dm_dsigma12"))]
     B, CH, H, W = img1.shape
     grad = torch.empty_like(img1)
-    with torch.cuda.device(img1.device):
+    with _native.device_guard(img1.device):
         _native.check(_native.lib().gs2m_ssim_backward(
             B, CH, H, W, _ptr(img1), _ptr(img2), _ptr(dL_dmap), _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]), _ptr(grad),
-            C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_ssim_backward")
+            C.c_void_p(_native.stream_ptr(img1.device))), "gs2m_ssim_backward")
     return grad
 
 
@@ -97,10 +97,10 @@ class _FusedSSIMAffineMean(torch.autograd.Function):
         import gs2m_losses
         ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = fusedssim(C1, C2, img1, img2, True)
         out = torch.empty(1, dtype=torch.float32, device=img1.device)
-        with torch.cuda.device(img1.device):
+        with _native.device_guard(img1.device):
             _native.check(_native.lib().gs2m_affine_mean(ssim_map.numel(), _ptr(ssim_map), float(a), float(b), _ptr(out),
                                                          _ptr(gs2m_losses._workspace(img1.device)),
-                                                         C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_affine_mean")
+                                                         C.c_void_p(_native.stream_ptr(img1.device))), "gs2m_affine_mean")
         ctx.save_for_backward(img1.detach().contiguous(), img2.contiguous(), dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
         ctx.b = float(b)
         return out[0]
@@ -110,10 +110,10 @@ class _FusedSSIMAffineMean(torch.autograd.Function):
         img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = ctx.saved_tensors
         B, CH, H, W = img1.shape
         grad = torch.empty_like(img1)
-        with torch.cuda.device(img1.device):
+        with _native.device_guard(img1.device):
             _native.check(_native.lib().gs2m_ssim_backward_uniform(
                 B, CH, H, W, _ptr(img1), _ptr(img2), _ptr(g.contiguous()), ctx.b, float(img1.numel()), _ptr(dm_dmu1), _ptr(dm_dsigma1_sq),
-                _ptr(dm_dsigma12), _ptr(grad), C.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)), "gs2m_ssim_backward_uniform")
+                _ptr(dm_dsigma12), _ptr(grad), C.c_void_p(_native.stream_ptr(img1.device))), "gs2m_ssim_backward_uniform")
         return None, None, grad, None, None, None
 
 

@@ -79,18 +79,19 @@ def _ptr(t):
 
 
 def _stream(device):
-    return torch.cuda.current_stream(device)
+    """raw hipStream_t (int) of torch's current stream on `device`"""
+    return _native().stream_ptr(device)
 
 
 def _workspace(device):
     """The reducing kernels' scratch (partial sums + ticket): zero when created, left zeroed by every call; one per
     (device, stream) because concurrent launches on two streams must not share it."""
     st = _stream(device)
-    key = (device.index, st.cuda_stream)
+    key = (device.index, st)
     ws = _workspaces.get(key)
     if ws is None:
-        with torch.cuda.stream(st):
-            ws = torch.zeros(_native().lib().gs2m_loss_workspace_bytes() // 4, dtype=torch.float32, device=device)
+        # zero-filled on the current stream: the one that will use it
+        ws = torch.zeros(_native().lib().gs2m_loss_workspace_bytes() // 4, dtype=torch.float32, device=device)
         _workspaces[key] = ws
     return ws
 
@@ -113,9 +114,9 @@ def edge_gradient(gt_image):
     _, H, W = gt.shape
     edge = torch.empty(H, W, dtype=torch.float32, device=gt.device)
     minmax = torch.empty(2, dtype=torch.float32, device=gt.device)
-    with torch.cuda.device(gt.device):
+    with _native().device_guard(gt.device):
         _native().check(_native().lib().gs2m_edge_gradient(W, H, _ptr(gt), _ptr(edge), _ptr(minmax), _ptr(_workspace(gt.device)),
-                                                           C.c_void_p(_stream(gt.device).cuda_stream)), "gs2m_edge_gradient")
+                                                           C.c_void_p(_stream(gt.device))), "gs2m_edge_gradient")
     return edge, minmax
 
 
@@ -145,11 +146,11 @@ class _GeometryImageLoss(torch.autograd.Function):
             weight_map = _cuda_f32(weight_map.reshape(H, W), "weight_map")
         rgb = torch.empty_like(gt)
         out = torch.empty(3, dtype=torch.float32, device=image.device)
-        with torch.cuda.device(image.device):
+        with _native().device_guard(image.device):
             _native().check(_native().lib().gs2m_image_loss_forward(
                 W, H, _ptr(image), hwc, _ptr(mask), _ptr(background if mask is not None else None), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
                 float(w_l1), float(w_dn), _ptr(rgb), _ptr(out), _ptr(_workspace(image.device)),
-                C.c_void_p(_stream(image.device).cuda_stream)), "gs2m_image_loss_forward")
+                C.c_void_p(_stream(image.device))), "gs2m_image_loss_forward")
         ctx.save_for_backward(image, gt, normal_map, sobel_map, edge, minmax, weight_map, mask)
         ctx.w = (float(w_l1), float(w_dn))
         ctx.hwc = hwc
@@ -169,11 +170,11 @@ class _GeometryImageLoss(torch.autograd.Function):
         d_image = torch.empty_like(image)
         d_normal = torch.empty_like(normal_map) if normal_map is not None else None
         d_sobel = torch.empty_like(sobel_map) if sobel_map is not None else None
-        with torch.cuda.device(image.device):
+        with _native().device_guard(image.device):
             _native().check(_native().lib().gs2m_image_loss_backward(
                 W, H, _ptr(image), ctx.hwc, _ptr(mask), _ptr(gt), _ptr(normal_map), _ptr(sobel_map), _ptr(edge), _ptr(minmax), _ptr(weight_map),
                 ctx.w[0], ctx.w[1], _ptr(g_loss), _ptr(g_rgb), _ptr(d_image), _ptr(d_normal), _ptr(d_sobel),
-                C.c_void_p(_stream(image.device).cuda_stream)), "gs2m_image_loss_backward")
+                C.c_void_p(_stream(image.device))), "gs2m_image_loss_backward")
         return d_image, None, d_normal, d_sobel, None, None, None, None, None, None, None
 
 
@@ -199,9 +200,9 @@ class _PlaneLoss(torch.autograd.Function):
             raise RuntimeError("gs2m_losses: fused_plane_loss takes scaling (P,3) float32 and visibility_filter (P,) bool on one device")
         visible = visible.contiguous()
         out = torch.empty(2, dtype=torch.float32, device=scaling.device)
-        with torch.cuda.device(scaling.device):
+        with _native().device_guard(scaling.device):
             _native().check(_native().lib().gs2m_plane_loss_forward(P, _ptr(scaling), int(raw), _ptr(visible), float(weight), _ptr(out), _ptr(_workspace(scaling.device)),
-                                                                    C.c_void_p(_stream(scaling.device).cuda_stream)), "gs2m_plane_loss_forward")
+                                                                    C.c_void_p(_stream(scaling.device))), "gs2m_plane_loss_forward")
         ctx.save_for_backward(scaling, visible, out)
         ctx.raw, ctx.weight = int(raw), float(weight)
         return out[0]
@@ -210,9 +211,9 @@ class _PlaneLoss(torch.autograd.Function):
     def backward(ctx, g):
         scaling, visible, out = ctx.saved_tensors
         d = torch.empty_like(scaling)
-        with torch.cuda.device(scaling.device):
+        with _native().device_guard(scaling.device):
             _native().check(_native().lib().gs2m_plane_loss_backward(scaling.shape[0], _ptr(scaling), ctx.raw, _ptr(visible), ctx.weight, _ptr(out), _ptr(g.contiguous()),
-                                                                     _ptr(d), C.c_void_p(_stream(scaling.device).cuda_stream)), "gs2m_plane_loss_backward")
+                                                                     _ptr(d), C.c_void_p(_stream(scaling.device))), "gs2m_plane_loss_backward")
         return d, None, None, None
 
 
@@ -235,7 +236,7 @@ class _TvLoss(torch.autograd.Function):
         if weight_map is not None:
             weight_map = _cuda_f32(weight_map.reshape(H, W), "weight_map")
         out = torch.empty(1, dtype=torch.float32, device=pred.device)
-        with torch.cuda.device(pred.device):
+        with _native().device_guard(pred.device):
             _native().check(_native().lib().gs2m_tv_loss_forward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), int(bool(norm1)), float(weight), _ptr(out),
                                                                  _ptr(_workspace(pred.device)), C_void(_stream(pred.device))), "gs2m_tv_loss_forward")
         ctx.save_for_backward(gt, pred, weight_map)
@@ -247,14 +248,14 @@ class _TvLoss(torch.autograd.Function):
         gt, pred, weight_map = ctx.saved_tensors
         C, H, W = pred.shape
         d = torch.empty_like(pred)
-        with torch.cuda.device(pred.device):
+        with _native().device_guard(pred.device):
             _native().check(_native().lib().gs2m_tv_loss_backward(W, H, C, _ptr(gt), _ptr(pred), _ptr(weight_map), ctx.norm1, ctx.weight, _ptr(g.contiguous()),
                                                                   _ptr(d), C_void(_stream(pred.device))), "gs2m_tv_loss_backward")
         return None, d, None, None, None
 
 
 def C_void(stream):
-    return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(stream)
 
 
 def fused_tv_loss(gt_image, pred, norm1=True, weight_map=None, weight=1.0):
@@ -281,7 +282,7 @@ def densification_stats(viewspace_grad, visibility_filter, grad_accum, grad_accu
         observe, radii = observe.contiguous(), radii.contiguous()
         if observe.dtype != torch.int32 or radii.dtype != torch.int32 or observe.numel() != P or radii.numel() != P:
             raise RuntimeError("gs2m_losses: observe and radii must be (P,) int32")
-    with torch.cuda.device(vg.device):
+    with _native().device_guard(vg.device):
         _native().check(_native().lib().gs2m_densification_stats(
             P, _ptr(vg), _ptr(vis), _ptr(observe if max_radii is not None else None), _ptr(radii if max_radii is not None else None),
-            _ptr(grad_accum), _ptr(grad_accum_abs), _ptr(denom), _ptr(max_radii), C.c_void_p(_stream(vg.device).cuda_stream)), "gs2m_densification_stats")
+            _ptr(grad_accum), _ptr(grad_accum_abs), _ptr(denom), _ptr(max_radii), C.c_void_p(_stream(vg.device))), "gs2m_densification_stats")

@@ -57,10 +57,10 @@ class _PatchNCC(torch.autograd.Function):
         ncc = torch.empty((N, 1), dtype=torch.float32, device=pixels.device)
         consts = tuple((C.c_float * len(v))(*[float(x) for x in v]) for v in (M.reshape(-1).tolist(), b.reshape(-1).tolist(), Kinv.reshape(-1).tolist()))
         ctx.args = (N, w, h, consts, float(ncc_scale), int(patch))
-        with torch.cuda.device(pixels.device):
+        with _native.device_guard(pixels.device):
             _native.check(_native.lib().gs2m_patch_ncc_forward(
                 N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), ref_gray.data_ptr(), near_gray.data_ptr(), w, h, *consts,
-                float(ncc_scale), int(patch), ncc.data_ptr(), C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)), "gs2m_patch_ncc_forward")
+                float(ncc_scale), int(patch), ncc.data_ptr(), C.c_void_p(_native.stream_ptr(pixels.device))), "gs2m_patch_ncc_forward")
         ctx.save_for_backward(pixels, normals, dists, ref_gray, near_gray)
         return ncc
 
@@ -70,11 +70,11 @@ class _PatchNCC(torch.autograd.Function):
         N, w, h, consts, ncc_scale, patch = ctx.args
         d_ncc = d_ncc.contiguous().float()
         dn, dd = torch.empty_like(normals), torch.empty_like(dists)
-        with torch.cuda.device(pixels.device):
+        with _native.device_guard(pixels.device):
             _native.check(_native.lib().gs2m_patch_ncc_backward(
                 N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), ref_gray.data_ptr(), near_gray.data_ptr(), w, h, *consts,
                 ncc_scale, patch, d_ncc.data_ptr(), dn.data_ptr(), dd.data_ptr(),
-                C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)), "gs2m_patch_ncc_backward")
+                C.c_void_p(_native.stream_ptr(pixels.device))), "gs2m_patch_ncc_backward")
         return None, dn, dd, None, None, None, None, None, None, None
 
 
@@ -87,9 +87,9 @@ class _GridSampleBorder(torch.autograd.Function):
         Cc, H, W = image.shape
         N = grid.shape[0]
         out = torch.empty((N, Cc), dtype=torch.float32, device=image.device)
-        with torch.cuda.device(image.device):
+        with _native.device_guard(image.device):
             _native.check(_native.lib().gs2m_grid_sample_border_forward(N, Cc, H, W, image.data_ptr(), grid.data_ptr(), out.data_ptr(),
-                                                                        C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                                                                        C.c_void_p(_native.stream_ptr(image.device))),
                           "gs2m_grid_sample_border_forward")
         ctx.save_for_backward(image, grid)
         return out
@@ -101,10 +101,10 @@ class _GridSampleBorder(torch.autograd.Function):
         d_img = torch.zeros_like(image) if ctx.needs_input_grad[0] else None
         d_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
         d_out = d_out.contiguous().float()
-        with torch.cuda.device(image.device):
+        with _native.device_guard(image.device):
             _native.check(_native.lib().gs2m_grid_sample_border_backward(
                 grid.shape[0], Cc, H, W, image.data_ptr(), grid.data_ptr(), d_out.data_ptr(), None if d_img is None else d_img.data_ptr(),
-                None if d_grid is None else d_grid.data_ptr(), C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                None if d_grid is None else d_grid.data_ptr(), C.c_void_p(_native.stream_ptr(image.device))),
                 "gs2m_grid_sample_border_backward")
         return d_img, d_grid
 
@@ -144,10 +144,10 @@ class _MVGeo(torch.autograd.Function):
         noise = torch.empty(H * W, dtype=torch.float32, device=depth.device)
         angle = torch.empty_like(noise)
         valid = torch.empty(H * W, dtype=torch.uint8, device=depth.device)
-        with torch.cuda.device(depth.device):
+        with _native.device_guard(depth.device):
             _native.check(_native.lib().gs2m_mv_geo_forward(
                 W, H, Wn, Hn, depth.data_ptr(), normal.data_ptr(), depth_n.data_ptr(), normal_n.data_ptr(), *consts, float(occlusion),
-                noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), C.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream)),
+                noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), C.c_void_p(_native.stream_ptr(depth.device))),
                 "gs2m_mv_geo_forward")
         ctx.save_for_backward(depth, normal, depth_n, normal_n)
         ctx.args = (W, H, Wn, Hn, consts, float(occlusion))
@@ -163,11 +163,11 @@ class _MVGeo(torch.autograd.Function):
         d_noise, d_angle = z(d_noise), z(d_angle)
         dd, dn = torch.empty_like(depth), torch.empty_like(normal)
         ddn, dnn = torch.zeros_like(depth_n), torch.zeros_like(normal_n)
-        with torch.cuda.device(depth.device):
+        with _native.device_guard(depth.device):
             _native.check(_native.lib().gs2m_mv_geo_backward(
                 W, H, Wn, Hn, depth.data_ptr(), normal.data_ptr(), depth_n.data_ptr(), normal_n.data_ptr(), *consts, occlusion,
                 d_noise.data_ptr(), d_angle.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddn.data_ptr(), dnn.data_ptr(),
-                C.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream)), "gs2m_mv_geo_backward")
+                C.c_void_p(_native.stream_ptr(depth.device))), "gs2m_mv_geo_backward")
         return dd, dn, ddn, dnn, None, None, None
 
 
@@ -190,10 +190,10 @@ class _MVGeoLoss(torch.autograd.Function):
         pixel_valid = torch.empty(noise.shape, dtype=torch.bool, device=dev)
         w_ncc = torch.empty_like(noise)
         args = (float(angle_threshold), float(decay), float(factor), float(weight))
-        with torch.cuda.device(dev):
+        with _native.device_guard(dev):
             _native.check(_native.lib().gs2m_mv_geo_loss_forward(
                 n, noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), *args, out.data_ptr(), pixel_valid.data_ptr(), w_ncc.data_ptr(),
-                gs2m_losses._workspace(dev).data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gs2m_mv_geo_loss_forward")
+                gs2m_losses._workspace(dev).data_ptr(), C.c_void_p(_native.stream_ptr(dev))), "gs2m_mv_geo_loss_forward")
         ctx.save_for_backward(noise, angle, valid, out)
         ctx.args = args
         ctx.mark_non_differentiable(pixel_valid, w_ncc)
@@ -203,10 +203,10 @@ class _MVGeoLoss(torch.autograd.Function):
     def backward(ctx, g, _gv, _gw):
         noise, angle, valid, out = ctx.saved_tensors
         d_noise, d_angle = torch.empty_like(noise), torch.empty_like(angle)
-        with torch.cuda.device(noise.device):
+        with _native.device_guard(noise.device):
             _native.check(_native.lib().gs2m_mv_geo_loss_backward(
                 noise.numel(), noise.data_ptr(), angle.data_ptr(), valid.data_ptr(), *ctx.args, out.data_ptr(), g.contiguous().data_ptr(),
-                d_noise.data_ptr(), d_angle.data_ptr(), C.c_void_p(torch.cuda.current_stream(noise.device).cuda_stream)), "gs2m_mv_geo_loss_backward")
+                d_noise.data_ptr(), d_angle.data_ptr(), C.c_void_p(_native.stream_ptr(noise.device))), "gs2m_mv_geo_loss_backward")
         return d_noise, d_angle, None, None, None, None, None
 
 
@@ -269,10 +269,10 @@ def patch_ncc_roughness(pixels, normals, dists, ref_cam, near_cam, ncc_scale, pa
     N = pixels.shape[0]
     out = torch.empty((3, N, 1), dtype=torch.float32, device=pixels.device)
     consts = tuple((C.c_float * len(v))(*[float(x) for x in v]) for v in (M.reshape(-1).tolist(), b.reshape(-1).tolist(), Kinv.reshape(-1).tolist()))
-    with torch.cuda.device(pixels.device):
+    with _native.device_guard(pixels.device):
         _native.check(_native.lib().gs2m_patch_ncc_roughness(
             N, pixels.data_ptr(), normals.data_ptr(), dists.data_ptr(), rg.data_ptr(), ng.data_ptr(), w, h, *consts, float(ncc_scale), int(patch),
-            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), C.c_void_p(torch.cuda.current_stream(pixels.device).cuda_stream)),
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), C.c_void_p(_native.stream_ptr(pixels.device))),
             "gs2m_patch_ncc_roughness")
     return out[0], out[1], torch.sqrt(out[2]) < 0.01
 

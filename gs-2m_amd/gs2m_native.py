@@ -190,6 +190,37 @@ def lib():
 ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocation failed", -4: "unsupported size"}
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with torch.cuda.device(device)` without its cost when `device` is already the current one (every call of every
+    wrapper: ~10 us of host time each, 0.2 ms per training iteration)."""
+    import torch
+    idx = device.index if hasattr(device, "index") else device
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+def stream_ptr(device=None):
+    """The raw hipStream_t of torch's current stream on `device` (the current device when None) as an int -- one C call
+    instead of building a torch.cuda.Stream object per launch."""
+    import torch
+    idx = None if device is None else (device.index if hasattr(device, "index") else device)
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
 def check(rc, what):
     if rc <= -100:  # debug mode: GS2M_ERR_STAGE(stage)
         raise RuntimeError(f"gs2m: {what} failed in stage `{lib().gs2m_stage_name(-100 - rc).decode()}` (debug mode)")

@@ -92,8 +92,8 @@ class Adam(torch.optim.Optimizer):
             for a, (p, g, m, v, lr, step) in zip(arr, items):
                 a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
                 a.numel, a.lr, a.step = p.numel(), lr, step
-            with torch.cuda.device(device):
+            with _native.device_guard(device):
                 _native.check(_native.lib().gs2m_adam_step(len(items), arr, beta1, beta2, eps,
-                                                           C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                                                           C.c_void_p(_native.stream_ptr(device))),
                               "gs2m_adam_step")
         return loss

@@ -15,7 +15,7 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _native.stream_ptr()
 
 
 def _f32c(t, name):
@@ -34,7 +34,7 @@ class _PackFeatures(torch.autograd.Function):
         campos, view = _f32c(campos, "camera_center"), _f32c(view, "world_view_transform")
         P = xyz.shape[0]
         features = torch.empty((P, 10), dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with _native.device_guard(xyz.device):
             _native.check(_native.lib().gs2m_pack_features_forward(
                 P, _ptr(xyz), _ptr(scales), _ptr(rotations), _ptr(albedo), _ptr(roughness), _ptr(metallic), _ptr(campos),
                 _ptr(view), int(bool(z_depth)), int(bool(blend_metallic)), _ptr(features), _stream()), "gs2m_pack_features_forward")
@@ -49,7 +49,7 @@ class _PackFeatures(torch.autograd.Function):
         P = xyz.shape[0]
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=xyz.device)
         d_xyz, d_rot, d_alb, d_rgh, d_met = e(P, 3), e(P, 4), e(P, 3), e(P, 1), e(P, 1)
-        with torch.cuda.device(xyz.device):
+        with _native.device_guard(xyz.device):
             _native.check(_native.lib().gs2m_pack_features_backward(
                 P, _ptr(xyz), _ptr(scales), _ptr(rotations), _ptr(campos), _ptr(view), ctx.flags[0], ctx.flags[1], _ptr(dF),
                 _ptr(d_xyz), _ptr(d_rot), _ptr(d_alb), _ptr(d_rgh), _ptr(d_met), _stream()), "gs2m_pack_features_backward")
@@ -73,7 +73,7 @@ class _GBufferPost(torch.autograd.Function):
         mask = torch.empty((1, H, W), dtype=torch.bool, device=buffer.device)  # one byte per pixel, the kernel writes 0 / 1
         local_normal = torch.empty((3, H, W), dtype=torch.float32, device=buffer.device)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=buffer.device)
-        with torch.cuda.device(buffer.device):
+        with _native.device_guard(buffer.device):
             _native.check(_native.lib().gs2m_gbuffer_post_forward(
                 W, H, _ptr(buffer), _ptr(rays), _ptr(view), int(bool(z_depth)), _ptr(mask), _ptr(local_normal), _ptr(depth),
                 _stream()), "gs2m_gbuffer_post_forward")
@@ -89,7 +89,7 @@ class _GBufferPost(torch.autograd.Function):
         d_buffer = torch.zeros_like(buffer)  # channels 0, 5..9 get no gradient from here
         dl = None if d_local_normal is None else _f32c(d_local_normal, "grad_local_normal_map")
         dd = None if d_depth is None else _f32c(d_depth, "grad_depth_map")
-        with torch.cuda.device(buffer.device):
+        with _native.device_guard(buffer.device):
             _native.check(_native.lib().gs2m_gbuffer_post_backward(
                 W, H, _ptr(buffer), _ptr(rays), _ptr(view), ctx.z_depth, _ptr(dl), _ptr(dd), _ptr(d_buffer), _stream()),
                 "gs2m_gbuffer_post_backward")
@@ -118,7 +118,7 @@ class _GBufferMaps(torch.autograd.Function):
         _, H, W = buffer.shape
         d_buffer = torch.empty_like(buffer)  # the kernel writes all ten channels
         c = lambda t, n: None if t is None else _f32c(t, n)
-        with torch.cuda.device(buffer.device):
+        with _native.device_guard(buffer.device):
             _native.check(_native.lib().gs2m_gbuffer_maps_backward(
                 W, H, _ptr(buffer), _ptr(rays), _ptr(view), ctx.z_depth, _ptr(c(d_local_normal, "grad_local_normal_map")),
                 _ptr(c(d_depth, "grad_depth_map")), _ptr(c(d_alpha, "grad_alpha_map")), _ptr(c(d_dist, "grad_distance_map")),
@@ -140,7 +140,7 @@ class _Activate(torch.autograd.Function):
                                            ("_scaling", "_rotation", "_opacity", "_albedo", "_roughness", "_metallic"))]
         P = raw[0].shape[0]
         out = [torch.empty_like(t) for t in raw]
-        with torch.cuda.device(raw[0].device):
+        with _native.device_guard(raw[0].device):
             _native.check(_native.lib().gs2m_activate_forward(P, *[_ptr(t) for t in raw], *[_ptr(t) for t in out], _stream()),
                           "gs2m_activate_forward")
         ctx.save_for_backward(raw[1], out[0], *out[2:])
@@ -159,7 +159,7 @@ class _Activate(torch.autograd.Function):
         names = ("scaling", "rotation", "opacity", "albedo", "roughness", "metallic")
         arena = _arena.GradArena(rotation.device, [(nm, t.shape) for nm, t, n in zip(names, like, need) if n], key="activate")
         d = [arena[nm] if n else None for nm, n in zip(names, need)]
-        with torch.cuda.device(rotation.device):
+        with _native.device_guard(rotation.device):
             _native.check(_native.lib().gs2m_activate_backward(
                 P, _ptr(rotation), _ptr(scales), _ptr(opac), _ptr(alb), _ptr(rgh), _ptr(met), *[_ptr(t) for t in g],
                 *[_ptr(t) for t in d], _stream()), "gs2m_activate_backward")
@@ -178,7 +178,7 @@ class _SobelNormal(torch.autograd.Function):
         depth, alpha, bg, view = _f32c(depth, "depth"), _f32c(alpha, "alpha_map"), _f32c(bg, "bg_color"), _f32c(view, "world_view_transform")
         H, W = depth.shape
         out = torch.empty((3, H, W), dtype=torch.float32, device=depth.device)
-        with torch.cuda.device(depth.device):
+        with _native.device_guard(depth.device):
             _native.check(_native.lib().gs2m_sobel_normal_forward(W, H, _ptr(depth), _ptr(alpha), _ptr(bg), _ptr(view), fx, fy, cx, cy,
                                                                   _ptr(out), _stream()), "gs2m_sobel_normal_forward")
         ctx.save_for_backward(depth, alpha, bg, view)
@@ -191,7 +191,7 @@ class _SobelNormal(torch.autograd.Function):
         g = _f32c(g, "grad_sobel_map")
         H, W = depth.shape
         d_depth, d_alpha = torch.empty_like(depth), torch.empty_like(alpha)
-        with torch.cuda.device(depth.device):
+        with _native.device_guard(depth.device):
             _native.check(_native.lib().gs2m_sobel_normal_backward(W, H, _ptr(depth), _ptr(alpha), _ptr(bg), _ptr(view), *ctx.k,
                                                                    _ptr(g), _ptr(d_depth), _ptr(d_alpha), _stream()),
                           "gs2m_sobel_normal_backward")

@@ -20,7 +20,7 @@ def _check(t, name, ch):
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return C.c_void_p(_native.stream_ptr(dev))
 
 
 class _diffuse_cubemap_func(torch.autograd.Function):
@@ -28,7 +28,7 @@ class _diffuse_cubemap_func(torch.autograd.Function):
     def forward(ctx, cubemap):
         cubemap = _check(cubemap, "cubemap", 3)
         out = torch.empty_like(cubemap)
-        with torch.cuda.device(cubemap.device):
+        with _native.device_guard(cubemap.device):
             _native.check(_native.lib().gs2m_diffuse_cubemap_forward(cubemap.shape[1], cubemap.data_ptr(), out.data_ptr(),
                                                                      _stream(cubemap.device)), "gs2m_diffuse_cubemap_forward")
         return out
@@ -37,7 +37,7 @@ class _diffuse_cubemap_func(torch.autograd.Function):
     def backward(ctx, dout):
         dout = _check(dout, "grad", 3)
         g = torch.empty_like(dout)
-        with torch.cuda.device(dout.device):
+        with _native.device_guard(dout.device):
             _native.check(_native.lib().gs2m_diffuse_cubemap_backward(dout.shape[1], dout.data_ptr(), g.data_ptr(),
                                                                       _stream(dout.device)), "gs2m_diffuse_cubemap_backward")
         return g
@@ -56,7 +56,7 @@ def _texel_table(res, device):
     key = (str(device), int(res))
     if key not in _tables:
         t = torch.empty((res,), dtype=torch.float32, device=device)
-        with torch.cuda.device(device):
+        with _native.device_guard(device):
             _native.check(_native.lib().gs2m_cubemap_texel_table(res, t.data_ptr(), _stream(device)), "gs2m_cubemap_texel_table")
         _tables[key] = t
     return _tables[key]
@@ -68,7 +68,7 @@ class _specular_cubemap(torch.autograd.Function):
         cubemap = _check(cubemap, "cubemap", 3)
         res = cubemap.shape[1]
         out = torch.empty((6, res, res, 4), dtype=torch.float32, device=cubemap.device)
-        with torch.cuda.device(cubemap.device):
+        with _native.device_guard(cubemap.device):
             _native.check(_native.lib().gs2m_specular_cubemap_forward(res, float(roughness), float(costheta_cutoff), _texel_table(res, cubemap.device).data_ptr(),
                                                                       cubemap.data_ptr(), out.data_ptr(), _stream(cubemap.device)), "gs2m_specular_cubemap_forward")
         ctx.args = (float(roughness), float(costheta_cutoff))
@@ -79,7 +79,7 @@ class _specular_cubemap(torch.autograd.Function):
         dout = _check(dout, "grad", 4)
         res = dout.shape[1]
         g = torch.empty((6, res, res, 3), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
+        with _native.device_guard(dout.device):
             _native.check(_native.lib().gs2m_specular_cubemap_backward(res, ctx.args[0], ctx.args[1], _texel_table(res, dout.device).data_ptr(), dout.data_ptr(), g.data_ptr(),
                                                                        _stream(dout.device)), "gs2m_specular_cubemap_backward")
         return g, None, None
@@ -95,7 +95,7 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         res = cubemap.shape[1]
         raw = torch.empty((6, res, res, 4), dtype=torch.float32, device=cubemap.device)
         out = torch.empty_like(cubemap)
-        with torch.cuda.device(cubemap.device):
+        with _native.device_guard(cubemap.device):
             _native.check(_native.lib().gs2m_specular_cubemap_normalized_forward(
                 res, float(roughness), float(costheta_cutoff), _texel_table(res, cubemap.device).data_ptr(), cubemap.data_ptr(), raw.data_ptr(),
                 out.data_ptr(), _stream(cubemap.device)), "gs2m_specular_cubemap_normalized_forward")
@@ -110,7 +110,7 @@ class _specular_cubemap_normalized(torch.autograd.Function):
         res = dout.shape[1]
         scratch = torch.empty_like(raw)
         g = torch.empty_like(dout)
-        with torch.cuda.device(dout.device):
+        with _native.device_guard(dout.device):
             _native.check(_native.lib().gs2m_specular_cubemap_normalized_backward(
                 res, ctx.args[0], ctx.args[1], _texel_table(res, dout.device).data_ptr(), raw.data_ptr(), dout.data_ptr(), scratch.data_ptr(),
                 g.data_ptr(), _stream(dout.device)), "gs2m_specular_cubemap_normalized_backward")

@@ -20,7 +20,7 @@ REF = "--reference-formulation" in sys.argv
 TORCH_TAIL = REF or "--torch-loss-tail" in sys.argv  # the losses / statistics around the fused pieces as PyTorch expressions
 MAT = "--material" in sys.argv  # the material stage (train.py:132-196): deferred PBR shading under a learnable 512^2 environment light
 MV = "--multi-view" in sys.argv   # + multi_view_loss against a second, nearby camera (fused path only)
-P, W, H = 1_000_000, 1920, 1080
+P, W, H = (int(os.environ.get(k, d)) for k, d in (("GS2M_TSB_P", 1_000_000), ("GS2M_TSB_W", 1920), ("GS2M_TSB_H", 1080)))  # small sizes: the host side alone
 dev = "cuda"
 cam0 = S.make_camera(W, H)
 g = {k: v.to(dev) for k, v in S.make_gaussians(P, cam0, seed=0).items()}
@@ -168,6 +168,15 @@ for _ in range(n):
     step()
 torch.cuda.synchronize()
 print("%s iteration (%s): %.3f ms" % ("material-stage" if MAT else "training", "reference formulation on the drop-in rasterizer" if REF else "fused", (time.perf_counter() - t0) / n * 1e3))
+if "--host-profile" in sys.argv:  # where the Python side of an iteration goes (run with a small scene: GS2M_TSB_P=2000 GS2M_TSB_W=64 GS2M_TSB_H=64)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 if "--profile" in sys.argv:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
