@@ -362,3 +362,33 @@ def test_ply_bytes_match_the_reference_layout(tmp_path, device):
     for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("scaling", "_scaling"),
                     ("rotation", "_rotation"), ("albedo", "_albedo"), ("roughness", "_roughness"), ("metallic", "_metallic")):
         assert np.array_equal(getattr(back, attr).detach().cpu().numpy(), z[k]), k
+
+
+@pytest.mark.gpu
+def test_accumulate_view_stats_fused_equals_the_two_reference_updates():
+    """train.py:223-227 for one view: the model's one-launch form (gs2m_losses.densification_stats) against
+    update_max_radii + add_densification_stats (GM:569-573) on the same state."""
+    import types
+    P = 5001
+    ms = []
+    g = torch.Generator().manual_seed(11)
+    vg = torch.randn(P, 4, generator=g).cuda()
+    vis = (torch.rand(P, generator=g) < 0.7).cuda()
+    observe = torch.randint(0, 3, (P,), generator=g, dtype=torch.int32).cuda()
+    radii = torch.randint(0, 300, (P,), generator=g, dtype=torch.int32).cuda()
+    for fused in (False, True):
+        from gs2m_model import GaussianModel
+        gm = torch.Generator().manual_seed(0)
+        r = lambda *sh: torch.randn(*sh, generator=gm).cuda()
+        m = GaussianModel(3, device="cuda")
+        m.parameterize((r(P, 3), r(P, 1, 3), r(P, 15, 3), r(P, 3), r(P, 4), r(P, 1), r(P, 3), r(P, 1), r(P, 1)))
+        m.xyz_gradient_accum = torch.rand(P, 1, generator=torch.Generator().manual_seed(1)).cuda()
+        m.xyz_gradient_accum_abs = torch.rand(P, 1, generator=torch.Generator().manual_seed(2)).cuda()
+        m.denom = torch.randint(0, 5, (P, 1), generator=torch.Generator().manual_seed(3)).float().cuda()
+        m.max_radii2D = (torch.rand(P, generator=torch.Generator().manual_seed(4)) * 200).cuda()
+        m.accumulate_view_stats(types.SimpleNamespace(grad=vg), vis, observe, radii, fused=fused)
+        ms.append(m)
+    a, b = ms
+    assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+    assert torch.allclose(a.xyz_gradient_accum, b.xyz_gradient_accum, rtol=3e-7, atol=0)
+    assert torch.allclose(a.xyz_gradient_accum_abs, b.xyz_gradient_accum_abs, rtol=3e-7, atol=0)
