@@ -153,6 +153,54 @@ def colmap_small():
     print("wrote colmap_small/ and colmap_small.npz")
 
 
+def ref_losses():
+    """(5) ref_losses.npz -- outputs of the reference's own loss functions (utils/loss_utils.py: l1_loss :24-25, ssim :30-70,
+    plane_loss :72-78, depth_normal_loss :111-117, _get_img_grad_weight :119-131, tv_loss :536-557) on small random inputs:
+    they pin gs2m_losses' PyTorch expressions and, through them, the fused HIP kernels of csrc/loss_ops.hip and the fused
+    SSIM.  The module imports cv2 (absent here; used by _erode_cv only) and the CUDA-only gaussian_renderer (used by the
+    multi-view terms only) at its top: it is loaded with EMPTY placeholder modules under those two names -- none of the
+    functions called below touches either."""
+    import importlib.util
+    import types
+    for name in ("cv2", "gaussian_renderer"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.render = None
+            sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("ref_loss_utils", "/root/reference/utils/loss_utils.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for name in ("cv2", "gaussian_renderer"):
+        if getattr(sys.modules.get(name), "render", 0) is None and not hasattr(sys.modules[name], "__file__"):
+            del sys.modules[name]
+    g = torch.Generator().manual_seed(4321)
+    H, W, P = 24, 32, 200
+    out = {}
+    img = torch.randn(3, H, W, generator=g) * 0.4 + 0.5
+    gt = torch.rand(3, H, W, generator=g)
+    normal = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    sobel = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    wm = torch.rand(1, H, W, generator=g)
+    pred1, pred3 = torch.rand(1, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    raw_scale = torch.randn(P, 3, generator=g) - 3.0
+    vis = torch.rand(P, generator=g) < 0.6
+    out.update(img=img.numpy(), gt=gt.numpy(), normal=normal.numpy(), sobel=sobel.numpy(), wm=wm.numpy(), pred1=pred1.numpy(),
+               pred3=pred3.numpy(), raw_scale=raw_scale.numpy(), vis=vis.numpy())
+    rgb = img.clamp(0, 1)
+    out["l1"] = ref.l1_loss(rgb, gt).numpy()
+    out["ssim"] = ref.ssim(rgb.unsqueeze(0), gt.unsqueeze(0)).numpy()
+    out["img_grad_weight"] = ref._get_img_grad_weight(gt).numpy()
+    out["depth_normal"] = ref.depth_normal_loss(normal, sobel, gt).numpy()
+    out["depth_normal_wm"] = ref.depth_normal_loss(normal, sobel, gt, weight_map=wm).numpy()
+    out["tv_l2_c1"] = ref.tv_loss(gt, pred1, norm1=False).numpy()
+    out["tv_l1_c3"] = ref.tv_loss(gt, pred3).numpy()
+    out["tv_l1_c3_wm"] = ref.tv_loss(gt, pred3, weight_map=wm).numpy()
+    out["plane"] = np.asarray(ref.plane_loss(vis, types.SimpleNamespace(get_scaling=torch.exp(raw_scale))))
+    out["plane_none_visible"] = np.asarray(ref.plane_loss(torch.zeros(P, dtype=torch.bool), types.SimpleNamespace(get_scaling=torch.exp(raw_scale))), dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "ref_losses.npz"), **out)
+    print("wrote ref_losses.npz", {k: float(v) for k, v in out.items() if np.asarray(v).ndim == 0})
+
+
 def raster_small():
     import helpers as Hh
     from oracle import oracle
@@ -182,8 +230,12 @@ if __name__ == "__main__":
     if "--colmap-only" in sys.argv:
         colmap_small()
         sys.exit(0)
+    if "--losses-only" in sys.argv:
+        ref_losses()
+        sys.exit(0)
     ref_helpers()
     ref_model_helpers()
     ref_defaults()
     colmap_small()
+    ref_losses()
     raster_small()

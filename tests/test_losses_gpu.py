@@ -4,6 +4,7 @@ values and gradients, on the device."""
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -196,3 +197,30 @@ def test_geometry_image_loss_on_the_shaded_image_of_the_material_stage(H, W):
     assert x1.grad.shape == (H, W, 3) and torch.allclose(x1.grad, x0.grad, rtol=1e-5, atol=1e-10)
     assert torch.allclose(n1.grad, n0.grad, rtol=2e-5, atol=1e-12) and torch.allclose(s1.grad, s0.grad, rtol=2e-5, atol=1e-12)
     assert float(x1.grad[~mask[0]].abs().sum()) == 0.0
+
+
+def test_fused_forms_reproduce_the_reference_functions():
+    """The fused kernels against OUTPUTS OF THE REFERENCE's own loss functions (tests/golden/ref_losses.npz, generated from
+    /root/reference/utils/loss_utils.py by tests/golden/make_golden.py): the pinned vectors of this row."""
+    import types
+    import gs2m_losses as L
+    from fused_ssim import dssim_loss, fused_ssim
+    z = {k: torch.tensor(v).cuda() for k, v in np.load(os.path.join(ROOT, "tests", "golden", "ref_losses.npz")).items()}
+    val = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)
+    close = lambda a, b, tol=2e-5: abs(val(a) - val(b)) <= tol * max(1.0, abs(val(b)))
+    edge = L.edge_gradient(z["gt"])
+    rgb, loss, terms = L.geometry_image_loss(z["img"], z["gt"], z["normal"], z["sobel"], edge=edge, w_l1=1.0, w_dn=1.0)
+    assert close(terms[0], z["l1"]) and close(terms[1], z["depth_normal"]) and close(loss, z["l1"] + z["depth_normal"])
+    assert torch.equal(rgb, z["img"].clamp(0, 1))
+    _, _, t2 = L.geometry_image_loss(z["img"], z["gt"], z["normal"], z["sobel"], edge=edge, weight_map=z["wm"], w_l1=0.0, w_dn=1.0)
+    assert close(t2[1], z["depth_normal_wm"])
+    w = (1.0 - (edge[0] - edge[1][0]) / (edge[1][1] - edge[1][0])).clamp(0, 1)
+    assert torch.allclose((1.0 - w)[1:-1, 1:-1], z["img_grad_weight"][1:-1, 1:-1], rtol=1e-5, atol=1e-6)
+    assert close(L.fused_tv_loss(z["gt"], z["pred1"], norm1=False), z["tv_l2_c1"])
+    assert close(L.fused_tv_loss(z["gt"], z["pred3"]), z["tv_l1_c3"])
+    assert close(L.fused_tv_loss(z["gt"], z["pred3"], weight_map=z["wm"]), z["tv_l1_c3_wm"])
+    raw = z["raw_scale"]
+    assert close(L.fused_plane_loss(z["vis"], types.SimpleNamespace(_scaling=raw, get_scaling=torch.exp(raw))), z["plane"])
+    assert float(L.fused_plane_loss(torch.zeros_like(z["vis"]), types.SimpleNamespace(get_scaling=torch.exp(raw)))) == 0.0
+    assert close(fused_ssim(rgb.unsqueeze(0), z["gt"].unsqueeze(0), train=False), z["ssim"], 1e-4)
+    assert close(dssim_loss(rgb.unsqueeze(0).requires_grad_(True), z["gt"].unsqueeze(0), 0.2), 0.2 * (1.0 - float(z["ssim"])), 1e-4)
