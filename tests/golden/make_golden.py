@@ -160,19 +160,8 @@ def ref_losses():
     SSIM.  The module imports cv2 (absent here; used by _erode_cv only) and the CUDA-only gaussian_renderer (used by the
     multi-view terms only) at its top: it is loaded with EMPTY placeholder modules under those two names -- none of the
     functions called below touches either."""
-    import importlib.util
     import types
-    for name in ("cv2", "gaussian_renderer"):
-        if name not in sys.modules:
-            m = types.ModuleType(name)
-            m.render = None
-            sys.modules[name] = m
-    spec = importlib.util.spec_from_file_location("ref_loss_utils", "/root/reference/utils/loss_utils.py")
-    ref = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ref)
-    for name in ("cv2", "gaussian_renderer"):
-        if getattr(sys.modules.get(name), "render", 0) is None and not hasattr(sys.modules[name], "__file__"):
-            del sys.modules[name]
+    ref = _load_ref_loss_utils()
     g = torch.Generator().manual_seed(4321)
     H, W, P = 24, 32, 200
     out = {}
@@ -199,6 +188,64 @@ def ref_losses():
     out["plane_none_visible"] = np.asarray(ref.plane_loss(torch.zeros(P, dtype=torch.bool), types.SimpleNamespace(get_scaling=torch.exp(raw_scale))), dtype=np.float32)
     np.savez_compressed(os.path.join(HERE, "ref_losses.npz"), **out)
     print("wrote ref_losses.npz", {k: float(v) for k, v in out.items() if np.asarray(v).ndim == 0})
+
+
+def _load_ref_loss_utils():
+    """utils/loss_utils.py with EMPTY placeholder modules for its two top-level imports that cannot be satisfied here (cv2:
+    absent, used by _erode_cv only; gaussian_renderer: CUDA-only, used by multi_view_loss / roughness_loss only)."""
+    import importlib.util
+    import types
+    added = []
+    for name in ("cv2", "gaussian_renderer"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.render = None
+            sys.modules[name] = m
+            added.append(name)
+    spec = importlib.util.spec_from_file_location("ref_loss_utils", "/root/reference/utils/loss_utils.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for name in added:
+        del sys.modules[name]
+    return ref
+
+
+def ref_mvs():
+    """(6) ref_mvs.npz -- outputs of the reference's own pure helpers of the multi-view terms (utils/loss_utils.py:
+    _patch_gradient :234-240, _sample_depth_normal :366-414, _sample_normal_map :432-453, _patch_offsets :455-457,
+    _patch_warp :459-468, _loss_ncc :470-509): they pin gs2m_mvs' restatements, against which the fused patch-NCC and
+    multi-view geometry kernels are tested.  (_get_points_from_depth and _reproject_points move tensors with .cuda() and
+    cannot run here.)"""
+    import types
+    ref = _load_ref_loss_utils()
+    g = torch.Generator().manual_seed(9876)
+    out = {}
+    for h in (1, 3):
+        out[f"offsets_h{h}"] = ref._patch_offsets(h, "cpu").numpy()
+    B, P = 13, 49
+    Hm = torch.eye(3).repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, generator=g)
+    uv = torch.rand(B, P, 2, generator=g) * 60.0
+    out.update(warp_H=Hm.numpy(), warp_uv=uv.numpy(), warp_grid=ref._patch_warp(Hm.reshape(B, 9), uv).numpy())
+    refp, neap = torch.rand(B, P, generator=g), torch.rand(B, P, generator=g)
+    neap[:4] = refp[:4] * 0.7 + 0.1          # well correlated patches
+    refp[4] = 0.5                            # a flat patch: the std mask
+    ncc, mask = ref._loss_ncc(refp, neap)
+    ncc2, smask = ref._loss_ncc(refp, neap, std_mask=True)
+    out.update(ncc_ref=refp.numpy(), ncc_nea=neap.numpy(), ncc=ncc.numpy(), ncc_mask=mask.numpy(), ncc_std_mask=smask.numpy())
+    out["patch_gradient"] = ref._patch_gradient(refp, 7).numpy()
+    Hh, Ww = 20, 28
+    normal_map = torch.nn.functional.normalize(torch.randn(3, Hh, Ww, generator=g), dim=0)
+    depth_map = 2.0 + torch.rand(1, Hh, Ww, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(Hh, dtype=torch.float32), torch.arange(Ww, dtype=torch.float32), indexing="ij")
+    pixels = torch.stack([xs, ys], dim=-1)
+    out.update(sn_normal_map=normal_map.numpy(), sn_pixels=pixels.numpy(), sn_out=ref._sample_normal_map(pixels, normal_map).numpy())
+    cam = types.SimpleNamespace(Fx=30.0, Fy=29.0, Cx=14.0, Cy=10.0, image_width=Ww, image_height=Hh)
+    pts = torch.randn(300, 3, generator=g) * torch.tensor([1.2, 0.9, 1.0]) + torch.tensor([0.0, 0.0, 2.5])
+    z, n, valid = ref._sample_depth_normal(pts, cam, {"depth_map": depth_map, "normal_map": normal_map})
+    out.update(sdn_depth_map=depth_map.numpy(), sdn_pts=pts.numpy(), sdn_cam=np.array([cam.Fx, cam.Fy, cam.Cx, cam.Cy, Ww, Hh]),
+               sdn_z=z.numpy(), sdn_n=n.numpy(), sdn_valid=valid.numpy())
+    np.savez_compressed(os.path.join(HERE, "ref_mvs.npz"), **out)
+    print("wrote ref_mvs.npz")
 
 
 def raster_small():
@@ -232,10 +279,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--losses-only" in sys.argv:
         ref_losses()
+        ref_mvs()
         sys.exit(0)
     ref_helpers()
     ref_model_helpers()
     ref_defaults()
     colmap_small()
     ref_losses()
+    ref_mvs()
     raster_small()

@@ -35,3 +35,27 @@ def test_pytorch_expressions_reproduce_the_reference_functions():
     model = types.SimpleNamespace(get_scaling=torch.exp(z["raw_scale"]))
     assert close(L.plane_loss(z["vis"], model), z["plane"])
     assert float(L.plane_loss(torch.zeros_like(z["vis"]), model)) == float(z["plane_none_visible"]) == 0.0
+
+
+def test_multi_view_helpers_reproduce_the_reference_functions():
+    """gs2m_mvs' restatements of the pure helpers of the multi-view terms against OUTPUTS OF THE REFERENCE's own functions
+    (tests/golden/ref_mvs.npz: _patch_offsets, _patch_warp, _loss_ncc in both modes, _patch_gradient, _sample_normal_map,
+    _sample_depth_normal of utils/loss_utils.py) -- the formulation the fused patch-NCC / geometry kernels are tested against."""
+    import gs2m_mvs as M
+    z = np.load(os.path.join(os.path.dirname(GOLD), "ref_mvs.npz"))
+    t = lambda k: torch.tensor(z[k])
+    for h in (1, 3):
+        assert torch.equal(M._patch_offsets(h, "cpu"), t(f"offsets_h{h}"))
+    B = t("warp_H").shape[0]
+    assert torch.allclose(M._patch_warp(t("warp_H").reshape(B, 9), t("warp_uv")), t("warp_grid"), rtol=1e-6, atol=1e-6)
+    ncc, mask = M._loss_ncc(t("ncc_ref"), t("ncc_nea"))
+    assert torch.allclose(ncc, t("ncc"), rtol=1e-5, atol=1e-6) and torch.equal(mask, t("ncc_mask"))
+    _, smask = M._loss_ncc(t("ncc_ref"), t("ncc_nea"), std_mask=True)
+    assert torch.equal(smask, t("ncc_std_mask")) and bool(smask[4].all()) and not bool(smask[5:].any())
+    assert torch.allclose(M._patch_gradient(t("ncc_ref"), 7), t("patch_gradient"), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(M._sample_normal_map(t("sn_pixels"), t("sn_normal_map"), fused=False), t("sn_out"), rtol=1e-6, atol=1e-6)
+    fx, fy, cx, cy, W, H = (float(v) for v in z["sdn_cam"])
+    cam = types.SimpleNamespace(Fx=fx, Fy=fy, Cx=cx, Cy=cy, image_width=int(W), image_height=int(H))
+    zz, n, valid = M._sample_depth_normal(t("sdn_pts"), cam, {"depth_map": t("sdn_depth_map"), "normal_map": t("sn_normal_map")}, fused=False)
+    assert torch.equal(valid, t("sdn_valid"))
+    assert torch.allclose(zz, t("sdn_z"), rtol=1e-6, atol=1e-6) and torch.allclose(n, t("sdn_n"), rtol=1e-5, atol=1e-6)
