@@ -4,7 +4,8 @@ import torch
 import torch.nn.functional as F
 
 from .light import CubemapLight
-from .shade import get_brdf_lut, pbr_shading, pbr_shading_fused, shading_inputs_fused, saturate_dot, linear_to_srgb, srgb_to_linear
+from .shade import (aces_film, envBRDF_approx, get_brdf_lut, linear_to_srgb, pbr_shading, pbr_shading_fused, rgb_to_srgb, saturate_dot,
+                    shading_inputs_fused, srgb_to_linear, srgb_to_rgb)
 
 __all__ = ["CubemapLight", "get_brdf_lut", "pbr_shading", "pbr_shading_fused", "saturate_dot", "linear_to_srgb", "srgb_to_linear", "pbr_render"]
 

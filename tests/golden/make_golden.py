@@ -248,6 +248,78 @@ def ref_mvs():
     print("wrote ref_mvs.npz")
 
 
+def _load_ref_pbr():
+    """pbr/light.py and pbr/shade.py with EMPTY placeholder modules for the imports that cannot be satisfied here (cv2,
+    nvdiffrast.torch, render_utils: absent / CUDA-only).  Only functions that never touch them are called below."""
+    import importlib.util
+    import types
+    added = []
+    for name in ("cv2", "nvdiffrast", "nvdiffrast.torch", "render_utils"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.diffuse_cubemap = m.specular_cubemap = None
+            sys.modules[name] = m
+            added.append(name)
+    sys.modules["nvdiffrast"].torch = sys.modules["nvdiffrast.torch"]
+    mods = {}
+    pkg = types.ModuleType("ref_pbr"); pkg.__path__ = ["/root/reference/pbr"]; sys.modules["ref_pbr"] = pkg
+    for name in ("light", "shade"):
+        spec = importlib.util.spec_from_file_location("ref_pbr." + name, "/root/reference/pbr/%s.py" % name)
+        mods[name] = importlib.util.module_from_spec(spec)
+        sys.modules["ref_pbr." + name] = mods[name]
+        spec.loader.exec_module(mods[name])
+    for name in added + ["ref_pbr", "ref_pbr.light", "ref_pbr.shade"]:
+        sys.modules.pop(name, None)
+    return mods["light"], mods["shade"]
+
+
+def ref_pbr():
+    """(8) ref_pbr.npz -- outputs of the reference's own pure-PyTorch shading helpers (pbr/shade.py: saturate_dot :27,
+    aces_film :32, linear_to_srgb :46, srgb_to_linear :61, rgb_to_srgb :95, srgb_to_rgb :112, envBRDF_approx :14; pbr/light.py:
+    cube_to_dir :13, cubemap_mip.forward :31, CubemapLight.get_mip :75) and a 32 x 32 sub-sample of the environment-BRDF
+    table it ships (pbr/brdf_256_256.bin, a data file), which tools/make_brdf_lut.py's table is held to."""
+    import types
+    light, shade = _load_ref_pbr()
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+    a = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    b = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    out["dot_a"], out["dot_b"] = a.numpy(), b.numpy()
+    out["saturate_dot"] = shade.saturate_dot(a, b).numpy()
+    x = torch.cat([torch.rand(500, generator=g) * 1.5 - 0.1, torch.tensor([0.0, 0.0031308, 0.003, 0.0032, 0.04045, 0.04, 0.041, 1.0])]).reshape(-1, 1, 4)[:, :, :3].contiguous()
+    out["tone_x"] = x.numpy()
+    out["aces_film"] = shade.aces_film(x).numpy()
+    out["aces_film_np"] = shade.aces_film(x.numpy())
+    out["linear_to_srgb"] = shade.linear_to_srgb(x).numpy()
+    out["linear_to_srgb_np"] = shade.linear_to_srgb(x.numpy())
+    out["srgb_to_linear"] = shade.srgb_to_linear(x).numpy()
+    out["srgb_to_linear_np"] = shade.srgb_to_linear(x.numpy())
+    x3 = x.reshape(1, 1, -1, 3).expand(1, 2, -1, 3).contiguous()
+    out["rgb_to_srgb"] = shade.rgb_to_srgb(x3).numpy()
+    out["srgb_to_rgb"] = shade.srgb_to_rgb(x3).numpy()
+    rough = torch.rand(97, 1, generator=g); nov = torch.rand(97, 1, generator=g)
+    out["env_rough"], out["env_nov"] = rough.numpy(), nov.numpy()
+    out["envBRDF_approx"] = shade.envBRDF_approx(rough, nov).numpy()
+    gx = torch.rand(5, 7, generator=g) * 2 - 1; gy = torch.rand(5, 7, generator=g) * 2 - 1
+    out["cube_x"], out["cube_y"] = gx.numpy(), gy.numpy()
+    out["cube_to_dir"] = np.stack([light.cube_to_dir(s, gx, gy).numpy() for s in range(6)])
+    cm = torch.rand(6, 8, 8, 3, generator=g)
+    out["mip_in"] = cm.numpy()
+    out["mip_out"] = light.cubemap_mip.forward(None, cm).numpy()
+    r = torch.cat([torch.rand(200, generator=g), torch.tensor([0.0, 0.04, 0.5, 0.4999, 1.0])]).reshape(-1, 1)
+    out["mip_rough"] = r.numpy()
+    for levels in (7, 4):
+        fake = types.SimpleNamespace(MIN_ROUGHNESS=light.CubemapLight.MIN_ROUGHNESS, MAX_ROUGHNESS=light.CubemapLight.MAX_ROUGHNESS, specular=[None] * levels)
+        out["get_mip_%d" % levels] = light.CubemapLight.get_mip(fake, r).numpy()
+    out["light_consts"] = np.array([light.CubemapLight.LIGHT_MIN_RES, light.CubemapLight.MIN_ROUGHNESS, light.CubemapLight.MAX_ROUGHNESS])
+    lut = np.fromfile("/root/reference/pbr/brdf_256_256.bin", dtype=np.float32).reshape(256, 256, 2)
+    idx = np.arange(32) * 8 + 3
+    out["brdf_idx"] = idx
+    out["brdf_sub"] = lut[np.ix_(idx, idx)]
+    np.savez_compressed(os.path.join(HERE, "ref_pbr.npz"), **out)
+    print("wrote ref_pbr.npz")
+
+
 def raster_small():
     import helpers as Hh
     from oracle import oracle
@@ -281,10 +353,14 @@ if __name__ == "__main__":
         ref_losses()
         ref_mvs()
         sys.exit(0)
+    if "--pbr-only" in sys.argv:
+        ref_pbr()
+        sys.exit(0)
     ref_helpers()
     ref_model_helpers()
     ref_defaults()
     colmap_small()
     ref_losses()
     ref_mvs()
+    ref_pbr()
     raster_small()
