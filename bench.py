@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
                          "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
+    ap.add_argument("--split-sh", action="store_true", help="experiment: hand the SH coefficients over as the model stores them, DC (P,1,3) "
+                    "and rest (P,15,3) (this repository's shs_rest extension), instead of the reference op's one (P,16,3) tensor")
     ap.add_argument("--heavy-tail", default=None, metavar="F:K",
                     help="not the metric's workload: a fraction F of the Gaussians K times larger (splats over hundreds of tiles, as "
                          "close-ups and background blobs of real scenes have them) -- how the stages hold up off the uniform scene")
@@ -281,7 +283,13 @@ def main():
         scale_modifier=1.0, viewmatrix=cam["viewmatrix"].to(dev), projmatrix=cam["projmatrix"].to(dev), sh_degree=3,
         campos=cam["campos"].to(dev), prefiltered=False, feature_count=fc)
     empty = torch.Tensor([])
-    leaves = [prm["means3D"], means2D, prm["shs"], prm["opacities"], prm["scales"], prm["rotations"], prm["features"]]
+    sh_in, sh_rest = prm["shs"], None
+    if a.split_sh:
+        sh_in = prm["shs"][:, :1].detach().clone().requires_grad_(True)
+        sh_rest = prm["shs"][:, 1:].detach().clone().requires_grad_(True)
+    leaves = [prm["means3D"], means2D, sh_in, prm["opacities"], prm["scales"], prm["rotations"], prm["features"]]
+    if sh_rest is not None:
+        leaves.append(sh_rest)
     reducer = GradReducer(mode=a.dp_mode)
     if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
         gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
@@ -296,8 +304,8 @@ def main():
         for t in leaves:
             t.grad = None
         color, radii, observe, buffer = rasterize_gaussians(
-            prm["means3D"], means2D, prm["shs"], empty, prm["opacities"], prm["scales"], prm["rotations"], empty,
-            prm["features"], st)
+            prm["means3D"], means2D, sh_in, empty, prm["opacities"], prm["scales"], prm["rotations"], empty,
+            prm["features"], st, sh_rest)
         torch.autograd.backward([color, buffer], [Gc, Gb])
         if world > 1:
             # The sum of this view's gradients: ONE collective over the arena the binding allocated them in (the leaves'

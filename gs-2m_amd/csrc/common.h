@@ -126,34 +126,45 @@ __device__ __forceinline__ void gs2m_stage_sh(const float* __restrict__ shs, con
             const float v = dbase + e < dlim ? shs[dbase + e] : 0.f;
             s_sh[(e / 3) * 49 + (e % 3)] = v;
         }
+        // rest: float4 k4 = tid + 256 i of the block's 2880; its first element e = 4 k4 sits in row e / 45 at column e % 45.
+        // One division per thread: a step of 256 float4 is 1024 elements = 22 rows + 34 columns.  A block that lies
+        // completely inside the tensor (all but the last) loads without per-element bounds tests (wave-uniform branch).
         const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
+        const bool full = rbase + 11520 <= rlim;
         float4 t[12];
+        if (full) {
+            const float4* g4 = reinterpret_cast<const float4*>(rest + rbase);
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int k4 = tid + 256 * i;
-            const size_t ge = rbase + 4 * (size_t)k4;
-            t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k4 < 2880) {
-                if (ge + 3 < rlim) {
-                    t[i] = *reinterpret_cast<const float4*>(rest + ge);
-                } else {  // the tensor ends inside this float4
-                    if (ge < rlim) t[i].x = rest[ge];
-                    if (ge + 1 < rlim) t[i].y = rest[ge + 1];
-                    if (ge + 2 < rlim) t[i].z = rest[ge + 2];
+            for (int i = 0; i < 11; i++) t[i] = g4[tid + 256 * i];
+            t[11] = tid < 64 ? g4[tid + 2816] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const int k4 = tid + 256 * i;
+                const size_t ge = rbase + 4 * (size_t)k4;
+                t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k4 < 2880) {
+                    if (ge + 3 < rlim) {
+                        t[i] = *reinterpret_cast<const float4*>(rest + ge);
+                    } else {  // the tensor ends inside this float4
+                        if (ge < rlim) t[i].x = rest[ge];
+                        if (ge + 1 < rlim) t[i].y = rest[ge + 1];
+                        if (ge + 2 < rlim) t[i].z = rest[ge + 2];
+                    }
                 }
             }
         }
+        int row = (4 * tid) / 45, col = 4 * tid - 45 * row;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            const int k4 = tid + 256 * i;
-            if (k4 < 2880) {
+            if (i < 11 || tid < 64) {
                 const float v[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+                int a = row * 49 + 3 + col, left = 45 - col;  // elements left in this row
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int e = 4 * k4 + c;
-                    s_sh[(e / 45) * 49 + 3 + (e % 45)] = v[c];
-                }
+                for (int c = 0; c < 4; c++) s_sh[a + c + (c >= left ? 4 : 0)] = v[c];
             }
+            row += 22; col += 34;
+            if (col >= 45) { col -= 45; row += 1; }
         }
     }
 }
@@ -180,18 +191,17 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
             if (dbase + e < dlim) dshs[dbase + e] = s_sh[(e / 3) * 49 + (e % 3)];
         }
         const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
+        const bool full = rbase + 11520 <= rlim;
+        int row = (4 * tid) / 45, col = 4 * tid - 45 * row;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            const int k4 = tid + 256 * i;
-            if (k4 < 2880) {
+            if (i < 11 || tid < 64) {
+                const int a = row * 49 + 3 + col, left = 45 - col;
                 float v[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int e = 4 * k4 + c;
-                    v[c] = s_sh[(e / 45) * 49 + 3 + (e % 45)];
-                }
-                const size_t ge = rbase + 4 * (size_t)k4;
-                if (ge + 3 < rlim) {
+                for (int c = 0; c < 4; c++) v[c] = s_sh[a + c + (c >= left ? 4 : 0)];
+                const size_t ge = rbase + 4 * (size_t)(tid + 256 * i);
+                if (full || ge + 3 < rlim) {
                     *reinterpret_cast<float4*>(drest + ge) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     if (ge < rlim) drest[ge] = v[0];
@@ -199,6 +209,8 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
                     if (ge + 2 < rlim) drest[ge + 2] = v[2];
                 }
             }
+            row += 22; col += 34;
+            if (col >= 45) { col -= 45; row += 1; }
         }
     }
 }

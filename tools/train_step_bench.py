@@ -37,7 +37,7 @@ opt = (torch.optim.Adam if REF else gs2m_optim.Adam)(groups, lr=0.0, eps=1e-15)
 cam = Camera(cam0, dev)
 pipe = PipelineParams()
 pipe.fused_render_ops = not REF
-pipe.split_sh = not REF
+pipe.split_sh = not REF and "--no-split-sh" not in sys.argv
 bg = torch.zeros(3, device=dev)
 gt = torch.rand(3, H, W, device=dev)
 accum, accum_abs, denom = (torch.zeros(P, 1, device=dev) for _ in range(3))
