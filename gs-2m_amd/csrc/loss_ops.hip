@@ -225,11 +225,27 @@ __global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, con
 __global__ void __launch_bounds__(RB) plane_loss_fwd_kernel(int P, const float* __restrict__ scaling, int raw, const uint8_t* __restrict__ vis,
                                                             float weight, float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
     float v[2] = {0.f, 0.f};
-    for (int i = blockIdx.x * RB + threadIdx.x; i < P; i += LG * RB) {
-        if (vis[i]) {
-            const float m = fminf(fminf(scaling[3 * i], scaling[3 * i + 1]), scaling[3 * i + 2]);
-            v[0] += raw ? expf(m) : m;
-            v[1] += 1.0f;
+    // four elements per trip, every load requested before the first use and none behind the visibility test: the loop is
+    // a chain of memory round trips otherwise (two per element at 1 M Gaussians on 262144 threads)
+    constexpr int U = 4;
+    for (int i0 = blockIdx.x * RB + threadIdx.x; i0 < P; i0 += U * LG * RB) {
+        uint8_t seen[U];
+        float sc[U][3];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * LG * RB;
+            const int j = i < P ? i : i0;
+            seen[u] = i < P ? vis[j] : (uint8_t)0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) sc[u][c] = scaling[3 * (size_t)j + c];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // same order of additions as the one-element loop
+            if (seen[u]) {
+                const float m = fminf(fminf(sc[u][0], sc[u][1]), sc[u][2]);
+                v[0] += raw ? expf(m) : m;
+                v[1] += 1.0f;
+            }
         }
     }
     if (publish_partials<2>(v, ws, ticket, 0)) {

@@ -444,37 +444,69 @@ struct ActGradPtrs {
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }  // at::sigmoid: 1 / (1 + exp(-x))
 __device__ __forceinline__ float act_sigmoid_bwd(float g, float y) { return g * (1.f - y) * y; }
 
+// Both kernels request ALL of a thread's inputs before the first result is stored: written group by group (load, compute,
+// store, next group) every group is a memory round trip of its own -- the stores may alias the later loads as far as
+// the compiler knows -- and a one-pass kernel over 64 B per Gaussian then costs six latencies instead of one.
 __global__ void __launch_bounds__(256) activate_kernel(int P, ActPtrs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    float s[3] = {0.f, 0.f, 0.f}, al[3] = {0.f, 0.f, 0.f}, op = 0.f, ro = 0.f, me = 0.f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.scaling != nullptr) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.scales[3 * i + c] = expf(a.scaling[3 * i + c]);
+        for (int c = 0; c < 3; c++) s[c] = a.scaling[3 * i + c];
+    }
+    if (a.rotation != nullptr) q = reinterpret_cast<const float4*>(a.rotation)[i];
+    if (a.opacity != nullptr) op = a.opacity[i];
+    if (a.albedo != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) al[c] = a.albedo[3 * i + c];
+    }
+    if (a.roughness != nullptr) ro = a.roughness[i];
+    if (a.metallic != nullptr) me = a.metallic[i];
+    if (a.scaling != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.scales[3 * i + c] = expf(s[c]);
     }
     if (a.rotation != nullptr) {  // F.normalize(p=2, dim=1, eps=1e-12)
-        const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
         const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
         reinterpret_cast<float4*>(a.rotations)[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
     }
-    if (a.opacity != nullptr) a.opacities[i] = act_sigmoid(a.opacity[i]);
+    if (a.opacity != nullptr) a.opacities[i] = act_sigmoid(op);
     if (a.albedo != nullptr) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.albedo_a[3 * i + c] = act_sigmoid(a.albedo[3 * i + c]);
+        for (int c = 0; c < 3; c++) a.albedo_a[3 * i + c] = act_sigmoid(al[c]);
     }
-    if (a.roughness != nullptr) a.roughness_a[i] = act_sigmoid(a.roughness[i]);
-    if (a.metallic != nullptr) a.metallic_a[i] = act_sigmoid(a.metallic[i]);
+    if (a.roughness != nullptr) a.roughness_a[i] = act_sigmoid(ro);
+    if (a.metallic != nullptr) a.metallic_a[i] = act_sigmoid(me);
 }
 
 __global__ void __launch_bounds__(256) activate_bwd_kernel(int P, ActGradPtrs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    float gs[3] = {0.f, 0.f, 0.f}, ys[3] = {0.f, 0.f, 0.f}, ga[3] = {0.f, 0.f, 0.f}, ya[3] = {0.f, 0.f, 0.f};
+    float go = 0.f, yo = 0.f, gr = 0.f, yr = 0.f, gm = 0.f, ym = 0.f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q;
     if (a.d_scaling != nullptr) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.d_scaling[3 * i + c] = a.d_scales[3 * i + c] * a.scales[3 * i + c];
+        for (int c = 0; c < 3; c++) { gs[c] = a.d_scales[3 * i + c]; ys[c] = a.scales[3 * i + c]; }
     }
     if (a.d_rotation != nullptr) {
-        const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
-        const float4 g = reinterpret_cast<const float4*>(a.d_rotations)[i];
+        q = reinterpret_cast<const float4*>(a.rotation)[i];
+        g = reinterpret_cast<const float4*>(a.d_rotations)[i];
+    }
+    if (a.d_opacity != nullptr) { go = a.d_opacities[i]; yo = a.opacities[i]; }
+    if (a.d_albedo != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { ga[c] = a.d_albedo_a[3 * i + c]; ya[c] = a.albedo_a[3 * i + c]; }
+    }
+    if (a.d_roughness != nullptr) { gr = a.d_roughness_a[i]; yr = a.roughness_a[i]; }
+    if (a.d_metallic != nullptr) { gm = a.d_metallic_a[i]; ym = a.metallic_a[i]; }
+    if (a.d_scaling != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.d_scaling[3 * i + c] = gs[c] * ys[c];
+    }
+    if (a.d_rotation != nullptr) {
         const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
         const float n = fmaxf(nn, 1e-12f);
         // y = q / n: dq = g / n - q (g . q) / (n^2 |q|); below the eps clamp the denominator is a constant
@@ -482,13 +514,13 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(int P, ActGradPtrs a)
         const float k = nn >= 1e-12f ? dot / (n * n * nn) : 0.f;
         reinterpret_cast<float4*>(a.d_rotation)[i] = make_float4(g.x / n - q.x * k, g.y / n - q.y * k, g.z / n - q.z * k, g.w / n - q.w * k);
     }
-    if (a.d_opacity != nullptr) a.d_opacity[i] = act_sigmoid_bwd(a.d_opacities[i], a.opacities[i]);
+    if (a.d_opacity != nullptr) a.d_opacity[i] = act_sigmoid_bwd(go, yo);
     if (a.d_albedo != nullptr) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.d_albedo[3 * i + c] = act_sigmoid_bwd(a.d_albedo_a[3 * i + c], a.albedo_a[3 * i + c]);
+        for (int c = 0; c < 3; c++) a.d_albedo[3 * i + c] = act_sigmoid_bwd(ga[c], ya[c]);
     }
-    if (a.d_roughness != nullptr) a.d_roughness[i] = act_sigmoid_bwd(a.d_roughness_a[i], a.roughness_a[i]);
-    if (a.d_metallic != nullptr) a.d_metallic[i] = act_sigmoid_bwd(a.d_metallic_a[i], a.metallic_a[i]);
+    if (a.d_roughness != nullptr) a.d_roughness[i] = act_sigmoid_bwd(gr, yr);
+    if (a.d_metallic != nullptr) a.d_metallic[i] = act_sigmoid_bwd(gm, ym);
 }
 
 }  // namespace
