@@ -25,6 +25,7 @@ constexpr int LB = 256;     // threads per workgroup of the elementwise launches
 // partial sums do not depend on the problem size and the ticket (a same-address atomic, ~10 ns each) is taken 256 times.
 constexpr int RB = 1024;
 constexpr int LG = 256;
+constexpr int RU = 4;      // elements per trip of a reducing kernel's grid-stride loop (their loads are issued together)
 constexpr int WS_K = 4;     // partial sums per workgroup the workspace holds (the ticket word sits behind them)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -64,7 +65,18 @@ __device__ __forceinline__ bool publish_partials(const float (&v)[K], float* __r
             for (int w = 1; w < RB / 64; w++) r = op == 0 ? r + s_p[k][w] : (k == 0 ? fminf(r, s_p[k][w]) : fmaxf(r, s_p[k][w]));
             __hip_atomic_store(&ws[k * LG + blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef GS2M_TICKET_FENCED
         const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        // No release / acquire fence: at agent scope those write back and invalidate the XCD's whole L2 (which holds the
+        // megabytes this kernel has just stored) once per workgroup.  The partials above are agent-scope atomic stores (written
+        // through to memory), s_waitcnt vmcnt(0) holds the ticket back until they have been acknowledged, and the last workgroup
+        // reads them with agent-scope atomic loads behind the ticket's return value.
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         s_last = t == gridDim.x - 1;
         if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -114,23 +126,46 @@ __global__ void __launch_bounds__(RB) edge_gradient_kernel(int W, int H, const f
                                                            float* __restrict__ minmax, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
     const size_t HW = (size_t)H * W;
     float v[2] = {INFINITY, -INFINITY};
-    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
-        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-        float e = 0.f;
-        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
-            float ax[3], ay[3];
+    // RU pixels per trip, all their loads requested before the first use: at 1080p a thread of the fixed grid walks 8
+    // pixels, and one pixel per trip is a chain of 8 memory round trips (20 us for 33 MB)
+    // A workgroup owns a contiguous run of pixels (~4 rows at 1080p): the rows above and below a pixel are then mostly its
+    // own (L1 / the XCD's L2); with workgroup b on pixels b RB + k LG RB they belong to workgroups on other XCDs and every
+    // line comes from memory three times.
+    const size_t chunk = (HW + LG - 1) / LG, cbeg = (size_t)blockIdx.x * chunk, cend = cbeg + chunk < HW ? cbeg + chunk : HW;
+    for (size_t p0 = cbeg + threadIdx.x; p0 < cend; p0 += (size_t)RU * RB) {
+        float t[RU][3][4];
+        bool in[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const size_t p = p0 + (size_t)u * RB;
+            const bool have = p < cend;
+            const int y = have ? (int)((uint32_t)p / (uint32_t)W) : 0, x = have ? (int)((uint32_t)p - (uint32_t)y * (uint32_t)W) : 0;  // 32-bit: H W < 2^31 (checked by the caller)
+            in[u] = have && x > 0 && x < W - 1 && y > 0 && y < H - 1;
+            const size_t pc = in[u] ? p : (size_t)W + 1;   // a pixel whose four neighbours exist (W, H >= 3)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float* q = gt + c * HW + p;
-                ax[c] = fabsf(q[1] - q[-1]);
-                ay[c] = fabsf(q[-W] - q[W]);
+                const float* q = gt + c * HW + pc;
+                t[u][c][0] = q[1]; t[u][c][1] = q[-1]; t[u][c][2] = q[-W]; t[u][c][3] = q[W];
             }
-            const float gx = ((ax[0] + ax[1]) + ax[2]) / 3.0f, gy = ((ay[0] + ay[1]) + ay[2]) / 3.0f;
-            e = fmaxf(gx, gy);
-            v[0] = fminf(v[0], e);
-            v[1] = fmaxf(v[1], e);
         }
-        g[p] = e;
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const size_t p = p0 + (size_t)u * RB;
+            float e = 0.f;
+            if (in[u]) {
+                float ax[3], ay[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    ax[c] = fabsf(t[u][c][0] - t[u][c][1]);
+                    ay[c] = fabsf(t[u][c][2] - t[u][c][3]);
+                }
+                const float gx = ((ax[0] + ax[1]) + ax[2]) / 3.0f, gy = ((ay[0] + ay[1]) + ay[2]) / 3.0f;
+                e = fmaxf(gx, gy);
+                v[0] = fminf(v[0], e);
+                v[1] = fmaxf(v[1], e);
+            }
+            if (p < cend) g[p] = e;
+        }
     }
     if (publish_partials<2>(v, ws, ticket, 1)) {
         const float mn = final_minmax(ws, 0), mx = final_minmax(ws, 1);
@@ -162,21 +197,46 @@ __global__ void __launch_bounds__(RB) image_loss_fwd_kernel(ImageLossArgs a, flo
     float mn = 0.f, mx = 1.f;
     if (dn && a.edge) { mn = a.edge_minmax[0]; mx = a.edge_minmax[1]; }
     float v[2] = {0.f, 0.f};
-    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
-        const bool inside = a.mask == nullptr || a.mask[p] != 0;
+    for (size_t p0 = (size_t)blockIdx.x * RB + threadIdx.x; p0 < HW; p0 += (size_t)RU * LG * RB) {  // RU pixels per trip: edge_gradient_kernel
+        float im[RU][3], g[RU][3], so[RU][3], no[RU][3], ed[RU], wm[RU];
+        bool inside[RU];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float r = inside ? clamp01(a.image[image_index(a, HW, p, c)]) : a.bg[c];
-            rgb[c * HW + p] = r;
-            v[0] += fabsf(r - a.gt[c * HW + p]);
+        for (int u = 0; u < RU; u++) {
+            const size_t p = p0 + (size_t)u * LG * RB, q = p < HW ? p : p0;
+            inside[u] = a.mask == nullptr || a.mask[q] != 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                im[u][c] = a.image[image_index(a, HW, q, c)];
+                g[u][c] = a.gt[c * HW + q];
+            }
+            ed[u] = wm[u] = 1.0f;
+            if (dn) {
+                if (a.edge) ed[u] = a.edge[q];
+                if (a.weight_map) wm[u] = a.weight_map[q];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    so[u][c] = a.sobel[c * HW + q];
+                    no[u][c] = a.normal[c * HW + q];
+                }
+            }
         }
-        if (dn) {
-            const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
-            float w = a.edge ? edge_weight(a.edge[p], mn, mx, x > 0 && x < a.W - 1 && y > 0 && y < a.H - 1) : 1.0f;
-            if (a.weight_map) w *= a.weight_map[p];
-            const float d0 = fabsf(a.sobel[p] - a.normal[p]), d1 = fabsf(a.sobel[HW + p] - a.normal[HW + p]),
-                        d2 = fabsf(a.sobel[2 * HW + p] - a.normal[2 * HW + p]);
-            v[1] += w * ((d0 + d1) + d2);
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const size_t p = p0 + (size_t)u * LG * RB;
+            if (p >= HW) break;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float r = inside[u] ? clamp01(im[u][c]) : a.bg[c];
+                rgb[c * HW + p] = r;
+                v[0] += fabsf(r - g[u][c]);
+            }
+            if (dn) {
+                const int y = (int)((uint32_t)p / (uint32_t)a.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)a.W);
+                float w = a.edge ? edge_weight(ed[u], mn, mx, x > 0 && x < a.W - 1 && y > 0 && y < a.H - 1) : 1.0f;
+                if (a.weight_map) w *= wm[u];
+                const float d0 = fabsf(so[u][0] - no[u][0]), d1 = fabsf(so[u][1] - no[u][1]), d2 = fabsf(so[u][2] - no[u][2]);
+                v[1] += w * ((d0 + d1) + d2);
+            }
         }
     }
     if (publish_partials<2>(v, ws, ticket, 0)) {
@@ -207,7 +267,7 @@ __global__ void __launch_bounds__(LB) image_loss_bwd_kernel(ImageLossArgs a, con
         d_image[image_index(a, HW, p, c)] = (inside && x >= 0.f && x <= 1.f) ? up : 0.f;
     }
     if (a.normal != nullptr) {
-        const int y = (int)(p / a.W), xx = (int)(p - (size_t)y * a.W);
+        const int y = (int)((uint32_t)p / (uint32_t)a.W), xx = (int)((uint32_t)p - (uint32_t)y * (uint32_t)a.W);
         float w = a.edge ? edge_weight(a.edge[p], a.edge_minmax[0], a.edge_minmax[1], xx > 0 && xx < a.W - 1 && y > 0 && y < a.H - 1) : 1.0f;
         if (a.weight_map) w *= a.weight_map[p];
         const float k2 = g * a.w_dn / (float)HW * w;
@@ -307,20 +367,64 @@ __device__ __forceinline__ float tv_pair_weight(const TvArgs& a, size_t HW, size
 __global__ void __launch_bounds__(RB) tv_loss_fwd_kernel(TvArgs a, float* __restrict__ out, float* __restrict__ ws, uint32_t* __restrict__ ticket) {
     const size_t HW = (size_t)a.H * a.W;
     float v[2] = {0.f, 0.f};
-    for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
-        const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
-        if (y < a.H - 1) {
-            const float w = tv_pair_weight(a, HW, p, a.W);
-            for (int c = 0; c < a.C; c++) {
-                const float d = a.pred[c * HW + p + a.W] - a.pred[c * HW + p];
-                v[0] += (a.norm1 ? fabsf(d) : d * d) * w;
+    // TU pixels per trip; the loads of a trip carry no test (a pair that does not exist reads the pixel itself and is not
+    // added): edge_gradient_kernel.  Channels beyond 3 (none in the reference's calls) take the one-pixel path.
+    constexpr int TU = 2;
+    if (a.C <= 3) {
+        // a contiguous run of pixels per workgroup (edge_gradient_kernel): the row below is mostly its own
+        const size_t chunk = (HW + LG - 1) / LG, cbeg = (size_t)blockIdx.x * chunk, cend = cbeg + chunk < HW ? cbeg + chunk : HW;
+        for (size_t p0 = cbeg + threadIdx.x; p0 < cend; p0 += (size_t)TU * RB) {
+            float gq[TU][3][3], pq[TU][3][3], wq[TU][3];
+            bool down[TU], right[TU];
+#pragma unroll
+            for (int u = 0; u < TU; u++) {
+                const size_t p = p0 + (size_t)u * RB, q = p < cend ? p : p0;
+                const int y = (int)((uint32_t)q / (uint32_t)a.W), x = (int)((uint32_t)q - (uint32_t)y * (uint32_t)a.W);
+                down[u] = p < cend && y < a.H - 1;
+                right[u] = p < cend && x < a.W - 1;
+                const size_t qd = down[u] ? q + a.W : q, qr = right[u] ? q + 1 : q;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    gq[u][c][0] = a.gt[c * HW + q]; gq[u][c][1] = a.gt[c * HW + qd]; gq[u][c][2] = a.gt[c * HW + qr];
+                    if (c < a.C) { pq[u][c][0] = a.pred[c * HW + q]; pq[u][c][1] = a.pred[c * HW + qd]; pq[u][c][2] = a.pred[c * HW + qr]; }
+                }
+                if (a.wm) { wq[u][0] = a.wm[q]; wq[u][1] = a.wm[qd]; wq[u][2] = a.wm[qr]; }
+            }
+#pragma unroll
+            for (int u = 0; u < TU; u++) {
+#pragma unroll
+                for (int k = 1; k <= 2; k++) {  // k = 1: the pair (p, p + W); k = 2: (p, p + 1)
+                    if (k == 1 ? down[u] : right[u]) {
+                        const float e0 = fabsf(gq[u][0][k] - gq[u][0][0]), e1 = fabsf(gq[u][1][k] - gq[u][1][0]), e2 = fabsf(gq[u][2][k] - gq[u][2][0]);
+                        float w = expf(-(((e0 + e1) + e2) / 3.0f));
+                        if (a.wm) w *= (wq[u][k] + wq[u][0]) / 2.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            if (c < a.C) {
+                                const float d = pq[u][c][k] - pq[u][c][0];
+                                v[k - 1] += (a.norm1 ? fabsf(d) : d * d) * w;
+                            }
+                        }
+                    }
+                }
             }
         }
-        if (x < a.W - 1) {
-            const float w = tv_pair_weight(a, HW, p, 1);
-            for (int c = 0; c < a.C; c++) {
-                const float d = a.pred[c * HW + p + 1] - a.pred[c * HW + p];
-                v[1] += (a.norm1 ? fabsf(d) : d * d) * w;
+    } else {
+        for (size_t p = (size_t)blockIdx.x * RB + threadIdx.x; p < HW; p += (size_t)LG * RB) {
+            const int y = (int)((uint32_t)p / (uint32_t)a.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)a.W);
+            if (y < a.H - 1) {
+                const float w = tv_pair_weight(a, HW, p, a.W);
+                for (int c = 0; c < a.C; c++) {
+                    const float d = a.pred[c * HW + p + a.W] - a.pred[c * HW + p];
+                    v[0] += (a.norm1 ? fabsf(d) : d * d) * w;
+                }
+            }
+            if (x < a.W - 1) {
+                const float w = tv_pair_weight(a, HW, p, 1);
+                for (int c = 0; c < a.C; c++) {
+                    const float d = a.pred[c * HW + p + 1] - a.pred[c * HW + p];
+                    v[1] += (a.norm1 ? fabsf(d) : d * d) * w;
+                }
             }
         }
     }
@@ -334,9 +438,13 @@ __global__ void __launch_bounds__(RB) tv_loss_fwd_kernel(TvArgs a, float* __rest
 // one row up / one column left
 __global__ void __launch_bounds__(LB) tv_loss_bwd_kernel(TvArgs a, const float* __restrict__ g_loss, float* __restrict__ d_pred) {
     const size_t HW = (size_t)a.H * a.W;
-    const size_t p = (size_t)blockIdx.x * LB + threadIdx.x;
+    // workgroups are dealt to the 8 XCDs round robin: block b works on pixel block (b % 8) * ceil(n / 8) + b / 8, so that an
+    // XCD's L2 sees a contiguous eighth of the image and the rows above and below a pixel hit it
+    // (the grid is a multiple of 8)
+    const uint32_t per = gridDim.x >> 3, lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const size_t p = (size_t)lb * LB + threadIdx.x;
     if (p >= HW) return;
-    const int y = (int)(p / a.W), x = (int)(p - (size_t)y * a.W);
+    const int y = (int)((uint32_t)p / (uint32_t)a.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)a.W);
     const float g = g_loss[0] * a.weight;
     const float kh = g / (float)((double)a.C * (a.H - 1) * a.W), kw = g / (float)((double)a.C * a.H * (a.W - 1));
     const float wd = y < a.H - 1 ? kh * tv_pair_weight(a, HW, p, a.W) : 0.f;       // pair (p, p + W)
@@ -422,6 +530,7 @@ __global__ void __launch_bounds__(RB) affine_mean_kernel(size_t n, const float* 
 }
 
 inline int launched() { return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP; }
+inline bool too_large(int W, int H) { return (long long)W * H >= (1ll << 31); }  // the kernels split a pixel index with 32-bit arithmetic
 
 }  // namespace
 
@@ -431,6 +540,7 @@ int gs2m_loss_workspace_bytes(void) { return (int)(WS_K * LG * sizeof(float) + 6
 
 int gs2m_edge_gradient(int W, int H, const float* gt, float* edge, float* edge_minmax, void* workspace, void* stream) {
     if (W < 3 || H < 3 || !gt || !edge || !edge_minmax || !workspace) return GS2M_ERR_INVALID_ARG;
+    if (too_large(W, H)) return GS2M_ERR_UNSUPPORTED;
     float* ws = (float*)workspace;
     edge_gradient_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(W, H, gt, edge, edge_minmax, ws, (uint32_t*)(ws + WS_K * LG));
     return launched();
@@ -441,6 +551,7 @@ int gs2m_image_loss_forward(int W, int H, const float* image, int image_hwc, con
                             const float* edge, const float* edge_minmax, const float* weight_map, float w_l1, float w_dn,
                             float* rgb, float* out, void* workspace, void* stream) {
     if (W < 1 || H < 1 || !image || !gt || !rgb || !out || !workspace || (mask && !background)) return GS2M_ERR_INVALID_ARG;
+    if (too_large(W, H)) return GS2M_ERR_UNSUPPORTED;
     if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
     float* ws = (float*)workspace;
     // (no NULL for the wave-uniform scalars: the compiler hoists scalar loads such as bg[c] above the test that guards them;
@@ -456,6 +567,7 @@ int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, co
                              const float* g_loss, const float* g_rgb, float* d_image, float* d_normal_map, float* d_sobel_map,
                              void* stream) {
     if (W < 1 || H < 1 || !image || !gt || !d_image) return GS2M_ERR_INVALID_ARG;
+    if (too_large(W, H)) return GS2M_ERR_UNSUPPORTED;
     if ((normal_map == nullptr) != (sobel_map == nullptr) || (edge == nullptr) != (edge_minmax == nullptr)) return GS2M_ERR_INVALID_ARG;
     if (normal_map && (!d_normal_map || !d_sobel_map)) return GS2M_ERR_INVALID_ARG;
     const ImageLossArgs a = {W, H, image, gt, normal_map, sobel_map, edge, edge ? edge_minmax : gt, weight_map, w_l1, w_dn, image_hwc, mask, gt};
@@ -468,6 +580,7 @@ int gs2m_image_loss_backward(int W, int H, const float* image, int image_hwc, co
 int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
                          float* out, void* workspace, void* stream) {
     if (W < 2 || H < 2 || C < 1 || !gt || !pred || !out || !workspace) return GS2M_ERR_INVALID_ARG;
+    if (too_large(W, H)) return GS2M_ERR_UNSUPPORTED;
     float* ws = (float*)workspace;
     const TvArgs a = {W, H, C, norm1, gt, pred, weight_map, weight};
     tv_loss_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(a, out, ws, (uint32_t*)(ws + WS_K * LG));
@@ -477,9 +590,10 @@ int gs2m_tv_loss_forward(int W, int H, int C, const float* gt, const float* pred
 int gs2m_tv_loss_backward(int W, int H, int C, const float* gt, const float* pred, const float* weight_map, int norm1, float weight,
                           const float* g_loss, float* d_pred, void* stream) {
     if (W < 2 || H < 2 || C < 1 || !gt || !pred || !g_loss || !d_pred) return GS2M_ERR_INVALID_ARG;
+    if (too_large(W, H)) return GS2M_ERR_UNSUPPORTED;
     const TvArgs a = {W, H, C, norm1, gt, pred, weight_map, weight};
     const size_t HW = (size_t)W * H;
-    tv_loss_bwd_kernel<<<(unsigned)((HW + LB - 1) / LB), LB, 0, (hipStream_t)stream>>>(a, g_loss, d_pred);
+    tv_loss_bwd_kernel<<<(unsigned)(((HW + LB - 1) / LB + 7) / 8 * 8), LB, 0, (hipStream_t)stream>>>(a, g_loss, d_pred);
     return launched();
 }
 
