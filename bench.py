@@ -106,7 +106,7 @@ def cpu_baseline(P, W, H, fc, seed):
     return out
 
 
-def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
+def caller_levels(P, W, H, seed, dev, steps=10, warmup=6):
     """the same op one and two levels up.  render_level_ms: gaussian_renderer.render(material stage)
     forward + backward of a weighted sum of its maps.  train_step_ms: one geometry-stage training iteration
     (train.py:94-130, 223-227, 258-259 without the multi-view term): render with the Sobel normal, clamp,
@@ -191,12 +191,18 @@ def caller_levels(P, W, H, seed, dev, steps=20, warmup=6):
                 t.copy_(t0)
         for _ in range(warmup):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        res[key] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        # three blocks of `steps` iterations, the fastest block reported: one allocator growth (a hipMalloc of the caching
+        # allocator: milliseconds) inside a block of 20 moved this number by 25 % from box to box
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            best = ms if best is None else min(best, ms)
+        res[key] = round(best, 4)
     return res
 
 
