@@ -6,10 +6,14 @@
  * rasterizer and of simple-knn's distCUDA2.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this library.
  *
- * PARITY STATUS: "parity unpinned".  The reference ships no tests, golden vectors
- * or CPU implementation for this path and its CUDA sources cannot be compiled or
- * run in the build container (no nvcc, no GPU), see DESIGN.md.  This file follows
- * the reference sources line by line (citations below, paths relative to
+ * PARITY STATUS: PINNED for the rasterizer since round 3 -- tests/test_reference_gpu.py
+ * holds this file to oracle/_ref/libgs2m_ref.so, the reference's own kernels passed
+ * through the image's hipify-perl and built for gfx950 (oracle/ref_build/Makefile):
+ * integer artefacts and the per-Gaussian forward bit for bit, images and gradients up
+ * to the summation order (DESIGN.md "Oracle").  The reference ships no tests, golden
+ * vectors or CPU implementation for this path; distCUDA2 below is the exhaustive
+ * 3-nearest-neighbour definition (exact by construction, not pinned to a build of
+ * simple-knn).  This file follows the reference sources line by line (citations below, paths relative to
  * /root/reference/submodules/diff-gaussian-rasterization unless stated):
  *
  *   CR = cuda_rasterizer/

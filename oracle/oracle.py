@@ -1,6 +1,6 @@
 """ctypes front-end of the CPU oracle (oracle/gs2m_oracle.c).
 
-TEST INFRASTRUCTURE ONLY -- parity unpinned (see the C file's header).  Only tests/,
+TEST INFRASTRUCTURE ONLY -- pinned to the reference build oracle/_ref by tests/test_reference_gpu.py (see the C file's header).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product package (gs-2m_amd/) never does.
 

@@ -37,6 +37,23 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in ctypes.cast(lib.gs2m_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
 
 
+def test_reference_build_recipe_and_library():
+    """oracle/ref_build/: the recipe and this repository's shim are committed, no translated reference text is; where the
+    library has been built (the build container; it travels prebuilt), it loads without a GPU and exports the shim's
+    entry points"""
+    d = os.path.join(ROOT, "oracle", "ref_build")
+    assert sorted(os.listdir(d)) == ["Makefile", "ref_shim.hip"]
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.isdir(ref_dir):
+        assert all(f.endswith(".so") for f in os.listdir(ref_dir)), "only built libraries belong in oracle/_ref"
+    so = os.path.join(ref_dir, "libgs2m_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libgs2m_ref.so not built here")
+    lib = ctypes.CDLL(so)
+    for n in ("gs2m_ref_create", "gs2m_ref_destroy", "gs2m_ref_forward", "gs2m_ref_backward", "gs2m_ref_state", "gs2m_ref_mark_visible"):
+        assert hasattr(lib, n), n
+
+
 def test_product_package_never_imports_the_oracle():
     """the oracle is test infrastructure: nothing under gs-2m_amd/ may import, include or link it."""
     pkg = os.path.join(ROOT, "gs-2m_amd")
