@@ -13,6 +13,7 @@
 
 #include "rasterizer.h"
 #include "rasterizer_impl.h"
+#include "simple_knn.h"
 
 namespace {
 
@@ -142,6 +143,13 @@ int gs2m_ref_state(void* handle, float* z_depths, int* internal_radii, float* me
 // markVisible (rasterizer.h:19-24); present: P bytes
 int gs2m_ref_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present) {
     CudaRasterizer::Rasterizer::markVisible(P, means3D, viewmatrix, projmatrix, reinterpret_cast<bool*>(present));
+    return sync_status();
+}
+
+// distCUDA2's kernel side (simple-knn/spatial.cu:15-26 calls SimpleKNN::knn on the (P, 3) points): mean squared distance to
+// the three nearest neighbours
+int gs2m_ref_knn(int P, const float* points, float* mean_dists) {
+    SimpleKNN::knn(P, reinterpret_cast<float3*>(const_cast<float*>(points)), mean_dists);
     return sync_status();
 }
 

@@ -50,6 +50,12 @@ def lib():
         L.gs2m_ref_state.argtypes = [p] * 15
         L.gs2m_ref_mark_visible.restype = i
         L.gs2m_ref_mark_visible.argtypes = [i, p, p, p, p]
+        L.gs2m_ref_knn.restype = i
+        L.gs2m_ref_knn.argtypes = [i, p, p]
+        for name, sig in (("diffuse_cubemap_fwd", [i, p, p]), ("diffuse_cubemap_bwd", [i, p, p, p]), ("specular_bounds", [i, f, p]),
+                          ("specular_cubemap_fwd", [i, p, p, f, f, p]), ("specular_cubemap_bwd", [i, p, p, p, f, f, p])):
+            fn = getattr(L, "gs2m_ref_" + name)
+            fn.restype, fn.argtypes = i, sig
         _lib = L
     return _lib
 
@@ -166,6 +172,67 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     if P and lib().gs2m_ref_mark_visible(P, _ptr(m), _ptr(v), _ptr(p), _ptr(out)) != 0:
         raise RuntimeError("reference markVisible failed")
     return out[:P].cpu().numpy().astype(bool)
+
+
+def knn_dist2(points):
+    """simple-knn's SimpleKNN::knn (what distCUDA2 returns, spatial.cu:15-26): mean squared distance to the three nearest
+    neighbours, (P,) float32."""
+    pts = _dev(points)
+    P = int(pts.shape[0])
+    out = torch.zeros(max(P, 1), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    if P and lib().gs2m_ref_knn(P, _ptr(pts), _ptr(out)) != 0:
+        raise RuntimeError("reference knn failed")
+    return out[:P].cpu().numpy()
+
+
+# ---- render-utils' cube-map prefilters (c_src/cubemap.cu): torch CUDA tensors in and out, (6, res, res, C) float32 ----
+
+def _cube(t, ch):
+    t = _dev(t)
+    assert t.dim() == 4 and t.shape[0] == 6 and t.shape[1] == t.shape[2] and t.shape[3] == ch, tuple(t.shape)
+    return t
+
+
+def _call(name, *args):
+    torch.cuda.synchronize()
+    if getattr(lib(), "gs2m_ref_" + name)(*args) != 0:
+        raise RuntimeError("reference %s failed" % name)
+
+
+def diffuse_cubemap_fwd(cubemap):
+    x = _cube(cubemap, 3)
+    out = torch.empty_like(x)
+    _call("diffuse_cubemap_fwd", x.shape[1], _ptr(x), _ptr(out))
+    return out
+
+
+def diffuse_cubemap_bwd(cubemap, grad):
+    x, g = _cube(cubemap, 3), _cube(grad, 3)
+    out = torch.zeros_like(x)
+    _call("diffuse_cubemap_bwd", x.shape[1], _ptr(x), _ptr(g), _ptr(out))
+    return out
+
+
+def specular_bounds(res, costheta_cutoff):
+    out = torch.zeros(6, res, res, 24, dtype=torch.float32, device="cuda")
+    _call("specular_bounds", res, float(costheta_cutoff), _ptr(out))
+    return out
+
+
+def specular_cubemap_fwd(cubemap, bounds, roughness, costheta_cutoff):
+    """-> (6, res, res, 4): weighted colour sums and the weight sum (render_utils/ops.py:406 divides them)"""
+    x, b = _cube(cubemap, 3), _cube(bounds, 24)
+    out = torch.empty(6, x.shape[1], x.shape[1], 4, dtype=torch.float32, device="cuda")
+    _call("specular_cubemap_fwd", x.shape[1], _ptr(x), _ptr(b), float(roughness), float(costheta_cutoff), _ptr(out))
+    return out
+
+
+def specular_cubemap_bwd(cubemap, bounds, grad, roughness, costheta_cutoff):
+    x, b, g = _cube(cubemap, 3), _cube(bounds, 24), _cube(grad, 4)
+    out = torch.zeros_like(x)
+    _call("specular_cubemap_bwd", x.shape[1], _ptr(x), _ptr(b), _ptr(g), float(roughness), float(costheta_cutoff), _ptr(out))
+    return out
 
 
 def timed_forward_backward(fwd, grad_color, grad_buffer, n=10):

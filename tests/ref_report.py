@@ -24,7 +24,7 @@ def cmp(name, a, b):
         print(f"  {name:16s} bit-identical={same} max abs {d.max() if d.size else 0:.3e} rel-to-max {d.max() / max(np.abs(b).max(), 1e-30) if d.size else 0:.3e} differing {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size}")
 
 
-for (P, W, H, seed, fc, hi) in ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
+for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
     sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
     f, gr = Hh.run_oracle(oracle, sc)
     r, rg = Hh.run_oracle(reference, sc)
@@ -38,6 +38,47 @@ for (P, W, H, seed, fc, hi) in ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2
         cmp(k, getattr(r, k), getattr(f, k))
     for k in gr:
         cmp("d" + k, rg[k], gr[k])
+
+if "--cubemap" in sys.argv:
+    import render_utils as RU
+    for res, rough in ((16, 1.0), (32, 0.5), (64, 0.385), (128, 0.27), (256, 0.155), (512, 0.04)):
+        g = torch.Generator().manual_seed(res)
+        x = torch.rand(6, res, res, 3, generator=g).cuda()
+        G4 = torch.randn(6, res, res, 4, generator=g).cuda()
+        cut = RU.ndf_cutoff(rough, 0.99)
+        b = reference.specular_bounds(res, cut)
+        t0 = time.perf_counter(); r4 = reference.specular_cubemap_fwd(x, b, rough, cut); t1 = time.perf_counter()
+        rg = reference.specular_cubemap_bwd(x, b, G4, rough, cut); t2 = time.perf_counter()
+        xx = x.clone().requires_grad_(True)
+        o4 = RU._specular_cubemap.apply(xx, rough, cut)
+        (o4 * G4).sum().backward()
+        print(f"specular res {res} roughness {rough}: reference fwd {1e3 * (t1 - t0):.2f} ms bwd {1e3 * (t2 - t1):.2f} ms")
+        cmp("raw out", o4.detach().cpu().numpy(), r4.cpu().numpy())
+        cmp("weight sum", o4.detach()[..., 3].cpu().numpy(), r4[..., 3].cpu().numpy())
+        cmp("ratio", (o4.detach()[..., :3] / o4.detach()[..., 3:]).cpu().numpy(), (r4[..., :3] / r4[..., 3:]).cpu().numpy())
+        cmp("grad", xx.grad.cpu().numpy(), rg.cpu().numpy())
+        if res >= 128:  # ill-conditioned lobes: both against the fp64 restatement on sampled output texels
+            from oracle import cubemap_oracle as O
+            T = 6 * res * res
+            rows = np.unique(torch.randint(0, T, (24,), generator=g).numpy())
+            xs = x.cpu().double().numpy().reshape(-1, 3)
+            eo, er = 0.0, 0.0
+            for k in range(0, len(rows), 2):
+                r = rows[k:k + 2]
+                W = O.specular_matrix(res, rough, cut, rows=r)
+                exact = np.concatenate([W @ xs, W.sum(1, keepdims=True)], axis=1)
+                eo = max(eo, float(np.abs(o4.detach().cpu().double().numpy().reshape(-1, 4)[r] - exact).max() / np.abs(exact).max()))
+                er = max(er, float(np.abs(r4.cpu().double().numpy().reshape(-1, 4)[r] - exact).max() / np.abs(exact).max()))
+            print(f"  against fp64 on {len(rows)} texels: HIP path {eo:.3e}, reference build {er:.3e} (relative to the largest value)")
+    for res in (8, 16, 32):
+        g = torch.Generator().manual_seed(res)
+        x = torch.rand(6, res, res, 3, generator=g).cuda(); G = torch.randn(6, res, res, 3, generator=g).cuda()
+        xx = x.clone().requires_grad_(True)
+        o = RU.diffuse_cubemap(xx); (o * G).sum().backward()
+        print(f"diffuse res {res}")
+        cmp("out", o.detach().cpu().numpy(), reference.diffuse_cubemap_fwd(x).cpu().numpy())
+        cmp("grad", xx.grad.cpu().numpy(), reference.diffuse_cubemap_bwd(x, G).cpu().numpy())
+    sys.exit(0)
 
 if "--full" in sys.argv:
     # the bench workloads (bench.py CONFIGS) through the reference build on this GPU: what a hipify port of the reference

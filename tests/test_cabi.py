@@ -42,7 +42,7 @@ def test_reference_build_recipe_and_library():
     library has been built (the build container; it travels prebuilt), it loads without a GPU and exports the shim's
     entry points"""
     d = os.path.join(ROOT, "oracle", "ref_build")
-    assert sorted(os.listdir(d)) == ["Makefile", "ref_shim.hip"]
+    assert sorted(os.listdir(d)) == ["Makefile", "ref_shim.hip", "ref_shim_cubemap.hip"]
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     if os.path.isdir(ref_dir):
         assert all(f.endswith(".so") for f in os.listdir(ref_dir)), "only built libraries belong in oracle/_ref"
@@ -50,7 +50,9 @@ def test_reference_build_recipe_and_library():
     if not os.path.exists(so):
         pytest.skip("oracle/_ref/libgs2m_ref.so not built here")
     lib = ctypes.CDLL(so)
-    for n in ("gs2m_ref_create", "gs2m_ref_destroy", "gs2m_ref_forward", "gs2m_ref_backward", "gs2m_ref_state", "gs2m_ref_mark_visible"):
+    for n in ("gs2m_ref_create", "gs2m_ref_destroy", "gs2m_ref_forward", "gs2m_ref_backward", "gs2m_ref_state", "gs2m_ref_mark_visible", "gs2m_ref_knn",
+              "gs2m_ref_diffuse_cubemap_fwd", "gs2m_ref_diffuse_cubemap_bwd", "gs2m_ref_specular_bounds", "gs2m_ref_specular_cubemap_fwd",
+              "gs2m_ref_specular_cubemap_bwd"):
         assert hasattr(lib, n), n
 
 

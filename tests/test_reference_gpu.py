@@ -135,6 +135,21 @@ def test_mark_visible_equals_the_reference_build(oracle_lib, reference):
     assert np.array_equal(vis, ref) and 0 < ref.sum() < 5000
 
 
+@pytest.mark.parametrize("P", [4, 5, 1000, 1024, 1025, 50_000, 300_000])
+def test_knn_equals_the_reference_build(oracle_lib, reference, P):
+    """distCUDA2 (row K): simple-knn's own kernels through the same recipe, the exhaustive oracle and the HIP kernel"""
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    pts = torch.rand(P, 3, generator=g) * torch.tensor([4.0, 2.0, 1.0]) - 1.0
+    if P > 1000:
+        pts[: P // 8] = pts[P // 8: 2 * (P // 8)]  # duplicates: distance 0 neighbours
+    ref = reference.knn_dist2(pts.numpy())
+    got = distCUDA2(pts.cuda()).cpu().numpy()
+    assert np.allclose(got, ref, rtol=2e-6, atol=0), float(np.abs(got - ref).max())
+    if P <= 50_000:  # the exhaustive oracle is O(P^2)
+        assert np.allclose(oracle_lib.knn_dist2(pts.numpy()), ref, rtol=2e-6, atol=0)
+
+
 # ---- the HIP product path against the reference build ----------------------------------------------------------------
 
 GRADS = ("means3D", "means2D", "opacities", "shs", "scales", "rotations", "features")
@@ -194,3 +209,103 @@ def test_bench_workload_at_full_size_against_the_reference_build(reference):
             Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
         for k in GRADS:
             Hh.assert_grad_close(k, g[k], rg[k])
+
+
+# ---- environment-map prefilters (row N2): render-utils' own kernels through the same recipe --------------------------------
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("res", [8, 16, 32])
+def test_diffuse_prefilter_against_the_reference_build(reference, res):
+    import render_utils as RU
+    from oracle import cubemap_oracle as O
+    g = torch.Generator().manual_seed(res)
+    x = torch.rand(6, res, res, 3, generator=g).cuda()
+    G = torch.randn(6, res, res, 3, generator=g).cuda()
+    xx = x.clone().requires_grad_(True)
+    out = RU.diffuse_cubemap(xx)
+    (out * G).sum().backward()
+    ro, rg = reference.diffuse_cubemap_fwd(x), reference.diffuse_cubemap_bwd(x, G)
+    assert _rel(out, ro) <= 1e-5 and _rel(xx.grad, rg) <= 1e-5
+    if res <= 16:  # the dense-matrix restatement the other cubemap tests lean on, pinned
+        W = O.diffuse_matrix(res)
+        assert np.abs(W @ x.cpu().double().numpy().reshape(-1, 3) - ro.cpu().double().numpy().reshape(-1, 3)).max() <= 1e-5
+        assert np.abs(W.T @ G.cpu().double().numpy().reshape(-1, 3) - rg.cpu().double().numpy().reshape(-1, 3)).max() <= 1e-5
+
+
+# the levels of the reference's 512^2 light (pbr/light.py:101-108): resolution, roughness; and how far the HIP operator's raw
+# sums / gradient may be from the reference build's, relative to the largest element.  The GGX lobe of the sharp levels is
+# evaluated at cos ~ 1 where d = 1 - c^2 (1 - alpha^4) loses its digits in fp32: there the reference's OWN result is
+# 4e-5 (128^2), 5e-4 (256^2) and 5e-2 (512^2, roughness 0.04) from the fp64 value, so the two fp32 evaluations are compared
+# through that value instead (below).
+LEVELS = [(16, 1.0, 2e-5, 2e-5), (32, 0.5, 5e-5, 5e-5), (64, 0.385, 1e-4, 1e-4), (128, 0.27, None, None), (256, 0.155, None, None), (512, 0.04, None, None)]
+
+
+@pytest.mark.parametrize("res,roughness,tol_out,tol_grad", LEVELS)
+def test_specular_prefilter_against_the_reference_build(reference, res, roughness, tol_out, tol_grad):
+    import render_utils as RU
+    from oracle import cubemap_oracle as O
+    g = torch.Generator().manual_seed(res)
+    x = torch.rand(6, res, res, 3, generator=g).cuda()
+    G4 = torch.randn(6, res, res, 4, generator=g).cuda()
+    cut = RU.ndf_cutoff(roughness, 0.99)
+    bounds = reference.specular_bounds(res, cut)
+    r4 = reference.specular_cubemap_fwd(x, bounds, roughness, cut)
+    rg = reference.specular_cubemap_bwd(x, bounds, G4, roughness, cut)
+    xx = x.clone().requires_grad_(True)
+    o4 = RU._specular_cubemap.apply(xx, roughness, cut)
+    (o4 * G4).sum().backward()
+    if tol_out is not None:
+        assert _rel(o4, r4) <= tol_out and _rel(xx.grad, rg) <= tol_grad, (_rel(o4, r4), _rel(xx.grad, rg))
+        # what pbr/light.py uses: the normalised colour
+        assert _rel(RU.specular_cubemap(x, roughness), r4[..., :3] / r4[..., 3:]) <= 2e-5
+        return
+    # ill-conditioned lobe: both fp32 results against the fp64 restatement on sampled output texels -- the HIP operator must be
+    # at least as close to it as the reference's own kernels are
+    T = 6 * res * res
+    rows = np.unique(np.concatenate([[0, res - 1, (res // 2) * res + res // 2, T - 1], torch.randint(0, T, (20,), generator=g).numpy()]))
+    xs = x.cpu().double().numpy().reshape(-1, 3)
+    o, r = o4.detach().cpu().double().numpy().reshape(-1, 4), r4.cpu().double().numpy().reshape(-1, 4)
+    err_hip = err_ref = 0.0
+    for k in range(0, len(rows), 2):
+        rr = rows[k:k + 2]
+        W = O.specular_matrix(res, roughness, cut, rows=rr)
+        exact = np.concatenate([W @ xs, W.sum(1, keepdims=True)], axis=1)
+        # a texel whose direction sits within fp32 rounding of the cone boundary may fall on either side in any fp32 evaluation
+        rim = np.abs(O.specular_matrix(res, roughness, cut + 2e-6, rows=rr) - O.specular_matrix(res, roughness, cut - 2e-6, rows=rr)).max(axis=1) > 0
+        for j in np.nonzero(~rim)[0]:
+            s = np.abs(exact[j]).max()
+            err_hip, err_ref = max(err_hip, np.abs(o[rr[j]] - exact[j]).max() / s), max(err_ref, np.abs(r[rr[j]] - exact[j]).max() / s)
+    assert err_ref > 0 and err_hip <= 1.25 * err_ref + 1e-5, (err_hip, err_ref)
+    # and the two fp32 results agree to the size of the reference's own error
+    assert _rel(o4, r4) <= 6 * err_ref + 1e-4, (_rel(o4, r4), err_ref)
+
+
+@pytest.mark.parametrize("res,roughness", [(16, 0.5), (16, 1.0), (32, 0.385)])
+def test_cubemap_oracle_is_pinned_to_the_reference_build(reference, res, roughness):
+    """oracle/cubemap_oracle.py's dense weight matrices (what tests/test_cubemap_gpu.py checks the HIP operators with) against
+    the reference's kernels at well-conditioned levels: forward W x and the weight sums, backward W^T g"""
+    import render_utils as RU
+    from oracle import cubemap_oracle as O
+    g = torch.Generator().manual_seed(res + int(100 * roughness))
+    x = torch.rand(6, res, res, 3, generator=g).cuda()
+    G4 = torch.randn(6, res, res, 4, generator=g).cuda()
+    cut = RU.ndf_cutoff(roughness, 0.99)
+    bounds = reference.specular_bounds(res, cut)
+    r4 = reference.specular_cubemap_fwd(x, bounds, roughness, cut).cpu().double().numpy().reshape(-1, 4)
+    rg = reference.specular_cubemap_bwd(x, bounds, G4, roughness, cut).cpu().double().numpy().reshape(-1, 3)
+    Wlo, Whi = O.specular_matrix(res, roughness, cut + 2e-6), O.specular_matrix(res, roughness, cut - 2e-6)
+    xs, Gn = x.cpu().double().numpy().reshape(-1, 3), G4.cpu().double().numpy().reshape(-1, 4)
+    lo = np.concatenate([Wlo @ xs, Wlo.sum(1, keepdims=True)], axis=1)
+    hi = np.concatenate([Whi @ xs, Whi.sum(1, keepdims=True)], axis=1)
+    scale = np.abs(hi).max()
+    assert (r4 >= np.minimum(lo, hi) - 2e-5 * scale).all() and (r4 <= np.maximum(lo, hi) + 2e-5 * scale).all()
+    exact_rows = np.abs(Whi - Wlo).max(axis=1) == 0
+    assert exact_rows.mean() > 0.3
+    assert np.abs(r4[exact_rows] - lo[exact_rows]).max() <= 2e-5 * scale
+    if np.abs(Whi - Wlo).max() == 0:  # no pair on the rim at all: the gradient is the transpose, colour and weight-sum channels
+        want = Wlo.T @ Gn[:, :3]
+        assert np.abs(rg - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
