@@ -47,7 +47,7 @@ def _scene(name):
     return Hh.make_scene(kw.pop("P"), kw.pop("W"), kw.pop("H"), **kw)
 
 
-def _assert_oracle_equals_reference(f, gr, r, rg, sh_path=True):
+def _assert_oracle_equals_reference(f, gr, r, rg, sh_path=True, tight=True, oracle=None):
     assert f.num_rendered == r.num_rendered
     for k in ("radii", "tiles_touched", "point_offsets", "keys_sorted", "vals_sorted", "ranges", "observe"):
         assert np.array_equal(getattr(f, k), getattr(r, k)), k
@@ -64,7 +64,14 @@ def _assert_oracle_equals_reference(f, gr, r, rg, sh_path=True):
     assert np.abs(f.color - r.color).max() <= 2e-6
     for ch in range(10):
         assert np.abs(f.buffer[ch] - r.buffer[ch]).max() <= 2e-6 * max(1.0, float(np.abs(r.buffer[ch]).max())), f"buffer[{ch}]"
-    if gr is not None:
+    if gr is not None and not tight:
+        # random scenes hold splats whose covariance chain amplifies the last bits of the blend sums a thousandfold (the
+        # reference's float atomics add in arbitrary order, the oracle in double), so the backward is compared in its two
+        # halves: (A) the per-Gaussian sums the reference accumulates with atomicAdd, element-wise at north_star's 1e-3;
+        # (B) the reference's cov2D / projection / SH / cov3D chain against the ORACLE's chain evaluated on the reference's
+        # own sums: 1e-5 relative, no exceptions
+        Hh.assert_two_stage(oracle, f, gr, rg)
+    elif gr is not None:
         for k, v in gr.items():
             scale = float(np.abs(rg[k]).max()) if rg[k].size else 0.0
             # relative to the tensor's largest element: the reference's own run-to-run spread (atomic order) is of this size;
@@ -79,6 +86,28 @@ def test_oracle_is_pinned_to_the_reference_build(oracle_lib, reference, name):
     f, gr = Hh.run_oracle(oracle_lib, sc)
     r, rg = Hh.run_oracle(reference, sc)
     _assert_oracle_equals_reference(f, gr, r, rg)
+    Hh.assert_two_stage(oracle_lib, f, gr, rg)  # and the per-Gaussian chain on the reference's own sums: 1e-5, no exceptions
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_oracle_is_pinned_on_random_scenes(oracle_lib, reference, case):
+    """the scenes of tests/test_fuzz_gpu.py's sweep (and 16 more): sizes from one Gaussian to screen-filling splats, every
+    feature count, scale ranges over three decades, opaque layers, random backgrounds"""
+    import random
+    rng = random.Random(9000 + case)
+    P = rng.choice([1, 7, 64, 300, 1500, 4000, 9000])
+    W, H = rng.choice([(16, 16), (33, 17), (64, 48), (130, 70), (200, 120), (97, 255)])
+    fc = rng.choice([0, 1, 3, 5, 8, 9, 10])
+    lo = rng.choice([0.0005, 0.005, 0.02])
+    hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
+    seed = rng.randrange(1 << 30)
+    rng.choice([0, 1, 2, 2]); rng.choice([False, True])  # (draws of the fuzz sweep that do not concern this comparison)
+    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()))
+    if rng.random() < 0.3:
+        sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+    f, gr = Hh.run_oracle(oracle_lib, sc)
+    r, rg = Hh.run_oracle(reference, sc)
+    _assert_oracle_equals_reference(f, gr, r, rg, tight=False, oracle=oracle_lib)
 
 
 def test_oracle_is_pinned_with_depth_ties_and_culled_gaussians(oracle_lib, reference):
@@ -189,13 +218,14 @@ def test_hip_binning_reproduces_the_reference_builds_lists(reference):
         gs2m_native.set_reference_binning(False)
 
 
-def test_bench_workload_at_full_size_against_the_reference_build(reference):
-    """BASELINE configs[2] as bench.py runs it (1M Gaussians, 1920x1080, feature_count 9): forward + backward of the HIP
+@pytest.mark.parametrize("name,P,fc", [("c3 (the bench workload)", 1_000_000, 9), ("c2", 500_000, 5), ("c5 per-GPU shape", 2_000_000, 9)])
+def test_bench_workloads_at_full_size_against_the_reference_build(reference, name, P, fc):
+    """BASELINE configs as bench.py runs them (1920x1080; C3: 1M Gaussians, feature_count 9): forward + backward of the HIP
     path against the reference's kernels on the same device, in both binning modes"""
     import gs2m_native
-    sc = Hh.make_scene(1_000_000, 1920, 1080, seed=0, fc=9)
+    sc = Hh.make_scene(P, 1920, 1080, seed=0, fc=fc)
     r, rg = Hh.run_oracle(reference, sc)
-    assert r.num_rendered > 3_000_000
+    assert r.num_rendered > 3 * P
     for mode in (False, True):
         gs2m_native.set_reference_binning(mode)
         try:
@@ -209,6 +239,7 @@ def test_bench_workload_at_full_size_against_the_reference_build(reference):
             Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
         for k in GRADS:
             Hh.assert_grad_close(k, g[k], rg[k])
+        del out, g
 
 
 # ---- environment-map prefilters (row N2): render-utils' own kernels through the same recipe --------------------------------
