@@ -60,6 +60,51 @@ def lib():
     return _lib
 
 
+SSIM_LIB_PATH = os.path.join(_HERE, "_ref", "libgs2m_ref_ssim.so")
+_ssim_lib = None
+
+
+def ssim_available():
+    return os.path.exists(SSIM_LIB_PATH) and torch.cuda.is_available()
+
+
+def _ssim():
+    global _ssim_lib
+    if _ssim_lib is None:
+        L = C.CDLL(SSIM_LIB_PATH)
+        p, i, f = C.c_void_p, C.c_int, C.c_float
+        L.gs2m_ref_ssim_forward.restype = i
+        L.gs2m_ref_ssim_forward.argtypes = [i, i, i, i, f, f, p, p, p, p, p, p]
+        L.gs2m_ref_ssim_backward.restype = i
+        L.gs2m_ref_ssim_backward.argtypes = [i, i, i, i, f, f, p, p, p, p, p, p, p]
+        _ssim_lib = L
+    return _ssim_lib
+
+
+def fusedssim(C1, C2, img1, img2, train):
+    """fused-ssim's extension function of the same name (ssim.cu:368-404): (B, CH, H, W) CUDA tensors ->
+    (ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12), the last three empty when `train` is false"""
+    a, b = _dev(img1), _dev(img2)
+    B, CH, H, W = a.shape
+    out = [torch.empty_like(a) for _ in range(4 if train else 1)]
+    torch.cuda.synchronize()
+    ptrs = [_ptr(t) for t in out] + [None] * (4 - len(out))
+    if _ssim().gs2m_ref_ssim_forward(B, CH, H, W, C1, C2, _ptr(a), _ptr(b), *ptrs) != 0:
+        raise RuntimeError("reference fusedssim failed")
+    return tuple(out) + tuple(torch.empty(0) for _ in range(4 - len(out)))
+
+
+def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
+    a, b, g = _dev(img1), _dev(img2), _dev(dL_dmap)
+    B, CH, H, W = a.shape
+    out = torch.empty_like(a)
+    torch.cuda.synchronize()
+    if _ssim().gs2m_ref_ssim_backward(B, CH, H, W, C1, C2, _ptr(a), _ptr(b), _ptr(g), _ptr(_dev(dm_dmu1)), _ptr(_dev(dm_dsigma1_sq)),
+                                      _ptr(_dev(dm_dsigma12)), _ptr(out)) != 0:
+        raise RuntimeError("reference fusedssim_backward failed")
+    return out
+
+
 def _dev(a, dtype=torch.float32):
     if a is None:
         return None

@@ -42,7 +42,7 @@ def test_reference_build_recipe_and_library():
     library has been built (the build container; it travels prebuilt), it loads without a GPU and exports the shim's
     entry points"""
     d = os.path.join(ROOT, "oracle", "ref_build")
-    assert sorted(os.listdir(d)) == ["Makefile", "ref_shim.hip", "ref_shim_cubemap.hip"]
+    assert sorted(os.listdir(d)) == ["Makefile", "ref_shim.hip", "ref_shim_cubemap.hip", "ref_shim_ssim.hip"]
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     if os.path.isdir(ref_dir):
         assert all(f.endswith(".so") for f in os.listdir(ref_dir)), "only built libraries belong in oracle/_ref"

@@ -340,3 +340,29 @@ def test_cubemap_oracle_is_pinned_to_the_reference_build(reference, res, roughne
     if np.abs(Whi - Wlo).max() == 0:  # no pair on the rim at all: the gradient is the transpose, colour and weight-sum channels
         want = Wlo.T @ Gn[:, :3]
         assert np.abs(rg - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+# ---- D-SSIM (row N2): fused-ssim's own extension through the same recipe ---------------------------------------------------
+
+@pytest.mark.parametrize("B,CH,H,W", [(1, 3, 1080, 1920), (2, 3, 67, 131), (1, 1, 16, 16), (1, 4, 11, 300), (3, 2, 5, 7)])
+def test_fused_ssim_against_the_reference_build(B, CH, H, W):
+    """fused_ssim.fusedssim / fusedssim_backward -- same names and signatures as the reference extension's -- against the
+    extension itself: the SSIM map, the three partial derivatives it keeps for the backward, and dL/dimg1"""
+    from oracle import reference as R
+    if not R.ssim_available():
+        pytest.skip("oracle/_ref/libgs2m_ref_ssim.so is not there")
+    import fused_ssim as FS
+    g = torch.Generator().manual_seed(H * W)
+    a = torch.rand(B, CH, H, W, generator=g).cuda()
+    b = (a.cpu() + 0.1 * torch.randn(B, CH, H, W, generator=g)).clamp(0, 1).cuda()
+    G = torch.randn(B, CH, H, W, generator=g).cuda() / (B * CH * H * W)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ours, ref = FS.fusedssim(C1, C2, a, b, True), R.fusedssim(C1, C2, a, b, True)
+    for name, x, y in zip(("ssim_map", "dm_dmu1", "dm_dsigma1_sq", "dm_dsigma12"), ours, ref):
+        assert _rel(x, y) <= 2e-5, (name, _rel(x, y))
+    assert abs(float(ours[0].mean()) - float(ref[0].mean())) <= 1e-6
+    gi = FS.fusedssim_backward(C1, C2, a, b, G, *ours[1:])
+    gr = R.fusedssim_backward(C1, C2, a, b, G, *ref[1:])
+    assert _rel(gi, gr) <= 1e-4, _rel(gi, gr)
+    # inference form: the map alone
+    assert _rel(FS.fusedssim(C1, C2, a, b, False)[0], R.fusedssim(C1, C2, a, b, False)[0]) <= 2e-5
