@@ -25,7 +25,7 @@ def available():
 def build():
     """Only where /root/reference exists (the build container): oracle/ref_build/Makefile."""
     import subprocess
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref_build")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-j2", "-C", os.path.join(_HERE, "ref_build")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return LIB_PATH
 
 
