@@ -24,7 +24,7 @@ def cmp(name, a, b):
         print(f"  {name:16s} bit-identical={same} max abs {d.max() if d.size else 0:.3e} rel-to-max {d.max() / max(np.abs(b).max(), 1e-30) if d.size else 0:.3e} differing {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size}")
 
 
-for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
+for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
     sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
     f, gr = Hh.run_oracle(oracle, sc)
     r, rg = Hh.run_oracle(reference, sc)
@@ -83,7 +83,8 @@ if "--cubemap" in sys.argv:
 if "--full" in sys.argv:
     # the bench workloads (bench.py CONFIGS) through the reference build on this GPU: what a hipify port of the reference
     # delivers on MI355X, to read next to bench.py's ms_per_step for the same workloads (profiles/r03_bench*.json)
-    for name, (P, W, H, fc) in (("c3", (1_000_000, 1920, 1080, 9)), ("c2", (500_000, 1920, 1080, 5)), ("c5 shape", (2_000_000, 1920, 1080, 9))):
+    cfgs = (("c3", (1_000_000, 1920, 1080, 9)), ("c2", (500_000, 1920, 1080, 5)), ("c5 shape", (2_000_000, 1920, 1080, 9)))
+    for name, (P, W, H, fc) in cfgs[:1] if "--c3-only" in sys.argv else cfgs:
         sc = Hh.make_scene(P, W, H, seed=0, fc=fc)
         r, _ = Hh.run_oracle(reference, sc, backward=False)
         ms_ref = reference.timed_forward_backward(r, sc["Gc"].numpy(), sc["Gb"].numpy(), n=10)
