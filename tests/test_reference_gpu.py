@@ -242,6 +242,34 @@ def test_bench_workloads_at_full_size_against_the_reference_build(reference, nam
         del out, g
 
 
+@pytest.mark.parametrize("frac,factor", [(0.002, 30.0), (0.02, 8.0)])
+def test_heavy_tailed_scene_at_1080p_against_the_reference_build(reference, frac, factor):
+    """bench.py --heavy-tail F:K: a fraction F of the Gaussians K times larger (the close-ups and background blobs of real
+    scenes): splats with hundreds of tile instances, tile lists thousands long, rows of one Gaussian spanning many windows of the
+    row reduction -- 300k Gaussians at 1920x1080, both binning modes"""
+    import gs2m_native
+    P = 300_000
+    sc = Hh.make_scene(P, 1920, 1080, seed=5, fc=9)
+    big = torch.rand(P, generator=torch.Generator().manual_seed(6)) < frac
+    sc["g"]["scales"] = torch.where(big[:, None], sc["g"]["scales"] * factor, sc["g"]["scales"])
+    r, rg = Hh.run_oracle(reference, sc)
+    assert r.tiles_touched.max() > 200
+    for mode in (False, True):
+        gs2m_native.set_reference_binning(mode)
+        try:
+            out, g = Hh.run_hip(sc)
+        finally:
+            gs2m_native.set_reference_binning(False)
+        assert np.array_equal(out["radii"], r.radii)
+        Hh.assert_observe_close(out["observe"], r)
+        Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
+        for ch in range(10):
+            Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
+        for k in ("means2D", "opacities", "shs", "features"):
+            Hh.assert_grad_close(k, g[k], rg[k])
+        del out, g
+
+
 # ---- environment-map prefilters (row N2): render-utils' own kernels through the same recipe --------------------------------
 
 def _rel(a, b):
