@@ -24,7 +24,7 @@ def cmp(name, a, b):
         print(f"  {name:16s} bit-identical={same} max abs {d.max() if d.size else 0:.3e} rel-to-max {d.max() / max(np.abs(b).max(), 1e-30) if d.size else 0:.3e} differing {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size}")
 
 
-for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
+for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv or "--sweep" in sys.argv or "--arbitrate" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
     sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
     f, gr = Hh.run_oracle(oracle, sc)
     r, rg = Hh.run_oracle(reference, sc)
@@ -99,3 +99,91 @@ if "--full" in sys.argv:
             del r
             reference.use_library(std)
         print(line)
+
+
+def sweep(n, start=0):
+    """`--sweep N [START]`: N random scenes, HIP path against the reference build (radii exact, observe / images with threshold
+    proofs, blend sums and well-conditioned gradients element-wise); prints the failing cases."""
+    import random
+    import gs2m_native
+    bad = 0
+    for case in range(start, start + n):
+        rng = random.Random(77000 + case)
+        P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
+        W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
+        fc = rng.choice([0, 1, 3, 5, 8, 9, 10])
+        deg = rng.choice([0, 1, 2, 3, 3])
+        lo = rng.choice([0.0005, 0.005, 0.02])
+        hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
+        if P >= 30000:
+            hi = min(hi, 0.1)
+        seed = rng.randrange(1 << 30)
+        refbin = rng.choice([False, True])
+        sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
+                           behind_frac=rng.choice([0.0, 0.01, 0.3]))
+        if rng.random() < 0.3:
+            sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+        tag = f"case {case}: P={P} {W}x{H} fc={fc} deg={deg} scales=[{lo},{hi}] seed={seed} refbin={refbin}"
+        try:
+            r, rg = Hh.run_oracle(reference, sc)
+            gs2m_native.set_reference_binning(refbin)
+            out, g = Hh.run_hip(sc)
+            sums = Hh.run_hip_sums(sc)
+            gs2m_native.set_reference_binning(False)
+            assert np.array_equal(out["radii"], r.radii), "radii"
+            Hh.assert_observe_close(out["observe"], r)
+            Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
+            for ch in range(10):
+                Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
+            for k in ("means2D", "conics", "opacities", "colors", "features"):
+                Hh.assert_grad_close("sum:" + k, sums[k], rg[k].reshape(sums[k].shape), floor_frac=1e-4 if k == "conics" else 1e-5)
+            for k in ("shs", "opacities", "features", "means2D"):
+                Hh.assert_grad_close(k, g[k], rg[k])
+        except AssertionError as e:
+            bad += 1
+            gs2m_native.set_reference_binning(False)
+            print("FAIL", tag, "::", str(e)[:200])
+    print(f"sweep: {n} scenes from case {start}, {bad} failing")
+
+
+if "--sweep" in sys.argv:
+    i = sys.argv.index("--sweep")
+    sweep(int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 0)
+
+
+def arbitrate(cases):
+    """`--arbitrate c1,c2,...`: for sweep cases, the blend sums and images of the HIP path and of the reference build, each against
+    the CPU oracle (double accumulators): which of the two fp32 evaluations is off when they disagree."""
+    import random
+    import gs2m_native
+    for case in cases:
+        rng = random.Random(77000 + case)
+        P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
+        W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
+        fc = rng.choice([0, 1, 3, 5, 8, 9, 10]); deg = rng.choice([0, 1, 2, 3, 3])
+        lo = rng.choice([0.0005, 0.005, 0.02]); hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
+        if P >= 30000:
+            hi = min(hi, 0.1)
+        seed = rng.randrange(1 << 30); refbin = rng.choice([False, True])
+        sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
+                           behind_frac=rng.choice([0.0, 0.01, 0.3]))
+        if rng.random() < 0.3:
+            sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+        f, gr = Hh.run_oracle(oracle, sc)
+        r, rg = Hh.run_oracle(reference, sc)
+        gs2m_native.set_reference_binning(refbin)
+        out, g = Hh.run_hip(sc); sums = Hh.run_hip_sums(sc)
+        gs2m_native.set_reference_binning(False)
+        print(f"case {case}: P={P} {W}x{H} fc={fc}")
+        for k in ("means2D", "conics", "opacities", "colors", "features"):
+            ff = 1e-4 if k == "conics" else 1e-5
+            a = Hh.grad_stats(sums[k], gr[k].reshape(sums[k].shape), floor_frac=ff)[0]
+            b = Hh.grad_stats(rg[k].reshape(sums[k].shape), gr[k].reshape(sums[k].shape), floor_frac=ff)[0]
+            c = Hh.grad_stats(sums[k], rg[k].reshape(sums[k].shape), floor_frac=ff)[0]
+            print(f"  sum:{k:10s} elements outside 1e-3: HIP vs oracle {a:.2e}, reference build vs oracle {b:.2e}, HIP vs reference build {c:.2e}")
+        for name, x, y, z in (("color", out["color"], r.color, f.color), ("buffer[0]", out["buffer"][0], r.buffer[0], f.buffer[0])):
+            print(f"  {name}: pixels off by more than 1e-4: HIP vs oracle {(np.abs(x - z) > 1e-4).mean():.2e}, reference build vs oracle {(np.abs(y - z) > 1e-4).mean():.2e}, HIP vs reference build {(np.abs(x - y) > 1e-4).mean():.2e}")
+
+
+if "--arbitrate" in sys.argv:
+    arbitrate([int(c) for c in sys.argv[sys.argv.index("--arbitrate") + 1].split(",")])
