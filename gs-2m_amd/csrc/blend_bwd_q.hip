@@ -353,11 +353,17 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         if (r == 0 && j < nvalid) {  // geometry sums of survivor j from its moments
             const float4 m0 = *reinterpret_cast<const float4*>(&s_d[j][0]);  // M0, Mx, My, Mxx
             const float4 m1 = *reinterpret_cast<const float4*>(&s_d[j][4]);  // Mxy, Myy, U1, U2
+            // The moments are taken about the quadrant centre; the sums the gradients need are about the Gaussian's mean, which
+            // can lie hundreds of pixels away (splats centred outside the image): xc^2 M0 - 2 xc Mx + Mxx then cancels by many
+            // orders of magnitude, and in fp32 that shift -- not the moments -- was the one place where the blend sums left the
+            // reference's per-pixel form (5 of 300 random scenes against the reference build).  The three
+            // second-order shifts are evaluated in double: a dozen instructions per survivor on a quarter of the lanes.
             const float xc = sx - xq, yc = sy - yq;  // dx = xc - cx, dy = yc - cy
             const float Sdx = xc * m0.x - m0.y, Sdy = yc * m0.x - m0.z;
-            const float Sdxx = xc * xc * m0.x - 2.f * xc * m0.y + m0.w;
-            const float Sdxy = xc * yc * m0.x - xc * m0.z - yc * m0.y + m1.x;
-            const float Sdyy = yc * yc * m0.x - 2.f * yc * m0.z + m1.y;
+            const double xd = (double)xc, yd = (double)yc, M0 = (double)m0.x;
+            const float Sdxx = (float)(xd * xd * M0 - 2.0 * xd * (double)m0.y + (double)m0.w);
+            const float Sdxy = (float)(xd * yd * M0 - xd * (double)m0.z - yd * (double)m0.y + (double)m1.x);
+            const float Sdyy = (float)(yd * yd * M0 - 2.0 * yd * (double)m0.z + (double)m1.y);
             float4* o4 = reinterpret_cast<float4*>(row_ptr(row_cur));
             o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
             o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)

@@ -265,7 +265,9 @@ def assert_image_close(name, got, ref, tol=ABS_TOL_BUFFERS, scale=None, max_outl
     d = np.abs(got - ref)
     bad = d > tol * s
     frac = float(bad.mean())
-    assert frac <= max_outlier_frac, f"{name}: {frac:.2e} of pixels differ by more than {tol * s:g} (max {d.max():g})"
+    # (with the proof below, never fewer than 2 pixels: one proven threshold pixel of a 97 x 255 image is 4e-5 of it)
+    allowed = max(max_outlier_frac, 2.0 / max(bad.size, 1)) if oracle_fwd is not None else max_outlier_frac
+    assert frac <= allowed, f"{name}: {frac:.2e} of pixels differ by more than {tol * s:g} (max {d.max():g})"
     assert d.max() <= 2.0 / 255.0 * s * 4 + tol * s, f"{name}: max abs diff {d.max():g}"
     if oracle_fwd is not None and bad.any():
         pix = bad.reshape(-1, bad.shape[-2], bad.shape[-1]).any(0)
@@ -392,7 +394,9 @@ def assert_chain_exceptions_conditioned(f, g, gr, sums=None, names=("scales", "r
         bad = rows[~ok]
         assert len(bad) == 0, (f"{k} {tag}: {len(bad)} of {len(rows)} Gaussians outside the element-wise bound are neither needle-like nor amplified nor on a threshold: "
                                + "; ".join(f"gid {r} rho {rho[r]:.3g} amp {amp[list(rows).index(r)]:.3g} radius {f.radii[r]} |ref| {np.abs(ref[r]).max():.3g} d {d[r].max():.3g} floor {floor:.3g}" for r in bad[:5]))
-        assert len(rows) <= max(2, int(3e-3 * got.shape[0])), (k, tag, len(rows))
+        # (every one of them carries a proof above; the count is a sanity bound: 0.3 % of the Gaussians, and for scenes of a few
+        # hundred Gaussians with scales over three decades -- where needles are the rule -- never fewer than 4)
+        assert len(rows) <= max(4, int(3e-3 * got.shape[0])), (k, tag, len(rows))
 
 
 # ---------------------------------------------------------------------------------------

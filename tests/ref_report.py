@@ -24,7 +24,7 @@ def cmp(name, a, b):
         print(f"  {name:16s} bit-identical={same} max abs {d.max() if d.size else 0:.3e} rel-to-max {d.max() / max(np.abs(b).max(), 1e-30) if d.size else 0:.3e} differing {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size}")
 
 
-for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv or "--sweep" in sys.argv or "--arbitrate" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
+for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv or "--sweep" in sys.argv or "--arbitrate" in sys.argv or "--pixel" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
     sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
     f, gr = Hh.run_oracle(oracle, sc)
     r, rg = Hh.run_oracle(reference, sc)
@@ -187,3 +187,54 @@ def arbitrate(cases):
 
 if "--arbitrate" in sys.argv:
     arbitrate([int(c) for c in sys.argv[sys.argv.index("--arbitrate") + 1].split(",")])
+
+
+def pixel_case(case):
+    """`--pixel CASE`: the worst alpha-channel pixel of a sweep case and every contributor of its tile list with its alpha and
+    transmittance there (reference-order fp32 arithmetic on the reference build's own state)."""
+    import random
+    import gs2m_native
+    rng = random.Random(77000 + case)
+    P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
+    W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
+    fc = rng.choice([0, 1, 3, 5, 8, 9, 10]); deg = rng.choice([0, 1, 2, 3, 3])
+    lo = rng.choice([0.0005, 0.005, 0.02]); hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
+    if P >= 30000:
+        hi = min(hi, 0.1)
+    seed = rng.randrange(1 << 30); refbin = rng.choice([False, True])
+    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
+                       behind_frac=rng.choice([0.0, 0.01, 0.3]))
+    if rng.random() < 0.3:
+        sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+    r, _ = Hh.run_oracle(reference, sc, backward=False)
+    gs2m_native.set_reference_binning(refbin)
+    out, _ = Hh.run_hip(sc, backward=False)
+    gs2m_native.set_reference_binning(False)
+    d = np.abs(out["buffer"][0] - r.buffer[0])
+    y, x = np.unravel_index(d.argmax(), d.shape)
+    print(f"case {case}: worst alpha-channel pixel ({x}, {y}) HIP {out['buffer'][0][y, x]:.7f} reference {r.buffer[0][y, x]:.7f} diff {d[y, x]:.3e}; quadrant ({(x % 16) // 8}, {(y % 16) // 8})")
+    f32 = np.float32
+    tile = (y // 16) * r.tiles_x + (x // 16)
+    lo_, hi_ = int(r.ranges[tile, 0]), int(r.ranges[tile, 1])
+    T = f32(1.0)
+    for k, gid in enumerate(r.vals_sorted[lo_:hi_]):
+        mx, my = r.means2D[gid]; A, B, C, op = r.conic_opacity[gid]
+        dx = f32(mx - f32(x)); dy = f32(my - f32(y))
+        power = f32(f32(f32(-0.5) * f32(f32(f32(A * dx) * dx) + f32(f32(C * dy) * dy))) - f32(f32(B * dx) * dy))
+        if power > 0:
+            continue
+        alpha = min(0.99, float(op) * float(np.exp(np.float64(power))))
+        if alpha < 1.0 / 255.0:
+            if alpha > 0.9 / 255.0:
+                print(f"   (k={k} gid={gid} alpha*255={alpha * 255:.5f}: below the threshold)")
+            continue
+        contrib = alpha * float(T)
+        if abs(contrib - d[y, x]) < 0.3 * d[y, x] or alpha * 255 < 1.05:
+            print(f"   k={k} gid={gid} alpha*255={alpha * 255:.5f} T={float(T):.5f} alpha*T={contrib:.3e} radius={r.radii[gid]} mean=({mx:.1f},{my:.1f}) conic=({A:.3e},{B:.3e},{C:.3e}) opacity={op:.4f}")
+        if f32(T * f32(1.0 - f32(alpha))) < f32(1e-4):
+            break
+        T = f32(T * f32(1.0 - f32(alpha)))
+
+
+if "--pixel" in sys.argv:
+    pixel_case(int(sys.argv[sys.argv.index("--pixel") + 1]))
