@@ -1,5 +1,12 @@
-"""Report: the reference build (oracle/_ref/libgs2m_ref.so: the reference's kernels through hipify-perl, on this GPU) against
-the CPU oracle and against the HIP path, array by array.  Test infrastructure, not product."""
+"""Reports on the reference build (oracle/_ref/libgs2m_ref.so: the reference's kernels through hipify-perl, on this GPU).
+Test infrastructure, not product.
+
+    python tests/ref_report.py                     three scenes, every array of the reference build against the CPU oracle's
+    python tests/ref_report.py --full [--c3-only]  its time per view at the bench workloads
+    python tests/ref_report.py --cubemap           the cube-map prefilters level by level against the HIP operators
+    python tests/ref_report.py --sweep N [START]   N random scenes, HIP path against the reference build
+    python tests/ref_report.py --arbitrate 32,89   sweep cases with the CPU oracle between the two
+    python tests/ref_report.py --pixel 217         the worst pixel of a sweep case and the contributors near a threshold there"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gs-2m_amd"), os.path.join(ROOT, "tests")):
@@ -24,22 +31,25 @@ def cmp(name, a, b):
         print(f"  {name:16s} bit-identical={same} max abs {d.max() if d.size else 0:.3e} rel-to-max {d.max() / max(np.abs(b).max(), 1e-30) if d.size else 0:.3e} differing {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size}")
 
 
-for (P, W, H, seed, fc, hi) in () if "--cubemap" in sys.argv or "--c3-only" in sys.argv or "--sweep" in sys.argv or "--arbitrate" in sys.argv or "--pixel" in sys.argv else ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
-    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
-    f, gr = Hh.run_oracle(oracle, sc)
-    r, rg = Hh.run_oracle(reference, sc)
-    print(f"scene P={P} {W}x{H} fc={fc}: num_rendered oracle {f.num_rendered} reference {r.num_rendered}")
-    for k in ("radii", "tiles_touched", "point_offsets", "clamped", "keys_sorted", "vals_sorted", "ranges", "n_contrib", "observe"):
-        cmp(k, getattr(r, k), getattr(f, k))
-    vis = f.radii > 0
-    for k in ("depths", "means2D", "cov3D", "conic_opacity", "rgb"):
-        cmp(k + "[vis]", getattr(r, k)[vis], getattr(f, k)[vis])
-    for k in ("color", "buffer", "final_T"):
-        cmp(k, getattr(r, k), getattr(f, k))
-    for k in gr:
-        cmp("d" + k, rg[k], gr[k])
+def scenes():
+    """(no flag) three scenes: every array of the reference build against the CPU oracle's"""
+    for (P, W, H, seed, fc, hi) in ((3000, 160, 96, 1, 9, 0.06), (20000, 320, 200, 2, 5, 0.05), (50000, 640, 360, 3, 10, 0.03)):
+        sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, scale_hi=hi)
+        f, gr = Hh.run_oracle(oracle, sc)
+        r, rg = Hh.run_oracle(reference, sc)
+        print(f"scene P={P} {W}x{H} fc={fc}: num_rendered oracle {f.num_rendered} reference {r.num_rendered}")
+        for k in ("radii", "tiles_touched", "point_offsets", "clamped", "keys_sorted", "vals_sorted", "ranges", "n_contrib", "observe"):
+            cmp(k, getattr(r, k), getattr(f, k))
+        vis = f.radii > 0
+        for k in ("depths", "means2D", "cov3D", "conic_opacity", "rgb"):
+            cmp(k + "[vis]", getattr(r, k)[vis], getattr(f, k)[vis])
+        for k in ("color", "buffer", "final_T"):
+            cmp(k, getattr(r, k), getattr(f, k))
+        for k in gr:
+            cmp("d" + k, rg[k], gr[k])
 
-if "--cubemap" in sys.argv:
+def cubemap():
+    """`--cubemap`: the prefilters level by level, HIP operators against render-utils' kernels"""
     import render_utils as RU
     for res, rough in ((16, 1.0), (32, 0.5), (64, 0.385), (128, 0.27), (256, 0.155), (512, 0.04)):
         g = torch.Generator().manual_seed(res)
@@ -78,13 +88,13 @@ if "--cubemap" in sys.argv:
         print(f"diffuse res {res}")
         cmp("out", o.detach().cpu().numpy(), reference.diffuse_cubemap_fwd(x).cpu().numpy())
         cmp("grad", xx.grad.cpu().numpy(), reference.diffuse_cubemap_bwd(x, G).cpu().numpy())
-    sys.exit(0)
 
-if "--full" in sys.argv:
+def full(c3_only=False):
+    """`--full [--c3-only]`: time the reference build at the bench workloads"""
     # the bench workloads (bench.py CONFIGS) through the reference build on this GPU: what a hipify port of the reference
     # delivers on MI355X, to read next to bench.py's ms_per_step for the same workloads (profiles/r03_bench*.json)
     cfgs = (("c3", (1_000_000, 1920, 1080, 9)), ("c2", (500_000, 1920, 1080, 5)), ("c5 shape", (2_000_000, 1920, 1080, 9)))
-    for name, (P, W, H, fc) in cfgs[:1] if "--c3-only" in sys.argv else cfgs:
+    for name, (P, W, H, fc) in cfgs[:1] if c3_only else cfgs:
         sc = Hh.make_scene(P, W, H, seed=0, fc=fc)
         r, _ = Hh.run_oracle(reference, sc, backward=False)
         ms_ref = reference.timed_forward_backward(r, sc["Gc"].numpy(), sc["Gb"].numpy(), n=10)
@@ -101,29 +111,34 @@ if "--full" in sys.argv:
         print(line)
 
 
+def sweep_scene(case):
+    """the random scene of sweep case `case` -> (scene, reference-binning flag, tag)"""
+    import random
+    rng = random.Random(77000 + case)
+    P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
+    W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
+    fc = rng.choice([0, 1, 3, 5, 8, 9, 10])
+    deg = rng.choice([0, 1, 2, 3, 3])
+    lo = rng.choice([0.0005, 0.005, 0.02])
+    hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
+    if P >= 30000:
+        hi = min(hi, 0.1)
+    seed = rng.randrange(1 << 30)
+    refbin = rng.choice([False, True])
+    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
+                       behind_frac=rng.choice([0.0, 0.01, 0.3]))
+    if rng.random() < 0.3:
+        sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+    return sc, refbin, f"case {case}: P={P} {W}x{H} fc={fc} deg={deg} scales=[{lo},{hi}] seed={seed} refbin={refbin}"
+
+
 def sweep(n, start=0):
     """`--sweep N [START]`: N random scenes, HIP path against the reference build (radii exact, observe / images with threshold
     proofs, blend sums and well-conditioned gradients element-wise); prints the failing cases."""
-    import random
     import gs2m_native
     bad = 0
     for case in range(start, start + n):
-        rng = random.Random(77000 + case)
-        P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
-        W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
-        fc = rng.choice([0, 1, 3, 5, 8, 9, 10])
-        deg = rng.choice([0, 1, 2, 3, 3])
-        lo = rng.choice([0.0005, 0.005, 0.02])
-        hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
-        if P >= 30000:
-            hi = min(hi, 0.1)
-        seed = rng.randrange(1 << 30)
-        refbin = rng.choice([False, True])
-        sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
-                           behind_frac=rng.choice([0.0, 0.01, 0.3]))
-        if rng.random() < 0.3:
-            sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
-        tag = f"case {case}: P={P} {W}x{H} fc={fc} deg={deg} scales=[{lo},{hi}] seed={seed} refbin={refbin}"
+        sc, refbin, tag = sweep_scene(case)
         try:
             r, rg = Hh.run_oracle(reference, sc)
             gs2m_native.set_reference_binning(refbin)
@@ -146,35 +161,19 @@ def sweep(n, start=0):
     print(f"sweep: {n} scenes from case {start}, {bad} failing")
 
 
-if "--sweep" in sys.argv:
-    i = sys.argv.index("--sweep")
-    sweep(int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 0)
-
 
 def arbitrate(cases):
     """`--arbitrate c1,c2,...`: for sweep cases, the blend sums and images of the HIP path and of the reference build, each against
     the CPU oracle (double accumulators): which of the two fp32 evaluations is off when they disagree."""
-    import random
     import gs2m_native
     for case in cases:
-        rng = random.Random(77000 + case)
-        P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
-        W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
-        fc = rng.choice([0, 1, 3, 5, 8, 9, 10]); deg = rng.choice([0, 1, 2, 3, 3])
-        lo = rng.choice([0.0005, 0.005, 0.02]); hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
-        if P >= 30000:
-            hi = min(hi, 0.1)
-        seed = rng.randrange(1 << 30); refbin = rng.choice([False, True])
-        sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
-                           behind_frac=rng.choice([0.0, 0.01, 0.3]))
-        if rng.random() < 0.3:
-            sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+        sc, refbin, tag = sweep_scene(case)
         f, gr = Hh.run_oracle(oracle, sc)
         r, rg = Hh.run_oracle(reference, sc)
         gs2m_native.set_reference_binning(refbin)
         out, g = Hh.run_hip(sc); sums = Hh.run_hip_sums(sc)
         gs2m_native.set_reference_binning(False)
-        print(f"case {case}: P={P} {W}x{H} fc={fc}")
+        print(tag)
         for k in ("means2D", "conics", "opacities", "colors", "features"):
             ff = 1e-4 if k == "conics" else 1e-5
             a = Hh.grad_stats(sums[k], gr[k].reshape(sums[k].shape), floor_frac=ff)[0]
@@ -185,34 +184,19 @@ def arbitrate(cases):
             print(f"  {name}: pixels off by more than 1e-4: HIP vs oracle {(np.abs(x - z) > 1e-4).mean():.2e}, reference build vs oracle {(np.abs(y - z) > 1e-4).mean():.2e}, HIP vs reference build {(np.abs(x - y) > 1e-4).mean():.2e}")
 
 
-if "--arbitrate" in sys.argv:
-    arbitrate([int(c) for c in sys.argv[sys.argv.index("--arbitrate") + 1].split(",")])
-
 
 def pixel_case(case):
     """`--pixel CASE`: the worst alpha-channel pixel of a sweep case and every contributor of its tile list with its alpha and
     transmittance there (reference-order fp32 arithmetic on the reference build's own state)."""
-    import random
     import gs2m_native
-    rng = random.Random(77000 + case)
-    P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
-    W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
-    fc = rng.choice([0, 1, 3, 5, 8, 9, 10]); deg = rng.choice([0, 1, 2, 3, 3])
-    lo = rng.choice([0.0005, 0.005, 0.02]); hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
-    if P >= 30000:
-        hi = min(hi, 0.1)
-    seed = rng.randrange(1 << 30); refbin = rng.choice([False, True])
-    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
-                       behind_frac=rng.choice([0.0, 0.01, 0.3]))
-    if rng.random() < 0.3:
-        sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
+    sc, refbin, tag = sweep_scene(case)
     r, _ = Hh.run_oracle(reference, sc, backward=False)
     gs2m_native.set_reference_binning(refbin)
     out, _ = Hh.run_hip(sc, backward=False)
     gs2m_native.set_reference_binning(False)
     d = np.abs(out["buffer"][0] - r.buffer[0])
     y, x = np.unravel_index(d.argmax(), d.shape)
-    print(f"case {case}: worst alpha-channel pixel ({x}, {y}) HIP {out['buffer'][0][y, x]:.7f} reference {r.buffer[0][y, x]:.7f} diff {d[y, x]:.3e}; quadrant ({(x % 16) // 8}, {(y % 16) // 8})")
+    print(f"{tag}: worst alpha-channel pixel ({x}, {y}) HIP {out['buffer'][0][y, x]:.7f} reference {r.buffer[0][y, x]:.7f} diff {d[y, x]:.3e}; quadrant ({(x % 16) // 8}, {(y % 16) // 8})")
     f32 = np.float32
     tile = (y // 16) * r.tiles_x + (x // 16)
     lo_, hi_ = int(r.ranges[tile, 0]), int(r.ranges[tile, 1])
@@ -236,5 +220,18 @@ def pixel_case(case):
         T = f32(T * f32(1.0 - f32(alpha)))
 
 
-if "--pixel" in sys.argv:
-    pixel_case(int(sys.argv[sys.argv.index("--pixel") + 1]))
+if __name__ == "__main__":
+    arg = lambda flag, k=1: sys.argv[sys.argv.index(flag) + k]
+    if "--cubemap" in sys.argv:
+        cubemap()
+    elif "--sweep" in sys.argv:
+        i = sys.argv.index("--sweep")
+        sweep(int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 and not sys.argv[i + 2].startswith("-") else 0)
+    elif "--arbitrate" in sys.argv:
+        arbitrate([int(c) for c in arg("--arbitrate").split(",")])
+    elif "--pixel" in sys.argv:
+        pixel_case(int(arg("--pixel")))
+    elif "--full" in sys.argv:
+        full("--c3-only" in sys.argv)
+    else:
+        scenes()
