@@ -4,7 +4,8 @@ Test infrastructure, not product.
     python tests/ref_report.py                     three scenes, every array of the reference build against the CPU oracle's
     python tests/ref_report.py --full [--c3-only]  its time per view at the bench workloads
     python tests/ref_report.py --cubemap           the cube-map prefilters level by level against the HIP operators
-    python tests/ref_report.py --sweep N [START]   N random scenes, HIP path against the reference build
+    python tests/ref_report.py --sweep N [START] [--precomputed]   N random scenes, HIP path against the reference build
+                                                   (--precomputed: every other one with precomputed colours and covariances)
     python tests/ref_report.py --arbitrate 32,89   sweep cases with the CPU oracle between the two
     python tests/ref_report.py --pixel 217         the worst pixel of a sweep case and the contributors near a threshold there"""
 import os, sys, time
@@ -132,28 +133,38 @@ def sweep_scene(case):
     return sc, refbin, f"case {case}: P={P} {W}x{H} fc={fc} deg={deg} scales=[{lo},{hi}] seed={seed} refbin={refbin}"
 
 
-def sweep(n, start=0):
+def sweep(n, start=0, precomputed=False):
     """`--sweep N [START]`: N random scenes, HIP path against the reference build (radii exact, observe / images with threshold
     proofs, blend sums and well-conditioned gradients element-wise); prints the failing cases."""
     import gs2m_native
     bad = 0
     for case in range(start, start + n):
         sc, refbin, tag = sweep_scene(case)
+        kw = {}
+        if precomputed and case % 2:  # precomputed colours and 3-D covariances instead of SH + scale / rotation
+            import gs2m_scene
+            P = sc["g"]["means3D"].shape[0]
+            prm = gs2m_scene.GaussianParams.from_activated(sc["g"]["means3D"], sc["g"]["shs"], sc["g"]["scales"], sc["g"]["rotations"], sc["g"]["opacities"],
+                                                           torch.full((P, 3), 0.5), torch.full((P, 1), 0.5), torch.full((P, 1), 0.5))
+            kw = dict(colors_precomp=torch.rand(P, 3, generator=torch.Generator().manual_seed(case)), cov3D_precomp=prm.get_covariance().contiguous())
+            tag += " precomputed"
         try:
-            r, rg = Hh.run_oracle(reference, sc)
+            r, rg = Hh.run_oracle(reference, sc, **kw)
             gs2m_native.set_reference_binning(refbin)
-            out, g = Hh.run_hip(sc)
-            sums = Hh.run_hip_sums(sc)
+            out, g = Hh.run_hip(sc, **kw)
+            sums = Hh.run_hip_sums(sc) if not kw else None
             gs2m_native.set_reference_binning(False)
             assert np.array_equal(out["radii"], r.radii), "radii"
             Hh.assert_observe_close(out["observe"], r)
             Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
             for ch in range(10):
                 Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
-            for k in ("means2D", "conics", "opacities", "colors", "features"):
-                Hh.assert_grad_close("sum:" + k, sums[k], rg[k].reshape(sums[k].shape), floor_frac=1e-4 if k == "conics" else 1e-5)
-            for k in ("shs", "opacities", "features", "means2D"):
-                Hh.assert_grad_close(k, g[k], rg[k])
+            if sums is not None:
+                for k in ("means2D", "conics", "opacities", "colors", "features"):
+                    Hh.assert_grad_close("sum:" + k, sums[k], rg[k].reshape(sums[k].shape), floor_frac=1e-4 if k == "conics" else 1e-5)
+            for k in ("shs", "opacities", "features", "means2D", "colors"):
+                if k in g and g[k] is not None:
+                    Hh.assert_grad_close(k, g[k], rg[k])
         except AssertionError as e:
             bad += 1
             gs2m_native.set_reference_binning(False)
@@ -226,7 +237,8 @@ if __name__ == "__main__":
         cubemap()
     elif "--sweep" in sys.argv:
         i = sys.argv.index("--sweep")
-        sweep(int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 and not sys.argv[i + 2].startswith("-") else 0)
+        sweep(int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 and not sys.argv[i + 2].startswith("-") else 0,
+              precomputed="--precomputed" in sys.argv)
     elif "--arbitrate" in sys.argv:
         arbitrate([int(c) for c in arg("--arbitrate").split(",")])
     elif "--pixel" in sys.argv:
