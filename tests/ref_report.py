@@ -205,9 +205,10 @@ def pixel_case(case):
     gs2m_native.set_reference_binning(refbin)
     out, _ = Hh.run_hip(sc, backward=False)
     gs2m_native.set_reference_binning(False)
-    d = np.abs(out["buffer"][0] - r.buffer[0])
+    d = np.maximum(np.abs(out["buffer"][0] - r.buffer[0]), np.abs(out["color"] - r.color).max(0))
     y, x = np.unravel_index(d.argmax(), d.shape)
-    print(f"{tag}: worst alpha-channel pixel ({x}, {y}) HIP {out['buffer'][0][y, x]:.7f} reference {r.buffer[0][y, x]:.7f} diff {d[y, x]:.3e}; quadrant ({(x % 16) // 8}, {(y % 16) // 8})")
+    print(f"{tag}: worst pixel ({x}, {y}) (alpha channel and colour): HIP alpha {out['buffer'][0][y, x]:.7f} colour {out['color'][:, y, x]} reference alpha {r.buffer[0][y, x]:.7f} "
+          f"colour {r.color[:, y, x]} diff {d[y, x]:.3e}; quadrant ({(x % 16) // 8}, {(y % 16) // 8})")
     f32 = np.float32
     tile = (y // 16) * r.tiles_x + (x // 16)
     lo_, hi_ = int(r.ranges[tile, 0]), int(r.ranges[tile, 1])
@@ -224,7 +225,7 @@ def pixel_case(case):
                 print(f"   (k={k} gid={gid} alpha*255={alpha * 255:.5f}: below the threshold)")
             continue
         contrib = alpha * float(T)
-        if abs(contrib - d[y, x]) < 0.3 * d[y, x] or alpha * 255 < 1.05:
+        if abs(contrib - d[y, x]) < 0.5 * d[y, x] or alpha * 255 < 1.05 or contrib > 0.5 * d[y, x] and alpha * 255 < 1.3:
             print(f"   k={k} gid={gid} alpha*255={alpha * 255:.5f} T={float(T):.5f} alpha*T={contrib:.3e} radius={r.radii[gid]} mean=({mx:.1f},{my:.1f}) conic=({A:.3e},{B:.3e},{C:.3e}) opacity={op:.4f}")
         if f32(T * f32(1.0 - f32(alpha))) < f32(1e-4):
             break
