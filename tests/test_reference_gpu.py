@@ -270,6 +270,35 @@ def test_heavy_tailed_scene_at_1080p_against_the_reference_build(reference, frac
         del out, g
 
 
+@pytest.mark.parametrize("scale_modifier", [0.5, 1.7])
+def test_scale_modifier_against_the_reference_build(reference, scale_modifier):
+    """GaussianRasterizationSettings.scale_modifier (the viewer's splat-size slider; 1.0 everywhere else in the tests)"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    P = 20000
+    sc = Hh.make_scene(P, 320, 200, seed=3, fc=9, scale_hi=0.05)
+    g, cam = sc["g"], sc["cam"]
+    r = reference.forward(g["means3D"].numpy(), g["opacities"].numpy(), bg=sc["bg"].numpy(), viewmatrix=cam["viewmatrix"].numpy(),
+                          projmatrix=cam["projmatrix"].numpy(), campos=cam["campos"].numpy(), W=sc["W"], H=sc["H"], tanfovx=cam["tanfovx"],
+                          tanfovy=cam["tanfovy"], sh_degree=sc["sh_degree"], feature_count=sc["fc"], features=g["features"].numpy(), shs=g["shs"].numpy(),
+                          scales=g["scales"].numpy(), rotations=g["rotations"].numpy(), scale_modifier=scale_modifier)
+    rg = reference.backward(r, sc["Gc"].numpy(), sc["Gb"].numpy())
+    st = Hh.settings_for(sc, "cuda")._replace(scale_modifier=scale_modifier)
+    gd = {k: v.cuda().requires_grad_(True) for k, v in g.items()}
+    m2 = torch.zeros(P, 4, device="cuda", requires_grad=True)
+    color, radii, observe, buffer = GaussianRasterizer(st)(gd["means3D"], m2, gd["opacities"], shs=gd["shs"], scales=gd["scales"],
+                                                           rotations=gd["rotations"], features=gd["features"])
+    ((color * sc["Gc"].cuda()).sum() + (buffer * sc["Gb"].cuda()).sum()).backward()
+    assert np.array_equal(radii.cpu().numpy(), r.radii)
+    Hh.assert_image_close("color", color.detach().cpu().numpy(), r.color, oracle_fwd=r)
+    Hh.assert_image_close("buffer[1]", buffer.detach().cpu().numpy()[1], r.buffer[1], scale=max(1.0, float(np.abs(r.buffer[1]).max())), oracle_fwd=r)
+    for k in ("scales", "means3D", "shs", "opacities", "rotations"):
+        Hh.assert_grad_close(k, gd[k].grad.cpu().numpy(), rg[k])
+    assert r.num_rendered != reference.forward(g["means3D"].numpy(), g["opacities"].numpy(), bg=sc["bg"].numpy(), viewmatrix=cam["viewmatrix"].numpy(),
+                                               projmatrix=cam["projmatrix"].numpy(), campos=cam["campos"].numpy(), W=sc["W"], H=sc["H"], tanfovx=cam["tanfovx"],
+                                               tanfovy=cam["tanfovy"], sh_degree=sc["sh_degree"], feature_count=sc["fc"], features=g["features"].numpy(),
+                                               shs=g["shs"].numpy(), scales=g["scales"].numpy(), rotations=g["rotations"].numpy(), state=False).num_rendered
+
+
 # ---- environment-map prefilters (row N2): render-utils' own kernels through the same recipe --------------------------------
 
 def _rel(a, b):
