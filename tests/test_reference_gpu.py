@@ -270,6 +270,30 @@ def test_heavy_tailed_scene_at_1080p_against_the_reference_build(reference, frac
         del out, g
 
 
+@pytest.mark.parametrize("max_degree", [0, 1, 2])
+def test_models_with_fewer_sh_bands_against_the_reference_build(reference, max_degree):
+    """a model trained with --sh_degree 0 / 1 / 2 holds (d + 1)^2 coefficients per channel, not 16: the kernels' path without the
+    LDS staging of 192-byte SH rows (csrc/preprocess.hip, gaussian_bwd.hip: SH_LDS = false)"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    P, M = 5000, (max_degree + 1) ** 2
+    sc = Hh.make_scene(P, 160, 120, seed=40 + max_degree, fc=9, scale_hi=0.05, sh_degree=max_degree)
+    sc["g"]["shs"] = sc["g"]["shs"][:, :M].contiguous()
+    r, rg = Hh.run_oracle(reference, sc)
+    out, g = Hh.run_hip(sc)
+    assert np.array_equal(out["radii"], r.radii)
+    Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
+    for k in GRADS:
+        Hh.assert_grad_close(k, g[k], rg[k])
+    assert g["shs"].shape == (P, M, 3)
+    if M > 1:  # handed over as DC + rest, the extension of this repository, such a model is refused loudly (degree-3 layout only;
+        # gaussian_renderer.render() concatenates as the reference does)
+        gd = {k: v.cuda() for k, v in sc["g"].items()}
+        with pytest.raises(RuntimeError, match="unsupported"):
+            GaussianRasterizer(Hh.settings_for(sc, "cuda"))(gd["means3D"], torch.zeros(P, 4, device="cuda"), gd["opacities"], shs=gd["shs"][:, :1].contiguous(),
+                                                             shs_rest=gd["shs"][:, 1:].contiguous(), scales=gd["scales"], rotations=gd["rotations"],
+                                                             features=gd["features"])
+
+
 @pytest.mark.parametrize("scale_modifier", [0.5, 1.7])
 def test_scale_modifier_against_the_reference_build(reference, scale_modifier):
     """GaussianRasterizationSettings.scale_modifier (the viewer's splat-size slider; 1.0 everywhere else in the tests)"""
