@@ -2,8 +2,8 @@
 through hipify-perl by oracle/ref_build/Makefile in the build container, compiled for gfx950) behind this repository's
 C shim (oracle/ref_build/ref_shim.hip).
 
-TEST INFRASTRUCTURE ONLY: only tests/ (and tools/ that report on the checker) import this module; the product package
-never does.  Needs a GPU.  `forward` / `backward` take and return the same things as oracle/oracle.py's, so the two can
+TEST INFRASTRUCTURE ONLY: only tests/ (its test modules and report scripts) and __graft_entry__ import this module; the product
+package never does.  Needs a GPU.  `forward` / `backward` take and return the same things as oracle/oracle.py's, so the two can
 stand in for each other in tests/helpers.py (numpy in, numpy out; arguments as rasterize_points.cu:28-129, 131-218
 hands them to CudaRasterizer::Rasterizer)."""
 import ctypes as C

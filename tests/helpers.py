@@ -121,7 +121,7 @@ def assert_two_stage(oracle, f, gr, hip, floor_frac=1e-5):
         assert_grad_close("sum:" + k, hip[k], ref, floor_frac=10 * floor_frac if k == "conics" else floor_frac)
     chain = oracle.backward_pergaussian(f, hip["means2D"], hip["conics"], hip["colors"])
     for k in ("means3D", "shs", "scales", "rotations"):
-        # measured: bit-identical (tools/parity_report.py); the bound leaves room for a compiler reassociating one product
+        # measured: bit-identical (tests/parity_report.py); the bound leaves room for a compiler reassociating one product
         assert_grad_close("chain:" + k, hip[k], chain[k].reshape(hip[k].shape), rel=1e-5, floor_frac=1e-6, max_exceptions=0.0)
 
 
@@ -349,7 +349,7 @@ def assert_chain_exceptions_conditioned(f, g, gr, sums=None, names=("scales", "r
     """End to end, dL/dscale and dL/drot element-wise at north_star's 1e-3 (floor: 1e-4 of the tensor's rms), max-norm
     error <= 1e-3 -- and every Gaussian that owns an element outside the element-wise bound must be ILL-CONDITIONED in
     a stated sense: either rho = det(cov2D) / (a c) <= CHAIN_RHO_MAX (a needle: measured on the random sweep,
-    tools/chain_exceptions.py, every exception has rho <= 0.024, the 1-3 % most needle-like Gaussians of its scene), or,
+    tests/chain_exceptions.py, every exception has rho <= 0.024, the 1-3 % most needle-like Gaussians of its scene), or,
     with `sums` (the HIP path's own per-Gaussian blend sums, run_hip_sums), the chain provably AMPLIFIES there: the
     relative difference of the Gaussian's outputs is at least CHAIN_AMP_MIN times the relative difference of its
     dL/dconic, dL/dmean2D sums (whose own element-wise check is assert_two_stage's half A; the median Gaussian

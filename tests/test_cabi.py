@@ -65,6 +65,11 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "gs2m_oracle" not in txt and "oracle/" not in txt, f
+    # nor do the scripts under tools/ (reports that use the checkers live in tests/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
 
 
 def test_op_fails_loudly_without_a_device():
