@@ -139,7 +139,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                         float tan_fovy, int prefiltered, int feature_count, float* out_color, int* out_radii,
                         int* out_observe, float* out_buffer, void* stream_) {
-    (void)prefiltered;
     hipStream_t s = (hipStream_t)stream_;
     const int reference_binning = g_reference_binning.load(), spin_wait = g_spin_wait.load();
     int failed_stage = 0;  // debug mode: 1 + the first stage whose kernels faulted
@@ -211,6 +210,10 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         // run, and has the binning kernels queued behind them before they finish: no idle gap.
         volatile uint32_t* land = t_pinned.p;
         land[0] = 0xFFFFFFFFu;
+        land[1] = 0u;
+        // `prefiltered`: honoured as a checked promise (preprocess.hip); the check runs ahead of the histogram kernel whose
+        // last workgroup publishes num_rendered, so its flag has landed when the wait below returns
+        if (prefiltered) gs2m_launch_prefiltered_check(P, means3D, viewmatrix, t_pinned.dev + 1, s);
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
             const SideSum sum = {acc ? g.tiles_touched : nullptr, acc, t_pinned.dev};
@@ -233,6 +236,10 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             }
         }
         if (land[0] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
+        if (prefiltered && land[1] != 0u) {  // a Gaussian behind the near plane: the reference traps the device here
+            HIP_TRY(hipStreamSynchronize(s));  // nothing of this call is left in flight when the caller frees its buffers
+            return GS2M_ERR_PREFILTERED;
+        }
         if (land[0] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // the look-back status words carry 30 value bits
         R = (int)land[0];
         if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: the side sum against the scan's own total

@@ -274,6 +274,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s);
+void gs2m_launch_prefiltered_check(int P, const float* means3D, const float* viewmatrix, uint32_t* flag, hipStream_t s);
 void gs2m_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 #ifdef __HIPCC__

@@ -71,7 +71,14 @@ __device__ __forceinline__ bool publish_partials(const float (&v)[K], float* __r
         // No release / acquire fence: at agent scope those write back and invalidate the XCD's whole L2 (which holds the
         // megabytes this kernel has just stored) once per workgroup.  The partials above are agent-scope atomic stores (written
         // through to memory), s_waitcnt vmcnt(0) holds the ticket back until they have been acknowledged, and the last workgroup
-        // reads them with agent-scope atomic loads behind the ticket's return value.
+        // reads them with agent-scope atomic loads behind the ticket's return value.  This is NOT a release / acquire pair of
+        // the HIP memory model: it is the hand-off MI355X_MICROARCH.md lists as measured-valid on gfx950 (one lane of each
+        // storing workgroup: sc1 stores, s_waitcnt vmcnt(0), agent-scope atomic add; the workgroup whose add came last loads
+        // with sc1 loads behind a workgroup barrier), so the build is pinned to that target below; -DGS2M_TICKET_FENCED
+        // selects the portable form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "publish_partials: the unfenced ticket relies on gfx950 cache behaviour (sc1 write-through); build with -DGS2M_TICKET_FENCED elsewhere"
+#endif
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_s_waitcnt(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -483,7 +490,7 @@ __global__ void __launch_bounds__(RB) mv_geo_loss_fwd_kernel(MvGeoArgs a, float*
         const bool ok = a.valid[i] != 0;
         const bool pv = ok && nz < 1.0f, av = ok && an < a.angle_threshold;
         const float gw = pv ? expf(-nz * a.decay) : 0.f;
-        v[0] += gw * nz;
+        v[0] += pv ? gw * nz : 0.f;  // the reference indexes [pixel_valid] (loss_utils.py:286): an invalid pixel's inf / NaN noise never enters the sum
         v[1] += pv ? 1.0f : 0.f;
         v[2] += av ? gw * (a.factor * an) : 0.f;
         v[3] += av ? 1.0f : 0.f;

@@ -290,7 +290,25 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
     present[idx] = vz <= 0.2f ? 0 : 1;
 }
 
+// `prefiltered` (auxiliary.h:155-158): the caller promises that no Gaussian is behind the near plane; the reference traps
+// when one is.  Launched only when the flag is set: any such Gaussian raises `flag` (a mapped pinned word the host reads
+// after its num_rendered wait).
+__global__ void prefiltered_check_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm, uint32_t* flag) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (idx < P) {
+        const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+        bad = !(vm[2] * px + vm[6] * py + vm[10] * pz + vm[14] > 0.2f);  // the complement of preprocess_kernel's test
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0)
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+void gs2m_launch_prefiltered_check(int P, const float* means3D, const float* viewmatrix, uint32_t* flag, hipStream_t s) {
+    prefiltered_check_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, viewmatrix, flag);
+}
 
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                             const float* rotations, const float* opacities, const float* shs, const float* shs_rest,

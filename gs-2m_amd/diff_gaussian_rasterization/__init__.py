@@ -112,18 +112,21 @@ class _ScratchCache(_Alloc):
 
 
 class _BinningLease:
-    """Exclusive use of one cache entry's buffer; given back when this object dies.  The autograd Function keeps it on
-    `ctx`, so the buffer is the forward's for exactly as long as its graph node lives: until the backward has run and
-    the outputs are gone, or for good while a retained graph keeps the node."""
+    """Exclusive use of one cache entry's buffer; given back when this object dies or -- sooner -- when nothing but the
+    cache references the buffer any more (_BinningCache.acquire).  The autograd Function keeps it on `ctx`: a training loop
+    that still holds the previous iteration's outputs when it renders again (train.py's `out = render(...)`) keeps that
+    graph node, hence this object, alive into the next forward although the backward has long released its saved tensors."""
 
     def __init__(self, entry):
         self.entry = entry
 
     def __del__(self):
+        # no lock: a cyclic-GC run inside acquire() (which allocates while holding the lock) may finalise a lease, and the
+        # lock is not re-entrant.  A stale lease (the entry has been taken over, `owner` is another lease) does nothing.
         e, self.entry = self.entry, None
-        if e is not None:
-            with _BinningCache._lock:
-                e.busy = False
+        if e is not None and e.owner is self:
+            e.owner = None
+            e.busy = False
 
 
 class _BinningCache:
@@ -137,24 +140,30 @@ class _BinningCache:
     stream is ordered, so the next forward on THAT stream may overwrite what the previous backward has finished with.
     Retained memory: 1.25 x the largest binning buffer per (device, stream) until release_scratch()."""
     _cache = {}
-    _lock = threading.Lock()
+    _lock = threading.RLock()
 
     def __init__(self):
         self.tensor = None
         self.busy = False
+        self.owner = None  # the lease that set `busy`
 
     @classmethod
     def acquire(cls, device, stream):
-        """-> (entry, lease); lease is None when the entry is in use."""
+        """-> (entry, lease); lease is None when the entry is in use.  In use = leased AND the buffer still referenced by
+        something other than the cache (the saved tensors of a graph whose backward has not run, or a retained graph): once
+        the backward has released them the entry is free again even if the old graph node -- and its lease -- lives on."""
         key = (torch.device(device).index, stream)
+        lease = _BinningLease(None)  # allocated outside the lock
         with cls._lock:
             e = cls._cache.get(key)
             if e is None:
                 e = cls._cache[key] = cls()
-            if e.busy:
+            if e.busy and not (e.tensor is not None and e.tensor._use_count() == 1):
                 return e, None
             e.busy = True
-        return e, _BinningLease(e)
+            e.owner = lease
+            lease.entry = e
+        return e, lease
 
     @classmethod
     def release(cls):

@@ -15,12 +15,23 @@ _ALIGN = 4  # floats: entries start on 16-B boundaries (the kernels stream SH ro
 _KEEP = 2   # arenas kept registered (and thereby alive) per producer and device
 _lock = threading.Lock()
 _registry = {}  # (producer key, device index) -> deque of the producer's latest GradArenas
+_enabled = False  # arenas are registered (and thereby kept alive) only once a reducer exists: enable()
+
+
+def enable(on=True):
+    """Start (stop) registering new arenas.  Called by gs2m_dp.GradReducer: only a reducer ever looks an arena up, and a
+    registered arena outlives its gradients (`_KEEP` per producer: ~0.65 GB at 1M Gaussians for the rasterizer's), which
+    single-GPU training should not pay for."""
+    global _enabled
+    _enabled = bool(on)
+    if not on:
+        release()
 
 
 class GradArena:
     """entries: list of (name, shape).  `self[name]` is the view; `self.layout` = [(name, offset, numel, shape)] in floats, in
     the order given -- callers put what a data-parallel step sums FIRST / ADJACENT so that it forms one contiguous range.
-    The registry holds the `_KEEP` latest arenas of every producer (`key`) per device: a registered arena's buffer is
+    Once enable() has been called (a data-parallel reducer exists) the registry holds the `_KEEP` latest arenas of every producer (`key`) per device: a registered arena's buffer is
     alive, so a tensor whose storage starts where the arena's does IS one of its views (an address cannot have been
     reused).  Older arenas drop out -- their gradients are then summed through a copy -- and gs2m_arena.release() (also
     called by diff_gaussian_rasterization.release_scratch) lets go of all of them.  Retained memory: at most `_KEEP`
@@ -40,8 +51,9 @@ class GradArena:
         # backward clone all of its gradients
         self._index = {name: (off, n, shape) for name, off, n, shape in self.layout}
         self.ptr = self.flat.untyped_storage().data_ptr()
-        with _lock:
-            _registry.setdefault((key, self.flat.device.index), collections.deque(maxlen=_KEEP)).append(self)
+        if _enabled:
+            with _lock:
+                _registry.setdefault((key, self.flat.device.index), collections.deque(maxlen=_KEEP)).append(self)
 
     def __getitem__(self, name):
         off, n, shape = self._index[name]

@@ -56,6 +56,8 @@ class GradReducer:
         self.sh_active_coeffs = sh_active_coeffs
         self.always_communicate = always_communicate  # issue the collectives at world size 1 too (tests of the RCCL path on one GPU)
         self.last_plan = []
+        import gs2m_arena
+        gs2m_arena.enable()  # from now on the producers' gradient arenas are registered (summed in place)
 
     @property
     def world_size(self):

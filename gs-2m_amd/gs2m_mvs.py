@@ -448,7 +448,7 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
         pixel_valid = valid & (pixel_noise < 1.0)
         geo_w = torch.where(pixel_valid, torch.exp(-pixel_noise * opt.mv_geo_weight_decay), 0.0).detach()
         # masked means instead of boolean-mask gathers (same values up to the summation order; no nonzero / host sync)
-        pixel_loss = (geo_w * pixel_noise * pixel_valid).sum() / pixel_valid.sum().clamp(min=1)
+        pixel_loss = torch.where(pixel_valid, geo_w * pixel_noise, 0.0).sum() / pixel_valid.sum().clamp(min=1)  # where, not *: 0 * inf = NaN
         angle_loss = (geo_w * (opt.mv_angle_factor * angle) * angle_valid).sum() / angle_valid.sum().clamp(min=1)
         w_geo_loss = opt.multi_view_geo_weight * (pixel_loss + angle_loss)
         w_ncc_map = None

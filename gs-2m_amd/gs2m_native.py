@@ -16,7 +16,9 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_raster_forward_split_sh", "gs2m_raster_backward_split_sh", "gs2m_knn_dist2",
            "gs2m_debug_layout", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
-           "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version")
+           "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_collect", "gs2m_version",
+           # include/gs2m_loss.h (round 3: the loss tail of the training iteration)
+           "gs2m_affine_mean", "gs2m_densification_stats", "gs2m_edge_gradient", "gs2m_image_loss_backward", "gs2m_image_loss_forward", "gs2m_loss_workspace_bytes", "gs2m_mv_geo_loss_backward", "gs2m_mv_geo_loss_forward", "gs2m_pbr_inputs_backward", "gs2m_pbr_inputs_forward", "gs2m_plane_loss_backward", "gs2m_plane_loss_forward", "gs2m_ssim_backward_uniform", "gs2m_tv_loss_backward", "gs2m_tv_loss_forward")
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
           "gaussian_bwd")
@@ -187,7 +189,8 @@ def lib():
     return L
 
 
-ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocation failed", -4: "unsupported size"}
+ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocation failed", -4: "unsupported size",
+          -5: "Point culled! This point should have been prefiltered (prefiltered=True and a Gaussian has view z <= 0.2; the reference traps the device here, cuda_rasterizer/auxiliary.h:155-158)"}
 
 
 class _NoGuard:

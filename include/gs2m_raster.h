@@ -53,6 +53,10 @@ extern "C" {
 #define GS2M_ERR_HIP (-2)
 #define GS2M_ERR_ALLOC (-3)
 #define GS2M_ERR_UNSUPPORTED (-4)
+/* `prefiltered` was set and a Gaussian lies behind the near plane (view z <= 0.2): the reference prints "Point culled!
+ * This point should have been prefiltered" and TRAPS the device there (cuda_rasterizer/auxiliary.h:155-158); this
+ * library reports it through the forward's return value instead and leaves the context usable. */
+#define GS2M_ERR_PREFILTERED (-5)
 /* debug mode (gs2m_set_debug): the kernels of pipeline stage `st` (order below, GS2M_NUM_STAGES) faulted */
 #define GS2M_ERR_STAGE(st) (-100 - (st))
 

@@ -3,6 +3,8 @@ import torch
 
 import gs2m_arena
 
+gs2m_arena.enable()  # what gs2m_dp.GradReducer does: without a reducer nothing is registered
+
 
 def test_lookup_finds_exact_entries_only():
     a = gs2m_arena.GradArena("cpu", [("m", (5, 3)), ("o", (5, 1)), ("sh", (5, 16, 3))], key="t1")
@@ -47,3 +49,12 @@ def test_registry_keeps_the_latest_arenas_of_a_producer_and_releases():
     assert gs2m_arena.lookup(third["x"])[0] is third
     gs2m_arena.release()
     assert gs2m_arena.lookup(third["x"]) is None
+
+
+def test_nothing_is_registered_without_a_reducer():
+    gs2m_arena.enable(False)
+    try:
+        a = gs2m_arena.GradArena("cpu", [("x", (4,))], key="t5")
+        assert gs2m_arena.lookup(a["x"]) is None, "single-GPU training must not keep arenas alive"
+    finally:
+        gs2m_arena.enable()

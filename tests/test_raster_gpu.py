@@ -161,6 +161,29 @@ def test_argument_errors():
           features=g["features"])
 
 
+def test_prefiltered_is_a_checked_promise():
+    """`prefiltered=True` (settings tuple, __init__.py:153): identical outputs while every Gaussian is in front of the near
+    plane; with one behind it the reference traps the device (auxiliary.h:155-158) -- here the forward raises and the
+    context stays usable."""
+    _require_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = Hh.make_scene(500, 96, 64, seed=12, fc=9, behind_frac=0.0)
+    g = {k: v.cuda() for k, v in sc["g"].items()}
+    m2 = torch.zeros(500, 4, device="cuda")
+    st = Hh.settings_for(sc, "cuda")
+    args = dict(shs=g["shs"], scales=g["scales"], rotations=g["rotations"], features=g["features"])
+    ref = GaussianRasterizer(st)(g["means3D"], m2, g["opacities"], **args)
+    pre = GaussianRasterizer(st._replace(prefiltered=True))(g["means3D"], m2, g["opacities"], **args)
+    for a, b in zip(ref, pre):
+        assert torch.equal(a, b)
+    bad = g["means3D"].clone()
+    bad[17, 2] = 0.1  # view z <= 0.2
+    with pytest.raises(RuntimeError, match="should have been prefiltered"):
+        GaussianRasterizer(st._replace(prefiltered=True))(bad, m2, g["opacities"], **args)
+    again = GaussianRasterizer(st)(bad, m2, g["opacities"], **args)  # the same scene without the promise renders
+    assert int(again[1][17]) == 0 and torch.isfinite(again[0]).all()
+
+
 def test_binning_artefacts_bit_exact(oracle_lib):
     """radii, tiles_touched, depth keys, the sorted (tile, depth) list, ranges and n_contrib against the
     oracle, including ties in depth (stability of both sorts)."""
