@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     __shared__ float2 s_T2[32];
     __shared__ float2 s_S2[32];
     __shared__ uint2 s_N2[32];
-    __shared__ __align__(16) float s_d[16][8];     // per survivor of the current group: 6 moments, 2 |.| sums
-    __shared__ uint32_t s_rowg[16];                // gradient-row index of each survivor of the current group
+    __shared__ __align__(16) float s_out[16][ROWF];  // the group's 16 gradient rows, assembled here and stored as whole float4s
+    __shared__ uint32_t s_rowg[16];                  // gradient-row index of each survivor of the current group
 
     const int b = blockIdx.x;
     const int tile = (b >> 5) * 8 + (b & 7);
@@ -149,7 +149,6 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     // in order, so the next group's read sees this group's write.
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
     const float halfW = 0.5f * W, halfH = 0.5f * H;
-    const float xq = (float)qx0 + 3.5f, yq = (float)qy0 + 3.5f;
 
     float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f;
     // colour . gradient dot products gc[survivor][pixel] come from the matrix pipe as well:
@@ -165,7 +164,6 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const float* gA = &s_g[4 * (j & 3) + (j >> 2)][r];  // + 16 b rows, + 4 kk columns
     uint32_t spos = 0xFFFFFFFFu;  // empty slot: behind every pixel's last contributor
     const v2f pxf2 = {qxr, qxr + 4.0f};                      // this lane's two pixel columns
-    const float cx0 = (float)r - 3.5f, cx1 = (float)r + 0.5f;  // ... relative to the quadrant centre
 
     // The quadrant's list, from its last contributor backwards: group g holds entries top - 16 g - j, j = 0..15
     // (j = 0 is the back-most).  `np` = entries up to and including the last one that contributes to any pixel of
@@ -227,16 +225,35 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         if (g_cur + 1 < ngroups) f = load_fill(e_next);
         if (g_cur + 2 < ngroups) e_next = load_entry(g_cur + 2);
     };
+    // the rows of the previous group, parked in s_out by its epilogue: 16 x ROWF / 4 float4, one per lane and round
+    int pending = 0;  // survivors of the previous group whose rows are still in LDS (wave-uniform)
+    auto flush_rows = [&]() {
+        constexpr int RQ = ROWF / 4;  // float4 per row
+#pragma unroll
+        for (int t0 = 0; t0 < 16 * RQ; t0 += GS2M_WAVE) {
+            const int t = t0 + lane, e = t / RQ, q = t - e * RQ;
+            if (t < 16 * RQ && e < pending)
+                reinterpret_cast<float4*>(row_ptr(s_rowg[e]))[q] = *reinterpret_cast<const float4*>(&s_out[e][4 * q]);
+        }
+        pending = 0;
+    };
     // one group = up to 16 survivors: 16 steps of (16 survivors x 4 pixels), then the epilogue
     auto process_group = [&](int nvalid) {
         v4f acc1 = {0.f, 0.f, 0.f, 0.f};
         float U1 = 0.f, U2 = 0.f;  // per-lane partial |.| sums over this lane's 16 pixels
-        // per-lane moments of s over its 16 pixels, per pixel column (.x: cx0, .y: cx1): sum s, sum s cy, sum s cy^2
+        // per-lane moments of s over its 16 pixels, per pixel column, about the survivor's OWN mean (dy = mean.y - pixel.y):
+        // sum s, sum s dy, sum s dy^2.  (Rounds 1-3 took them about the quadrant centre -- per-pixel constants -- and shifted
+        // them to the mean afterwards: for splats centred hundreds of pixels outside the image that shift cancels by orders of
+        // magnitude and had to be done in double; these sums are what the reference itself accumulates, backward.cu:571-592.)
         v2f m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
         auto gc_block = [&](int b) {
             v4f a = {0.f, 0.f, 0.f, 0.f};
+#ifndef GS2M_KO_GC
 #pragma unroll
             for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * GST + 4 * k], scB[k], a, 0, 0, 0);
+#else
+            a[0] = gA[(16 * b) * GST] * scB[0]; a[1] = a[0]; a[2] = a[0]; a[3] = a[0];
+#endif
             return a;
         };
         v4f gnext = gc_block(0);
@@ -244,7 +261,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll GS2M_BWDQ_UNROLL_B
         for (int b = 0; b < 4; b++) {
             const v4f gcur = gnext;
-            const float pyb = qyf + (float)(2 * b), cyb = (float)(2 * b) - 3.5f;
+            const float pyb = qyf + (float)(2 * b);
             // the block's LDS operands up front: the compiler cannot move these reads above the s_T2/s_S2 writes
             // of earlier steps on its own (it cannot see that the pixels differ), and every step would wait out
             // a full LDS latency twice
@@ -267,7 +284,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
                 const int pi = (2 * b + h) * 4 + r;
-                const float pyf = h ? pyb + 1.0f : pyb, cy = h ? cyb + 1.0f : cyb;
+                const float pyf = h ? pyb + 1.0f : pyb;
                 const float dy = sy - pyf;
                 const v2f dx = sx2 - pxf2;
                 // gs2m_power's operation order (the forward's alpha must be reproduced bit for bit)
@@ -277,23 +294,37 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f t3 = (sB2 * dx) * dy;
                 const v2f power = (-0.5f * (t1 + t2)) - t3;
                 const v2f e = power * GS2M_LOG2E;
+#ifndef GS2M_KO_TRANS
                 const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+#else
+                const v2f G = e * 0.001f;
+#endif
                 const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
                 const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
                 const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
                 const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
                 const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
                 const v2f om = 1.0f - am;
+#ifndef GS2M_KO_TRANS
                 const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+#else
+                const v2f inv = om * 1.01f;
+#endif
                 float Px = inv.x, Py = inv.y;
+#ifndef GS2M_KO_SCAN
                 row_scan_mul2(Px, Py);
+#endif
                 const v2f Pinc = {Px, Py};
                 const v2f Ti = T2[h] * Pinc;  // transmittance in front of survivor j at the two pixels
                 const v2f w = am * Ti;
                 const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
                 const v2f qv = gc * w;
                 float Sx, Sy;
+#ifndef GS2M_KO_SCAN
                 row_scan_add2(qv.x, qv.y, Sx, Sy);
+#else
+                Sx = qv.x + gc.x; Sy = qv.y + gc.y;
+#endif
                 const v2f Sinc = {Sx, Sy};
                 const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
                 const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of this file)
@@ -305,20 +336,33 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f sv = da * sg;  // s = opacity * dL/dalpha * G
                 const v2f u1 = dx * sA2 + dy * sB, u2 = cdy + dx * sB2;
                 const v2f a1 = sv * u1, a2 = sv * u2;
+#ifndef GS2M_KO_ABS
                 U1 += fabsf(a1.x); U1 += fabsf(a1.y);
                 U2 += fabsf(a2.x); U2 += fabsf(a2.y);
+#else
+                U1 += sv.x; U2 += sv.y;
+#endif
+#ifndef GS2M_KO_WG
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, gBv[2 * h], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, gBv[2 * h + 1], acc1, 0, 0, 0);
+#else
+                acc1[0] += w.x * gBv[2 * h]; acc1[1] += w.y * gBv[2 * h + 1];
+#endif
                 m0 += sv;
-                m1 = __builtin_elementwise_fma(sv, v2f{cy, cy}, m1);
-                m2 = __builtin_elementwise_fma(sv, v2f{cy * cy, cy * cy}, m2);
+                m1 = __builtin_elementwise_fma(sv, v2f{dy, dy}, m1);
+                m2 = __builtin_elementwise_fma(sv, v2f{dy * dy, dy * dy}, m2);
                 if (h == 0 && b < 3) {  // one block ahead, operands long since loaded: the result is there when the next block starts
                     v4f a = {0.f, 0.f, 0.f, 0.f};
+#ifndef GS2M_KO_GC
 #pragma unroll
                     for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
+#else
+                    a[0] = gAn[0] * scB[0]; a[1] = a[0]; a[2] = a[0]; a[3] = a[0];
+#endif
                     gnext = a;
                 }
             }
+            if (b == 0 && pending) flush_rows();  // the previous group's rows: their LDS writes are a whole block old by now
         }
         issue_next();
         // ---- per-survivor totals: add the 4 pixel rows of each survivor (lanes j, j+16, j+32, j+48) ----
@@ -332,42 +376,28 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(hab), __float_as_uint(hcd), false, false);
             return __uint_as_float(z[0]) + __uint_as_float(z[1]);  // row 0: A, row 1: C, row 2: B, row 3: D
         };
-        // moments about the quadrant centre: M0, Mx, My, Mxx, Mxy, Myy
-        const float M0 = m0.x + m0.y, Mx = cx0 * m0.x + cx1 * m0.y, My = m1.x + m1.y;
-        const float Mxx = cx0 * cx0 * m0.x + cx1 * cx1 * m0.y, Mxy = cx0 * m1.x + cx1 * m1.y, Myy = m2.x + m2.y;
-        const float R1 = reduce4(M0, My, Mx, Mxx);   // rows: M0, Mx, My, Mxx
-        const float R2 = reduce4(Mxy, U1, Myy, U2);  // rows: Mxy, Myy, U1, U2
-        gs2m_sync();
-        s_d[j][r] = R1;
-        s_d[j][4 + r] = R2;
+        // sums over this lane's 16 pixels: s, s dx, s dy, s dx^2, s dx dy, s dy^2 (dx is fixed per pixel column)
+        const v2f dxc = sx2 - pxf2;
+        const float M0 = m0.x + m0.y, Sx = dxc.x * m0.x + dxc.y * m0.y, Sy = m1.x + m1.y;
+        const float Sxx = (dxc.x * dxc.x) * m0.x + (dxc.y * dxc.y) * m0.y, Sxy = dxc.x * m1.x + dxc.y * m1.y, Syy = m2.x + m2.y;
+        // The row's eight geometry entries (backward.cu:571-592) are linear in those sums: every lane scales its OWN partial
+        // sums and the four pixel-column lanes of a survivor are added afterwards, so the totals land already final, entry r
+        // and 4 + r of the row in lane (j, r) -- no second pass by a quarter of the lanes over exchanged sums.
+        const float o0 = -halfW * (sA * Sx + sB * Sy), o1 = -halfH * (sC * Sy + sB * Sx), o2 = halfW * U1, o3 = halfH * U2;
+        const float o7 = so > 0.f ? M0 * __builtin_amdgcn_rcpf(so) : 0.f;  // sum G dL/dalpha (v_rcp: 1 ulp); opacity 0 contributes nowhere
+        const float R1 = reduce4(o0, o2, o1, o3);                               // rows: o0, o1, o2, o3
+        const float R2 = reduce4(-0.5f * Sxx, -0.5f * Syy, -0.5f * Sxy, o7);  // rows: cxx, cxy, cyy, dopacity
+        // The group's 16 rows are assembled in LDS and leave as whole float4s, 16 bytes per lane (rounds 1-3: four 4-byte
+        // stores per lane for the colour part, two 16-byte stores from a quarter of the lanes for the geometry, each with its
+        // own 64-bit address arithmetic).  One wave, in-order LDS: flush_rows() -- called from inside the NEXT group's steps,
+        // so that nothing waits for the LDS round trip -- reads what is written here.
+        s_out[j][r] = R1;
+        s_out[j][4 + r] = R2;
         if (r == 0) s_rowg[j] = row_cur;
-        gs2m_sync();
-        // ---- epilogue: lane (j, r) holds the colour / feature sums D[4r + rr][j], rr = 0..3 ----
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {  // colour / feature sums: 16 consecutive lanes own one survivor's row
-            const int i = 4 * r + rr;
-            if (i < nvalid && j < ROWF - ROW_COL) {
-                row_ptr(s_rowg[i])[ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
-            }
-        }
-        if (r == 0 && j < nvalid) {  // geometry sums of survivor j from its moments
-            const float4 m0 = *reinterpret_cast<const float4*>(&s_d[j][0]);  // M0, Mx, My, Mxx
-            const float4 m1 = *reinterpret_cast<const float4*>(&s_d[j][4]);  // Mxy, Myy, U1, U2
-            // The moments are taken about the quadrant centre; the sums the gradients need are about the Gaussian's mean, which
-            // can lie hundreds of pixels away (splats centred outside the image): xc^2 M0 - 2 xc Mx + Mxx then cancels by many
-            // orders of magnitude, and in fp32 that shift -- not the moments -- was the one place where the blend sums left the
-            // reference's per-pixel form (5 of 300 random scenes against the reference build).  The three
-            // second-order shifts are evaluated in double: a dozen instructions per survivor on a quarter of the lanes.
-            const float xc = sx - xq, yc = sy - yq;  // dx = xc - cx, dy = yc - cy
-            const float Sdx = xc * m0.x - m0.y, Sdy = yc * m0.x - m0.z;
-            const double xd = (double)xc, yd = (double)yc, M0 = (double)m0.x;
-            const float Sdxx = (float)(xd * xd * M0 - 2.0 * xd * (double)m0.y + (double)m0.w);
-            const float Sdxy = (float)(xd * yd * M0 - xd * (double)m0.z - yd * (double)m0.y + (double)m1.x);
-            const float Sdyy = (float)(yd * yd * M0 - 2.0 * yd * (double)m0.z + (double)m1.y);
-            float4* o4 = reinterpret_cast<float4*>(row_ptr(row_cur));
-            o4[0] = make_float4(-halfW * (sA * Sdx + sB * Sdy), -halfH * (sC * Sdy + sB * Sdx), halfW * m1.z, halfH * m1.w);
-            o4[1] = make_float4(-0.5f * Sdxx, -0.5f * Sdxy, -0.5f * Sdyy, m0.x != 0.f ? m0.x * __builtin_amdgcn_rcpf(so) : 0.f);  // sum G dL/dalpha (v_rcp: 1 ulp)
-        }
+        for (int rr = 0; rr < 4; rr++)  // lane (j, r) holds the colour / feature sums D[4r + rr][j]
+            if (j < ROWF - ROW_COL) s_out[4 * r + rr][ROW_COL + j] = j < NC ? acc1[rr] : 0.f;
+        pending = nvalid;
     };
 
     // Entries behind the quadrant's last contributor are never processed (backward.cu:493-494) but own a row each:
@@ -395,6 +425,8 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             row_cur = row_of(f.bin, f.below);  // one gather (the instance's offset inside its wave's range), in flight while the group's steps run
             process_group(min(16, np - 16 * g_cur));
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flush_rows();  // the last group's
     }
 }
 

@@ -18,6 +18,12 @@ _registry = {}  # (producer key, device index) -> deque of the producer's latest
 _enabled = False  # arenas are registered (and thereby kept alive) only once a reducer exists: enable()
 
 
+def _dist_up():
+    """a process group exists: a reducer may be created at any moment (and sum gradients that already exist)"""
+    d = torch.distributed
+    return d.is_available() and d.is_initialized()
+
+
 def enable(on=True):
     """Start (stop) registering new arenas.  Called by gs2m_dp.GradReducer: only a reducer ever looks an arena up, and a
     registered arena outlives its gradients (`_KEEP` per producer: ~0.65 GB at 1M Gaussians for the rasterizer's), which
@@ -51,7 +57,7 @@ class GradArena:
         # backward clone all of its gradients
         self._index = {name: (off, n, shape) for name, off, n, shape in self.layout}
         self.ptr = self.flat.untyped_storage().data_ptr()
-        if _enabled:
+        if _enabled or _dist_up():
             with _lock:
                 _registry.setdefault((key, self.flat.device.index), collections.deque(maxlen=_KEEP)).append(self)
 
