@@ -87,7 +87,11 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
         const float2 b = *reinterpret_cast<const float2*>(&q_at(buf, 1, jj));
         float4 c[KQ];
 #pragma unroll
+#ifndef GS2M_KO_FWD_CLDS
         for (int q = 0; q < KQ; q++) c[q] = q_at(buf, 2 + q, jj);
+#else
+        for (int q = 0; q < KQ; q++) c[q] = make_float4(a.x, a.y, a.z + (float)q, a.w);
+#endif
         const uint2 ec = e_at(buf, jj);
         const float dx = a.x - pxf, dy = a.y - pyf;
         const float p2 = gs2m_power(dx, dy, a.z, a.w, b.x);
@@ -102,11 +106,15 @@ __global__ void __launch_bounds__(64) blend_fwd_q_kernel(
         asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tw) : "v"(T), "s"(contrib));
         const float w = alpha * tw;
         const v2f ww = {w, w};
+#ifndef GS2M_KO_FWD_CFMA
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
             if (4 * q < NC) acc[2 * q] = __builtin_elementwise_fma(v2f{c[q].x, c[q].y}, ww, acc[2 * q]);
             if (4 * q + 2 < NC) acc[2 * q + 1] = __builtin_elementwise_fma(v2f{c[q].z, c[q].w}, ww, acc[2 * q + 1]);
         }
+#else
+        acc[0] = __builtin_elementwise_fma(v2f{c[0].x + c[1].x + c[2].x, c[0].y + c[1].y + c[2].y}, ww, acc[0]);
+#endif
         const uint32_t pos1 = ec.y;  // position in the tile list + 1 (parked that way), as the reference counts contributors
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(last_contributor) : "v"(pos1), "s"(contrib));
         if (watch) {

@@ -27,6 +27,10 @@ def test_bench_line_has_the_contract_fields():
     assert rf["kernel"] == "blend_bwd" and rf["measured"] == "timed region", "the contract workload: live bracket of the backward blend"
     assert d["render_level_ms"] > d["ms_per_step"] * 0.9 and d["train_step_ms"] > d["ms_per_step"] * 0.9  # the callers
     assert d["material_step_ms"] > d["train_step_ms"], "the material stage adds the light's prefilter and the deferred shading"
+    # the same workload on the reference's own (bit-identical) instance list, beside the default mode's subset of it
+    rb = d["reference_binning"]
+    assert d["reference_binning_ms_per_step"] == rb["ms_per_step"] > 0 and rb["num_rendered"] > d["config"]["num_rendered"]
+    assert abs(sum(d["stages_ms"].values()) - d["ms_per_step"]) < 0.25 * d["ms_per_step"], "stage totals add up to about the step"
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
 

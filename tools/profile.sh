@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
 STEPS=${STEPS:-10}
-CMD="python3 $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-caller-levels ${BENCH_ARGS:-}"
+CMD="python3 $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-caller-levels --no-reference-binning ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -- $CMD > $OUT/pmc_lds.log 2>&1

@@ -59,7 +59,8 @@ if pmc:
     for k, a in avg.items():
         role = "blend_fwd" if k.startswith("blend_fwd") else "blend_bwd" if k.startswith("blend_bwd") else k
         e = {c: a[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
-                               "SQ_LDS_IDX_ACTIVE", "SQ_WAVES") if c in a}
+                               "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                               "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE") if c in a}
         if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
             e.update(fetch_kib=a["FETCH_SIZE"], write_kib=a["WRITE_SIZE"], hbm_bytes=(2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024)
         kernels[role] = e
