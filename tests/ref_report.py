@@ -112,65 +112,22 @@ def full(c3_only=False):
         print(line)
 
 
-def sweep_scene(case):
-    """the random scene of sweep case `case` -> (scene, reference-binning flag, tag)"""
-    import random
-    rng = random.Random(77000 + case)
-    P = rng.choice([1, 3, 50, 400, 2000, 8000, 30000, 120000])
-    W, H = rng.choice([(16, 16), (31, 47), (64, 48), (130, 70), (320, 200), (333, 201), (640, 360), (97, 255), (1280, 720)])
-    fc = rng.choice([0, 1, 3, 5, 8, 9, 10])
-    deg = rng.choice([0, 1, 2, 3, 3])
-    lo = rng.choice([0.0005, 0.005, 0.02])
-    hi = max(rng.choice([0.03, 0.1, 0.5, 1.2]), 2 * lo)
-    if P >= 30000:
-        hi = min(hi, 0.1)
-    seed = rng.randrange(1 << 30)
-    refbin = rng.choice([False, True])
-    sc = Hh.make_scene(P, W, H, seed=seed, fc=fc, sh_degree=deg, scale_lo=lo, scale_hi=hi, bg=(rng.random(), rng.random(), rng.random()),
-                       behind_frac=rng.choice([0.0, 0.01, 0.3]))
-    if rng.random() < 0.3:
-        sc["g"]["opacities"] = torch.clamp(sc["g"]["opacities"] * 2.5, max=0.999)
-    return sc, refbin, f"case {case}: P={P} {W}x{H} fc={fc} deg={deg} scales=[{lo},{hi}] seed={seed} refbin={refbin}"
+sweep_scene = Hh.sweep_scene
 
 
 def sweep(n, start=0, precomputed=False):
-    """`--sweep N [START]`: N random scenes, HIP path against the reference build (radii exact, observe / images with threshold
-    proofs, blend sums and well-conditioned gradients element-wise); prints the failing cases."""
-    import gs2m_native
+    """`--sweep N [START]`: N random scenes (helpers.sweep_scene), HIP path against the reference build (helpers.check_sweep_case:
+    radii exact, observe / images with threshold proofs, blend sums and well-conditioned gradients element-wise, exceptions
+    beyond the counted budget with their threshold proof); prints the failing cases.  tests/test_reference_gpu.py runs a
+    slice of it under -m gpu."""
     bad = 0
     for case in range(start, start + n):
-        sc, refbin, tag = sweep_scene(case)
-        kw = {}
-        if precomputed and case % 2:  # precomputed colours and 3-D covariances instead of SH + scale / rotation
-            import gs2m_scene
-            P = sc["g"]["means3D"].shape[0]
-            prm = gs2m_scene.GaussianParams.from_activated(sc["g"]["means3D"], sc["g"]["shs"], sc["g"]["scales"], sc["g"]["rotations"], sc["g"]["opacities"],
-                                                           torch.full((P, 3), 0.5), torch.full((P, 1), 0.5), torch.full((P, 1), 0.5))
-            kw = dict(colors_precomp=torch.rand(P, 3, generator=torch.Generator().manual_seed(case)), cov3D_precomp=prm.get_covariance().contiguous())
-            tag += " precomputed"
         try:
-            r, rg = Hh.run_oracle(reference, sc, **kw)
-            gs2m_native.set_reference_binning(refbin)
-            out, g = Hh.run_hip(sc, **kw)
-            sums = Hh.run_hip_sums(sc) if not kw else None
-            gs2m_native.set_reference_binning(False)
-            assert np.array_equal(out["radii"], r.radii), "radii"
-            Hh.assert_observe_close(out["observe"], r)
-            Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
-            for ch in range(10):
-                Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
-            if sums is not None:
-                for k in ("means2D", "conics", "opacities", "colors", "features"):
-                    Hh.assert_grad_close("sum:" + k, sums[k], rg[k].reshape(sums[k].shape), floor_frac=1e-4 if k == "conics" else 1e-5)
-            for k in ("shs", "opacities", "features", "means2D", "colors"):
-                if k in g and g[k] is not None:
-                    Hh.assert_grad_close(k, g[k], rg[k])
+            Hh.check_sweep_case(reference, case, precomputed=precomputed and case % 2 == 1)
         except AssertionError as e:
             bad += 1
-            gs2m_native.set_reference_binning(False)
-            print("FAIL", tag, "::", str(e)[:200])
+            print("FAIL", Hh.sweep_scene(case)[2], "::", str(e)[:240])
     print(f"sweep: {n} scenes from case {start}, {bad} failing")
-
 
 
 def arbitrate(cases):

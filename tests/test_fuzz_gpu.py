@@ -7,6 +7,7 @@ with the proof that every Gaussian outside the bound is ill-conditioned (helpers
 a needle-like 2-D covariance, or a measured amplification of the sums' difference by the chain; for such splats the
 chain's 1/det^2 amplifies last-bit differences of the sums up to a thousandfold -- the reference's float atomics have
 the same spread)."""
+import os
 import random
 
 import numpy as np
@@ -18,7 +19,10 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", range(24))
+N_CASES = int(os.environ.get("GS2M_FUZZ_CASES", "100"))  # round 3 ran 24 under -m gpu and 400 once by hand; the long form is the test now
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
 def test_random_scene(oracle_lib, case):
     assert torch.cuda.is_available()
     import gs2m_native
@@ -46,7 +50,8 @@ def test_random_scene(oracle_lib, case):
         Hh.assert_image_close(f"buffer[{ch}] " + tag, out["buffer"][ch], f.buffer[ch], scale=scale, oracle_fwd=f)
     sums = Hh.run_hip_sums(sc)
     for k, v in g.items():
-        if k in ("scales", "rotations"):  # end to end: element-wise, and every exception must be an ill-conditioned Gaussian
+        if k in ("scales", "rotations", "means3D"):  # end to end: element-wise, and every exception must be an ill-conditioned Gaussian
+            # (dL/dmeans3D runs through the same 1 / det^2 chain, backward.cu:209-280: without the proof 29 of 400 scenes failed on it)
             Hh.assert_chain_exceptions_conditioned(f, g, gr, sums, names=(k,), tag=tag)
         else:
             Hh.assert_grad_close(k, v, gr[k])

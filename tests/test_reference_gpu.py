@@ -205,6 +205,23 @@ def test_hip_path_against_the_reference_build(reference, name):
     _check_hip(reference, _scene(name))
 
 
+# A slice of the long sweep (tests/ref_report.py --sweep, 1000 scenes once per round: profiles/r04_reference_sweep.txt) under
+# -m gpu: the first 52 cases plus the ones the long form has ever failed on -- 32 / 57 / 217 (threshold pixels), 89 (a
+# threshold pixel that moves the colour sums of the ~130 Gaussians behind it), 586 / 710 and 41 / 66 (thousands of splats
+# centred far outside a 16 x 16 image: the family that exposed the fp32 moment shift of rounds 1-3's backward).
+SWEEP_SLICE = sorted(set(range(52)) | {57, 66, 89, 217, 586, 710, 333, 404})
+
+
+@pytest.mark.parametrize("case", SWEEP_SLICE)
+def test_sweep_slice_against_the_reference_build(reference, case):
+    Hh.check_sweep_case(reference, case)
+
+
+@pytest.mark.parametrize("case", [1001, 1003, 1005, 1007, 1009, 1011])
+def test_sweep_slice_with_precomputed_colours_and_covariances(reference, case):
+    Hh.check_sweep_case(reference, case, precomputed=True)
+
+
 def test_hip_binning_reproduces_the_reference_builds_lists(reference):
     """reference-binning mode: radii, tiles_touched, depth keys, the sorted (tile | depth) list with ties, ranges and
     n_contrib of the HIP path against the arrays inside the reference's own state buffers"""
