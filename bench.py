@@ -219,7 +219,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms / material_step_ms")
-    ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "rs_ag"],
+                    help="auto: reduce-scatter + all-gather from 4 ranks on (every link of the xGMI mesh busy), all-reduce below")
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
                          "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
@@ -228,6 +229,10 @@ def main():
     ap.add_argument("--heavy-tail", default=None, metavar="F:K",
                     help="not the metric's workload: a fraction F of the Gaussians K times larger (splats over hundreds of tiles, as "
                          "close-ups and background blobs of real scenes have them) -- how the stages hold up off the uniform scene")
+    ap.add_argument("--views-per-rank", type=int, default=None,
+                    help="views every rank renders per step; with more than one their gradients ACCUMULATE and one reduction follows the "
+                         "last view (exact sums, no stale gradients; the collective is paid once per that many views).  Default: 1 on one "
+                         "GPU (the metric's step), 2 on several")
     ap.add_argument("--no-reference-binning", action="store_true", help="skip the second timing of the same workload in reference-binning mode")
     a = ap.parse_args()
 
@@ -266,14 +271,18 @@ def main():
     # the N-GPU workload renders cameras on a circle of radius 6 around the cloud centre (0, 0, 6), looking at
     # it, 8 positions 45 degrees apart; rank r takes position r (position 0 is the single-GPU camera at the origin).  The
     # views differ in work (instances per view): the step time is the slowest rank's.
-    ring = rank if world > 1 else (a.ring_position or 0)
-    if ring % 8 == 0:
-        cam = S.make_camera(W, H)
-    else:
+    def ring_camera(pos):
+        if pos % 8 == 0:
+            return S.make_camera(W, H)
         import math
-        th = 2.0 * math.pi * (ring % 8) / 8.0
+        th = 2.0 * math.pi * (pos % 8) / 8.0
         eye = (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th))
-        cam = S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
+        return S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
+    Vn = a.views_per_rank or (1 if world == 1 else 2)
+    # rank r, view v of a step: ring position r + v * world (world == 1: the single-GPU camera, then the ring)
+    ring = rank if world > 1 else (a.ring_position or 0)
+    cams_v = [ring_camera(ring + v * world) for v in range(Vn)]
+    cam = cams_v[0]
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
     if a.heavy_tail:
@@ -285,10 +294,10 @@ def main():
     Gc, Gb = Gc.to(dev), Gb.to(dev)
     prm = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
     means2D = torch.zeros(P, 4, device=dev, requires_grad=True)
-    st = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
-        scale_modifier=1.0, viewmatrix=cam["viewmatrix"].to(dev), projmatrix=cam["projmatrix"].to(dev), sh_degree=3,
-        campos=cam["campos"].to(dev), prefiltered=False, feature_count=fc)
+    sts = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=torch.zeros(3, device=dev),
+        scale_modifier=1.0, viewmatrix=c["viewmatrix"].to(dev), projmatrix=c["projmatrix"].to(dev), sh_degree=3,
+        campos=c["campos"].to(dev), prefiltered=False, feature_count=fc) for c in cams_v]
     empty = torch.Tensor([])
     sh_in, sh_rest = prm["shs"], None
     if a.split_sh:
@@ -297,7 +306,9 @@ def main():
     leaves = [prm["means3D"], means2D, sh_in, prm["opacities"], prm["scales"], prm["rotations"], prm["features"]]
     if sh_rest is not None:
         leaves.append(sh_rest)
-    reducer = GradReducer(mode=a.dp_mode)
+    dp_mode = ("rs_ag" if world >= 4 else "allreduce") if a.dp_mode == "auto" else a.dp_mode
+    reducer = GradReducer(mode=dp_mode)
+    V = Vn
     if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
         gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
     info = {}
@@ -307,24 +318,34 @@ def main():
         while pending:
             pending.pop(0).wait()
 
+    vv = [V]  # views per rank of the step being timed
+
     def step(pipelined=False):
         for t in leaves:
             t.grad = None
-        color, radii, observe, buffer = rasterize_gaussians(
-            prm["means3D"], means2D, sh_in, empty, prm["opacities"], prm["scales"], prm["rotations"], empty,
-            prm["features"], st, sh_rest)
-        torch.autograd.backward([color, buffer], [Gc, Gb])
+        local = None
+        for v in range(vv[0]):
+            if v:  # dL/dmeans2D is per view (densification accumulates NORMS of it, train.py:223-227): not accumulated
+                means2D.grad = None
+            color, radii, observe, buffer = rasterize_gaussians(
+                prm["means3D"], means2D, sh_in, empty, prm["opacities"], prm["scales"], prm["rotations"], empty,
+                prm["features"], sts[v], sh_rest)
+            torch.autograd.backward([color, buffer], [Gc, Gb])  # v > 0: autograd ADDS to the first view's gradients, in its arena
+            if world > 1 and vv[0] > 1:
+                with torch.no_grad():
+                    local = reducer.local_densification_stats(means2D.grad, radii, observe, into=local)
         if world > 1:
-            # The sum of this view's gradients: ONE collective over the arena the binding allocated them in (the leaves'
-            # .grad are views of it), plus the densification side channels.  Blocking form (the metric): the step ends
-            # when the sums have landed.  Pipelined form: started here, waited for right before the NEXT step's own
-            # reduction starts, so it runs on RCCL's stream beside the next view's rasterization; every step's
-            # gradients are still fully reduced, a training loop built that way applies them one step late.
+            # The sum of this step's gradients: ONE collective over the arena the binding allocated them in (the leaves'
+            # .grad are views of it; with several views per rank they hold the views' accumulated sums), plus the
+            # densification side channels.  Blocking form (the metric): the step ends when the sums have landed.
+            # Pipelined form: started here, waited for right before the NEXT step's own reduction starts, so it runs on
+            # RCCL's stream beside the next step's rasterization; every step's gradients are still fully reduced, a
+            # training loop built that way applies them one step late.
             if pipelined:
                 drain()
             # the densification side channels first: per-view norms of THIS rank's dL/dmeans2D (train.py:223-227), computed
             # before anything is summed; dL/dmeans2D itself is not part of the summed range (its sum is never used)
-            pending.append(reducer.reduce_densification_stats_async(means2D.grad, radii, observe))
+            pending.append(reducer.reduce_densification_stats_async(means2D.grad, radii, observe, local=local))
             pending.append(reducer.reduce_flat_async([t.grad for t in leaves if t is not means2D]))
             if not pipelined:
                 drain()
@@ -360,6 +381,14 @@ def main():
     blend = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
     ms_pipelined = timed(True) if world > 1 else None
+    ms_single = None
+    if world > 1 and V > 1:  # beside the accumulate mode: north_star's plain form, one view per rank and step, blocking sum
+        vv[0] = 1
+        for _ in range(2):
+            step()
+        ms_single = timed(False)
+        vv[0] = V
+        step()
 
     # untimed: per-stage breakdown of the same step
     STAGE_STEPS = 5
@@ -380,7 +409,7 @@ def main():
         for _ in range(max(3, a.warmup // 2)):
             step()
         ms_ref = timed(False)
-        ref_binning = {"ms_per_step": round(ms_ref, 4), "value": round(1e3 / ms_ref, 3),
+        ref_binning = {"ms_per_step": round(ms_ref, 4), "value": round(V * 1e3 / ms_ref, 3),
                        "num_rendered": int(info["R"]) if info["R"] is not None else -1}
         gs2m_native.lib().gs2m_set_reference_binning(0)
         for _ in range(2):
@@ -430,16 +459,18 @@ def main():
                 roof["counters"]["mfma_busy_share"] = round(ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / (ctr["GRBM_GUI_ACTIVE"] / 8.0), 4)
         out = {
             "metric": "train views/s (fwd+bwd raster) at 1M Gaussians 1080p",
-            "value": round(world * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
+            "value": round(world * V * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
                                    + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
-                                   + ("" if world == 1 else ", cameras on the 8-position ring of SURVEY.md 8(d) (rank r: position r), blocking RCCL sum of "
-                                      "the view's gradients (one in-place collective over the gradient arena) at step end")
+                                   + ("" if world == 1 else f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}), "
+                                      + (f"{V} views per rank and step whose gradients accumulate, " if V > 1 else "")
+                                      + f"blocking RCCL sum ({dp_mode}) of the step's gradients (one in-place collective over the gradient arena) at step end")
+                                   + (f" [{V} views per step, gradients accumulated]" if world == 1 and V > 1 else "")
                                    + (f" [ring position {a.ring_position}: NOT the metric's camera]" if world == 1 and a.ring_position else ""),
                        "gaussians": P, "visible": V, "num_rendered": R, "width": W, "height": H, "feature_count": fc,
-                       "parallelism": f"view-parallel x{world}"},
+                       "parallelism": f"view-parallel x{world}", "views_per_rank": V},
             "roofline": roof,
             # stage TOTALS per step (a stage with two launches per step -- ranges + quadrant lists -- counts both)
             "stages_ms": {k: round(v[0] / STAGE_STEPS, 5) for k, v in stages.items()},
@@ -449,7 +480,11 @@ def main():
             out["reference_binning"] = ref_binning
         if ms_pipelined is not None:
             out["pipelined_ms_per_step"] = round(ms_pipelined, 4)
-            out["pipelined_value"] = round(world * 1e3 / ms_pipelined, 3)
+            out["pipelined_value"] = round(world * V * 1e3 / ms_pipelined, 3)
+        out["views_per_step"] = world * V
+        if ms_single is not None:
+            out["one_view_per_rank_ms_per_step"] = round(ms_single, 4)
+            out["one_view_per_rank_value"] = round(world * 1e3 / ms_single, 3)
     if world == 1 and rank == 0:
         torch.cuda.empty_cache()
         if not a.no_caller_levels:

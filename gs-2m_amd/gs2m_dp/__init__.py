@@ -179,20 +179,31 @@ class GradReducer:
             if g is not p.grad:
                 p.grad = g
 
-    def reduce_densification_stats_async(self, viewspace_grad, radii, observe):
-        """Per-view statistics -> what a single process would have accumulated over all ranks' views; returns a
-        PendingReduce whose `.wait()` gives (grad_norm_sum (P,1), grad_abs_norm_sum (P,1), visible_count (P,1),
-        max_radii (P), observe_sum (P))."""
+    @staticmethod
+    def local_densification_stats(viewspace_grad, radii, observe, into=None):
+        """One view's densification statistics as (packed (P,4): gradient norm, |.|-gradient norm, visible, observe; radii
+        (P)), added to `into` (the same pair from the rank's earlier views of this step: sums, and the max of the radii) when
+        given -- the accumulate mode (several views per rank and step) reduces them ONCE, after the last view."""
         vis = (radii > 0)
         gn = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
         ga = torch.norm(viewspace_grad[:, 2:], dim=-1, keepdim=True) * vis[:, None]
         packed = torch.cat([gn, ga, vis[:, None].to(gn.dtype), observe[:, None].to(gn.dtype)], dim=1).contiguous()
-        mr = radii.clone()
+        if into is None:
+            return packed, radii.clone()
+        into[0].add_(packed)
+        torch.maximum(into[1], radii, out=into[1])
+        return into
+
+    def reduce_densification_stats_async(self, viewspace_grad, radii, observe, local=None):
+        """Per-view statistics -> what a single process would have accumulated over all ranks' views; returns a
+        PendingReduce whose `.wait()` gives (grad_norm_sum (P,1), grad_abs_norm_sum (P,1), visible_count (P,1),
+        max_radii (P), observe_sum (P)).  `local`: the rank's views already added up (local_densification_stats)."""
+        packed, mr = local if local is not None else self.local_densification_stats(viewspace_grad, radii, observe)
         pend = PendingReduce(None)
         if self.world_size > 1:
             pend.handles.append(dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             pend.handles.append(dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
-        pend.finish = lambda: (packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr, packed[:, 3].round().to(observe.dtype))
+        pend.finish = lambda: (packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr, packed[:, 3].round().to(torch.int32 if observe is None else observe.dtype))
         return pend
 
     def reduce_densification_stats(self, viewspace_grad, radii, observe):

@@ -82,19 +82,28 @@ def multi_view_observe_trim(gaussians, cams, pipe, bg, observe_threshold=2):
     return n
 
 
-def _reduced_densification_stats(reducer, out, vis, radii):
-    """What a single process that rendered every rank's view would have added to the densification statistics this
-    iteration (train.py:223-227, GM:569-573): sums of the per-view screen-space gradient norms over the views that
-    see the Gaussian, the number of such views, and the largest radius among the views that both see and observe it."""
-    import torch.distributed as dist
+def _view_densification_stats(out, vis, radii):
+    """One view's contribution to the densification statistics (train.py:223-227, GM:569-573): the screen-space gradient
+    norms where the view sees the Gaussian, the visibility count, and the radius where it both sees and observes it."""
     g = out["viewspace_points"].grad
     f = vis[:, None]
     packed = torch.cat([torch.where(f, torch.norm(g[:, :2], dim=-1, keepdim=True), 0.0),
                         torch.where(f, torch.norm(g[:, 2:], dim=-1, keepdim=True), 0.0), f.to(g.dtype)], dim=1).contiguous()
     mr = torch.where((out["observe"] > 0) & vis, radii, torch.zeros_like(radii)).to(torch.float32)
-    h1 = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=reducer.group, async_op=True)
-    h2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=reducer.group, async_op=True)
-    h1.wait(); h2.wait()
+    return packed, mr
+
+
+def _reduced_densification_stats(reducer, out, vis, radii, local=None):
+    """What a single process that rendered every rank's view(s) would have added to the densification statistics this
+    iteration: sums of the per-view screen-space gradient norms over the views that see the Gaussian, the number of such
+    views, and the largest radius among the views that both see and observe it.  `local`: the rank's own views already added
+    up (views_per_rank > 1); `reducer` None: no other ranks."""
+    packed, mr = local if local is not None else _view_densification_stats(out, vis, radii)
+    if reducer is not None:
+        import torch.distributed as dist
+        h1 = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=reducer.group, async_op=True)
+        h2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=reducer.group, async_op=True)
+        h1.wait(); h2.wait()
     return packed[:, 0:1], packed[:, 1:2], packed[:, 2:3], mr
 
 
@@ -180,7 +189,7 @@ def load_blender_dataset(folder, transforms="transforms_train.json", extension="
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
           lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000, alpha_masks=None,
-          white_background=False, dp=False, dp_mode="allreduce", ssim_fn=None, optimizer_cls=None, pipe=None):
+          white_background=False, dp=False, dp_mode="auto", ssim_fn=None, optimizer_cls=None, pipe=None, views_per_rank=1):
     """`dp=True`: view-parallel data parallelism over the initialised torch.distributed group: every
     rank holds the full model, an iteration renders `world_size` different views (rank r takes the r-th of the next
     `world_size` entries of the shared random view order), the parameter gradients are SUMMED over the ranks with one
@@ -189,7 +198,14 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     scene/gaussian_model.py:569-573).  Every rank then takes the same densify / prune / reset decisions -- the
     generator behind densify_and_split's torch.normal is seeded identically and consumed identically -- so the
     replicas stay bit-identical (tests/test_dp.py).  Schedules (densification, resets, stages) count iterations, i.e.
-    one iteration consumes `world_size` views."""
+    one iteration consumes `world_size` x `views_per_rank` views.
+    `views_per_rank` > 1 (with or without dp): gradient ACCUMULATION over that many views per rank and iteration -- each
+    backward adds to the gradients, the densification statistics of the rank's views are added up locally, one reduction
+    follows the last view and the optimizer steps once: the sums are exact (no gradient is applied a step late) and the
+    collective is paid once per `views_per_rank` views, which is what lets the view-parallel form scale past the point
+    where one view's gradients cost as much wire time as the view costs compute.
+    `dp_mode`: "allreduce", "rs_ag" (reduce-scatter + all-gather: every link of the xGMI mesh busy) or "auto" = rs_ag from 4
+    ranks on."""
     opt = opt or OptimizationParams()
     ssim = ssim_fn or fused_ssim
     rank, world, reducer = 0, 1, None
@@ -198,7 +214,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         from gs2m_dp import GradReducer
         assert dist.is_initialized(), "train(dp=True) needs an initialised torch.distributed process group"
         rank, world = dist.get_rank(), dist.get_world_size()
-        reducer = GradReducer(mode=dp_mode)
+        reducer = GradReducer(mode=("rs_ag" if world >= 4 else "allreduce") if dp_mode == "auto" else dp_mode)
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
     cams, gts, pts, cols, extent = scene or synthetic_scene(n_true, n_views, W, H, seed=seed, device=device)
@@ -234,82 +250,96 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
             gaussians.oneupSHdegree()
         if not stack:
             stack = torch.randperm(len(cams), generator=order).tolist()
-        if dp:  # the next `world` views of the shared order, one per rank (the order is refilled when it runs short)
-            while len(stack) < world:
-                stack = torch.randperm(len(cams), generator=order).tolist() + stack
-            mine = [stack.pop() for _ in range(world)]
-            k = mine[rank]
-        else:
-            k = stack.pop()
-        cam, gt = cams[k], gts[k]
+        # the views of this iteration: `views_per_rank` per rank (1: the reference's loop, train.py:86-97).  With more than one,
+        # every view's backward ADDS to the parameters' gradients (autograd's accumulation), the per-view densification
+        # statistics are added up locally, and ONE reduction per iteration follows the last view: exact gradient accumulation,
+        # no stale gradients -- the collective's cost is paid once per `views_per_rank` views.
+        need = world * views_per_rank
+        while len(stack) < need:
+            stack = torch.randperm(len(cams), generator=order).tolist() + stack
+        mine = [stack.pop() for _ in range(need)]
+        my_views = mine[rank * views_per_rank:(rank + 1) * views_per_rank]  # rank r: a contiguous block of the shared order
         geometry_stage = it > geometry_from_iter
         material_stage = it > material_from_iter
-        out = render(cam, gaussians, pipe, bg, geometry_stage, material_stage, sobel_normal=geometry_stage)
-        vis, radii = out["visibility_filter"], out["radii"]
-        # the loss tail as fused kernels (gs2m_losses, csrc/loss_ops.hip) on the GPU; the PyTorch expressions otherwise
-        fused_tail = out["render"].is_cuda and getattr(pipe, "fused_loss_tail", True)
-        fused_image = fused_tail and not material_stage
-        rgb = None if fused_image else out["render"].clamp(0, 1)
-        loss = fused_plane_loss(vis, gaussians, weight=opt.lambda_plane) if fused_tail else opt.lambda_plane * plane_loss(vis, gaussians)
-        if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
-            loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
-        if fused_image:  # train.py:101-120 in one pass: clamp, L1 and the edge-weighted depth-normal term
-            if geometry_stage and k not in dn_edges:  # a function of the ground-truth image only (the reference recomputes it every iteration)
-                dn_edges[k] = edge_gradient(gt)
-            rgb, Limg, _ = geometry_image_loss(out["render"], gt, out["normal_map"] if geometry_stage else None,
-                                               out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
-                                               w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0)
-            if ssim_fn is None:  # lambda (1 - ssim) as one node
-                loss = loss + Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
-            else:
-                loss = loss + Limg + opt.lambda_ssim * (1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0)))
-        elif not material_stage:  # train.py:101-115
-            Lssim = 1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
-            loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
-        if geometry_stage:
-            if fused_tail and material_stage and ssim_fn is None:
-                pass  # rides along with the shaded image's L1 below (one pass over the frame)
-            elif not fused_image:
-                if k not in dn_weights:
-                    dn_weights[k] = edge_weights(gt)
-                loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
-            if mv_scene is not None and lambda_multi_view > 0:
-                Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render,
-                                               fused=os.environ.get("GS2M_MV_OP_BY_OP") is None)  # debugging aid: the op-by-op formulation
-                loss = loss + lambda_multi_view * Lmv
-                stats.setdefault("mv_loss", []).append(float(Lmv.detach()) if torch.is_tensor(Lmv) else float(Lmv))
-        if material_stage:  # train.py:132-196
-            if k not in rays:
-                rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
-            pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
-            if fused_tail and ssim_fn is None:
-                # where(normal_mask, clamp(render_rgb^T, 0, 1), bg), its L1 to the ground truth and (geometry stage) the
-                # depth-normal term in ONE pass -- the shading's (H,W,3) output goes in as it is -- and D-SSIM as one node
-                if geometry_stage and k not in dn_edges:
+
+        def view_step(k):
+            """forward, losses and backward of view k (train.py:98-217); gradients accumulate in the parameters' .grad"""
+            cam, gt = cams[k], gts[k]
+            out = render(cam, gaussians, pipe, bg, geometry_stage, material_stage, sobel_normal=geometry_stage)
+            vis, radii = out["visibility_filter"], out["radii"]
+            # the loss tail as fused kernels (gs2m_losses, csrc/loss_ops.hip) on the GPU; the PyTorch expressions otherwise
+            fused_tail = out["render"].is_cuda and getattr(pipe, "fused_loss_tail", True)
+            fused_image = fused_tail and not material_stage
+            rgb = None if fused_image else out["render"].clamp(0, 1)
+            loss = fused_plane_loss(vis, gaussians, weight=opt.lambda_plane) if fused_tail else opt.lambda_plane * plane_loss(vis, gaussians)
+            if alpha_masks is not None:  # train.py:108-109: opacity against the foreground mask (white-background / masked datasets)
+                loss = loss + opt.lambda_alpha * torch.nn.functional.binary_cross_entropy(out["alpha_map"].clamp(0.0, 1.0), alpha_masks[k])
+            if fused_image:  # train.py:101-120 in one pass: clamp, L1 and the edge-weighted depth-normal term
+                if geometry_stage and k not in dn_edges:  # a function of the ground-truth image only (the reference recomputes it every iteration)
                     dn_edges[k] = edge_gradient(gt)
-                pbr, Limg, terms = geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"] if geometry_stage else None,
-                                                       out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
-                                                       w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0,
-                                                       mask=out["normal_mask"], background=bg)
-                Lds = dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
-                Lpbr = Limg + Lds                                               # in the graph (carries the depth-normal term too)
-                Lpbr_log = (1.0 - opt.lambda_ssim) * terms[0] + Lds.detach()    # the reference's Lpbr, for the statistics
-            else:
-                pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
-                Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
-                Lpbr_log = Lpbr
-            wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
-            if fused_tail:  # the lambdas folded into the nodes
-                Lsm = (fused_tv_loss(gt, out["roughness_map"], norm1=False, weight=lambda_smooth) + fused_tv_loss(gt, out["albedo_map"], weight=0.01)
-                       + fused_tv_loss(gt, out["normal_map"], weight_map=wn, weight=lambda_normal))
-            else:
-                Lsm = (lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
-                       + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn))
-            loss = loss + Lpbr + Lsm
-            if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
-                loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
-            stats["pbr_loss"].append(Lpbr_log.item())
-        loss.backward()
+                rgb, Limg, _ = geometry_image_loss(out["render"], gt, out["normal_map"] if geometry_stage else None,
+                                                   out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
+                                                   w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0)
+                if ssim_fn is None:  # lambda (1 - ssim) as one node
+                    loss = loss + Limg + dssim_loss(rgb.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+                else:
+                    loss = loss + Limg + opt.lambda_ssim * (1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0)))
+            elif not material_stage:  # train.py:101-115
+                Lssim = 1.0 - ssim(rgb.unsqueeze(0), gt.unsqueeze(0))
+                loss = loss + (1.0 - opt.lambda_ssim) * l1_loss(rgb, gt) + opt.lambda_ssim * Lssim
+            if geometry_stage:
+                if fused_tail and material_stage and ssim_fn is None:
+                    pass  # rides along with the shaded image's L1 below (one pass over the frame)
+                elif not fused_image:
+                    if k not in dn_weights:
+                        dn_weights[k] = edge_weights(gt)
+                    loss = loss + opt.lambda_depth_normal * depth_normal_loss(out["normal_map"], out["sobel_map"], weights=dn_weights[k])
+                if mv_scene is not None and lambda_multi_view > 0:
+                    Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render,
+                                                   fused=os.environ.get("GS2M_MV_OP_BY_OP") is None)  # debugging aid: the op-by-op formulation
+                    loss = loss + lambda_multi_view * Lmv
+                    stats.setdefault("mv_loss", []).append(float(Lmv.detach()) if torch.is_tensor(Lmv) else float(Lmv))
+            if material_stage:  # train.py:132-196
+                if k not in rays:
+                    rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
+                pkg = pbr_render(lighting, cam, rays[k], out, metallic=False)
+                if fused_tail and ssim_fn is None:
+                    # where(normal_mask, clamp(render_rgb^T, 0, 1), bg), its L1 to the ground truth and (geometry stage) the
+                    # depth-normal term in ONE pass -- the shading's (H,W,3) output goes in as it is -- and D-SSIM as one node
+                    if geometry_stage and k not in dn_edges:
+                        dn_edges[k] = edge_gradient(gt)
+                    pbr, Limg, terms = geometry_image_loss(pkg["render_rgb"], gt, out["normal_map"] if geometry_stage else None,
+                                                           out["sobel_map"] if geometry_stage else None, edge=dn_edges[k] if geometry_stage else None,
+                                                           w_l1=1.0 - opt.lambda_ssim, w_dn=opt.lambda_depth_normal if geometry_stage else 0.0,
+                                                           mask=out["normal_mask"], background=bg)
+                    Lds = dssim_loss(pbr.unsqueeze(0), gt.unsqueeze(0), opt.lambda_ssim)
+                    Lpbr = Limg + Lds                                               # in the graph (carries the depth-normal term too)
+                    Lpbr_log = (1.0 - opt.lambda_ssim) * terms[0] + Lds.detach()    # the reference's Lpbr, for the statistics
+                else:
+                    pbr = torch.where(out["normal_mask"], pkg["render_rgb"].permute(2, 0, 1).clamp(0, 1), bg[:, None, None])
+                    Lpbr = (1.0 - opt.lambda_ssim) * l1_loss(pbr, gt) + opt.lambda_ssim * (1.0 - ssim(pbr.unsqueeze(0), gt.unsqueeze(0)))
+                    Lpbr_log = Lpbr
+                wn = (0.5 * torch.tanh(8.0 * ((1.0 - out["roughness_map"]).detach() - 0.5)) + 0.5).clamp(0, 1)
+                if fused_tail:  # the lambdas folded into the nodes
+                    Lsm = (fused_tv_loss(gt, out["roughness_map"], norm1=False, weight=lambda_smooth) + fused_tv_loss(gt, out["albedo_map"], weight=0.01)
+                           + fused_tv_loss(gt, out["normal_map"], weight_map=wn, weight=lambda_normal))
+                else:
+                    Lsm = (lambda_smooth * tv_loss(gt, out["roughness_map"], norm1=False) + 0.01 * tv_loss(gt, out["albedo_map"])
+                           + lambda_normal * tv_loss(gt, out["normal_map"], weight_map=wn))
+                loss = loss + Lpbr + Lsm
+                if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
+                    loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
+                stats["pbr_loss"].append(Lpbr_log.item())
+            loss.backward()
+            return loss, out, vis, radii, fused_tail
+
+        local = None  # views_per_rank > 1: this rank's densification statistics, added up view by view
+        for k in my_views:
+            loss, out, vis, radii, fused_tail = view_step(k)
+            if views_per_rank > 1 and it <= opt.densify_until_iter:
+                with torch.no_grad():
+                    pk, mr = _view_densification_stats(out, vis, radii)
+                    local = (pk, mr) if local is None else (local[0] + pk, torch.max(local[1], mr))
         with torch.no_grad():
             # ---- train.py:219-254, in the reference's order: densification statistics and densify / prune, the
             # multi-view observe trim, THEN the opacity reduce / reset (a trim that ran after a reset would count
@@ -323,8 +353,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 if lighting is not None and material_stage:
                     reducer.reduce_parameter_grads(list(lighting.cubemap.parameters()))
             if it <= opt.densify_until_iter:
-                if dp:
-                    gn, ga, cnt, mr = _reduced_densification_stats(reducer, out, vis, radii)
+                if dp or views_per_rank > 1:
+                    gn, ga, cnt, mr = _reduced_densification_stats(reducer if dp else None, out, vis, radii, local)
                     gaussians.max_radii2D = torch.max(gaussians.max_radii2D, mr)
                     gaussians.xyz_gradient_accum += gn
                     gaussians.xyz_gradient_accum_abs += ga

@@ -49,8 +49,12 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert len(lines) == 1, "rank 0 prints ONE line"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
-    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"], "whole-job views/s"
+    # default at N > 1: two views per rank and step, gradients accumulated, ONE blocking reduction per step (exact sums)
+    assert d["config"]["views_per_rank"] == 2 and d["views_per_step"] == 4
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"], "whole-job views/s"
     assert d["pipelined_ms_per_step"] > 0 and "cpu_baseline" not in d
+    assert d["one_view_per_rank_ms_per_step"] > 0 and abs(d["one_view_per_rank_value"] - 2 * 1e3 / d["one_view_per_rank_ms_per_step"]) < 1e-2 * d["one_view_per_rank_value"]
+    assert "accumulate" in d["config"]["workload"]
     assert "collective" in d["config"]["workload"] and "ring" in d["config"]["workload"]
     rf = d["roofline"]  # small frame: either blend kernel may be the longer one; the line says which and how it was timed
     assert rf["kernel"] in ("blend_bwd", "blend_fwd") and rf["avg_launch_ms"] > 0

@@ -80,7 +80,7 @@ def test_two_rank_gradient_sum(mode):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the training loop under data parallelism: replicas must stay bit-identical
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, views_per_rank=1, iterations=12):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -122,8 +122,9 @@ def _train_worker(rank, world, port, q):
         densify_grad_threshold = 1e-7      # so that clone AND split both fire on this tiny problem
         densify_grad_abs_threshold = 1e-7
         percent_dense = 0.012
-    model, st = gs2m_train.train(iterations=12, W=W, H=H, scene=scene, device="cpu", opt=Opt(), dp=world > 1, ssim_fn=ssim,
-                                 optimizer_cls=torch.optim.Adam, pipe=pipe, trim_interval=4, geometry_from_iter=7, seed=3)
+    model, st = gs2m_train.train(iterations=iterations, W=W, H=H, scene=scene, device="cpu", opt=Opt(), dp=world > 1, ssim_fn=ssim,
+                                 optimizer_cls=torch.optim.Adam, pipe=pipe, trim_interval=4, geometry_from_iter=7, seed=3,
+                                 views_per_rank=views_per_rank)
     state = {}
     for grp in model.optimizer.param_groups:
         p = grp["params"][0]
@@ -169,6 +170,87 @@ def test_training_replicas_stay_bit_identical():
         for a, b, what in zip(s0[name], s1[name], ("param", "exp_avg", "exp_avg_sq")):
             assert a.shape == b.shape and np.array_equal(a, b), (name, what)
     assert np.array_equal(mr0, mr1) and np.array_equal(dn0, dn1)
+
+
+def _run_train(world, views_per_rank, iterations, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, views_per_rank, iterations)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res = []
+    for _ in range(600):
+        try:
+            res.append(q.get(timeout=1.0))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(res) == world:
+            break
+    assert len(res) == world
+    res.sort(key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_accumulate_mode_replicas_stay_bit_identical_and_match_one_process():
+    """gs2m_train.train(dp=True, views_per_rank=2): every rank renders TWO views per iteration, their gradients accumulate,
+    ONE reduction follows the second view, one optimizer step.  (a) 12 iterations with densify / prune / trim / reset on two
+    gloo ranks: replicas bit-identical; (b) the gradients are exact sums, not a step late: two iterations (before any
+    densification) equal what ONE process accumulating the same four views per iteration produces, up to the association of
+    the fp32 sum ((v0 + v1) + (v2 + v3) against ((v0 + v1) + v2) + v3)."""
+    port = 35500 + (os.getpid() % 2000)
+    res = _run_train(2, 2, 12, port)
+    (_, s0, mr0, dn0, n0a, n0b, t0), (_, s1, mr1, dn1, n1a, n1b, t1) = res
+    assert n0b == n1b and n0a == n1a and t0 == t1 and n0b != n0a
+    for name in s0:
+        for a, b, what in zip(s0[name], s1[name], ("param", "exp_avg", "exp_avg_sq")):
+            assert a.shape == b.shape and np.array_equal(a, b), (name, what)
+    assert np.array_equal(mr0, mr1) and np.array_equal(dn0, dn1)
+    two = _run_train(2, 2, 2, port + 1)[0]
+    one = _run_train(1, 4, 2, port + 2)[0]
+    for name in two[1]:
+        for a, b, what in zip(two[1][name], one[1][name], ("param", "exp_avg", "exp_avg_sq")):
+            assert a.shape == b.shape and np.allclose(a, b, rtol=2e-4, atol=1e-7), (name, what, float(np.abs(a - b).max()))
+    assert np.array_equal(two[3], one[3]), "visibility counts (denom) are integers: identical"
+
+
+def _acc_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gs-2m_amd"))
+    from gs2m_dp import GradReducer
+    ga = _grads_for_view(2 * rank)[0]
+    gb = _grads_for_view(2 * rank + 1)[0]
+    for k in ga:  # what autograd's accumulation does with the second view's backward
+        ga[k] += gb[k]
+    GradReducer(mode="allreduce").reduce_grads(ga)
+    q.put((rank, {k: v.numpy() for k, v in ga.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulated_gradients_equal_the_sequential_sum_bit_for_bit():
+    """two ranks x two accumulated views, one all-reduce: every rank holds (g0 + g1) + (g2 + g3) BIT FOR BIT -- the sum a
+    single process forms when it adds the views' gradients in that order (no rounding is introduced by the collective)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_acc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = [_grads_for_view(v)[0] for v in range(4)]
+    for rank, got in res:
+        for k in g[0]:
+            exp = (g[0][k] + g[1][k]) + (g[2][k] + g[3][k])
+            assert np.array_equal(got[k], exp.numpy()), (rank, k)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
