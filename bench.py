@@ -308,7 +308,7 @@ def main():
         leaves.append(sh_rest)
     dp_mode = ("rs_ag" if world >= 4 else "allreduce") if a.dp_mode == "auto" else a.dp_mode
     reducer = GradReducer(mode=dp_mode)
-    V = Vn
+    VPR = Vn  # views per rank and step
     if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
         gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
     info = {}
@@ -318,7 +318,7 @@ def main():
         while pending:
             pending.pop(0).wait()
 
-    vv = [V]  # views per rank of the step being timed
+    vv = [VPR]  # views per rank of the step being timed
 
     def step(pipelined=False):
         for t in leaves:
@@ -382,12 +382,12 @@ def main():
     gs2m_native.profile_mode(0)
     ms_pipelined = timed(True) if world > 1 else None
     ms_single = None
-    if world > 1 and V > 1:  # beside the accumulate mode: north_star's plain form, one view per rank and step, blocking sum
+    if world > 1 and VPR > 1:  # beside the accumulate mode: north_star's plain form, one view per rank and step, blocking sum
         vv[0] = 1
         for _ in range(2):
             step()
         ms_single = timed(False)
-        vv[0] = V
+        vv[0] = VPR
         step()
 
     # untimed: per-stage breakdown of the same step
@@ -409,7 +409,7 @@ def main():
         for _ in range(max(3, a.warmup // 2)):
             step()
         ms_ref = timed(False)
-        ref_binning = {"ms_per_step": round(ms_ref, 4), "value": round(V * 1e3 / ms_ref, 3),
+        ref_binning = {"ms_per_step": round(ms_ref, 4), "value": round(VPR * 1e3 / ms_ref, 3),
                        "num_rendered": int(info["R"]) if info["R"] is not None else -1}
         gs2m_native.lib().gs2m_set_reference_binning(0)
         for _ in range(2):
@@ -439,7 +439,7 @@ def main():
                 "traffic": ctr.get("hbm_bytes"),
                 "algo_bytes_per_launch": ab[dom], "avg_launch_ms": round(k_ms[dom], 5),
                 "blend_fwd_ms": round(k_ms["blend_fwd"], 5), "blend_bwd_ms": round(k_ms["blend_bwd"], 5),
-                "whole_path_GBps": round(ab["total"] / (ms * 1e-3) / 1e9, 2)}
+                "whole_path_GBps": round(VPR * ab["total"] / (ms * 1e-3) / 1e9, 2)}
         if ctr.get("SQ_WAVE_CYCLES"):
             # What the dominant kernel's waves spent their time on, from the SQ counters of the same command (separate --pmc
             # passes): shares of SQ_WAVE_CYCLES -- issuing (SQ_ACTIVE_INST_ANY), stalled at issue on a dependency or a busy
@@ -459,18 +459,18 @@ def main():
                 roof["counters"]["mfma_busy_share"] = round(ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / (ctr["GRBM_GUI_ACTIVE"] / 8.0), 4)
         out = {
             "metric": "train views/s (fwd+bwd raster) at 1M Gaussians 1080p",
-            "value": round(world * V * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
+            "value": round(world * VPR * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
                                    + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
                                    + ("" if world == 1 else f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}), "
-                                      + (f"{V} views per rank and step whose gradients accumulate, " if V > 1 else "")
+                                      + (f"{VPR} views per rank and step whose gradients accumulate, " if VPR > 1 else "")
                                       + f"blocking RCCL sum ({dp_mode}) of the step's gradients (one in-place collective over the gradient arena) at step end")
-                                   + (f" [{V} views per step, gradients accumulated]" if world == 1 and V > 1 else "")
+                                   + (f" [{VPR} views per step, gradients accumulated]" if world == 1 and VPR > 1 else "")
                                    + (f" [ring position {a.ring_position}: NOT the metric's camera]" if world == 1 and a.ring_position else ""),
                        "gaussians": P, "visible": V, "num_rendered": R, "width": W, "height": H, "feature_count": fc,
-                       "parallelism": f"view-parallel x{world}", "views_per_rank": V},
+                       "parallelism": f"view-parallel x{world}", "views_per_rank": VPR},
             "roofline": roof,
             # stage TOTALS per step (a stage with two launches per step -- ranges + quadrant lists -- counts both)
             "stages_ms": {k: round(v[0] / STAGE_STEPS, 5) for k, v in stages.items()},
@@ -480,8 +480,8 @@ def main():
             out["reference_binning"] = ref_binning
         if ms_pipelined is not None:
             out["pipelined_ms_per_step"] = round(ms_pipelined, 4)
-            out["pipelined_value"] = round(world * V * 1e3 / ms_pipelined, 3)
-        out["views_per_step"] = world * V
+            out["pipelined_value"] = round(world * VPR * 1e3 / ms_pipelined, 3)
+        out["views_per_step"] = world * VPR
         if ms_single is not None:
             out["one_view_per_rank_ms_per_step"] = round(ms_single, 4)
             out["one_view_per_rank_value"] = round(world * 1e3 / ms_single, 3)
