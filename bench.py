@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms / material_step_ms")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "rs_ag"],
                     help="auto: reduce-scatter + all-gather from 4 ranks on (every link of the xGMI mesh busy), all-reduce below")
+    ap.add_argument("--camera-ring", action="store_true",
+                    help="N > 1: the 8-position camera ring of SURVEY.md 8(d) (45 degrees apart: the views differ in work by up to 1.6x, "
+                         "position k costs 1.24-2.03 ms) instead of the default equal-work arc (the single-GPU camera moved 0.4 degrees per "
+                         "view around the cloud centre: per-GPU work stays what it is at N = 1, i.e. weak scaling)")
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
                          "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
@@ -278,10 +282,17 @@ def main():
         th = 2.0 * math.pi * (pos % 8) / 8.0
         eye = (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th))
         return S.look_at_camera(W, H, eye, (0.0, 0.0, 6.0))
+    def arc_camera(k):  # the single-GPU camera moved k x 0.4 degrees on the circle around the cloud centre: the same work per view
+        if k == 0:
+            return S.make_camera(W, H)
+        import math
+        th = math.radians(0.4 * k)
+        return S.look_at_camera(W, H, (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th)), (0.0, 0.0, 6.0))
     Vn = a.views_per_rank or (1 if world == 1 else 2)
-    # rank r, view v of a step: ring position r + v * world (world == 1: the single-GPU camera, then the ring)
-    ring = rank if world > 1 else (a.ring_position or 0)
-    cams_v = [ring_camera(ring + v * world) for v in range(Vn)]
+    # rank r, view v of a step: camera r + v * world of the arc (default) or of the ring; world == 1: the single-GPU camera first
+    use_ring = a.camera_ring or (world == 1 and a.ring_position is not None)
+    first = rank if world > 1 else (a.ring_position or 0)
+    cams_v = [(ring_camera if use_ring else arc_camera)(first + v * world) for v in range(Vn)]
     cam = cams_v[0]
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
@@ -464,7 +475,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
                                    + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
-                                   + ("" if world == 1 else f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}), "
+                                   + ("" if world == 1 else (f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}: the views differ in work), " if use_ring else
+                                                             f", equal-work cameras (the single-GPU camera moved 0.4 degrees per view around the cloud centre; rank r, view v: camera r + v x {world}), ")
                                       + (f"{VPR} views per rank and step whose gradients accumulate, " if VPR > 1 else "")
                                       + f"blocking RCCL sum ({dp_mode}) of the step's gradients (one in-place collective over the gradient arena) at step end")
                                    + (f" [{VPR} views per step, gradients accumulated]" if world == 1 and VPR > 1 else "")

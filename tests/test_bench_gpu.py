@@ -55,7 +55,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["pipelined_ms_per_step"] > 0 and "cpu_baseline" not in d
     assert d["one_view_per_rank_ms_per_step"] > 0 and abs(d["one_view_per_rank_value"] - 2 * 1e3 / d["one_view_per_rank_ms_per_step"]) < 1e-2 * d["one_view_per_rank_value"]
     assert "accumulate" in d["config"]["workload"]
-    assert "collective" in d["config"]["workload"] and "ring" in d["config"]["workload"]
+    assert "collective" in d["config"]["workload"] and "equal-work cameras" in d["config"]["workload"]
     rf = d["roofline"]  # small frame: either blend kernel may be the longer one; the line says which and how it was timed
     assert rf["kernel"] in ("blend_bwd", "blend_fwd") and rf["avg_launch_ms"] > 0
     assert rf["measured"] == ("timed region" if rf["kernel"] == "blend_bwd" else "stage pass (untimed, same step)")
