@@ -100,6 +100,13 @@ namespace {
 // -- a wave with n instances owns at most 4 n rows, so the ranges cannot overlap and need no prefix sum over the waves
 // (the row scratch is sized for 4 R rows anyway).  So the rows of every Gaussian are one dense run and the
 // per-Gaussian sum streams them (gaussian_bwd.hip).
+// BIG SPLATS (round 4).  A Gaussian over hundreds of tiles (a close-up, a background blob) used to be walked by its one wave,
+// 64 tiles per step, while the wave's other 63 Gaussians waited: a thousand such splats doubled this kernel's time.  Gaussians
+// with at least GS2M_BIG_TILES tiles are now left out of the wave's own loop and expanded afterwards by ALL FOUR waves of the
+// workgroup together (64-instance chunks dealt round the waves: tests and key / value stores in a first pass, chunk totals
+// scanned in LDS, first-row numbers in a second pass that reads the masks back).  Their rows follow the wave's small rows
+// inside the wave's range -- small Gaussians in lane order from row 4 x (first slot), then the big ones in lane order --
+// and sorted_rows carries GS2M_ROWS_BIG for them, which row_reduce_dense_kernel (gaussian_bwd.hip) reads the same way.
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint32_t* __restrict__ sorted_gid,
                                                    const uint32_t* __restrict__ sorted_tt,
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
@@ -110,9 +117,15 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
+    __shared__ uint32_t s_off[4][GS2M_WAVE];  // first emission slot of the Gaussian
+    __shared__ uint32_t s_cnt[4][GS2M_WAVE];  // its instances
     __shared__ float4 s_geo[4][GS2M_WAVE];   // x, y, A, B
     __shared__ float2 s_ct[4][GS2M_WAVE];    // C, t2
     __shared__ uint32_t s_rc[4][GS2M_WAVE];  // gradient rows per Gaussian
+    __shared__ unsigned long long s_bigmask[4];  // per wave: lanes whose Gaussian is big
+    __shared__ uint32_t s_base4[4], s_smallrows[4];
+    __shared__ uint32_t s_ctot[1024];  // rows per 64-instance chunk of the big Gaussian being expanded, then their exclusive prefix
+    __shared__ uint32_t s_round_total;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
@@ -135,52 +148,113 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
         s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
     }
-    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
+    const bool big = cnt >= GS2M_BIG_TILES;
+    const uint32_t lcnt = big ? 0u : cnt;  // instances the wave expands itself
+    const uint32_t incl = wave_inclusive_scan_u32(lcnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
-    s_pref[wave][lane] = incl - cnt;
+    s_pref[wave][lane] = incl - lcnt;
     s_gid[wave][lane] = gid;
     s_rmin[wave][lane] = rmin;
     s_rw[wave][lane] = rw;
+    s_off[wave][lane] = off;
+    s_cnt[wave][lane] = cnt;
     s_rc[wave][lane] = 0u;
+    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
+    if (lane == 0) { s_bigmask[wave] = bigmask; s_base4[wave] = base; }
     gs2m_sync();
-    uint32_t rows_run = 0;  // gradient rows of the wave's instances so far
+    // tile and quadrant-hit mask of instance t of the Gaussian parked at [w][lo]; writes its key / value at `slot`
+    auto expand = [&](int w, int lo, uint32_t t, uint32_t slot) -> uint32_t {
+        const uint32_t rwid = s_rw[w][lo];
+        const uint32_t ry = t / rwid, rx = t - ry * rwid;
+        const uint32_t rm = s_rmin[w][lo];
+        const uint32_t tx = (rm & 0xFFFFu) + rx, ty = (rm >> 16) + ry;
+        const float4 a = s_geo[w][lo];
+        const float2 ct = s_ct[w][lo];
+        const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
+        uint32_t mask = gs2m_reaches_quads(a.x, a.y, a.z, a.w, ct.x, ct.y, (float)px0, (float)py0);
+        // quadrants outside the image have no pixels: no list entry, no gradient row
+        if (px0 + 8 >= W) mask &= 0x5u;
+        if (py0 + 8 >= H) mask &= 0x3u;
+        keys_out[slot] = ty * (uint32_t)tiles_x + tx;
+        vals_out[slot] = s_gid[w][lo] | (mask << GS2M_GID_BITS);
+        return mask;
+    };
+    uint32_t rows_run = 0;  // gradient rows of the wave's own (small) instances so far
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
         const uint32_t j = k + lane;
-        uint32_t pc = 0;
+        uint32_t pc = 0, slot = 0;
         if (j < total) {
             int lo = 0;
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
-                if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always
+                if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always (a big Gaussian has an empty range: never found)
             const uint32_t t = j - s_pref[wave][lo];
-            const uint32_t w = s_rw[wave][lo];
-            const uint32_t ry = t / w, rx = t - ry * w;
-            const uint32_t rm = s_rmin[wave][lo];
-            const uint32_t tx = (rm & 0xFFFFu) + rx, ty = (rm >> 16) + ry;
-            uint32_t val = s_gid[wave][lo];
-            {
-                const float4 a = s_geo[wave][lo];
-                const float2 ct = s_ct[wave][lo];
-                const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
-                uint32_t mask = gs2m_reaches_quads(a.x, a.y, a.z, a.w, ct.x, ct.y, (float)px0, (float)py0);
-                // quadrants outside the image have no pixels: no list entry, no gradient row
-                if (px0 + 8 >= W) mask &= 0x5u;
-                if (py0 + 8 >= H) mask &= 0x3u;
-                val |= mask << GS2M_GID_BITS;
-                pc = (uint32_t)__popc(mask);
-                if (pc) atomicAdd(&s_rc[wave][lo], pc);
-            }
-            keys_out[base + j] = ty * (uint32_t)tiles_x + tx;
-            vals_out[base + j] = val;
+            slot = s_off[wave][lo] + t;
+            pc = (uint32_t)__popc(expand(wave, lo, t, slot));
+            if (pc) atomicAdd(&s_rc[wave][lo], pc);
         }
         {
             const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
             // the instance's first gradient row: the wave's range starts at row 4 x (its first emission slot)
-            if (j < total) inst_obs[base + j] = 4u * base + rows_run + pin - pc;
+            if (j < total) inst_obs[slot] = 4u * base + rows_run + pin - pc;
             rows_run += __shfl(pin, 63, 64);
         }
     }
-    if (i < P) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
+    if (i < P && !big) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
+    if (lane == 0) s_smallrows[wave] = rows_run;
+    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case)
+    // ---- the workgroup's big Gaussians, one after the other, all four waves on each ----
+    for (int w = 0; w < 4; w++) {
+        unsigned long long m = s_bigmask[w];
+        uint32_t bigrows = 0;  // rows of wave w's earlier big Gaussians
+        while (m != 0ull) {
+            const int lo = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t bcnt = s_cnt[w][lo], boff = s_off[w][lo];
+            const uint32_t first_row = 4u * s_base4[w] + s_smallrows[w] + bigrows;
+            const uint32_t chunks = (bcnt + GS2M_WAVE - 1) / GS2M_WAVE;
+            uint32_t done_rows = 0;  // rows of the rounds before this one
+            for (uint32_t c0 = 0; c0 < chunks; c0 += 1024) {  // rounds of at most 1024 chunks (s_ctot)
+                const uint32_t c1 = min(chunks, c0 + 1024u);
+                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // first pass: tests, keys and values, rows per chunk
+                    const uint32_t t = c * GS2M_WAVE + lane;
+                    uint32_t pc = t < bcnt ? (uint32_t)__popc(expand(w, lo, t, boff + t)) : 0u;
+                    pc = wave_inclusive_scan_u32(pc, lane);
+                    if (lane == 63) s_ctot[c - c0] = pc;
+                }
+                gs2m_sync();
+                if (wave == 0) {  // exclusive prefix over the round's chunk totals, 16 per lane
+                    uint32_t v[16], sum = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const uint32_t idx = lane * 16 + e;
+                        v[e] = idx < c1 - c0 ? s_ctot[idx] : 0u;
+                        sum += v[e];
+                    }
+                    const uint32_t inc = wave_inclusive_scan_u32(sum, lane);
+                    uint32_t run = inc - sum;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const uint32_t idx = lane * 16 + e;
+                        if (idx < c1 - c0) s_ctot[idx] = run;
+                        run += v[e];
+                    }
+                    if (lane == 63) s_round_total = inc;
+                }
+                gs2m_sync();
+                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // second pass: first rows (the masks are read back: this thread wrote them)
+                    const uint32_t t = c * GS2M_WAVE + lane;
+                    const uint32_t pc = t < bcnt ? (uint32_t)__popc(vals_out[boff + t] >> GS2M_GID_BITS) : 0u;
+                    const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
+                    if (t < bcnt) inst_obs[boff + t] = first_row + done_rows + s_ctot[c - c0] + pin - pc;
+                }
+                done_rows += s_round_total;
+                gs2m_sync();  // s_ctot is rewritten by the next round / the next Gaussian
+            }
+            if (threadIdx.x == 0) sorted_rows[blockIdx.x * 256 + w * GS2M_WAVE + lo] = done_rows | GS2M_ROWS_BIG;
+            bigrows += done_rows;
+        }
+    }
 }
 
 // identifyTileRanges (rasterizer_impl.cu:108-129) on the sorted tile ids.

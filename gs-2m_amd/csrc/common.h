@@ -28,6 +28,11 @@
 // the sorted values carry the instance's quadrant-hit mask above the Gaussian id
 #define GS2M_GID_BITS 28
 #define GS2M_GID_MASK 0x0FFFFFFFu
+// A Gaussian with at least this many tile instances is "big": emit_kernel expands it with the whole workgroup and
+// row_reduce_dense_kernel sums its rows with the whole workgroup; its entry of GeomState::sorted_rows carries GS2M_ROWS_BIG
+// (rows < 2^31: num_rendered < 2^29 whenever a big Gaussian exists is checked by the forward)
+#define GS2M_BIG_TILES 512u
+#define GS2M_ROWS_BIG 0x80000000u
 
 // per tile-instance partial-gradient row produced by the blend backward (floats):
 // 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature

@@ -359,20 +359,36 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
     constexpr int MAXQ = RQ;
     __shared__ float4 s_row[4][GS2M_WAVE * MAXQ];  // one window: 64 rows x rq float4, row-major
     __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
+    __shared__ uint32_t s_bigrow[4][GS2M_WAVE], s_bigcnt[4][GS2M_WAVE], s_biggid[4][GS2M_WAVE];
+    __shared__ unsigned long long s_bigmask[4];
+    __shared__ float4 s_part[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t cnt = 0, gid = 0xFFFFFFFFu;
+    uint32_t cnt = 0, gid = 0xFFFFFFFFu, bigcnt = 0;
     if (i < P) {
         cnt = sorted_rows[i];
         gid = sorted_gid[i];
     }
+    // big Gaussians (binning.hip: GS2M_ROWS_BIG): their rows follow the wave's small rows; this wave's stream leaves them out
+    // and the whole workgroup sums them afterwards
+    const bool big = (cnt & GS2M_ROWS_BIG) != 0u;
+    if (big) {
+        bigcnt = cnt & ~GS2M_ROWS_BIG;
+        cnt = 0;
+    }
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's Gaussians
+    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's (small) Gaussians
+    const uint32_t bincl = wave_inclusive_scan_u32(bigcnt, lane);
     // the wave's rows start at 4 x the emission offset of its first Gaussian (binning.hip: emit_kernel)
     const uint32_t wb = (i >> 6) <= ((P - 1) >> 6) ? 4u * sorted_off[(i >> 6) << 6] : 0u;
     s_excl[wave][lane] = incl - cnt;
     s_cnt[wave][lane] = cnt;
-    s_gidw[wave][lane] = gid;
+    s_gidw[wave][lane] = big ? 0xFFFFFFFFu : gid;  // a big Gaussian's sum is not written by the stream below
+    s_bigrow[wave][lane] = big ? wb + total + (bincl - bigcnt) : 0u;  // first row of a big Gaussian
+    s_bigcnt[wave][lane] = bigcnt;
+    s_biggid[wave][lane] = gid;
+    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
+    if (lane == 0) s_bigmask[wave] = bigmask;
     constexpr int rq = RQ;
     const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
     const bool worker = g < G;
@@ -468,6 +484,47 @@ __global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint
         load_window(w + 4, a1);
         if (w + 2 <= nwin) consume(w + 2, a2);
         load_window(w + 5, a2);
+    }
+    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case)
+    // ---- big Gaussians: thousands of rows each (a splat over hundreds of tiles).  One wave streaming such a run with three
+    // windows in flight took 75 us per Gaussian (a thousand of them: +0.16 ms on this kernel); here the whole workgroup sums
+    // it, NT threads x 8 float4 in flight.  Thread t < NT takes float4 t, t + NT, ... of the run -- NT is a multiple of the
+    // row's float4 count, so a thread stays on one channel quad -- and the partials are added in thread order: a fixed order.
+    constexpr int NT = (256 / rq) * rq;  // threads that take part (255 at rq = 5)
+    const int tid = threadIdx.x;
+    for (int w2 = 0; w2 < 4; w2++) {
+        unsigned long long m = s_bigmask[w2];
+        while (m != 0ull) {
+            const int lo = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t nrows = s_bigcnt[w2][lo];
+            const float4* r4b = reinterpret_cast<const float4*>(rows) + (size_t)s_bigrow[w2][lo] * rq;
+            const uint32_t nq4 = nrows * (uint32_t)rq;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < NT) {
+                for (uint32_t q0 = (uint32_t)tid; q0 < nq4; q0 += 8u * NT) {
+                    float4 v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint32_t q = q0 + (uint32_t)e * NT;
+                        v[e] = q < nq4 ? r4b[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+                }
+            }
+            s_part[tid] = acc;
+            gs2m_sync();
+            if (tid < rq) {  // channel quad tid: the partials of threads tid, tid + rq, ... in that order
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = tid; k < NT; k += rq) {
+                    const float4 v = s_part[k];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                reinterpret_cast<float4*>(sums + (size_t)s_biggid[w2][lo] * rowf)[tid] = t;
+            }
+            gs2m_sync();
+        }
     }
 }
 

@@ -85,6 +85,26 @@ def test_many_instances_per_gaussian(oracle_lib):
     assert f.tiles_touched.max() > 128 and f.num_rendered > 20000
 
 
+@pytest.mark.parametrize("refbin", [False, True])
+def test_big_splats_take_the_workgroup_paths(oracle_lib, refbin):
+    """Gaussians with at least GS2M_BIG_TILES = 512 tile instances (here: screen-filling splats on a 48 x 27 tile image, several
+    per emit wave, next to thousands of small ones): expanded by the whole workgroup in emit_kernel, their rows after the
+    wave's small rows, summed by the whole workgroup in row_reduce_dense_kernel -- every check of the ordinary scenes, in both
+    binning modes, plus bitwise reproducibility of the gradients (fixed summation orders in the cooperative paths too)."""
+    _require_gpu()
+    import gs2m_native
+    sc = Hh.make_scene(6000, 768, 432, seed=31, fc=9, scale_lo=0.003, scale_hi=0.03, bg=(0.05, 0.1, 0.2))
+    big = torch.rand(6000, generator=torch.Generator().manual_seed(4)) < 0.02
+    sc["g"]["scales"] = torch.where(big[:, None], sc["g"]["scales"] * 60.0, sc["g"]["scales"])
+    gs2m_native.set_reference_binning(refbin)
+    f, out = _check(oracle_lib, sc)
+    assert (f.tiles_touched >= 512).sum() >= 20, "the scene is meant to hold big Gaussians"
+    a = Hh.run_hip_sums(sc)
+    b = Hh.run_hip_sums(sc)
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
 def test_dense_scene_terminates(oracle_lib):
     """many opaque layers: exercises T < 1e-4 termination, n_contrib < list length, block early-out."""
     _require_gpu()
