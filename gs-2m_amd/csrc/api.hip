@@ -261,21 +261,19 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (R > 0) {
         {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the per-instance observe counts
             StageTimer t(ST_EMIT, s, &failed_stage);
-            ZeroJobs zj = {{nullptr, nullptr, reinterpret_cast<uint32_t*>(im.ranges)}, {0, 0, tiles * 2}};
+            ZeroJobs zj = {{nullptr, nullptr, im.ranges_raw}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
             gs2m_launch_emit(P, width, height, tiles_x, g, b, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);
+            // the last pass also records every tile's range (identifyTileRanges, rasterizer_impl.cu:108-129)
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
-                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s));
-        }
-        {
-            StageTimer t(ST_RANGES, s, &failed_stage);
-            gs2m_launch_ranges(R, b, im, s);
+                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, SideSum{nullptr, nullptr, nullptr},
+                                          im.ranges_raw));
         }
     } else {
-        HIP_TRY(gs2m_zero_async(im.ranges, tiles * sizeof(uint2), s));
+        HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
     }
     DEBUG_CHECK();
     {

@@ -72,6 +72,7 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     im.final_T = (float*)take(N * 4);
     im.n_contrib = (uint32_t*)take(N * 4);
     im.ranges = (uint2*)take(tiles * sizeof(uint2));
+    im.ranges_raw = (uint32_t*)take(tiles * 2 * sizeof(uint32_t));
     im.qcount = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.qlast = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.total_bytes = off + GS2M_ALIGN;
@@ -257,23 +258,6 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     }
 }
 
-// identifyTileRanges (rasterizer_impl.cu:108-129) on the sorted tile ids.
-__global__ void ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L) return;
-    const uint32_t cur = tile_keys[idx];
-    if (idx == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = tile_keys[idx - 1];
-        if (cur != prev) {
-            ranges[prev].y = idx;
-            ranges[cur].x = idx;
-        }
-    }
-    if (idx == L - 1) ranges[cur].y = L;
-}
-
 // Second binning level: the sorted list of a 16x16 tile -> four order-preserving lists, one per 8x8 quadrant,
 // holding only the instances that can reach the quadrant with alpha >= 1/255 (the exact ellipse-vs-rectangle
 // test of common.h, evaluated by emit_kernel<true>, whose 4-bit result arrives above the Gaussian id in the sorted
@@ -282,13 +266,19 @@ __global__ void ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uin
 // are skipped anyway, no tests, no ballot walks.  Entries keep the position in the tile list, so n_contrib
 // (a tile-list position, as in the reference) and the gradient-row addressing stay what they were.
 // One workgroup per tile; 256 instances per step, one per thread.
-__global__ void __launch_bounds__(256) quad_lists_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+// Also identifyTileRanges (rasterizer_impl.cu:108-129): the tile sort's last pass has recorded where every tile's run of
+// instances starts and ends (radix_sort.hip: range_raw); this kernel writes ranges[tile] from it ((0, 0) for an untouched tile,
+// as the reference's memset leaves it) -- rounds 1-3 ran a kernel over all R sorted keys for that.
+__global__ void __launch_bounds__(256) quad_lists_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ point_list,
                                                          uint2* __restrict__ qlist, uint32_t* __restrict__ qcount) {
     // 512 instances per step, two per thread (k and k + 256)
     constexpr int SLOTS = 2;
     __shared__ uint32_t s_cnt[2][SLOTS][4][4];  // [parity][slot][wave][quadrant]
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint2 range = ranges[tile];
+    const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
+    const uint2 range = raw.y != 0u ? make_uint2(~raw.x, raw.y) : make_uint2(0u, 0u);
+    if (tid == 0) ranges[tile] = range;
     const int len = (int)(range.y - range.x);
     uint2* out = qlist + (size_t)4 * range.x;
     uint32_t run[4] = {0u, 0u, 0u, 0u};
@@ -357,11 +347,8 @@ hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s) {
-    if (R > 0) ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, b.tile_keys, im.ranges);
-}
 void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
                             const ImageState& im, hipStream_t s) {
     (void)W; (void)H; (void)g;
-    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges, b.point_list, b.qlist, im.qcount);
+    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges_raw, im.ranges, b.point_list, b.qlist, im.qcount);
 }

@@ -76,7 +76,8 @@ struct BinningState {
 struct ImageState {
     float* final_T;      // N
     uint32_t* n_contrib; // N
-    uint2* ranges;       // tiles
+    uint2* ranges;       // tiles (written by quad_lists_kernel from ranges_raw)
+    uint32_t* ranges_raw; // tiles * 2: per tile {~first position, last position + 1} as atomicMax targets of the tile sort's last pass; 0, 0 = untouched
     uint32_t* qcount;    // tiles * 4: entries in each quadrant list
     uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;
@@ -239,9 +240,12 @@ struct SideSum {
     uint32_t* acc;
     uint32_t* landing;
 };
+// `range_raw` (optional): the LAST pass also records, per full key value k, where its run of equal keys starts and ends in the
+// sorted output: atomicMax(range_raw[2k], ~first position), atomicMax(range_raw[2k + 1], last position + 1) -- zero before the
+// call; identifyTileRanges (rasterizer_impl.cu:108-129) without a kernel of its own.
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideSum sum = SideSum{nullptr, nullptr, nullptr});
+                                 SideSum sum = SideSum{nullptr, nullptr, nullptr}, uint32_t* range_raw = nullptr);
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 size_t gs2m_scan_temp_bytes(size_t n);
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
@@ -260,7 +264,6 @@ void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, cons
 void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
-void gs2m_launch_ranges(int R, const BinningState& b, const ImageState& im, hipStream_t s);
 void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
                             const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

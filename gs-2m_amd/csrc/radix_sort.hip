@@ -148,7 +148,7 @@ template <int BITS>
 __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ ghist, uint32_t* ticket,
-    uint32_t* status /* [tiles][256] */) {
+    uint32_t* status /* [tiles][256] */, uint32_t* range_raw) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t s_cnt[4][BINS];  // per-wave digit counters, later per-wave local bases
     __shared__ uint32_t s_gbase[256];    // global position of local index i with digit d: s_gbase[d] + i
@@ -271,13 +271,20 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
             const uint32_t pos = s_gbase[(kk >> shift) & (BINS - 1)] + i;
             keys_out[pos] = kk;
             vals_out[pos] = s_val[i];
+            if (range_raw != nullptr) {
+                // the last pass of the sort: equal full keys are contiguous in the reordered tile (stable passes), so the
+                // elements at the ends of a run know where the run begins / ends in the output; runs of one key in several
+                // workgroup tiles combine through the atomics
+                if (i == 0 || s_key[i - 1] != kk) atomicMax(&range_raw[2 * kk], ~pos);
+                if (i + 1 == tile_count || s_key[i + 1] != kk) atomicMax(&range_raw[2 * kk + 1], pos + 1u);
+            }
         }
     }
 }
 
 template <int BITS>
 void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
-                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s) {
+                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s, uint32_t* range_raw) {
     // Tile ids: blockIdx when every workgroup of the pass fits on the device at once with room to spare (then no tile
     // waits for one that cannot start, as long as the device is not shared with another resident kernel -- the call is
     // stream-ordered, and a look-back that does stall is still released by the dispatch of the earlier blocks, which
@@ -286,7 +293,7 @@ void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t*
     // GS2M_SORT_TICKETS=1 forces tickets (shared / CU-masked devices).
     static const bool force_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
     rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist,
-                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status);
+                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw);
 }
 
 }  // namespace
@@ -312,7 +319,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideSum sum) {
+                                 SideSum sum, uint32_t* range_raw) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -334,10 +341,10 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
         uint32_t* st = status + (size_t)i * tiles * 256;
         const uint32_t* gh = ghist + i * 256;
         switch (p.bits[i]) {
-#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s); break;
+#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr); break;
             RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
 #undef RS_CASE
-            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s); break;  // 0 bits: stable copy
+            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr); break;  // 0 bits: stable copy
         }
         ki = ko;
         vi = vo;
