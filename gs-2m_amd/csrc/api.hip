@@ -172,6 +172,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     ImageState im = gs2m_carve_image(ibase, N, tiles);
 
     int R = 0;
+    uint32_t* tile_hist = nullptr;  // the tile sort's digit histograms (zeroed by the preprocess kernel, filled by the emit kernel)
     if (P > 0) {
         // scratch of the depth sort and of the scan, side by side in g.temp; zeroed by the preprocess kernel
         char* sort_temp = g.temp;
@@ -194,6 +195,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         ZeroJobs zj = {{nullptr, nullptr, acc}, {0, 0, acc ? (size_t)4 : (size_t)0}};
         gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
         gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
+        tile_hist = gs2m_tile_hist_ptr(scan_temp, (size_t)P);
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
@@ -263,14 +265,14 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, nullptr, im.ranges_raw}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, g, b, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, tile_hist, g, b, zj, s);
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);
             // the last pass also records every tile's range (identifyTileRanges, rasterizer_impl.cu:108-129)
             HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
                                           b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, SideSum{nullptr, nullptr, nullptr},
-                                          im.ranges_raw));
+                                          im.ranges_raw, tile_hist));
         }
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));

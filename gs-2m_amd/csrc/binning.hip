@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                                                    const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                    uint32_t* __restrict__ inst_obs,
-                                                   uint32_t* __restrict__ sorted_rows, ZeroJobs zero) {
+                                                   uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ tile_hist,
+                                                   int npass, int4 hbits, int4 hshift, ZeroJobs zero) {
+    __shared__ uint32_t s_th[4][256];  // digit counts of this workgroup's keys, for the tile sort (radix_sort.hip: ext_hist)
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_gid[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
@@ -130,6 +132,17 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
+#pragma unroll
+    for (int p = 0; p < 4; p++) s_th[p][threadIdx.x] = 0u;
+    const int hb[4] = {hbits.x, hbits.y, hbits.z, hbits.w}, hs[4] = {hshift.x, hshift.y, hshift.z, hshift.w};
+    // this workgroup's counts into one of GS2M_HIST_COPIES copies of the global histogram (one add per non-empty bin)
+    auto flush_hist = [&]() {
+        uint32_t* dst = tile_hist + (blockIdx.x & (GS2M_HIST_COPIES - 1)) * GS2M_HIST_COPY_WORDS;
+        for (int p = 0; p < npass; p++) {
+            const uint32_t c = s_th[p][threadIdx.x];
+            if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
+        }
+    };
     uint32_t cnt = 0, gid = 0, off = 0, rmin = 0, rw = 1;
     if (i < P) {
         gid = sorted_gid[i];
@@ -176,8 +189,10 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         // quadrants outside the image have no pixels: no list entry, no gradient row
         if (px0 + 8 >= W) mask &= 0x5u;
         if (py0 + 8 >= H) mask &= 0x3u;
-        keys_out[slot] = ty * (uint32_t)tiles_x + tx;
+        const uint32_t key = ty * (uint32_t)tiles_x + tx;
+        keys_out[slot] = key;
         vals_out[slot] = s_gid[w][lo] | (mask << GS2M_GID_BITS);
+        for (int p = 0; p < npass; p++) atomicAdd(&s_th[p][(key >> hs[p]) & ((1u << hb[p]) - 1u)], 1u);
         return mask;
     };
     uint32_t rows_run = 0;  // gradient rows of the wave's own (small) instances so far
@@ -203,7 +218,10 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     }
     if (i < P && !big) sorted_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
     if (lane == 0) s_smallrows[wave] = rows_run;
-    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case)
+    if (gs2m_sync_or(bigmask != 0ull) == 0) {  // no big Gaussian in this workgroup (the common case)
+        flush_hist();
+        return;
+    }
     // ---- the workgroup's big Gaussians, one after the other, all four waves on each ----
     for (int w = 0; w < 4; w++) {
         unsigned long long m = s_bigmask[w];
@@ -256,6 +274,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
             bigrows += done_rows;
         }
     }
+    flush_hist();  // (a barrier closes the last round above: every count is in)
 }
 
 // Second binning level: the sorted list of a 16x16 tile -> four order-preserving lists, one per 8x8 quadrant,
@@ -323,9 +342,13 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint32_t* __restr
 
 }  // namespace
 
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s) {
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const GeomState& g, const BinningState& b,
+                      const ZeroJobs& zero, hipStream_t s) {
+    int npass = 0, bits[4], shift[4];
+    gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
-                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, zero);
+                                                b.vals_unsorted, b.inst_obs, g.sorted_rows, tile_hist, npass,
+                                                make_int4(bits[0], bits[1], bits[2], bits[3]), make_int4(shift[0], shift[1], shift[2], shift[3]), zero);
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack
 // leaves a ~10 us bubble on the stream around every call (kernel traces: tools/trace_timeline.sh); six of them

@@ -148,7 +148,7 @@ template <int BITS>
 __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ ghist, uint32_t* ticket,
-    uint32_t* status /* [tiles][256] */, uint32_t* range_raw) {
+    uint32_t* status /* [tiles][256] */, uint32_t* range_raw, int hist_copies /* ghist is the sum of this many copies, GS2M_HIST_COPY_WORDS apart */) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t s_cnt[4][BINS];  // per-wave digit counters, later per-wave local bases
     __shared__ uint32_t s_gbase[256];    // global position of local index i with digit d: s_gbase[d] + i
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     if (tid < BINS) {
         c0 = s_cnt[0][tid]; c1 = s_cnt[1][tid]; c2 = s_cnt[2][tid];
         tot = c0 + c1 + c2 + s_cnt[3][tid];
-        gh = ghist[tid];
+        for (int c = 0; c < hist_copies; c++) gh += ghist[c * GS2M_HIST_COPY_WORDS + tid];
     }
     const uint32_t inclA = wave_inclusive_scan_u32(tot, lane), inclB = wave_inclusive_scan_u32(gh, lane);
     if (lane == 63) {
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
 
 template <int BITS>
 void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
-                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s, uint32_t* range_raw) {
+                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s, uint32_t* range_raw, int hist_copies) {
     // Tile ids: blockIdx when every workgroup of the pass fits on the device at once with room to spare (then no tile
     // waits for one that cannot start, as long as the device is not shared with another resident kernel -- the call is
     // stream-ordered, and a look-back that does stall is still released by the dispatch of the earlier blocks, which
@@ -293,10 +293,16 @@ void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t*
     // GS2M_SORT_TICKETS=1 forces tickets (shared / CU-masked devices).
     static const bool force_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
     rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist,
-                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw);
+                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw, hist_copies);
 }
 
 }  // namespace
+
+void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]) {
+    const SortPlan p = make_plan(total_bits);
+    *npass = p.npass;
+    for (int i = 0; i < RS_MAXPASS; i++) { bits[i] = i < p.npass ? p.bits[i] : 0; shift[i] = i < p.npass ? p.shift[i] : 0; }
+}
 
 // temp layout: [ghist 4x256][tickets 4 (padded to 256 B)][status npass x tiles x 256]
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits) {
@@ -319,7 +325,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideSum sum, uint32_t* range_raw) {
+                                 SideSum sum, uint32_t* range_raw, const uint32_t* ext_hist) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -332,19 +338,23 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     const int workers = tiles < RS_HIST_WGS ? tiles : RS_HIST_WGS;
-    rs_hist_kernel<<<workers, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
-                                                                          make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, workers, sum);
+    // ext_hist: the producer of the keys has already counted every digit of every pass (binning.hip: emit_kernel, into
+    // GS2M_HIST_COPIES copies to spread its atomics): no histogram kernel, no second read of the keys
+    if (ext_hist == nullptr)
+        rs_hist_kernel<<<workers, RS_THREADS, 0, s>>>(kin, (uint32_t)n, p.npass, make_int4(p.bits[0], p.bits[1], p.bits[2], p.bits[3]),
+                                                      make_int4(p.shift[0], p.shift[1], p.shift[2], p.shift[3]), ghist, tiles, workers, sum);
     const uint32_t *ki = kin, *vi = vin;
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;
         uint32_t* vo = (i & 1) ? vB : vA;
         uint32_t* st = status + (size_t)i * tiles * 256;
-        const uint32_t* gh = ghist + i * 256;
+        const uint32_t* gh = (ext_hist ? ext_hist : ghist) + i * 256;
+        const int hc = ext_hist ? GS2M_HIST_COPIES : 1;
         switch (p.bits[i]) {
-#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr); break;
+#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc); break;
             RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
 #undef RS_CASE
-            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr); break;  // 0 bits: stable copy
+            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc); break;  // 0 bits: stable copy
         }
         ki = ko;
         vi = vo;
@@ -452,12 +462,14 @@ __global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t
 }
 }  // namespace
 
-size_t gs2m_scan_temp_bytes(size_t n) { return gs2m_align_up(((n + 4095) / 4096 + 64) * 4) + 2 * GS2M_ALIGN; }
+// + the tile sort's digit histograms (GS2M_HIST_COPIES copies, filled by emit_kernel): zeroed with the scan's status words
+size_t gs2m_scan_temp_bytes(size_t n) { return gs2m_align_up(((n + 4095) / 4096 + 64 + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS) * 4) + 2 * GS2M_ALIGN; }
+uint32_t* gs2m_tile_hist_ptr(void* scan_temp, size_t n) { return (uint32_t*)gs2m_align_up((size_t)(uintptr_t)scan_temp) + ((n + 4095) / 4096 + 64); }
 
 // num_rendered must stay below 2^30 (30-bit look-back payload)
 void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words) {
     *ptr = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    *words = (n + 4095) / 4096 + 64;
+    *words = (n + 4095) / 4096 + 64 + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS;
 }
 
 hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
