@@ -4,6 +4,7 @@
 // with the pipeline described in binning.hip.
 #include "common.h"
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <dlfcn.h>
 
@@ -32,7 +33,7 @@ uint32_t higher_msb(uint32_t n) {
 struct Pinned {
     uint32_t* p = nullptr;    // host pointer of the pinned landing zone
     uint32_t* dev = nullptr;  // the same memory as the device sees it
-    uint32_t* acc[16] = {};   // per device: two zeroed words the side sum of the histogram kernel works in
+    uint32_t* acc[256] = {};  // per device: two zeroed words the side sum of the histogram kernel works in
 };
 thread_local Pinned t_pinned;
 
@@ -51,6 +52,7 @@ struct Prof {
     int created = 0;
 };
 Prof g_prof;
+std::mutex g_prof_mutex;  // the record table is shared by every thread that calls into the library while profiling is on
 // Mode switches: process-wide, read once at the top of a call (atomic: setting them from another thread is safe, and a
 // call in flight keeps the values it started with).
 std::atomic<int> g_reference_binning{0};
@@ -92,14 +94,18 @@ struct StageTimer {
             if (g_roctx.push) { g_roctx.push(kStageNames[stage]); marked = true; }
         }
         const bool blend = stage == ST_BLEND_FWD || stage == ST_BLEND_BWD;
-        if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || (g_prof.mode == 3 && stage != ST_BLEND_BWD) || g_prof.n >= kMaxRecords) return;
-        slot = g_prof.n++;
-        if (slot >= g_prof.created) {
-            (void)hipEventCreate(&g_prof.ev[slot][0]);
-            (void)hipEventCreate(&g_prof.ev[slot][1]);
-            g_prof.created = slot + 1;
+        if (g_prof.mode == 0) return;  // (the common case takes no lock)
+        {
+            std::lock_guard<std::mutex> lock(g_prof_mutex);
+            if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || (g_prof.mode == 3 && stage != ST_BLEND_BWD) || g_prof.n >= kMaxRecords) return;
+            slot = g_prof.n++;
+            if (slot >= g_prof.created) {
+                (void)hipEventCreate(&g_prof.ev[slot][0]);
+                (void)hipEventCreate(&g_prof.ev[slot][1]);
+                g_prof.created = slot + 1;
+            }
+            g_prof.stage[slot] = stage;
         }
-        g_prof.stage[slot] = stage;
         (void)hipEventRecord(g_prof.ev[slot][0], s);
     }
     ~StageTimer() {
@@ -186,7 +192,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         int dev_id = 0;
         HIP_TRY(hipGetDevice(&dev_id));
         uint32_t* acc = nullptr;  // per device: the words the side sum of the histogram kernel works in
-        if (dev_id >= 0 && dev_id < 16) {
+        if (dev_id >= 0 && dev_id < 256) {
             if (!t_pinned.acc[dev_id]) HIP_TRY(hipMalloc((void**)&t_pinned.acc[dev_id], 64));
             acc = t_pinned.acc[dev_id];
         }
@@ -442,6 +448,7 @@ int gs2m_set_spin_wait(int on) {
 
 int gs2m_profile_mode(int mode) {
     if (mode < 0 || mode > 3) return GS2M_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof.mode = mode;
     g_prof.n = 0;
     return GS2M_OK;
@@ -449,6 +456,7 @@ int gs2m_profile_mode(int mode) {
 
 int gs2m_profile_collect(float* stage_ms, int* stage_count, int n_stages) {
     if (!stage_ms || !stage_count || n_stages < GS2M_NUM_STAGES) return GS2M_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (int i = 0; i < n_stages; i++) { stage_ms[i] = 0.f; stage_count[i] = 0; }
     for (int r = 0; r < g_prof.n; r++) {
         float ms = 0.f;

@@ -89,20 +89,23 @@ class _ScratchCache(_Alloc):
     the next backward may reuse it; handing a block of that size back to the caching allocator every step only
     invites it to split the block for smaller requests and to hipMalloc a new one the step after."""
     _cache = {}
+    _cache_lock = threading.Lock()  # autograd runs backwards on its own threads: two devices' backwards may get() at once
 
     @classmethod
     def get(cls, device, stream):
         key = (torch.device(device).index, stream)
-        a = cls._cache.get(key)
-        if a is None:
-            a = cls._cache[key] = cls(device)
+        with cls._cache_lock:
+            a = cls._cache.get(key)
+            if a is None:
+                a = cls._cache[key] = cls(device)
         return a
 
     @classmethod
     def release(cls):
         """Hand the cached scratch blocks back to PyTorch's allocator (e.g. after training, before evaluation at another
         resolution).  Only call with no backward in flight on the streams concerned."""
-        cls._cache.clear()
+        with cls._cache_lock:
+            cls._cache.clear()
 
     def _alloc(self, nbytes, _user):
         if self.tensor is not None and self.tensor.numel() >= int(nbytes):
