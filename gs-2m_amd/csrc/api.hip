@@ -179,12 +179,12 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
 
     int R = 0;
     uint32_t* tile_hist = nullptr;  // the tile sort's digit histograms (zeroed by the preprocess kernel, filled by the emit kernel)
+    uint32_t *block_sums = nullptr, *super_sums = nullptr;  // tiles_touched summed over blocks of 256 (and of 65536) depth-sorted Gaussians (filled by the depth sort's last pass)
     if (P > 0) {
         // scratch of the depth sort and of the scan, side by side in g.temp; zeroed by the preprocess kernel
         char* sort_temp = g.temp;
         const size_t sort_temp_bytes = gs2m_align_up(gs2m_radix_temp_bytes((size_t)P, 32));
-        char* scan_temp = g.temp + sort_temp_bytes;
-        const size_t scan_temp_bytes = g.temp_bytes - sort_temp_bytes;
+        char* front_temp = g.temp + sort_temp_bytes;  // block sums of tiles_touched + the tile sort's digit histograms
         if (!t_pinned.p) {
             HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
@@ -200,8 +200,10 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         // side sum's accumulator (so a call that died half way cannot leave a count behind for the next one)
         ZeroJobs zj = {{nullptr, nullptr, acc}, {0, 0, acc ? (size_t)4 : (size_t)0}};
         gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
-        gs2m_scan_zero_region(scan_temp, (size_t)P, &zj.p[1], &zj.words[1]);
-        tile_hist = gs2m_tile_hist_ptr(scan_temp, (size_t)P);
+        gs2m_front_zero_region(front_temp, (size_t)P, &zj.p[1], &zj.words[1]);
+        tile_hist = gs2m_tile_hist_ptr(front_temp, (size_t)P);
+        block_sums = gs2m_block_sums_ptr(front_temp);
+        super_sums = gs2m_super_sums_ptr(front_temp, (size_t)P);
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
@@ -214,7 +216,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         // of tiles_touched, whatever the order -- is added up on the side by the depth sort's histogram kernel, the first
         // kernel behind the preprocessing, and its last workgroup stores it into a mapped pinned word (one aligned
         // system-scope 32-bit store; a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen).
-        // The host polls that word (a sentinel no count can take: R < 2^30) while the sort passes and the scan still
+        // The host polls that word (a sentinel no count can take: R < 2^30) while the sort passes still
         // run, and has the binning kernels queued behind them before they finish: no idle gap.
         volatile uint32_t* land = t_pinned.p;
         land[0] = 0xFFFFFFFFu;
@@ -225,13 +227,10 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
             StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
             const SideSum sum = {acc ? g.tiles_touched : nullptr, acc, t_pinned.dev};
+            // the last pass also leaves the sums of tiles_touched over blocks of 256 sorted Gaussians (the emit kernel's prefix)
             HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
-                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, sum));
-        }
-        {   // 2. emission offsets in that order (publishes the count itself when the side sum is not available)
-            StageTimer t(ST_SCAN, s, &failed_stage);
-            HIP_TRY(gs2m_scan_tiles_touched(scan_temp, scan_temp_bytes, (size_t)P, g.sorted_gid, g.tiles_touched, g.sorted_tt,
-                                            g.sorted_off, g.counters, true, s, acc ? nullptr : t_pinned.dev));
+                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, sum, nullptr, nullptr,
+                                          SideBuckets{g.tiles_touched, block_sums, super_sums}));
         }
         HIP_TRY(hipGetLastError());
         DEBUG_CHECK();
@@ -250,12 +249,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
         if (land[0] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // the look-back status words carry 30 value bits
         R = (int)land[0];
-        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: the side sum against the scan's own total
-            uint32_t total = 0;
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(&total, g.counters, sizeof(total), hipMemcpyDeviceToHost));
-            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_SCAN);
-        }
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -271,7 +264,13 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, nullptr, im.ranges_raw}, {0, 0, tiles * 2}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, tile_hist, g, b, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, tile_hist, block_sums, super_sums, g, b, zj, s);
+        }
+        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: the histogram kernel's side sum against the emit kernel's own prefix-sum total
+            uint32_t total = 0;
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(&total, g.counters, sizeof(total), hipMemcpyDeviceToHost));
+            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_EMIT);
         }
         {
             StageTimer t(ST_TILE_SORT, s, &failed_stage);

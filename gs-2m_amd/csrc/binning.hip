@@ -28,7 +28,6 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     g.sort_valA = (uint32_t*)take(P * 4);
     g.depth_key_sorted = (uint32_t*)take(P * 4);
     g.sorted_gid = (uint32_t*)take(P * 4);
-    g.sorted_tt = (uint32_t*)take(P * 4);
     g.sorted_off = (uint32_t*)take(P * 4);
     g.clamped = (uint8_t*)take(P);
     g.counters = (uint32_t*)take(64 * 4);
@@ -81,7 +80,7 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
 
 size_t gs2m_geom_temp_bytes(size_t P) {
     // the depth sort's and the scan's scratch side by side: the preprocess kernel zeroes both ahead of time
-    return gs2m_align_up(gs2m_radix_temp_bytes(P, 32)) + gs2m_align_up(gs2m_scan_temp_bytes(P)) + GS2M_ALIGN;
+    return gs2m_align_up(gs2m_radix_temp_bytes(P, 32)) + gs2m_align_up(gs2m_front_temp_bytes(P)) + GS2M_ALIGN;
 }
 
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) { return gs2m_align_up(gs2m_radix_temp_bytes(R, tile_bits)) + GS2M_ALIGN; }
@@ -109,8 +108,10 @@ namespace {
 // inside the wave's range -- small Gaussians in lane order from row 4 x (first slot), then the big ones in lane order --
 // and sorted_rows carries GS2M_ROWS_BIG for them, which row_reduce_dense_kernel (gaussian_bwd.hip) reads the same way.
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint32_t* __restrict__ sorted_gid,
-                                                   const uint32_t* __restrict__ sorted_tt,
-                                                   const uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
+                                                   const uint32_t* __restrict__ tiles_touched,
+                                                   const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_sums,
+                                                   uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ sorted_off, float4* __restrict__ rec,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                    uint32_t* __restrict__ inst_obs,
                                                    uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ tile_hist,
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ float2 s_ct[4][GS2M_WAVE];    // C, t2
     __shared__ uint32_t s_rc[4][GS2M_WAVE];  // gradient rows per Gaussian
     __shared__ unsigned long long s_bigmask[4];  // per wave: lanes whose Gaussian is big
-    __shared__ uint32_t s_base4[4], s_smallrows[4];
+    __shared__ uint32_t s_base4[4], s_smallrows[4], s_wsum[4], s_wtot[4];
     __shared__ uint32_t s_ctot[1024];  // rows per 64-instance chunk of the big Gaussian being expanded, then their exclusive prefix
     __shared__ uint32_t s_round_total;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -143,13 +144,36 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
             if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
         }
     };
-    uint32_t cnt = 0, gid = 0, off = 0, rmin = 0, rw = 1;
+    uint32_t cnt = 0, gid = 0, rmin = 0, rw = 1;
     if (i < P) {
         gid = sorted_gid[i];
-        cnt = sorted_tt[i];
-        off = sorted_off[i];
+        cnt = tiles_touched[gid];
     }
-    const uint32_t base = __shfl(off, 0, 64);  // first emission slot of the wave (lane 0 is in range whenever the wave has work)
+    // ---- emission offsets: the exclusive prefix sum of tiles_touched in depth order (the reference's InclusiveSum,
+    // rasterizer_impl.cu:265-266).  The sum over all workgroups in front comes from the block sums the depth sort's last pass
+    // left behind (one per 256 Gaussians = one per workgroup of this kernel; radix_sort.hip: SideBuckets) -- every thread adds
+    // its share of them, no chain between workgroups -- the rest is a scan of the workgroup's own 256 counts.  Rounds 1-3
+    // ran a scan kernel (a gather, a look-back chain, two P-sized arrays) in front of this one.
+    // two levels, so that every thread adds one block sum (the blocks of this workgroup's own super-block of 256) and --
+    // beyond 16 M Gaussians: a few -- super-block sums, all requested at once: one memory round trip
+    uint32_t bsum = 0;
+    {
+        const uint32_t mysuper = blockIdx.x >> 8, b = (mysuper << 8) + threadIdx.x;
+        if (b < blockIdx.x) bsum = block_sums[b];
+        for (uint32_t sp = threadIdx.x; sp < mysuper; sp += 256) bsum += super_sums[sp];
+    }
+    bsum = wave_inclusive_scan_u32(bsum, lane);
+    const uint32_t incl_all = wave_inclusive_scan_u32(cnt, lane);
+    if (lane == 63) { s_wsum[wave] = bsum; s_wtot[wave] = incl_all; }
+    gs2m_sync();
+    uint32_t off = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];  // first emission slot of the workgroup ...
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (w < wave) off += s_wtot[w];
+    const uint32_t base = off;  // ... of the wave ...
+    off += incl_all - cnt;      // ... of the Gaussian
+    if (i < P) sorted_off[i] = off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) counters[0] = off + cnt;  // num_rendered (debug mode checks the side sum against it)
     if (cnt > 0) {
         float4* r = rec + (size_t)gid * REC_Q + REC_BIN;
         const float4 bin = *r;
@@ -342,11 +366,12 @@ __global__ void __launch_bounds__(256) quad_lists_kernel(const uint32_t* __restr
 
 }  // namespace
 
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const GeomState& g, const BinningState& b,
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const uint32_t* block_sums, const uint32_t* super_sums,
+                      const GeomState& g, const BinningState& b,
                       const ZeroJobs& zero, hipStream_t s) {
     int npass = 0, bits[4], shift[4];
     gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
-    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.sorted_tt, g.sorted_off, g.rec, b.keys_unsorted,
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.sorted_gid, g.tiles_touched, block_sums, super_sums, g.counters, g.sorted_off, g.rec, b.keys_unsorted,
                                                 b.vals_unsorted, b.inst_obs, g.sorted_rows, tile_hist, npass,
                                                 make_int4(bits[0], bits[1], bits[2], bits[3]), make_int4(shift[0], shift[1], shift[2], shift[3]), zero);
 }

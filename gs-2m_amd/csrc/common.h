@@ -50,7 +50,6 @@ struct GeomState {
     uint32_t* sort_valA;     // P
     uint32_t* depth_key_sorted; // P
     uint32_t* sorted_gid;    // P
-    uint32_t* sorted_tt;     // P
     uint32_t* sorted_off;    // P
     uint8_t* clamped;        // P
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
@@ -235,6 +234,13 @@ size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
 // published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = an 8-byte
 // aligned 64-bit word that is zero before the launch (the caller zeroes it on the stream ahead of every call): total and
 // finished-workgroup count in one.
+// side job of a sort's LAST pass: buckets[final position >> 8] += tt[value], supers[final position >> 16] += tt[value]
+// (both zero before the call)
+struct SideBuckets {
+    const uint32_t* tt;
+    uint32_t* buckets;
+    uint32_t* supers;
+};
 struct SideSum {
     const uint32_t* tt;
     uint32_t* acc;
@@ -246,19 +252,18 @@ struct SideSum {
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
                                  SideSum sum = SideSum{nullptr, nullptr, nullptr}, uint32_t* range_raw = nullptr,
-                                 const uint32_t* ext_hist = nullptr);
+                                 const uint32_t* ext_hist = nullptr, SideBuckets sb = SideBuckets{nullptr, nullptr, nullptr});
 // Digit histograms counted by the producer of the keys instead of a histogram kernel (ext_hist above): GS2M_HIST_COPIES copies
 // of [4 passes][256 bins], GS2M_HIST_COPY_WORDS apart; the digits of pass i are bits [shift[i], shift[i] + bits[i]) of the key.
 #define GS2M_HIST_COPIES 8
 #define GS2M_HIST_COPY_WORDS 1024
 void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]);
-uint32_t* gs2m_tile_hist_ptr(void* scan_temp, size_t n);
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
-size_t gs2m_scan_temp_bytes(size_t n);
-hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
-                                   const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, bool prezeroed, hipStream_t s, uint32_t* landing = nullptr);
-void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words);
+size_t gs2m_front_temp_bytes(size_t n);
+uint32_t* gs2m_block_sums_ptr(void* front_temp);
+uint32_t* gs2m_super_sums_ptr(void* front_temp, size_t n);
+uint32_t* gs2m_tile_hist_ptr(void* front_temp, size_t n);
+void gs2m_front_zero_region(void* front_temp, size_t n, uint32_t** ptr, size_t* words);
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -267,7 +272,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const uint32_t* block_sums, const uint32_t* super_sums, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
 void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 

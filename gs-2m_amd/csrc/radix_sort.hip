@@ -148,7 +148,8 @@ template <int BITS>
 __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ ghist, uint32_t* ticket,
-    uint32_t* status /* [tiles][256] */, uint32_t* range_raw, int hist_copies /* ghist is the sum of this many copies, GS2M_HIST_COPY_WORDS apart */) {
+    uint32_t* status /* [tiles][256] */, uint32_t* range_raw, int hist_copies /* ghist is the sum of this many copies, GS2M_HIST_COPY_WORDS apart */,
+    SideBuckets sb) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t s_cnt[4][BINS];  // per-wave digit counters, later per-wave local bases
     __shared__ uint32_t s_gbase[256];    // global position of local index i with digit d: s_gbase[d] + i
@@ -263,9 +264,19 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
         }
     }
     gs2m_sync();
+    // side job, second level: the sums over super-blocks of 65536 positions are collected per workgroup in LDS first (the
+    // per-wave counters are dead from here on: their 1024 words are reused) -- a workgroup's elements land in a handful of
+    // super-blocks, and tens of thousands of atomics on so few words ran at ~80 ns apiece: 0.19 ms
+    uint32_t* const s_sup = &s_cnt[0][0];
+    constexpr uint32_t SUP_LDS = 4 * BINS < 1024 ? 4 * BINS : 1024;
+    if (sb.tt != nullptr) {
+        for (int q = tid; q < (int)SUP_LDS; q += RS_THREADS) s_sup[q] = 0u;
+        gs2m_sync();
+    }
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
         const uint32_t i = k * RS_THREADS + tid;
+        uint32_t bpos = 0u, bval = 0u;
         if (i < tile_count) {
             const uint32_t kk = s_key[i];
             const uint32_t pos = s_gbase[(kk >> shift) & (BINS - 1)] + i;
@@ -278,13 +289,44 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
                 if (i == 0 || s_key[i - 1] != kk) atomicMax(&range_raw[2 * kk], ~pos);
                 if (i + 1 == tile_count || s_key[i + 1] != kk) atomicMax(&range_raw[2 * kk + 1], pos + 1u);
             }
+            bpos = pos;
+            bval = s_val[i];
         }
+        if (sb.tt != nullptr) {
+            // Side job of the LAST pass of the depth sort: sums of tt[value] over blocks of 256 FINAL positions, which is
+            // all the emit kernel needs from the reference's InclusiveSum (rasterizer_impl.cu:265-266) beyond its own 256
+            // counts -- the separate scan kernel of rounds 1-3 (20 us + a launch boundary) is gone.  The wave's 64
+            // elements are consecutive in the reordered tile, so their final positions increase: equal blocks are
+            // contiguous lanes, summed by a segmented scan, one atomic per (wave step, block).
+            uint32_t t = 0u, bkt = 0xFFFFFFFFu;
+            if (i < tile_count) {
+                t = sb.tt[bval];  // (gathering these at the top of the kernel and carrying them through LDS was slower: +16 KB of LDS in every pass)
+                bkt = bpos >> 8;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t tv = __shfl_up(t, d, 64), bv = __shfl_up(bkt, d, 64);
+                if (lane >= d && bv == bkt) t += tv;
+            }
+            const uint32_t bn = __shfl_down(bkt, 1, 64);
+            if (bkt != 0xFFFFFFFFu && (lane == 63 || bn != bkt) && t != 0u) {
+                atomicAdd(&sb.buckets[bkt], t);
+                // second level: sums over 256 blocks, so that a reader adds at most 256 + 256 words
+                if ((bkt >> 8) < SUP_LDS) atomicAdd(&s_sup[bkt >> 8], t);
+                else atomicAdd(&sb.supers[bkt >> 8], t);
+            }
+        }
+    }
+    if (sb.tt != nullptr) {
+        gs2m_sync();
+        for (int q = tid; q < (int)SUP_LDS; q += RS_THREADS)
+            if (s_sup[q] != 0u) atomicAdd(&sb.supers[q], s_sup[q]);
     }
 }
 
 template <int BITS>
 void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
-                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s, uint32_t* range_raw, int hist_copies) {
+                 const uint32_t* ghist, uint32_t* ticket, uint32_t* status, int tiles, hipStream_t s, uint32_t* range_raw, int hist_copies, SideBuckets sb) {
     // Tile ids: blockIdx when every workgroup of the pass fits on the device at once with room to spare (then no tile
     // waits for one that cannot start, as long as the device is not shared with another resident kernel -- the call is
     // stream-ordered, and a look-back that does stall is still released by the dispatch of the earlier blocks, which
@@ -293,7 +335,7 @@ void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t*
     // GS2M_SORT_TICKETS=1 forces tickets (shared / CU-masked devices).
     static const bool force_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
     rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist,
-                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw, hist_copies);
+                                                          (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw, hist_copies, sb);
 }
 
 }  // namespace
@@ -325,7 +367,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
-                                 SideSum sum, uint32_t* range_raw, const uint32_t* ext_hist) {
+                                 SideSum sum, uint32_t* range_raw, const uint32_t* ext_hist, SideBuckets sb) {
     if (n == 0) return hipSuccess;
     const SortPlan p = make_plan(total_bits);
     const int tiles = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -351,10 +393,10 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
         const uint32_t* gh = (ext_hist ? ext_hist : ghist) + i * 256;
         const int hc = ext_hist ? GS2M_HIST_COPIES : 1;
         switch (p.bits[i]) {
-#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc); break;
+#define RS_CASE(B) case B: launch_pass<B>(ki, vi, ko, vo, (uint32_t)n, p.shift[i], gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc, i == p.npass - 1 ? sb : SideBuckets{nullptr, nullptr, nullptr}); break;
             RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
 #undef RS_CASE
-            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc); break;  // 0 bits: stable copy
+            default: launch_pass<1>(ki, vi, ko, vo, (uint32_t)n, 31, gh, tickets + i, st, tiles, s, i == p.npass - 1 ? range_raw : nullptr, hc, i == p.npass - 1 ? sb : SideBuckets{nullptr, nullptr, nullptr}); break;  // 0 bits: stable copy
         }
         ki = ko;
         vi = vo;
@@ -362,125 +404,17 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     return hipGetLastError();
 }
 
-// ---- exclusive scan of tiles_touched in depth order, single pass with decoupled look-back ----
-// out: sorted_tt[i] = tiles_touched[sorted_gid[i]], sorted_off[i] = exclusive prefix, counters[0] = total.
-namespace {
-constexpr int SC_ITEMS = 16;
-__global__ void __launch_bounds__(256) scan_tt_kernel(uint32_t n, const uint32_t* __restrict__ sorted_gid,
-                                                      const uint32_t* __restrict__ tiles_touched,
-                                                      uint32_t* __restrict__ sorted_tt, uint32_t* __restrict__ sorted_off,
-                                                      uint32_t* __restrict__ counters, uint32_t* ticket, uint32_t* status,
-                                                      uint32_t* __restrict__ landing) {
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_tile, s_base;
-    __shared__ uint32_t s_t[256 * SC_ITEMS + 128], s_o[256 * SC_ITEMS + 128];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_tile = ticket != nullptr ? atomicAdd(ticket, 1u) : blockIdx.x;
-    gs2m_sync();
-    const uint32_t tile = s_tile;
-    // coalesced gather (element k*256 + tid), transposed through LDS so that each thread then owns 16
-    // consecutive elements; index + index/32 padding keeps both access patterns conflict-free
-    const uint32_t tbase = tile * (256 * SC_ITEMS);
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        const uint32_t e = k * 256 + tid, i = tbase + e;
-        s_t[e + (e >> 5)] = i < n ? tiles_touched[sorted_gid[i]] : 0u;
-    }
-    gs2m_sync();
-    uint32_t v[SC_ITEMS], sum = 0;
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        const uint32_t e = tid * SC_ITEMS + k;
-        v[k] = s_t[e + (e >> 5)];
-        sum += v[k];
-    }
-    const uint32_t incl = wave_inclusive_scan_u32(sum, lane);
-    if (lane == 63) s_w[wave] = incl;
-    gs2m_sync();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) wbase += s_w[w];
-        total += s_w[w];
-    }
-    if (wave == 0) {
-        // look-back by a whole wave: lane l reads the status of tile - 1 - l, so one round trip covers 64 predecessors (a
-        // single thread walking 4 per round trip needed ~11 round trips of ~1 us for the 245 tiles of 1M Gaussians)
-        uint32_t excl = 0;
-        if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(status, FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(status + tile, FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int p = (int)tile - 1;  // nearest predecessor not yet accounted for
-            bool found = false;
-            while (!found) {
-                const int q = p - lane;
-                // in front of tile 0: prefix 0
-                const uint32_t w = q >= 0 ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_PFX;
-                const uint32_t f = w & ~VAL_MASK;
-                const unsigned long long mp = __builtin_amdgcn_ballot_w64(f == FLAG_PFX), mz = __builtin_amdgcn_ballot_w64(f == 0u);
-                const int fp = mp ? (int)__builtin_ctzll(mp) : 64, fz = mz ? (int)__builtin_ctzll(mz) : 64;
-                const int take = fz < fp ? fz : (fp < 64 ? fp + 1 : 64);  // lanes [0, take) are summed
-                uint32_t v = lane < take ? (w & VAL_MASK) : 0u;
-                v = wave_inclusive_scan_u32(v, lane);
-                excl += __shfl(v, 63, 64);
-                p -= take;
-                found = fp < fz;  // a prefix was reached with every nearer tile published
-                if (!found && fz < 64) __builtin_amdgcn_s_sleep(1);  // an unpublished tile: poll again from there
-            }
-            if (lane == 0) __hip_atomic_store(status + tile, FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            s_base = excl;
-            if ((tile + 1) * (256 * SC_ITEMS) >= n) {  // last tile: num_rendered
-                counters[0] = excl + total;
-                // ... and straight to the host: ONE aligned 32-bit store at system scope into the mapped pinned word the host
-                // polls (a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen, api.hip)
-                if (landing) __hip_atomic_store(landing, excl + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-    gs2m_sync();
-    // results leave the way the inputs came: through LDS, so that every global store is a coalesced 256-B run
-    // (a thread owns 16 consecutive elements: storing them directly is a 64-B lane stride)
-    uint32_t run = s_base + wbase + (incl - sum);
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        const uint32_t e = tid * SC_ITEMS + k;
-        s_o[e + (e >> 5)] = run;
-        run += v[k];
-    }
-    gs2m_sync();
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-        const uint32_t e = k * 256 + tid, i = tbase + e;
-        if (i < n) {
-            sorted_tt[i] = s_t[e + (e >> 5)];
-            sorted_off[i] = s_o[e + (e >> 5)];
-        }
-    }
-}
-}  // namespace
-
-// + the tile sort's digit histograms (GS2M_HIST_COPIES copies, filled by emit_kernel): zeroed with the scan's status words
-size_t gs2m_scan_temp_bytes(size_t n) { return gs2m_align_up(((n + 4095) / 4096 + 64 + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS) * 4) + 2 * GS2M_ALIGN; }
-uint32_t* gs2m_tile_hist_ptr(void* scan_temp, size_t n) { return (uint32_t*)gs2m_align_up((size_t)(uintptr_t)scan_temp) + ((n + 4095) / 4096 + 64); }
-
-// num_rendered must stay below 2^30 (30-bit look-back payload)
-void gs2m_scan_zero_region(void* temp, size_t n, uint32_t** ptr, size_t* words) {
-    *ptr = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    *words = (n + 4095) / 4096 + 64 + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS;
-}
-
-hipError_t gs2m_scan_tiles_touched(void* temp, size_t temp_bytes, size_t n, const uint32_t* sorted_gid,
-                                   const uint32_t* tiles_touched, uint32_t* sorted_tt, uint32_t* sorted_off,
-                                   uint32_t* counters, bool prezeroed, hipStream_t s, uint32_t* landing) {
-    if (n == 0) return hipSuccess;
-    const int tiles = (int)((n + 4095) / 4096);
-    if (temp_bytes < gs2m_scan_temp_bytes(n)) return hipErrorInvalidValue;
-    uint32_t* base = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, (size_t)(tiles + 64) * 4, s);
-    if (e != hipSuccess) return e;
-    scan_tt_kernel<<<tiles, 256, 0, s>>>((uint32_t)n, sorted_gid, tiles_touched, sorted_tt, sorted_off, counters, base, base + 64, landing);
-    return hipGetLastError();
+// ---- scratch the preprocess kernel zeroes for the binning front end: [block sums of tiles_touched in depth order, one per
+// 256 Gaussians (filled by the depth sort's last pass, read by emit_kernel)][the tile sort's digit histograms, GS2M_HIST_COPIES
+// copies (filled by emit_kernel)] ----
+// [block sums: (n + 255) / 256 + 64 words][super-block sums (256 blocks each): (n + 65535) / 65536 + 64 words][histograms]
+static size_t front_blocks(size_t n) { return (n + 255) / 256 + 64; }
+static size_t front_supers(size_t n) { return (n + 65535) / 65536 + 64; }
+size_t gs2m_front_temp_bytes(size_t n) { return gs2m_align_up((front_blocks(n) + front_supers(n) + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS) * 4) + 2 * GS2M_ALIGN; }
+uint32_t* gs2m_block_sums_ptr(void* front_temp) { return (uint32_t*)gs2m_align_up((size_t)(uintptr_t)front_temp); }
+uint32_t* gs2m_super_sums_ptr(void* front_temp, size_t n) { return gs2m_block_sums_ptr(front_temp) + front_blocks(n); }
+uint32_t* gs2m_tile_hist_ptr(void* front_temp, size_t n) { return gs2m_super_sums_ptr(front_temp, n) + front_supers(n); }
+void gs2m_front_zero_region(void* front_temp, size_t n, uint32_t** ptr, size_t* words) {
+    *ptr = gs2m_block_sums_ptr(front_temp);
+    *words = front_blocks(n) + front_supers(n) + GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS;
 }
