@@ -3,14 +3,18 @@
 // The reference (cuda_rasterizer/rasterizer_impl.cu:63-103, 265-305) expands every visible
 // Gaussian into (tile<<32 | depth) u64 keys and runs one 45-bit radix sort over all R
 // instances.  Here the work is split so that far fewer bytes move through HBM:
-//   1. depth sort of the P Gaussians themselves (u32 fp32-bit key, id payload), stable;
-//   2. exclusive scan of tiles_touched in that order  -> emission offsets, R;
-//   3. load-balanced emit: instance (tile id, Gaussian id) pairs in depth order, every wave
-//      writes 64 consecutive slots per step (the reference loops serially per thread);
-//   4. stable sort of the R pairs on the tile bits only (13 bits at 1080p instead of 45).
+//   1. depth sort of the P Gaussians themselves (u32 fp32-bit key, id payload), stable; its last pass leaves the sums of
+//      tiles_touched over blocks of 256 sorted Gaussians (radix_sort.hip: SideBuckets);
+//   2. load-balanced emit: emission offsets from those block sums + a scan of the workgroup's own 256 counts (the
+//      reference's InclusiveSum, no kernel of its own since round 4); instance (tile id, Gaussian id) pairs in depth order,
+//      every wave writes 64 consecutive slots per step (the reference loops serially per thread); the digits of the keys
+//      are counted here for the tile sort; big Gaussians are expanded by the whole workgroup;
+//   3. stable sort of the R pairs on the tile bits only (13 bits at 1080p instead of 45); its last pass records every
+//      tile's range (identifyTileRanges);
+//   4. per tile: the sorted list -> four quadrant lists (quad_lists_kernel).
 // Stable sort by tile of a depth-ordered list == sort by (tile, depth) with ties kept in
 // Gaussian-id order, i.e. exactly the reference's sorted list.
-// Sort/scan primitives: radix_sort.hip (hand-written onesweep radix sort and look-back scan).
+// Sort primitives: radix_sort.hip (hand-written onesweep radix sort).
 #include "common.h"
 
 GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {

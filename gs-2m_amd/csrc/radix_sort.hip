@@ -5,7 +5,9 @@
 // scan pass.  Used for (1) the depth order of the Gaussians (32-bit fp32 depth keys) and (2) the
 // stable tile sort of the emitted instances (13 key bits at 1080p) -- the two places where the
 // reference calls cub::DeviceRadixSort (cuda_rasterizer/rasterizer_impl.cu:291-296 sorts R 64-bit
-// keys over 45 bits in one go).
+// keys over 45 bits in one go).  Round 4: a sort's last pass can carry side jobs that replace kernels of their own -- the
+// tile ranges (range_raw: identifyTileRanges) and block sums of a per-value term in final order (SideBuckets: the reference's
+// InclusiveSum over tiles_touched); the histogram can come from the producer of the keys (ext_hist).
 //
 // MI355X specifics:
 //  * 64-lane ranking: the lanes holding the same digit are found with BITS ballots (match-any);
