@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         s_geo[wave][lane] = rec[(size_t)gid * REC_Q + REC_GEO0];
         s_ct[wave][lane] = make_float2(rec[(size_t)gid * REC_Q + REC_GEO1].x, bin.w);
     }
-    const bool big = cnt >= GS2M_BIG_TILES;
+    const bool big = cnt >= GS2M_BIG_TILES && cnt < (1u << 29);  // (4 rows per instance at most: the row count must stay below the GS2M_ROWS_BIG bit)
     const uint32_t lcnt = big ? 0u : cnt;  // instances the wave expands itself
     const uint32_t incl = wave_inclusive_scan_u32(lcnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
