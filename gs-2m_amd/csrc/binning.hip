@@ -34,6 +34,7 @@ GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes) {
     g.sorted_gid = (uint32_t*)take(P * 4);
     g.sorted_off = (uint32_t*)take(P * 4);
     g.clamped = (uint8_t*)take(P);
+    g.sh_dir = (float*)take(P * 9 * sizeof(float));
     g.counters = (uint32_t*)take(64 * 4);
     g.sorted_rows = (uint32_t*)take(P * 4);
     g.temp = take(temp_bytes);

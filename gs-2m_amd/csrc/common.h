@@ -52,6 +52,7 @@ struct GeomState {
     uint32_t* sorted_gid;    // P
     uint32_t* sorted_off;    // P
     uint8_t* clamped;        // P
+    float* sh_dir;           // P * 9: d(SH colour)/d(view direction) of a visible Gaussian, {dRdx, dRdy, dRdz}[rgb] (preprocess -> gaussian_bwd)
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
     uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order
     char* temp;              // radix sort / scan temporary storage

@@ -55,13 +55,15 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ vm,
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
-    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ rows,
+    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ sh_dir,
+    const float* __restrict__ rows,
     int rowf, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
-    // SH rows in and dL/dSH rows out go through LDS so that every global access of the two
-    // (P,16,3) tensors is a coalesced stream (see preprocess.hip); row stride 49 floats.
+    // dL/dSH rows go out through LDS so that every global access of the (P,16,3) tensor is a coalesced stream (see
+    // preprocess.hip); row stride 49 floats.  The coefficients themselves are not read here: all the backward needs of them is
+    // d(colour)/d(direction), 9 floats per Gaussian that the forward's preprocess kernel left in GeomState::sh_dir.
     __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;
@@ -76,6 +78,11 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
         q_in = reinterpret_cast<const float4*>(rotations)[li];
         s_in[0] = scales[3 * li]; s_in[1] = scales[3 * li + 1]; s_in[2] = scales[3 * li + 2];
     }
+    float sdv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (visible && shs != nullptr && D > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) sdv[k] = sh_dir[9 * (size_t)li + k];
+    }
     float acc[24];
     {   // `rows` holds one reduced row per Gaussian (row_reduce_dense_kernel below): P x rowf floats
         const int rq = rowf >> 2;
@@ -85,10 +92,6 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             const float4 v = q < rq ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
             acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
         }
-    }
-    if (SH_LDS) {
-        gs2m_stage_sh(shs, shs_rest, P, s_sh);
-        gs2m_sync();
     }
     if (!SH_LDS && !in_range) return;
     if (in_range) {
@@ -212,13 +215,12 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             const float ox = mx - campos[0], oy = my - campos[1], oz = mz - campos[2];
             const float len = sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox / len, y = oy / len, z = oz / len;
-            const float* sh = SH_LDS ? (s_sh + threadIdx.x * 49) : (shs + (size_t)idx * M * 3);
             float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
             const uint8_t cl = clamped[idx];
             float g[3] = {acc[ROW_COL] * ((cl & 1) ? 0.f : 1.f), acc[ROW_COL + 1] * ((cl & 2) ? 0.f : 1.f),
                           acc[ROW_COL + 2] * ((cl & 4) ? 0.f : 1.f)};
-            float dRdx[3] = {0.f, 0.f, 0.f}, dRdy[3] = {0.f, 0.f, 0.f}, dRdz[3] = {0.f, 0.f, 0.f};
-#define SHv(k, c_) sh[(k) * 3 + (c_)]
+            // d(colour)/d(direction), evaluated by the forward (preprocess.hip) with the reference's expressions (backward.cu:62-146)
+            const float dRdx[3] = {sdv[0], sdv[1], sdv[2]}, dRdy[3] = {sdv[3], sdv[4], sdv[5]}, dRdz[3] = {sdv[6], sdv[7], sdv[8]};
 #define DSH(k, val)                                           \
     do {                                                      \
         const float v_ = (val);                               \
@@ -226,41 +228,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
         dsh[(k) * 3 + 1] = v_ * g[1];                         \
         dsh[(k) * 3 + 2] = v_ * g[2];                         \
     } while (0)
-            // pass 1: everything that READS the coefficients (the dL/dSH row may alias the SH row in LDS)
             float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
-            if (D > 0) {
-#pragma unroll
-                for (int c_ = 0; c_ < 3; c_++) {
-                    dRdx[c_] = -SH_C1 * SHv(3, c_);
-                    dRdy[c_] = -SH_C1 * SHv(1, c_);
-                    dRdz[c_] = SH_C1 * SHv(2, c_);
-                }
-                if (D > 1) {
-                    xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z;
-#pragma unroll
-                    for (int c_ = 0; c_ < 3; c_++) {
-                        dRdx[c_] += kC2[0] * y * SHv(4, c_) + kC2[2] * 2.f * -x * SHv(6, c_) + kC2[3] * z * SHv(7, c_) + kC2[4] * 2.f * x * SHv(8, c_);
-                        dRdy[c_] += kC2[0] * x * SHv(4, c_) + kC2[1] * z * SHv(5, c_) + kC2[2] * 2.f * -y * SHv(6, c_) + kC2[4] * 2.f * -y * SHv(8, c_);
-                        dRdz[c_] += kC2[1] * y * SHv(5, c_) + kC2[2] * 2.f * 2.f * z * SHv(6, c_) + kC2[3] * x * SHv(7, c_);
-                    }
-                    if (D > 2) {
-#pragma unroll
-                        for (int c_ = 0; c_ < 3; c_++) {
-                            dRdx[c_] += (kC3[0] * SHv(9, c_) * 3.f * 2.f * xy + kC3[1] * SHv(10, c_) * yz +
-                                         kC3[2] * SHv(11, c_) * -2.f * xy + kC3[3] * SHv(12, c_) * -3.f * 2.f * xz +
-                                         kC3[4] * SHv(13, c_) * (-3.f * xx + 4.f * zz - yy) +
-                                         kC3[5] * SHv(14, c_) * 2.f * xz + kC3[6] * SHv(15, c_) * 3.f * (xx - yy));
-                            dRdy[c_] += (kC3[0] * SHv(9, c_) * 3.f * (xx - yy) + kC3[1] * SHv(10, c_) * xz +
-                                         kC3[2] * SHv(11, c_) * (-3.f * yy + 4.f * zz - xx) +
-                                         kC3[3] * SHv(12, c_) * -3.f * 2.f * yz + kC3[4] * SHv(13, c_) * -2.f * xy +
-                                         kC3[5] * SHv(14, c_) * -2.f * yz + kC3[6] * SHv(15, c_) * -3.f * 2.f * xy);
-                            dRdz[c_] += (kC3[1] * SHv(10, c_) * xy + kC3[2] * SHv(11, c_) * 4.f * 2.f * yz +
-                                         kC3[3] * SHv(12, c_) * 3.f * (2.f * zz - xx - yy) +
-                                         kC3[4] * SHv(13, c_) * 4.f * 2.f * xz + kC3[5] * SHv(14, c_) * (xx - yy));
-                        }
-                    }
-                }
-            }
+            if (D > 1) { xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z; }
             // pass 2: dL/dSH_k = basis_k(dir) * dL/dRGB
             DSH(0, SH_C0);
             if (D > 0) {
@@ -286,7 +255,6 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             }
             // coefficients above the active degree receive no gradient
             for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
-#undef SHv
 #undef DSH
             const float ddx = dRdx[0] * g[0] + dRdx[1] * g[1] + dRdx[2] * g[2];
             const float ddy = dRdy[0] * g[0] + dRdy[1] * g[1] + dRdy[2] * g[2];
@@ -553,7 +521,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
     gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
         projmatrix,                                                                                                     \
-        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, rows, rowf,                 \
+        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, g.sh_dir, rows, rowf,                 \
         dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales,  \
         dL_drots,                                                                                                       \
         dL_dfeatures)

@@ -59,10 +59,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, int* __restrict__ observe_zero, float4* __restrict__ rec,
     uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, ZeroJobs zero) {
+    uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, float* __restrict__ sh_dir, ZeroJobs zero) {
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     // (the block's blend records are parked in the same LDS afterwards: 256 x 36 floats)
-    __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 36];
+    __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 45];  // (afterwards: 256 x 36 floats of records + 256 x 9 of sh_dir)
     __shared__ uint8_t s_seen[256];  // the thread's Gaussian has a radius: its record is stored
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     }
     gs2m_zero_jobs(zero, (size_t)idx, (size_t)gridDim.x * blockDim.x);  // the sort / scan scratch of the stages that follow
     int out_radius = 0;
+    float sd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d(SH colour)/d(direction): the backward's only use of the coefficients
     uint32_t out_tt = 0;
     uint32_t out_key = 0xFFFFFFFFu;
 
@@ -186,6 +187,35 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                         res[c] = fmaxf(r_, 0.0f);
                     }
                     cr = res[0]; cg = res[1]; cb = res[2];
+                    // The derivative of the colour with respect to the view direction (backward.cu:62-146), taken here where
+                    // the 48 coefficients are at hand: the per-Gaussian backward then reads these 36 bytes instead of the
+                    // 192-byte SH row.  Same expressions in the same order as the reference's backward: the bits it would get.
+                    if (D > 0) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            float ddx_ = -SH_C1 * sh[9 + c], ddy_ = -SH_C1 * sh[3 + c], ddz_ = SH_C1 * sh[6 + c];
+                            if (D > 1) {
+                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                ddx_ += kSH_C2[0] * y * sh[12 + c] + kSH_C2[2] * 2.f * -x * sh[18 + c] + kSH_C2[3] * z * sh[21 + c] + kSH_C2[4] * 2.f * x * sh[24 + c];
+                                ddy_ += kSH_C2[0] * x * sh[12 + c] + kSH_C2[1] * z * sh[15 + c] + kSH_C2[2] * 2.f * -y * sh[18 + c] + kSH_C2[4] * 2.f * -y * sh[24 + c];
+                                ddz_ += kSH_C2[1] * y * sh[15 + c] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + c] + kSH_C2[3] * x * sh[21 + c];
+                                if (D > 2) {
+                                    ddx_ += (kSH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + c] * yz +
+                                             kSH_C3[2] * sh[33 + c] * -2.f * xy + kSH_C3[3] * sh[36 + c] * -3.f * 2.f * xz +
+                                             kSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                                             kSH_C3[5] * sh[42 + c] * 2.f * xz + kSH_C3[6] * sh[45 + c] * 3.f * (xx - yy));
+                                    ddy_ += (kSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + c] * xz +
+                                             kSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
+                                             kSH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + c] * -2.f * xy +
+                                             kSH_C3[5] * sh[42 + c] * -2.f * yz + kSH_C3[6] * sh[45 + c] * -3.f * 2.f * xy);
+                                    ddz_ += (kSH_C3[1] * sh[30 + c] * xy + kSH_C3[2] * sh[33 + c] * 4.f * 2.f * yz +
+                                             kSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
+                                             kSH_C3[4] * sh[39 + c] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + c] * (xx - yy));
+                                }
+                            }
+                            sd[c] = ddx_; sd[3 + c] = ddy_; sd[6 + c] = ddz_;
+                        }
+                    }
                 } else {
                     cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
                 }
@@ -271,12 +301,33 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) s_rec[threadIdx.x * 9 + k] = rq[k];
     s_seen[threadIdx.x] = out_radius > 0 ? 1 : 0;
+    float* s_sd = s_sh + 256 * 36;  // the block's 256 x 9 direction derivatives: one contiguous 9-KB run of `sh_dir`
+    if (colors_precomp == nullptr) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_sd[threadIdx.x * 9 + k] = sd[k];
+    }
     gs2m_sync();
     const size_t lim4 = (size_t)P * REC_Q, base4 = (size_t)blockIdx.x * 256 * REC_Q;
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) {
         const int e = k * 256 + threadIdx.x;
         if (base4 + e < lim4 && s_seen[e >> 3]) rec[base4 + e] = s_rec[(e >> 3) * 9 + (e & 7)];
+    }
+    if (colors_precomp == nullptr) {  // as whole float4s (zeros for Gaussians without a radius), the array's last few floats one by one
+        const size_t limf = (size_t)P * 9, basef = (size_t)blockIdx.x * 256 * 9;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e4 = k * 256 + threadIdx.x;  // float4 number inside the block's run (576 of them)
+            if (e4 < 576) {
+                const size_t f0 = basef + 4 * (size_t)e4;
+                if (f0 + 3 < limf) {
+                    reinterpret_cast<float4*>(sh_dir + basef)[e4] = reinterpret_cast<const float4*>(s_sd)[e4];
+                } else {
+                    for (int t = 0; t < 4; t++)
+                        if (f0 + t < limf) sh_dir[f0 + t] = s_sd[4 * e4 + t];
+                }
+            }
+        }
     }
 }
 
@@ -321,7 +372,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                                                            shs, shs_rest, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, observe_zero, g.rec,             \
-                                                           g.tiles_touched, g.depth_key, g.clamped, zero)
+                                                           g.tiles_touched, g.depth_key, g.clamped, g.sh_dir, zero)
     // split SH (shs = DC, shs_rest = the other 15 coefficients) exists in the LDS-staged form only: api.hip checks
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 &&
                      (shs_rest ? (((uintptr_t)shs_rest) & 15) == 0 : (((uintptr_t)shs) & 15) == 0);
