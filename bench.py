@@ -8,8 +8,8 @@ over the binding's gradient arena -- plus the densification side channels (gs2m_
 step k overlapping step k + 1) is timed as well and reported beside it.  Prints ONE JSON line on rank 0.
 
 Order inside a run: W warm-up steps, K steps timed "at start" (`clock_ramp`: the GPU's clock governor is still ramping
-there), the auxiliary passes of the same step (pipelined / one-view forms at N > 1, the per-stage pass, the reference-binning
-pass), then W warm-up steps again and the K timed steps `value` is computed from.
+there), the auxiliary passes of the same step (pipelined / one-view forms at N > 1, the reference-binning pass), then W warm-up
+steps again and the K timed steps `value` is computed from, then the per-stage pass (`stages_ms`).
 
   --config c3 (default)  BASELINE.json configs[2]: 1M Gaussians, 1920x1080, feature_count 9 (material G-buffers) -- the
                          configuration the metric is quoted on; kept at every N so that the driver's scaling efficiency
@@ -404,15 +404,6 @@ def main():
         vv[0] = VPR
         step()
 
-    # untimed: per-stage breakdown of the same step
-    STAGE_STEPS = 5
-    gs2m_native.profile_mode(2)
-    for _ in range(STAGE_STEPS):
-        step()
-    fence()
-    stages = gs2m_native.profile_collect()
-    gs2m_native.profile_mode(0)
-
     # The same workload with the reference's own instance list (gs2m_set_reference_binning(1): every tile of the radius
     # rectangle, auxiliary.h:44-53 -- the mode whose sorted lists are bit-identical to the reference's).  The headline below
     # runs the default mode: a result-identical, order-preserving SUBSET of that list (tiles the alpha >= 1/255 ellipse cannot
@@ -435,6 +426,17 @@ def main():
     gs2m_native.profile_mode(3)
     ms = timed(False)
     blend = gs2m_native.profile_collect()
+    gs2m_native.profile_mode(0)
+
+    # untimed: per-stage breakdown of the same step, right behind the headline region (same clock).  Every stage is bracketed by
+    # HIP events of its own: a bracket also sees the dispatch latency that back-to-back kernels overlap with their predecessor's
+    # tail, so the stage times add up to slightly MORE than ms_per_step (by about 2-4 us per bracket).
+    STAGE_STEPS = 5
+    gs2m_native.profile_mode(2)
+    for _ in range(STAGE_STEPS):
+        step()
+    fence()
+    stages = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
 
     if rank == 0:
@@ -494,7 +496,8 @@ def main():
                        "gaussians": P, "visible": V, "num_rendered": R, "width": W, "height": H, "feature_count": fc,
                        "parallelism": f"view-parallel x{world}", "views_per_rank": VPR},
             "roofline": roof,
-            # stage TOTALS per step (a stage with two launches per step -- ranges + quadrant lists -- counts both)
+            # stage TOTALS per step (a stage with two launches per step -- ranges + quadrant lists -- counts both); each stage is
+            # its own event bracket, dispatch latency included: the sum exceeds ms_per_step by a few us per bracket
             "stages_ms": {k: round(v[0] / STAGE_STEPS, 5) for k, v in stages.items()},
         }
         if ref_binning is not None:
@@ -506,7 +509,7 @@ def main():
         out["views_per_step"] = world * VPR
         # the same K steps timed right behind the first W warm-up steps (where rounds 1-3 timed): inside the governor's clock ramp
         out["clock_ramp"] = {"ms_per_step_at_start": round(ms_start, 4), "value_at_start": round(world * VPR * 1e3 / ms_start, 3),
-                             "steps_before_headline": "W warm-up + K at-start + stage pass + reference-binning pass + W warm-up",
+                             "steps_before_headline": "W warm-up + K at-start + reference-binning pass (3 + K) + W warm-up",
                              "note": "sclk reaches 2400 MHz after ~0.5 s of continuous work (tools/clock_trace.py); "
                                      "`value` is timed after that, `value_at_start` before"}
         if ms_single is not None:
