@@ -23,8 +23,8 @@
 #include <stdlib.h>
 
 namespace {
-#ifndef LB_WIN
-#define LB_WIN 4
+#ifndef LB2_WIN
+#define LB2_WIN 16  // groups looked at per round trip of the look-back
 #endif
 
 constexpr int RS_THREADS = 256;
@@ -215,31 +215,64 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
             digit_base += s_w[1][w];
         }
     if (tid < BINS) {
-        uint32_t* my = status + (size_t)tile * 256 + tid;
-        uint32_t excl = 0;
-        if (tile == 0) {
-            __hip_atomic_store(my, FLAG_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(my, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // look-back, LB_WIN predecessors per round trip: the loads of one window are independent, so a chain
-            // of k not-yet-prefixed tiles costs k / LB_WIN memory latencies instead of k
-            int p = (int)tile - 1;
-            bool found = false;
-            while (!found) {
-                uint32_t w[LB_WIN];
+        // Where the tiles in front end, per digit.  Two levels, no chain through the tiles: every tile publishes its digit
+        // totals; a tile's own offset is (the totals of the tiles in front of it in its GROUP of 32, read directly -- up to 31
+        // independent loads) + (the totals of the groups in front).  A group's total is published by its LAST tile, which has
+        // it once it has read its 31 predecessors, followed by the group's inclusive prefix; every tile adds the group totals
+        // back to the nearest published prefix, 16 groups per round trip.  Rounds 1-4 walked back over the tiles themselves,
+        // 4 per round trip (with every tile of a pass resident and publishing at the same moment the prefixes spread as
+        // ~2 j^2 tiles after j round trips): the instance sort's passes took 31 us, now 28; the depth sort's 21, now 20;
+        // a pass without any look-back (wrong positions, timing only) takes 18 / 13.
+        const uint32_t grp = tile >> 5, r = tile & 31u;
+        uint32_t* const lvl2 = status + (size_t)gridDim.x * 256;  // [groups][256] behind the [tiles][256] totals
+        __hip_atomic_store(status + (size_t)tile * 256 + tid, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool leader = r == 31u;
+        uint32_t insum = 0;
 #pragma unroll
-                for (int k = 0; k < LB_WIN; k++)
-                    w[k] = p - k >= 0 ? __hip_atomic_load(status + (size_t)(p - k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : FLAG_PFX;  // in front of tile 0: prefix 0
+        for (int h = 0; h < 2; h++) {
+            uint32_t w[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t back = (uint32_t)(16 * h + k) + 1u;
+                w[k] = back <= r ? __hip_atomic_load(status + (size_t)(tile - back) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_AGG;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t back = (uint32_t)(16 * h + k) + 1u;
+                while ((w[k] & ~VAL_MASK) == 0u) {  // not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    w[k] = __hip_atomic_load(status + (size_t)(tile - back) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                insum += w[k] & VAL_MASK;
+            }
+        }
+        uint32_t* const my2 = lvl2 + (size_t)grp * 256 + tid;
+        const uint32_t gagg = insum + tot;
+        if (leader) __hip_atomic_store(my2, (grp == 0 ? FLAG_PFX : FLAG_AGG) | gagg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the groups in front, LB2_WIN per round trip (independent loads): totals are added up to the nearest group whose
+        // last tile has already published its prefix -- with the few dozen groups of a pass usually ONE round trip
+        uint32_t excl2 = 0;
+        {
+            int p = (int)grp - 1;
+            bool found = p < 0;
+#ifdef GS2M_KO_LOOKBACK
+            found = true;  // timing only: wrong output positions
+#endif
+            while (!found) {
+                uint32_t w[LB2_WIN];
+#pragma unroll
+                for (int k = 0; k < LB2_WIN; k++)
+                    w[k] = p - k >= 0 ? __hip_atomic_load(lvl2 + (size_t)(p - k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : FLAG_PFX;  // in front of group 0: prefix 0
                 bool stalled = false;
 #pragma unroll
-                for (int k = 0; k < LB_WIN; k++) {
+                for (int k = 0; k < LB2_WIN; k++) {
                     const uint32_t f = w[k] & ~VAL_MASK;
                     if (!found && !stalled) {
                         if (f == 0u) {
                             stalled = true;  // not published yet: poll again from here
                         } else {
-                            excl += w[k] & VAL_MASK;
+                            excl2 += w[k] & VAL_MASK;
                             p--;
                             found = f == FLAG_PFX;
                         }
@@ -247,8 +280,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
                 }
                 if (stalled) __builtin_amdgcn_s_sleep(1);
             }
-            __hip_atomic_store(my, FLAG_PFX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (leader && grp > 0) __hip_atomic_store(my2, FLAG_PFX | (excl2 + gagg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t excl = excl2 + insum;
         s_gbase[tid] = digit_base + excl - tile_excl;
         s_cnt[0][tid] = tile_excl;
         s_cnt[1][tid] = tile_excl + c0;
@@ -348,11 +382,12 @@ void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]) {
     for (int i = 0; i < RS_MAXPASS; i++) { bits[i] = i < p.npass ? p.bits[i] : 0; shift[i] = i < p.npass ? p.shift[i] : 0; }
 }
 
-// temp layout: [ghist 4x256][tickets 4 (padded to 256 B)][status npass x tiles x 256]
+// temp layout: [ghist 4x256][tickets 4 (padded to 256 B)][status npass x (tiles + groups of 32 tiles) x 256]
+static size_t status_rows(size_t tiles) { return tiles + (tiles + 31) / 32; }
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits) {
     const SortPlan p = make_plan(total_bits);
     const size_t tiles = (n + RS_TILE - 1) / RS_TILE;
-    return gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4 + 2 * GS2M_ALIGN;
+    return gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * status_rows(tiles) * 256 * 4 + 2 * GS2M_ALIGN;
 }
 
 // Sorts n pairs by key bits [0, total_bits), stable.  The input (kin, vin) is only read (vin may be
@@ -364,7 +399,7 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
     const SortPlan p = make_plan(total_bits);
     const size_t tiles = (n + RS_TILE - 1) / RS_TILE;
     *ptr = (uint32_t*)gs2m_align_up((size_t)(uintptr_t)temp);
-    *words = (gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4) / 4;
+    *words = (gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * status_rows(tiles) * 256 * 4) / 4;
 }
 
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
@@ -378,7 +413,7 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     uint32_t* ghist = (uint32_t*)base;
     uint32_t* tickets = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4));
     uint32_t* status = (uint32_t*)(base + gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN);
-    const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * tiles * 256 * 4;
+    const size_t zero_bytes = gs2m_align_up(RS_MAXPASS * 256 * 4) + GS2M_ALIGN + (size_t)p.npass * status_rows((size_t)tiles) * 256 * 4;
     hipError_t e = prezeroed ? hipSuccess : gs2m_zero_async(base, zero_bytes, s);
     if (e != hipSuccess) return e;
     const int workers = tiles < RS_HIST_WGS ? tiles : RS_HIST_WGS;
@@ -391,7 +426,7 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
     for (int i = 0; i < p.npass; i++) {
         uint32_t* ko = (i & 1) ? kB : kA;
         uint32_t* vo = (i & 1) ? vB : vA;
-        uint32_t* st = status + (size_t)i * tiles * 256;
+        uint32_t* st = status + (size_t)i * status_rows((size_t)tiles) * 256;
         const uint32_t* gh = (ext_hist ? ext_hist : ghist) + i * 256;
         const int hc = ext_hist ? GS2M_HIST_COPIES : 1;
         switch (p.bits[i]) {
