@@ -21,6 +21,9 @@ st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["t
 e = torch.Tensor([])
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(N)]
 wall = []
+if os.environ.get("REFBIN"):  # the reference's own instance list (gs2m_set_reference_binning)
+    import gs2m_native
+    gs2m_native.set_reference_binning(True)
 if os.environ.get("PREWARM"):
     x = torch.rand(16 << 20, 32, device=dev)  # 2 GB of 128-B rows
     idx = torch.randint(0, 16 << 20, (8 << 20,), device=dev)
