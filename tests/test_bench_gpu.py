@@ -31,6 +31,9 @@ def test_bench_line_has_the_contract_fields():
     rb = d["reference_binning"]
     assert d["reference_binning_ms_per_step"] == rb["ms_per_step"] > 0 and rb["num_rendered"] > d["config"]["num_rendered"]
     assert abs(sum(d["stages_ms"].values()) - d["ms_per_step"]) < 0.25 * d["ms_per_step"], "stage totals add up to about the step"
+    # the same K steps timed right behind the first warm-up (inside the clock governor's ramp), beside the headline
+    cr = d["clock_ramp"]
+    assert cr["ms_per_step_at_start"] > 0 and abs(cr["value_at_start"] - 1e3 / cr["ms_per_step_at_start"]) < 1e-2 * cr["value_at_start"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
 
