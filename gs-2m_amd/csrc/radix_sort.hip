@@ -31,8 +31,8 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_MAXPASS = 4;
-// Passes of at most this many tiles take their tile ids from blockIdx (see launch_pass): 3 workgroups per compute
-// unit of the CURRENT device (the kernel's LDS, 34 KB, and 256 threads allow 4) -- a
+// Passes of at most this many tiles take their tile ids from blockIdx (see launch_pass): 4 workgroups per compute
+// unit of the CURRENT device (the kernel's LDS, 38 KB, and its <= 128 VGPRs allow 4) -- a
 // partitioned device (CPX: 32 CUs) gets a proportionally smaller bound.
 int resident_tiles() {
     static int cached[64] = {0};
@@ -40,7 +40,7 @@ int resident_tiles() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (cached[dev] == 0) {
         int cus = 0;
-        cached[dev] = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? 3 * cus : -1;
+        cached[dev] = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? 4 * cus : -1;
     }
     return cached[dev] > 0 ? cached[dev] : 0;
 }
@@ -214,6 +214,26 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
             tile_excl += s_w[0][w];
             digit_base += s_w[1][w];
         }
+    // The tile's digit totals are published first (the tiles behind are waiting for them), then the tile is reordered by digit
+    // in LDS -- which needs only the tile's own counts -- and only then do the digit threads look back: the keys, values and
+    // ranks are out of the registers by then (128 instead of 162 VGPRs: four workgroups per compute unit instead of three).
+    if (tid < BINS) {
+        __hip_atomic_store(status + (size_t)tile * 256 + tid, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cnt[0][tid] = tile_excl;
+        s_cnt[1][tid] = tile_excl + c0;
+        s_cnt[2][tid] = tile_excl + c0 + c1;
+        s_cnt[3][tid] = tile_excl + c0 + c1 + c2;
+    }
+    gs2m_sync();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        if (segbase + k * 64 + lane < n) {
+            const uint32_t d = (key[k] >> shift) & (BINS - 1);
+            const uint32_t lp = s_cnt[wave][d] + rank[k];
+            s_key[lp] = key[k];
+            s_val[lp] = val[k];
+        }
+    }
     if (tid < BINS) {
         // Where the tiles in front end, per digit.  Two levels, no chain through the tiles: every tile publishes its digit
         // totals; a tile's own offset is (the totals of the tiles in front of it in its GROUP of 32, read directly -- up to 31
@@ -225,7 +245,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
         // a pass without any look-back (wrong positions, timing only) takes 18 / 13.
         const uint32_t grp = tile >> 5, r = tile & 31u;
         uint32_t* const lvl2 = status + (size_t)gridDim.x * 256;  // [groups][256] behind the [tiles][256] totals
-        __hip_atomic_store(status + (size_t)tile * 256 + tid, FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool leader = r == 31u;
         uint32_t insum = 0;
 #pragma unroll
@@ -284,20 +303,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
         if (leader && grp > 0) __hip_atomic_store(my2, FLAG_PFX | (excl2 + gagg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t excl = excl2 + insum;
         s_gbase[tid] = digit_base + excl - tile_excl;
-        s_cnt[0][tid] = tile_excl;
-        s_cnt[1][tid] = tile_excl + c0;
-        s_cnt[2][tid] = tile_excl + c0 + c1;
-        s_cnt[3][tid] = tile_excl + c0 + c1 + c2;
-    }
-    gs2m_sync();
-#pragma unroll
-    for (int k = 0; k < RS_ITEMS; k++) {
-        if (segbase + k * 64 + lane < n) {
-            const uint32_t d = (key[k] >> shift) & (BINS - 1);
-            const uint32_t lp = s_cnt[wave][d] + rank[k];
-            s_key[lp] = key[k];
-            s_val[lp] = val[k];
-        }
     }
     gs2m_sync();
     // side job, second level: the sums over super-blocks of 65536 positions are collected per workgroup in LDS first (the
