@@ -313,60 +313,45 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
 // The blend kernels then run one wave per quadrant straight down its list: no staging of instances that
 // are skipped anyway, no tests, no ballot walks.  Entries keep the position in the tile list, so n_contrib
 // (a tile-list position, as in the reference) and the gradient-row addressing stay what they were.
-// One workgroup per tile; 256 instances per step, one per thread.
 // Also identifyTileRanges (rasterizer_impl.cu:108-129): the tile sort's last pass has recorded where every tile's run of
 // instances starts and ends (radix_sort.hip: range_raw); this kernel writes ranges[tile] from it ((0, 0) for an untouched tile,
 // as the reference's memset leaves it) -- rounds 1-3 ran a kernel over all R sorted keys for that.
-__global__ void __launch_bounds__(256) quad_lists_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ point_list,
-                                                         uint2* __restrict__ qlist, uint32_t* __restrict__ qcount) {
-    // 512 instances per step, two per thread (k and k + 256)
-    constexpr int SLOTS = 2;
-    __shared__ uint32_t s_cnt[2][SLOTS][4][4];  // [parity][slot][wave][quadrant]
-    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__global__ void __launch_bounds__(64) quad_lists_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ point_list,
+                                                        uint2* __restrict__ qlist, uint32_t* __restrict__ qcount) {
+    // ONE WAVE per tile, 384 instances per step (six per lane, requested together): the 8160 tiles of a 1080p frame are one
+    // generation of waves on the chip, with no LDS and no barrier -- ballots give every instance its place in each of the four
+    // lists.  (Rounds 2-4 ran a workgroup of 256 threads per tile with the wave counts exchanged through LDS: four generations
+    // of workgroups, 17 us; a tile list of a few hundred entries is one or two steps of a single wave.)
+    constexpr int U = 6;
+    const int tile = blockIdx.x, lane = threadIdx.x;
     const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
     const uint2 range = raw.y != 0u ? make_uint2(~raw.x, raw.y) : make_uint2(0u, 0u);
-    if (tid == 0) ranges[tile] = range;
+    if (lane == 0) ranges[tile] = range;
     const int len = (int)(range.y - range.x);
     uint2* out = qlist + (size_t)4 * range.x;
     uint32_t run[4] = {0u, 0u, 0u, 0u};
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    int par = 0;
-    for (int base = 0; base < len; base += 256 * SLOTS, par ^= 1) {
-        uint32_t v[SLOTS];
-        unsigned long long m[SLOTS][4];
+    for (int base = 0; base < len; base += 64 * U) {
+        uint32_t v[U];
 #pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int k = base + s * 256 + tid;
-            v[s] = k < len ? point_list[range.x + k] : 0u;  // Gaussian id | quadrant-hit mask << 28 (emit_kernel<true>)
+        for (int u = 0; u < U; u++) {
+            const int k = base + u * 64 + lane;
+            v[u] = k < len ? point_list[range.x + k] : 0u;  // Gaussian id | quadrant-hit mask << 28 (emit_kernel)
         }
 #pragma unroll
-        for (int s = 0; s < SLOTS; s++)
+        for (int u = 0; u < U; u++) {
+            const int k = base + u * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                m[s][q] = __builtin_amdgcn_ballot_w64(((v[s] >> (GS2M_GID_BITS + q)) & 1u) != 0);
-                if (lane == 0) s_cnt[par][s][wave][q] = (uint32_t)__popcll(m[s][q]);
-            }
-        gs2m_sync();  // one barrier per step: the counters alternate between two sets
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int k = base + s * 256 + tid;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const uint32_t c = s_cnt[par][s][w][q];
-                    before += w < wave ? c : 0u;
-                    total += c;
-                }
-                if ((v[s] >> (GS2M_GID_BITS + q)) & 1u)
-                    out[(size_t)q * len + run[q] + before + (uint32_t)__popcll(m[s][q] & lt)] = make_uint2(v[s], (uint32_t)k);
-                run[q] += total;
+                const bool hit = ((v[u] >> (GS2M_GID_BITS + q)) & 1u) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (hit) out[(size_t)q * len + run[q] + (uint32_t)__popcll(m & lt)] = make_uint2(v[u], (uint32_t)k);
+                run[q] += (uint32_t)__popcll(m);
             }
         }
     }
-    if (tid < 4) qcount[tile * 4 + tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
+    if (lane < 4) qcount[tile * 4 + lane] = lane == 0 ? run[0] : (lane == 1 ? run[1] : (lane == 2 ? run[2] : run[3]));
 }
 
 }  // namespace
@@ -403,5 +388,5 @@ hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s) {
 void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
                             const ImageState& im, hipStream_t s) {
     (void)W; (void)H; (void)g;
-    quad_lists_kernel<<<tiles_x * tiles_y, 256, 0, s>>>(im.ranges_raw, im.ranges, b.point_list, b.qlist, im.qcount);
+    quad_lists_kernel<<<tiles_x * tiles_y, 64, 0, s>>>(im.ranges_raw, im.ranges, b.point_list, b.qlist, im.qcount);
 }
