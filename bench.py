@@ -419,11 +419,14 @@ def main():
         gs2m_native.lib().gs2m_set_reference_binning(0)
 
     # The headline: W untimed warm-up steps, then exactly K timed ones.
-    # HIP events on the launch stream around the dominant kernel (the backward blend) inside the timed region; every
-    # bracketed kernel costs the stream ~6 us of bubble, so the other stages are timed in the untimed pass above
+    # HIP events on the launch stream around the dominant kernel (the backward blend) inside the timed region.  An event pair
+    # leaves ~6 us of bubble on the stream on either side of the kernel it brackets (kernel trace: the only gaps of the step), so
+    # every BRACKET_EVERY-th launch is bracketed -- `roofline.launches_bracketed` of the K x views launches -- and the other
+    # stages are timed in the untimed pass below
+    BRACKET_EVERY = 4
     for _ in range(a.warmup):
         step()
-    gs2m_native.profile_mode(3)
+    gs2m_native.profile_mode(3, every=BRACKET_EVERY)
     ms = timed(False)
     blend = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
@@ -461,6 +464,7 @@ def main():
                 # on other kernel sources or another workload
                 "traffic": ctr.get("hbm_bytes"),
                 "algo_bytes_per_launch": ab[dom], "avg_launch_ms": round(k_ms[dom], 5),
+                "launches_bracketed": int(blend["blend_bwd"][1]) if dom == "blend_bwd" else int(stages["blend_fwd"][1]),
                 "blend_fwd_ms": round(k_ms["blend_fwd"], 5), "blend_bwd_ms": round(k_ms["blend_bwd"], 5),
                 "whole_path_GBps": round(VPR * ab["total"] / (ms * 1e-3) / 1e9, 2)}
         if ctr.get("SQ_WAVE_CYCLES"):

@@ -50,6 +50,8 @@ struct Prof {
     hipEvent_t ev[kMaxRecords][2];
     int stage[kMaxRecords];
     int created = 0;
+    int every = 1;   // mode 3: bracket every `every`-th launch of the backward blend only (gs2m_profile_sampling)
+    int seen3 = 0;   // launches of the backward blend since the mode was set
 };
 Prof g_prof;
 std::mutex g_prof_mutex;  // the record table is shared by every thread that calls into the library while profiling is on
@@ -98,6 +100,7 @@ struct StageTimer {
         {
             std::lock_guard<std::mutex> lock(g_prof_mutex);
             if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || (g_prof.mode == 3 && stage != ST_BLEND_BWD) || g_prof.n >= kMaxRecords) return;
+            if (g_prof.mode == 3 && (g_prof.seen3++ % g_prof.every) != 0) return;
             slot = g_prof.n++;
             if (slot >= g_prof.created) {
                 (void)hipEventCreate(&g_prof.ev[slot][0]);
@@ -450,6 +453,14 @@ int gs2m_profile_mode(int mode) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof.mode = mode;
     g_prof.n = 0;
+    g_prof.seen3 = 0;
+    return GS2M_OK;
+}
+
+int gs2m_profile_sampling(int every) {
+    if (every < 1) return GS2M_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof.every = every;
     return GS2M_OK;
 }
 

@@ -305,6 +305,10 @@ const char* gs2m_stage_name(int stage);
  * blend_bwd, gaussian_bwd. */
 #define GS2M_NUM_STAGES 10
 int gs2m_profile_mode(int mode);
+/* mode 3 brackets every `every`-th launch of the backward blend (default 1: each one).  An event pair leaves ~6 us of bubble on
+ * the stream on either side of the kernel it brackets; a caller that times a loop around the launches it measures (bench.py)
+ * samples them instead. */
+int gs2m_profile_sampling(int every);
 int gs2m_profile_collect(float* stage_ms, int* stage_count, int n_stages);
 
 /* Library version / build info string (static storage). */
