@@ -52,6 +52,9 @@ for i in range(N):
         for t in list(prm.values()) + [m2]:
             t.grad = None
         torch.cuda.empty_cache()
+    if os.environ.get("REFBIN_AT") and i == int(os.environ["REFBIN_AT"]):  # switch to the reference's instance list mid-run (bench.py's second leg)
+        import gs2m_native
+        gs2m_native.set_reference_binning(True)
     if os.environ.get("SLEEP_AT") and i == int(os.environ["SLEEP_AT"]):
         torch.cuda.synchronize()
         time.sleep(0.5)
