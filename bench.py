@@ -413,8 +413,11 @@ def main():
         gs2m_native.lib().gs2m_set_reference_binning(1)
         for _ in range(max(3, a.warmup // 2)):
             step()
+        import diff_gaussian_rasterization as _dgr
+        c0 = dict(_dgr.BINNING_CACHE_STATS)
         ms_ref = timed(False)
         ref_binning = {"ms_per_step": round(ms_ref, 4), "value": round(VPR * 1e3 / ms_ref, 3),
+                       "binning_cache": {k: _dgr.BINNING_CACHE_STATS[k] - c0[k] for k in c0},
                        "num_rendered": int(info["R"]) if info["R"] is not None else -1}
         gs2m_native.lib().gs2m_set_reference_binning(0)
 

@@ -114,6 +114,11 @@ class _ScratchCache(_Alloc):
         return super()._alloc(nbytes, _user)
 
 
+# forwards of the autograd path / of them: the cached binning buffer was leased to another graph ("busy": allocated through
+# Python inside the GPU-idle window) / was empty or too small ("grown": the same, once per size)
+BINNING_CACHE_STATS = {"calls": 0, "busy": 0, "grown": 0}
+
+
 class _BinningLease:
     """Exclusive use of one cache entry's buffer; given back when this object dies or -- sooner -- when nothing but the
     cache references the buffer any more (_BinningCache.acquire).  The autograd Function keeps it on `ctx`: a training loop
@@ -228,6 +233,12 @@ class _CModule:
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), int(featureCount), _ptr(out_color),
                 _ptr(radii), _ptr(observe), _ptr(out_buffer), _stream())
         _native.check(rendered, "gs2m_raster_forward")
+        if _cached_binning:
+            BINNING_CACHE_STATS["calls"] += 1
+            if lease is None:
+                BINNING_CACHE_STATS["busy"] += 1
+            elif pre is None or pre.used_fallback:
+                BINNING_CACHE_STATS["grown"] += 1
         if pre is not None and not pre.used_fallback:
             bin_tensor = cache.tensor
             if _lease_out is not None:
