@@ -17,6 +17,9 @@ steps again and the K timed steps `value` is computed from, then the per-stage p
   --config c2            configs[1]: 500k Gaussians, 1080p, feature_count 5 (colour + depth + normal)
   --config c5            configs[4]'s per-GPU shape: 2M Gaussians, 1080p, feature_count 9
   --config c1            configs[0]: 10k Gaussians, 256x256, feature_count 10 (the CPU-runnable case)
+  --config c4            configs[3]: the full train.py loop at DTU scan24's size on a SUBSTITUTE scene (the dataset is not on the
+                         box): 49 views 777x581 through the COLMAP loader at -r 2, ~30 k -> past 300 k points, geometry stage with
+                         lambda_depth_normal 0.015 and the multi-view term; prints training iterations/s (N = 1 only)
 At N = 1 the line also carries `cpu_baseline` (the oracle timed on this box's host cores), `render_level_ms`,
 `train_step_ms` and `material_step_ms` (render(), a full geometry-stage and a full material-stage training iteration around
 the same op).
@@ -210,12 +213,96 @@ def caller_levels(P, W, H, seed, dev, steps=10, warmup=6):
     return res
 
 
+def bench_c4(a):
+    """BASELINE.json configs[3] on the substitute scene (gs2m_train.c4_scene / c4_run; tests/test_c4_gpu.py checks the same run):
+    value = training iterations per second over the whole run (render, losses, backward, densify / prune / reset / trim, Adam),
+    the rasterizer's share of an iteration measured on the final model, and the CPU oracle's fwd+bwd of one training view of
+    the final model beside it."""
+    import tempfile
+    import numpy as np
+    import gs2m_native
+    import gs2m_synth as S
+    import gs2m_train
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    iters = a.c4_iterations
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        scene = gs2m_train.c4_scene(os.path.join(tmp, "c4"), seed=a.seed)
+        t_scene = time.perf_counter() - t0
+        for _ in range(max(1, a.warmup // 25)):  # warm-up: a short run (allocator, clocks, lazily loaded kernels)
+            gs2m_train.c4_run(None, iterations=150, schedule_iterations=iters, scene=scene, seed=a.seed)
+        model, st = gs2m_train.c4_run(None, iterations=iters, scene=scene, seed=a.seed)
+    cams = scene[0]
+    W, H = cams[0].image_width, cams[0].image_height
+    # the rasterizer inside one iteration of the final model: stage times of view 0's render + backward
+    from gaussian_renderer import render
+    from gs2m_scene import PipelineParams
+    pipe, bg = PipelineParams(), torch.zeros(3, device=dev)
+    gs2m_native.profile_mode(2)
+    info = {}
+    for _ in range(5):
+        for p in model.parameters():
+            p.grad = None
+        out = render(cams[0], model, pipe, bg, True, False, sobel_normal=True)
+        (out["render"].sum() + out["depth_map"].sum() + out["normal_map"].sum()).backward()
+        info["radii"] = out["radii"]
+    torch.cuda.synchronize()
+    stages = gs2m_native.profile_collect()
+    gs2m_native.profile_mode(0)
+    P = int(model.get_xyz.shape[0])
+    V = int((info["radii"] > 0).sum().item())
+    Tn = ((W + 15) // 16) * ((H + 15) // 16)
+    k_ms = {k: v[0] / max(v[1], 1) for k, v in stages.items()}
+    raster_ms = sum(v[0] for v in stages.values()) / 5.0
+    fc = 5  # geometry stage: colour + alpha + distance + normal
+    R = None
+    out_line = {
+        "metric": "train iterations/s, full train.py loop (BASELINE configs[3]; SUBSTITUTE scene: DTU scan24 is not on the box)",
+        "value": round(st["it_per_s"], 3), "unit": "iterations/s", "n_gpus": 1, "steps": iters, "warmup": a.warmup,
+        "ms_per_step": round(1e3 / st["it_per_s"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": st["workload"], "views": len(cams), "width": W, "height": H, "points_start": st["points_start"],
+                   "points_max": st["points_max"], "points_end": st["points_end"], "psnr_start": round(st["psnr_start"], 3),
+                   "psnr_end": round(st["psnr_end"], 3), "scene_build_s": round(t_scene, 2)},
+        "rasterizer_ms_per_iteration_at_end": round(raster_ms, 4),
+        "stages_ms_at_end": {k: round(v, 5) for k, v in k_ms.items() if v},
+    }
+    dom = "blend_bwd"
+    if not a.no_cpu_baseline:
+        # the CPU oracle on what render() hands the op for view 0 of the final model (checker infrastructure, never on the product path)
+        from test_c4_gpu import _capture_rasterizer_call
+        import helpers as Hh
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        flags = oracle.use_native_build() or "-O2 -fopenmp"
+        sc = _capture_rasterizer_call(cams[0], model, geometry_stage=True)
+        t0 = time.time()
+        f, gr = Hh.run_oracle(oracle, sc)
+        dt = time.time() - t0
+        R = int(f.num_rendered)
+        out_line["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "iterations/s (rasterizer forward + backward of ONE training view only: an upper bound for a CPU loop)",
+                                    "cores": cores, "kind": "port",
+                                    "sample": f"oracle fwd+bwd of view 0 of the final model ({P} points, {W}x{H}, fc {sc['fc']}; {dt:.2f} s on {cores} OpenMP threads, built with {flags})"}
+    if R is not None:
+        ab = S.algo_bytes(P, V, R, W * H, Tn, fc)
+        out_line["config"]["num_rendered_view0_reference_binning"] = R
+        ach = ab[dom] / (k_ms[dom] * 1e-3) / 1e9
+        out_line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                                "traffic": None, "algo_bytes_per_launch": ab[dom], "avg_launch_ms": round(k_ms[dom], 5),
+                                "measured": "stage pass on view 0 of the final model (algorithmic bytes priced with the reference's instance count)"}
+    print(json.dumps(out_line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"], help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--c4-iterations", type=int, default=5000, help="--config c4: training iterations (the reference runs 30000; the schedule is compressed)")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -255,6 +342,10 @@ def main():
         raise SystemExit(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU path)")
+    if a.config == "c4":
+        if world != 1:
+            raise SystemExit("bench.py --config c4 is a single-GPU run")
+        return bench_c4(a)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("GS2M_DIST_BACKEND", "nccl")  # "gloo": functional check of the N > 1 path on one GPU
     if world > 1 and backend == "nccl" and ndev < world:
@@ -505,7 +596,7 @@ def main():
             "roofline": roof,
             # stage TOTALS per step (a stage with two launches per step -- ranges + quadrant lists -- counts both); each stage is
             # its own event bracket, dispatch latency included: the sum exceeds ms_per_step by a few us per bracket
-            "stages_ms": {k: round(v[0] / STAGE_STEPS, 5) for k, v in stages.items()},
+            "stages_ms": {k: round(v[0] / STAGE_STEPS, 5) for k, v in stages.items() if not k.startswith("unused")},
         }
         if ref_binning is not None:
             out["reference_binning_ms_per_step"] = ref_binning["ms_per_step"]

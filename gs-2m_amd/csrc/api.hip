@@ -16,36 +16,32 @@
 
 namespace {
 
-// getHigherMsb (rasterizer_impl.cu:31-44): number of key bits that cover the tile ids
-uint32_t higher_msb(uint32_t n) {
-    uint32_t msb = sizeof(n) * 4;
-    uint32_t step = msb;
-    while (step > 1) {
-        step /= 2;
-        if (n >> msb) msb += step; else msb -= step;
-    }
-    if (n >> msb) msb++;
-    return msb;
-}
-
-// pinned landing zone for num_rendered, one per host thread (never freed: the HIP runtime
-// may already be gone when thread-local destructors run)
-struct Pinned {
-    uint32_t* p = nullptr;    // host pointer of the pinned landing zone
-    uint32_t* dev = nullptr;  // the same memory as the device sees it
-    uint32_t* acc[256] = {};  // per device: two zeroed words the side sum of the histogram kernel works in
+// Landing zones: mapped pinned words the GPU publishes a forward's counts into (common.h: GS2M_LAND_*), a ring of slots per
+// device (never freed: the HIP runtime may already be gone when static destructors run).  A forward takes the next slot; the
+// token it leaves behind (gs2m_raster_forward_token) names the slot and its generation, so that the dense-row count of THAT
+// forward can be read later -- at backward time, from whichever thread autograd runs the backward on -- unless the slot has
+// been reused since (64 forwards later: the caller then sizes for the worst case).
+constexpr int kLandSlots = 64, kLandWords = 16;
+struct LandRing {
+    uint32_t* host = nullptr;  // kLandSlots x kLandWords words
+    uint32_t* dev = nullptr;   // the same memory as the device sees it
+    std::atomic<uint32_t> next{0};
+    std::atomic<uint32_t> gen[kLandSlots];
 };
-thread_local Pinned t_pinned;
+LandRing g_land[64];
+std::mutex g_land_mutex;
+thread_local uint64_t t_last_token = 0;  // (device + 1) << 40 | generation << 8 | slot; 0: none
+thread_local long long t_rows_hint = -1;  // gs2m_raster_backward_rows_hint: consumed by this thread's next backward
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 // mode 0: off; 1: the two blend kernels only; 2: every stage; 3: the backward blend kernel only (an event pair costs
 // ~6 us of stream bubble around the kernel it brackets: bench.py's timed region brackets the dominant kernel alone).
 static_assert(GS2M_NUM_STAGES == 10, "stage table");
-enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_OBSERVE,
+enum Stage { ST_PREPROCESS = 0, ST_COUNT_TILES, ST_SCAN, ST_FILL, ST_TILE_SORT, ST_UNUSED5, ST_BLEND_FWD, ST_UNUSED7,
              ST_BLEND_BWD, ST_GAUSSIAN_BWD, ST_COUNT };
 constexpr int kMaxRecords = 8192;
 struct Prof {
-    int mode = 0;
+    std::atomic<int> mode{0};  // read without the lock on the fast path (StageTimer), written under it
     int n = 0;
     hipEvent_t ev[kMaxRecords][2];
     int stage[kMaxRecords];
@@ -62,8 +58,7 @@ std::atomic<int> g_spin_wait{1};  // forward: poll the pinned num_rendered inste
 std::atomic<int> g_debug{0};      // gs2m_set_debug: synchronize + check after every stage
 std::atomic<int> g_markers{0};    // gs2m_set_markers: roctx ranges around the stages
 
-const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges+quad_lists",
-                                           "blend_fwd", "observe", "blend_bwd", "gaussian_bwd"};
+const char* const kStageNames[ST_COUNT] = {"preprocess", "count", "scan", "fill", "tile_sort", "-", "blend_fwd", "-", "blend_bwd", "gaussian_bwd"};
 
 // roctx ranges (rocprofv3 --marker-trace): resolved at run time so that the library has no link-time dependency
 struct Roctx {
@@ -96,7 +91,7 @@ struct StageTimer {
             if (g_roctx.push) { g_roctx.push(kStageNames[stage]); marked = true; }
         }
         const bool blend = stage == ST_BLEND_FWD || stage == ST_BLEND_BWD;
-        if (g_prof.mode == 0) return;  // (the common case takes no lock)
+        if (g_prof.mode.load(std::memory_order_relaxed) == 0) return;  // (the common case takes no lock)
         {
             std::lock_guard<std::mutex> lock(g_prof_mutex);
             if (g_prof.mode == 0 || (g_prof.mode == 1 && !blend) || (g_prof.mode == 3 && stage != ST_BLEND_BWD) || g_prof.n >= kMaxRecords) return;
@@ -133,12 +128,13 @@ extern "C" {
 char* gs2m_prealloc_alloc(size_t bytes, void* user) {
     gs2m_prealloc* p = static_cast<gs2m_prealloc*>(user);
     if (!p) return nullptr;
+    p->requested = bytes;
     if (p->ptr && bytes <= p->capacity) return p->ptr;
     p->used_fallback = 1;
     return p->fallback ? p->fallback(bytes, p->fallback_user) : nullptr;
 }
 
-const char* gs2m_version(void) { return "gs2m_raster 0.3 (gfx950, round 3)"; }
+const char* gs2m_version(void) { return "gs2m_raster 0.5 (gfx950, round 5)"; }
 
 static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_alloc_fn binning_alloc,
                         void* binning_user, gs2m_alloc_fn image_alloc, void* image_user, int P, int D, int M,
@@ -160,6 +156,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (shs_rest && (!shs || M != 16 || (((uintptr_t)shs_rest) & 15))) return GS2M_ERR_UNSUPPORTED;  // split SH: M = 16 only
     if (P > 0 && feature_count > 0 && !features) return GS2M_ERR_INVALID_ARG;
     if (width > 16 * 65535 || height > 16 * 65535) return GS2M_ERR_UNSUPPORTED;
+    if ((size_t)((width + GS2M_TILE - 1) / GS2M_TILE) * (size_t)((height + GS2M_TILE - 1) / GS2M_TILE) > ((size_t)1 << 28)) return GS2M_ERR_UNSUPPORTED;
     // the sorted values carry a 4-bit quadrant mask above the Gaussian id (binning.hip): ids stay below 2^28
     if (P >= (1 << GS2M_GID_BITS)) return GS2M_ERR_UNSUPPORTED;
 
@@ -169,126 +166,125 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     const float focal_x = width / (2.0f * tan_fovx);
 
     const size_t Pn = P > 0 ? (size_t)P : 1;
-    const size_t gtemp = gs2m_geom_temp_bytes(Pn);
-    GeomState gsz = gs2m_carve_geom(nullptr, Pn, gtemp);
+    GeomState gsz = gs2m_carve_geom(nullptr, Pn);
     char* gbase = geometry_alloc(gsz.total_bytes, geometry_user);
     if (!gbase) return GS2M_ERR_ALLOC;
-    GeomState g = gs2m_carve_geom(gbase, Pn, gtemp);
+    GeomState g = gs2m_carve_geom(gbase, Pn);
 
     ImageState isz = gs2m_carve_image(nullptr, N, tiles);
     char* ibase = image_alloc(isz.total_bytes, image_user);
     if (!ibase) return GS2M_ERR_ALLOC;
     ImageState im = gs2m_carve_image(ibase, N, tiles);
 
+    // this call's landing slot
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 64) return GS2M_ERR_UNSUPPORTED;
+    LandRing& ring = g_land[dev_id];
+    if (!ring.host) {
+        std::lock_guard<std::mutex> lock(g_land_mutex);
+        if (!ring.host) {
+            uint32_t* h = nullptr;
+            HIP_TRY(hipHostMalloc((void**)&h, kLandSlots * kLandWords * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable));
+            HIP_TRY(hipHostGetDevicePointer((void**)&ring.dev, h, 0));
+            for (int k = 0; k < kLandSlots; k++) ring.gen[k] = 0;
+            ring.host = h;
+        }
+    }
+    const uint32_t seq = ring.next.fetch_add(1), slot = seq % kLandSlots;
+    const uint32_t generation = ring.gen[slot].fetch_add(1) + 1;
+    volatile uint32_t* land = ring.host + slot * kLandWords;
+    uint32_t* land_dev = ring.dev + slot * kLandWords;
+    land[GS2M_LAND_R] = 0xFFFFFFFFu;  // a sentinel no count can take (R < 2^30)
+    land[GS2M_LAND_PREFILTERED] = 0u;
+    land[GS2M_LAND_MAXTILE] = 0u;
+    land[GS2M_LAND_ROWS] = 0u;
+    t_last_token = ((uint64_t)(dev_id + 1) << 40) | ((uint64_t)(generation & 0xFFFFFFFFu) << 8) | slot;
+
     int R = 0;
-    uint32_t* tile_hist = nullptr;  // the tile sort's digit histograms (zeroed by the preprocess kernel, filled by the emit kernel)
-    uint32_t *block_sums = nullptr, *super_sums = nullptr;  // tiles_touched summed over blocks of 256 (and of 65536) depth-sorted Gaussians (filled by the depth sort's last pass)
     if (P > 0) {
-        // scratch of the depth sort and of the scan, side by side in g.temp; zeroed by the preprocess kernel
-        char* sort_temp = g.temp;
-        const size_t sort_temp_bytes = gs2m_align_up(gs2m_radix_temp_bytes((size_t)P, 32));
-        char* front_temp = g.temp + sort_temp_bytes;  // block sums of tiles_touched + the tile sort's digit histograms
-        if (!t_pinned.p) {
-            HIP_TRY(hipHostMalloc((void**)&t_pinned.p, 64, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer((void**)&t_pinned.dev, t_pinned.p, 0));
-        }
-        int dev_id = 0;
-        HIP_TRY(hipGetDevice(&dev_id));
-        uint32_t* acc = nullptr;  // per device: the words the side sum of the histogram kernel works in
-        if (dev_id >= 0 && dev_id < 256) {
-            if (!t_pinned.acc[dev_id]) HIP_TRY(hipMalloc((void**)&t_pinned.acc[dev_id], 64));
-            acc = t_pinned.acc[dev_id];
-        }
-        // zeroed by the preprocess kernel, on this stream, ahead of every use: the depth sort's scratch, the scan's, and the
-        // side sum's accumulator (so a call that died half way cannot leave a count behind for the next one)
-        ZeroJobs zj = {{nullptr, nullptr, acc}, {0, 0, acc ? (size_t)4 : (size_t)0}};
-        gs2m_radix_zero_region(sort_temp, (size_t)P, 32, &zj.p[0], &zj.words[0]);
-        gs2m_front_zero_region(front_temp, (size_t)P, &zj.p[1], &zj.words[1]);
-        tile_hist = gs2m_tile_hist_ptr(front_temp, (size_t)P);
-        block_sums = gs2m_block_sums_ptr(front_temp);
-        super_sums = gs2m_super_sums_ptr(front_temp, (size_t)P);
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
+            // the preprocess kernel zeroes the tile histogram the count kernel adds into
+            ZeroJobs zj = {{im.tile_count, nullptr, nullptr}, {tiles, 0, 0}};
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                                    tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, out_observe, g,
                                    reference_binning ? 0 : 1, zj, s);
         }
-        // The reference waits for num_rendered after its scan (rasterizer_impl.cu:269-270) and the GPU idles until the
-        // host has seen the value, sized the binning buffer and launched the next kernel.  Here the value -- the plain sum
-        // of tiles_touched, whatever the order -- is added up on the side by the depth sort's histogram kernel, the first
-        // kernel behind the preprocessing, and its last workgroup stores it into a mapped pinned word (one aligned
-        // system-scope 32-bit store; a 4-byte hipMemcpyAsync may be carried out byte by byte: torn counts were seen).
-        // The host polls that word (a sentinel no count can take: R < 2^30) while the sort passes still
-        // run, and has the binning kernels queued behind them before they finish: no idle gap.
-        volatile uint32_t* land = t_pinned.p;
-        land[0] = 0xFFFFFFFFu;
-        land[1] = 0u;
-        // `prefiltered`: honoured as a checked promise (preprocess.hip); the check runs ahead of the histogram kernel whose
-        // last workgroup publishes num_rendered, so its flag has landed when the wait below returns
-        if (prefiltered) gs2m_launch_prefiltered_check(P, means3D, viewmatrix, t_pinned.dev + 1, s);
-        {   // 1. depth order of the Gaussians themselves (stable: ties keep id order)
-            StageTimer t(ST_DEPTH_SORT, s, &failed_stage);
-            const SideSum sum = {acc ? g.tiles_touched : nullptr, acc, t_pinned.dev};
-            // the last pass also leaves the sums of tiles_touched over blocks of 256 sorted Gaussians (the emit kernel's prefix)
-            HIP_TRY(gs2m_radix_sort_pairs(sort_temp, sort_temp_bytes, g.depth_key, nullptr, g.sort_keyA, g.sort_valA,
-                                          g.depth_key_sorted, g.sorted_gid, (size_t)P, 32, true, s, sum, nullptr, nullptr,
-                                          SideBuckets{g.tiles_touched, block_sums, super_sums}));
+        // `prefiltered`: honoured as a checked promise (preprocess.hip); the check runs ahead of the count kernel, whose first
+        // workgroup publishes num_rendered, so its flag has landed when the wait below returns
+        if (prefiltered) gs2m_launch_prefiltered_check(P, means3D, viewmatrix, land_dev + GS2M_LAND_PREFILTERED, s);
+        // The reference waits for num_rendered after its scan (rasterizer_impl.cu:269-270) and the GPU idles until the host
+        // has seen the value, sized the binning buffer and launched the next kernel.  Here the value is published by the
+        // FIRST workgroup of the count kernel (the sum of the per-block counts the preprocess kernel left), and the host has
+        // the fill kernel queued while the count and scan kernels -- which need no binning memory -- still run.
+        {
+            StageTimer t(ST_COUNT_TILES, s, &failed_stage);
+            gs2m_launch_count(P, tiles_x, g, im, land_dev, s);
+        }
+        {
+            StageTimer t(ST_SCAN, s, &failed_stage);
+            gs2m_launch_scan(P, tiles, g, im, land_dev, s);
         }
         HIP_TRY(hipGetLastError());
         DEBUG_CHECK();
         if (spin_wait) {
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
-            while (land[0] == 0xFFFFFFFFu) {
+            while (land[GS2M_LAND_R] == 0xFFFFFFFFu) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
             }
         }
-        if (land[0] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
-        if (prefiltered && land[1] != 0u) {  // a Gaussian behind the near plane: the reference traps the device here
+        if (land[GS2M_LAND_R] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
+        if (prefiltered && land[GS2M_LAND_PREFILTERED] != 0u) {  // a Gaussian behind the near plane: the reference traps the device here
             HIP_TRY(hipStreamSynchronize(s));  // nothing of this call is left in flight when the caller frees its buffers
             return GS2M_ERR_PREFILTERED;
         }
-        if (land[0] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // the look-back status words carry 30 value bits
-        R = (int)land[0];
+        if (land[GS2M_LAND_R] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // slots, rows (4 per instance at most) and list offsets are 32-bit
+        R = (int)land[GS2M_LAND_R];
+    } else {
+        HIP_TRY(gs2m_zero_async(im.tile_count, tiles * sizeof(uint32_t), s));
+        gs2m_launch_scan(0, tiles, g, im, land_dev, s);
     }
 
-    const int tile_bits = (int)higher_msb((uint32_t)tiles);
     const size_t Rn = R > 0 ? (size_t)R : 1;
-    const size_t btemp = gs2m_binning_temp_bytes(Rn, tile_bits);
-    BinningState bsz = gs2m_carve_binning(nullptr, Rn, btemp);
+    BinningState bsz = gs2m_carve_binning(nullptr, Rn);
     char* bbase = binning_alloc(bsz.total_bytes, binning_user);
     if (!bbase) return GS2M_ERR_ALLOC;
-    BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
+    BinningState b = gs2m_carve_binning(bbase, Rn);
 
+    uint32_t max_tile = 0;
     if (R > 0) {
-        {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the per-instance observe counts
-            StageTimer t(ST_EMIT, s, &failed_stage);
-            ZeroJobs zj = {{nullptr, nullptr, im.ranges_raw}, {0, 0, tiles * 2}};
-            gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, tile_hist, block_sums, super_sums, g, b, zj, s);
+        {
+            StageTimer t(ST_FILL, s, &failed_stage);
+            gs2m_launch_fill(P, width, height, tiles_x, g, b, im, land_dev, s);
         }
-        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: the histogram kernel's side sum against the emit kernel's own prefix-sum total
+        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: what the host was told against the fill kernel's own offsets
             uint32_t total = 0;
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(&total, g.counters, sizeof(total), hipMemcpyDeviceToHost));
-            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_EMIT);
+            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_FILL);
         }
+        // the longest tile list selects the sort kernel; the scan kernel published it before the fill kernel could start
         {
-            StageTimer t(ST_TILE_SORT, s, &failed_stage);
-            // the last pass also records every tile's range (identifyTileRanges, rasterizer_impl.cu:108-129)
-            HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, b.vals_unsorted, b.sort_keyA, b.sort_valA,
-                                          b.tile_keys, b.point_list, (size_t)R, tile_bits, true, s, SideSum{nullptr, nullptr, nullptr},
-                                          im.ranges_raw, tile_hist));
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (land[GS2M_LAND_MAXTILE] == 0u) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            }
+            if (land[GS2M_LAND_MAXTILE] == 0u) HIP_TRY(hipStreamSynchronize(s));
+            max_tile = land[GS2M_LAND_MAXTILE] != 0u ? land[GS2M_LAND_MAXTILE] - 1u : 0xFFFFFFFFu;
         }
     } else {
-        HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
+        land[GS2M_LAND_ROWS] = 1u;  // no instance, no row
     }
     DEBUG_CHECK();
     {
-        StageTimer t(ST_RANGES, s, &failed_stage);  // second binning level: counted with the ranges stage
-        gs2m_launch_quad_lists(width, height, tiles_x, tiles_y, g, b, im, s);
+        StageTimer t(ST_TILE_SORT, s, &failed_stage);  // per-tile (depth, id) order + the quadrant lists (empty tiles get their zero counts)
+        gs2m_launch_tile_sort(tiles, max_tile, b, im, g, s);
     }
     {
         StageTimer t(ST_BLEND_FWD, s, &failed_stage);
@@ -326,20 +322,20 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Rn = R > 0 ? (size_t)R : 1;
-    GeomState g = gs2m_carve_geom(geom_buffer, (size_t)P, gs2m_geom_temp_bytes((size_t)P));
-    BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    GeomState g = gs2m_carve_geom(geom_buffer, (size_t)P);
+    BinningState b = gs2m_carve_binning(binning_buffer, Rn);
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
-    // one partial-gradient row per (instance, quadrant) at most, numbered densely (binning.hip), and one reduced row
-    // per Gaussian
+    // one partial-gradient row per (instance, quadrant), numbered densely over the view (binning.hip): `dense_rows` of them when
+    // the caller passed the forward's count on (gs2m_raster_backward_rows_hint), 4 per instance at most otherwise
     const int rowf = gs2m_row_floats(feature_count);
-    const size_t rows_bytes = gs2m_align_up(Rn * 4 * (size_t)rowf * sizeof(float));
-    const size_t sums_bytes = gs2m_align_up((size_t)(P > 0 ? P : 1) * rowf * sizeof(float));
-    char* sbase = scratch_alloc(rows_bytes + sums_bytes + 2 * GS2M_ALIGN, scratch_user);
+    const long long hint = t_rows_hint;
+    t_rows_hint = -1;
+    const size_t nrows = (hint >= 0 && (size_t)hint <= Rn * 4) ? (size_t)hint : Rn * 4;
+    const size_t rows_bytes = gs2m_align_up((nrows > 0 ? nrows : 1) * (size_t)rowf * sizeof(float));
+    char* sbase = scratch_alloc(rows_bytes + 2 * GS2M_ALIGN, scratch_user);
     if (!sbase) return GS2M_ERR_ALLOC;
-    char* al = (char*)gs2m_align_up((size_t)(uintptr_t)sbase);
-    float* rows = (float*)al;
-    float* sums = (float*)(al + rows_bytes);
+    float* rows = (float*)gs2m_align_up((size_t)(uintptr_t)sbase);
 
     if (R > 0) {
         StageTimer t(ST_BLEND_BWD, s, &failed_stage);
@@ -348,12 +344,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     }
     DEBUG_CHECK();
     {
-        StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);
-        if (R > 0) gs2m_launch_row_reduce_dense(P, g, rows, rowf, sums, s);
-        else HIP_TRY(gs2m_zero_async(sums, (size_t)P * rowf * sizeof(float), s));
+        StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);  // row sums + the per-Gaussian chain: one kernel
         gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
-                                 sums, rowf, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
+                                 rows, rowf, R > 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
                                  dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures, s);
     }
     DEBUG_CHECK();
@@ -484,24 +478,72 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out) {
     const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Pn = P > 0 ? (size_t)P : 1, Rn = R > 0 ? (size_t)R : 1;
-    GeomState g = gs2m_carve_geom(nullptr, Pn, gs2m_geom_temp_bytes(Pn));
-    BinningState b = gs2m_carve_binning(nullptr, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    GeomState g = gs2m_carve_geom(nullptr, Pn);
+    BinningState b = gs2m_carve_binning(nullptr, Rn);
     ImageState im = gs2m_carve_image(nullptr, N, tiles);
     out->geom_bytes = g.total_bytes;
     out->rec = (uint64_t)(uintptr_t)g.rec;
     out->tiles_touched = (uint64_t)(uintptr_t)g.tiles_touched;
     out->depth_key = (uint64_t)(uintptr_t)g.depth_key;
-    out->sorted_gid = (uint64_t)(uintptr_t)g.sorted_gid;
-    out->sorted_off = (uint64_t)(uintptr_t)g.sorted_off;
+    out->rect = (uint64_t)(uintptr_t)g.rect;
+    out->gauss_rows = (uint64_t)(uintptr_t)g.gauss_rows;
     out->clamped = (uint64_t)(uintptr_t)g.clamped;
+    out->wave_rowbase = (uint64_t)(uintptr_t)g.wave_rowbase;
+    out->counters = (uint64_t)(uintptr_t)g.counters;
     out->binning_bytes = b.total_bytes;
     out->point_list = (uint64_t)(uintptr_t)b.point_list;
     out->tile_keys = (uint64_t)(uintptr_t)b.tile_keys;
-    out->inst_obs = (uint64_t)(uintptr_t)b.inst_obs;
+    out->qlist = (uint64_t)(uintptr_t)b.qlist;
+    out->qrow = (uint64_t)(uintptr_t)b.qrow;
     out->image_bytes = im.total_bytes;
     out->final_T = (uint64_t)(uintptr_t)im.final_T;
     out->n_contrib = (uint64_t)(uintptr_t)im.n_contrib;
     out->ranges = (uint64_t)(uintptr_t)im.ranges;
+    out->qcount = (uint64_t)(uintptr_t)im.qcount;
+    return GS2M_OK;
+}
+
+unsigned long long gs2m_raster_forward_token(void) { return (unsigned long long)t_last_token; }
+
+long long gs2m_raster_dense_rows(unsigned long long token) {
+    if (token == 0ull) return -1;
+    const int dev = (int)(token >> 40) - 1;
+    const uint32_t slot = (uint32_t)(token & 0xFFull), generation = (uint32_t)((token >> 8) & 0xFFFFFFFFull);
+    if (dev < 0 || dev >= 64 || slot >= (uint32_t)kLandSlots || !g_land[dev].host) return -1;
+    LandRing& ring = g_land[dev];
+    volatile uint32_t* land = ring.host + slot * kLandWords;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    for (;;) {
+        if (ring.gen[slot].load() != generation) return -1;  // the slot has been handed to a later forward
+        const uint32_t v = land[GS2M_LAND_ROWS];
+        if (v != 0u) return ring.gen[slot].load() == generation ? (long long)v - 1 : -1;
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return -1;
+    }
+}
+
+int gs2m_raster_backward_rows_hint(long long dense_rows) {
+    t_rows_hint = dense_rows;
+    return GS2M_OK;
+}
+
+// Test hook: tile_sort.hip on caller-made spans (no rasterization): ranges (tiles x uint2), unsorted depth / value / row arrays of
+// n entries and a per-wave row base table -> sorted values, tile ids, the four quadrant lists and their rows and counts.
+int gs2m_debug_tile_sort(int tiles, unsigned max_tile, const unsigned* ranges, unsigned* u_depth, const unsigned* u_val, const unsigned* u_row,
+                         const unsigned* wave_rowbase, unsigned* point_list, unsigned* tile_keys, unsigned* qlist, unsigned* qrow,
+                         unsigned* qcount, void* stream_) {
+    if (tiles < 0 || !ranges || !u_depth || !u_val || !u_row || !wave_rowbase || !point_list || !tile_keys || !qlist || !qrow || !qcount) return GS2M_ERR_INVALID_ARG;
+    BinningState b = {};
+    b.u_depth = u_depth; b.u_val = const_cast<uint32_t*>(u_val); b.u_row = const_cast<uint32_t*>(u_row);
+    b.point_list = point_list; b.tile_keys = tile_keys; b.qlist = reinterpret_cast<uint2*>(qlist); b.qrow = qrow;
+    ImageState im = {};
+    im.ranges = reinterpret_cast<uint2*>(const_cast<unsigned*>(ranges));
+    im.qcount = qcount;
+    GeomState g = {};
+    g.wave_rowbase = const_cast<uint32_t*>(wave_rowbase);
+    gs2m_launch_tile_sort((size_t)tiles, max_tile, b, im, g, (hipStream_t)stream_);
+    HIP_TRY(hipGetLastError());
     return GS2M_OK;
 }
 

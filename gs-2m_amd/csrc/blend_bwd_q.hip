@@ -19,10 +19,11 @@
 //  * the geometry gradients (dL/dmean2D with its two |.| channels, dL/dconic, dL/dopacity) come from six moments of
 //    s = opacity dL/dalpha G about the quadrant centre, reduced over the 4 pixel-column lanes of a survivor with
 //    permlane32 / permlane16 swaps;
-//  * lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2); the loads for
-//    the next group are issued before the current group's epilogue and land behind it.
+//  * lane (j, r) loads the geometry and its channel of entry `top - j` straight from the 128-B record (L2) and the entry's
+//    gradient row from the list (round 5: it used to be two dependent gathers through the record's binning quad); the loads
+//    for the next group are issued before the current group's epilogue and land behind it.
 // One wave per quadrant (64-thread workgroups, no barriers), XCD-aware block ids, one partial-gradient row per
-// (instance, quadrant) in the DENSE numbering emit_kernel prepared (binning.hip): the rows of a Gaussian are one
+// (instance, quadrant) in the DENSE numbering fill_kernel prepared (binning.hip): the rows of a Gaussian are one
 // contiguous run, every row is written (zeros for the entries behind a quadrant's last contributor), and
 // gaussian_bwd.hip streams them.  No float atomics anywhere: gradients are bitwise reproducible.
 // Measured and not kept in round 3: one workgroup per TILE whose four quadrant waves combine an
@@ -83,7 +84,7 @@ __device__ __forceinline__ void row_scan_add2(const float x, const float y, floa
 template <int FC>
 __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qlast,
-    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ inst_row,
+    const uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qrow,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
@@ -170,43 +171,40 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     // the quadrant (written by the forward); later entries are never touched (backward.cu:493-494, 519-520).
     const uint32_t len = range.y - range.x;
     const uint2* list = qlist + (size_t)4 * range.x + (size_t)quad * len;
+    const uint32_t* lrow = qrow + (size_t)4 * range.x + (size_t)quad * len;  // gradient row of every list entry (tile_sort.hip)
     const int np = (int)qlast[tile * 4 + quad];
     const int ngroups = (np + 15) >> 4;
-    // what a lane takes from its survivor's record: geometry, its channel of every quad, the emission-slot words
+    // what a lane takes from its survivor's list entry and record: geometry, its channel of every quad, the gradient row
     struct Fill {
         float4 g0;       // x, y, A, B
         float2 g1;       // C, opacity
         float ch[KK];
-        float4 bin;      // emission offset, rect min, rect w|h, (t2)
         uint32_t pos1;   // position in the tile list + 1
-        uint32_t below;  // this instance's rows in the quadrants before this one
+        uint32_t row;    // gradient row of (instance, quadrant): dense numbering per Gaussian (binning.hip: fill_kernel)
     };
-    // Gradient-row index of (instance, quadrant): the rows of an emit wave's 64 Gaussians are numbered densely in
-    // emission order (binning.hip: emit_kernel): the instance's first row (per emission slot) + the number of its
-    // quadrants before this one.
-    auto row_of = [&](const float4 bin, uint32_t below) {
-        const uint32_t off = f2u(bin.x), rm = f2u(bin.y), rw = f2u(bin.z) & 0xFFFFu;
-        const uint32_t slot = off + ((uint32_t)tile_y - (rm >> 16)) * rw + ((uint32_t)tile_x - (rm & 0xFFFFu));
-        return inst_row[slot] + below;
+    struct Entry {
+        uint2 e;
+        uint32_t row;
     };
     // list entry of survivor j in group g.  Lanes past the front of the list (the last group may be partial) take
     // entry 0 with position ~0 = behind every pixel's last contributor: real, finite record data that no pixel accepts.
     auto load_entry = [&](int g) {
         const int p = np - 1 - (16 * g + j);
-        uint2 e = list[max(p, 0)];
-        e.y = p >= 0 ? e.y + 1u : 0xFFFFFFFFu;  // position in the tile list + 1
-        return e;
+        Entry en;
+        en.e = list[max(p, 0)];
+        en.row = lrow[max(p, 0)];
+        en.e.y = p >= 0 ? en.e.y + 1u : 0xFFFFFFFFu;  // position in the tile list + 1
+        return en;
     };
-    auto load_fill = [&](const uint2 e) {
+    auto load_fill = [&](const Entry en) {
         Fill f;
-        const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
+        const float4* p = rec + (size_t)(en.e.x & GS2M_GID_MASK) * REC_Q;
         f.g0 = p[REC_GEO0];
         f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
-        f.bin = p[REC_BIN];
 #pragma unroll
         for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
-        f.pos1 = e.y;
-        f.below = (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u));
+        f.pos1 = en.e.y;
+        f.row = en.row;
         return f;
     };
     // start of gradient row `row`: the row count is far below 2^32 / 6, so row * (floats per row / 4) is formed in 32 bits
@@ -217,7 +215,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     };
     Fill f;
     uint32_t row_cur = 0;  // gradient row of this lane's survivor in the current group
-    uint2 e_next = make_uint2(0u, 0u);
+    Entry e_next = {make_uint2(0u, 0u), 0u};
     int g_cur = 0;
     // the next group's record values are requested between this group's steps and its epilogue and land behind the
     // epilogue; the list entries one group further ahead
@@ -405,10 +403,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     {
         const int n = (int)qcount[tile * 4 + quad];
         for (int i = np + lane; i < n; i += GS2M_WAVE) {
-            const uint2 e = list[i];
-            const float4* p = rec + (size_t)(e.x & GS2M_GID_MASK) * REC_Q;
-            const uint32_t row = row_of(p[REC_BIN], (uint32_t)__popc((e.x >> GS2M_GID_BITS) & ((1u << quad) - 1u)));
-            float4* o4 = reinterpret_cast<float4*>(row_ptr(row));
+            float4* o4 = reinterpret_cast<float4*>(row_ptr(lrow[i]));
 #pragma unroll
             for (int q4 = 0; q4 < ROWF / 4; q4++) o4[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -422,7 +417,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;
-            row_cur = row_of(f.bin, f.below);  // one gather (the instance's offset inside its wave's range), in flight while the group's steps run
+            row_cur = f.row;
             process_group(min(16, np - 16 * g_cur));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -443,7 +438,7 @@ void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, con
     const int tiles = tiles_x * tiles_y;
     const int grid = ((tiles + 7) / 8) * 32;
 #define GS2M_BWDQ(FC)                                                                                                      \
-    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.inst_obs, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
+    blend_bwd_q_kernel<FC><<<grid, 64, 0, s>>>(im.ranges, b.qlist, im.qlast, im.qcount, b.qrow, g.rec, W, H, tiles_x, tiles, bg, fc, im.final_T, \
                                                   im.n_contrib, grad_color, grad_buffer, rows)
     switch (fc_template(fc)) {
         case 1: GS2M_BWDQ(1); break;

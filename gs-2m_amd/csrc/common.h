@@ -12,29 +12,28 @@
 // ---- blend record: 8 x float4 = 128 B per Gaussian (one aligned HBM line) -------------
 // q0: x, y, A, B          pixel-space mean, conic (A = conic.x, B = conic.y)
 // q1: C, opacity, hx, hy  conic.z, opacity, half extents of the alpha >= 1/255 ellipse
-// q2: off, rmin, rwh, t2  u32 emission offset, tile rect min (x | y << 16), rect (w | h << 16),
+// q2: 0, rmin, rwh, t2    (unused), tile rect min (x | y << 16), rect (w | h << 16) -- also in GeomState::rect --,
 //                        t2 = upper bound of A dx^2 + 2B dx dy + C dy^2 where alpha can reach 1/255
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad
 //         floats -- channel c is float 12 + c of the record, so a kernel blending fc features stages
 //         3 + ceil((3 + fc) / 4) quads and can feed whole quads to the matrix pipe
-// q7: unused (rounds 2-3 kept the first gradient row of the Gaussian's emit wave here; the per-slot row index in
-//     BinningState::inst_obs is absolute now: one scattered 4-byte store per Gaussian less in emit_kernel)
+// q7: unused
 #define REC_Q 8
 #define REC_GEO0 0
 #define REC_GEO1 1
 #define REC_BIN 2
 #define REC_CH 3
 #define REC_AUX 7
-// the sorted values carry the instance's quadrant-hit mask above the Gaussian id
+// the binned values carry the instance's quadrant-hit mask above the Gaussian id
 #define GS2M_GID_BITS 28
 #define GS2M_GID_MASK 0x0FFFFFFFu
-// A Gaussian with at least this many tile instances is "big": emit_kernel expands it with the whole workgroup and
-// row_reduce_dense_kernel sums its rows with the whole workgroup; its entry of GeomState::sorted_rows carries GS2M_ROWS_BIG
-// (rows < 2^31: num_rendered < 2^29 whenever a big Gaussian exists is checked by the forward)
+// A Gaussian with at least this many tile instances is "big": fill_kernel expands it with the whole workgroup and the
+// per-Gaussian backward sums its rows with the whole workgroup; its entry of GeomState::gauss_rows carries GS2M_ROWS_BIG
+// (rows < 2^31: a big Gaussian has fewer than 2^29 instances, fill_kernel's test)
 #define GS2M_BIG_TILES 512u
 #define GS2M_ROWS_BIG 0x80000000u
 
-// per tile-instance partial-gradient row produced by the blend backward (floats):
+// per (instance, quadrant) partial-gradient row produced by the blend backward (floats):
 // 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature
 #define ROW_GEOM 8
 #define ROW_COL 8
@@ -42,42 +41,41 @@
 
 static inline size_t gs2m_align_up(size_t x, size_t a = GS2M_ALIGN) { return (x + a - 1) & ~(a - 1); }
 
+// Round 5: no global sort.  Gaussians are binned in INDEX order (count -> scan -> fill, binning.hip) and every tile's span is
+// sorted by (depth, id) on chip (tile_sort.hip); rows of a Gaussian's gradient partials are numbered in index order too.
 struct GeomState {
     float4* rec;             // P * 8
-    uint32_t* tiles_touched; // P (by Gaussian id)
-    uint32_t* depth_key;     // P
-    uint32_t* sort_keyA;     // P (radix sort ping buffer)
-    uint32_t* sort_valA;     // P
-    uint32_t* depth_key_sorted; // P
-    uint32_t* sorted_gid;    // P
-    uint32_t* sorted_off;    // P
+    uint32_t* tiles_touched; // P (by Gaussian id): tiles emitted for the Gaussian (rect w x h)
+    uint2* rect;             // P: {tile rect min x | y << 16, w | h << 16} of the emitted rectangle (0, 0 when nothing is emitted)
+    uint32_t* depth_key;     // P: fp32 bits of the view depth, 0xFFFFFFFF when culled
     uint8_t* clamped;        // P
     float* sh_dir;           // P * 9: d(SH colour)/d(view direction) of a visible Gaussian, {dRdx, dRdy, dRdz}[rgb] (preprocess -> gaussian_bwd)
-    uint32_t* counters;      // 64 u32 (counters[0] = num_rendered)
-    uint32_t* sorted_rows;   // P: gradient rows of each Gaussian, in depth order
-    char* temp;              // radix sort / scan temporary storage
-    size_t temp_bytes;
+    uint32_t* counters;      // 64 u32 (counters[0] = num_rendered as fill_kernel's offsets add up: debug mode compares)
+    uint32_t* gauss_rows;    // P: gradient rows of each Gaussian (| GS2M_ROWS_BIG), written by fill_kernel
+    uint32_t* block_tt;      // ceil(P / 256): tiles_touched summed over blocks of 256 Gaussians (preprocess kernel)
+    uint32_t* block_pref;    // ceil(P / 256): exclusive prefix of block_tt (scan kernel): first emission offset of a block
+    uint32_t* wave_rows;     // ceil(P / 64): gradient rows of each wave of 64 consecutive Gaussians (fill_kernel)
+    uint32_t* wave_rowbase;  // ceil(P / 64): exclusive prefix of wave_rows (rowscan_kernel): first gradient row of the wave
     size_t total_bytes;      // including alignment slack
 };
 struct BinningState {
-    uint32_t* keys_unsorted; // R
-    uint32_t* vals_unsorted; // R
-    uint32_t* sort_keyA;     // R (radix sort ping buffer)
-    uint32_t* sort_valA;     // R
-    uint32_t* tile_keys;     // R (sorted)
-    uint32_t* point_list;    // R (sorted Gaussian ids)
-    uint32_t* inst_obs;      // R: per emission slot, the instance's first gradient row (dense numbering, binning.hip: emit_kernel)
-    uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id, position in the tile list};
+    uint32_t* u_depth;       // R: depth key of the instance binned at this slot (slots of a tile are contiguous: ranges[tile]; order
+                             //    inside a tile's span = arrival order of fill_kernel's atomics, i.e. arbitrary)
+    uint32_t* u_val;         // R: Gaussian id | quadrant-hit mask << 28
+    uint32_t* u_row;         // R: first gradient row of the instance
+    uint32_t* point_list;    // R: u_val sorted by (tile, depth, id) -- the reference's point_list (+ mask bits)
+    uint32_t* tile_keys;     // R: tile id of each sorted instance
+    uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id | mask << 28, position in the tile list};
                              //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
-    char* temp;
-    size_t temp_bytes;
+    uint32_t* qrow;          // 4R: gradient row of each list entry (parallel to qlist)
     size_t total_bytes;
 };
 struct ImageState {
     float* final_T;      // N
     uint32_t* n_contrib; // N
-    uint2* ranges;       // tiles (written by quad_lists_kernel from ranges_raw)
-    uint32_t* ranges_raw; // tiles * 2: per tile {~first position, last position + 1} as atomicMax targets of the tile sort's last pass; 0, 0 = untouched
+    uint2* ranges;       // tiles: [first, last + 1) slot of the tile (scan kernel)
+    uint32_t* tile_count; // tiles: instances per tile (count kernel; zeroed by the preprocess kernel)
+    uint32_t* cursor;    // tiles: next free slot of the tile while fill_kernel runs
     uint32_t* qcount;    // tiles * 4: entries in each quadrant list
     uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;
@@ -223,20 +221,14 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
 #endif
 
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
-GeomState gs2m_carve_geom(char* base, size_t P, size_t temp_bytes);
-BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
+GeomState gs2m_carve_geom(char* base, size_t P);
+BinningState gs2m_carve_binning(char* base, size_t R);
 ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 
-// hand-written radix sort / scan (radix_sort.hip)
-size_t gs2m_geom_temp_bytes(size_t P);
-size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
+// hand-written onesweep radix sort (radix_sort.hip).  Rounds 1-4 sorted the Gaussians by depth and the instances by tile with
+// it; since round 5 the rasterizer buckets by tile and sorts each tile on chip (binning.hip, tile_sort.hip), and the only
+// user left is distCUDA2's Morton order (knn.hip).
 size_t gs2m_radix_temp_bytes(size_t n, int total_bits);
-// side job of a sort's histogram kernel: sum of an n-element u32 array (the same indices the kernel reads keys at),
-// published by the last workgroup to finish with one system-scope store (tt == nullptr: none).  `acc` = an 8-byte
-// aligned 64-bit word that is zero before the launch (the caller zeroes it on the stream ahead of every call): total and
-// finished-workgroup count in one.
-// side job of a sort's LAST pass: buckets[final position >> 8] += tt[value], supers[final position >> 16] += tt[value]
-// (both zero before the call)
 struct SideBuckets {
     const uint32_t* tt;
     uint32_t* buckets;
@@ -247,24 +239,21 @@ struct SideSum {
     uint32_t* acc;
     uint32_t* landing;
 };
-// `range_raw` (optional): the LAST pass also records, per full key value k, where its run of equal keys starts and ends in the
-// sorted output: atomicMax(range_raw[2k], ~first position), atomicMax(range_raw[2k + 1], last position + 1) -- zero before the
-// call; identifyTileRanges (rasterizer_impl.cu:108-129) without a kernel of its own.
 hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* kin, const uint32_t* vin, uint32_t* kA,
                                  uint32_t* vA, uint32_t* kB, uint32_t* vB, size_t n, int total_bits, bool prezeroed, hipStream_t s,
                                  SideSum sum = SideSum{nullptr, nullptr, nullptr}, uint32_t* range_raw = nullptr,
                                  const uint32_t* ext_hist = nullptr, SideBuckets sb = SideBuckets{nullptr, nullptr, nullptr});
-// Digit histograms counted by the producer of the keys instead of a histogram kernel (ext_hist above): GS2M_HIST_COPIES copies
-// of [4 passes][256 bins], GS2M_HIST_COPY_WORDS apart; the digits of pass i are bits [shift[i], shift[i] + bits[i]) of the key.
 #define GS2M_HIST_COPIES 8
 #define GS2M_HIST_COPY_WORDS 1024
 void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]);
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
-size_t gs2m_front_temp_bytes(size_t n);
-uint32_t* gs2m_block_sums_ptr(void* front_temp);
-uint32_t* gs2m_super_sums_ptr(void* front_temp, size_t n);
-uint32_t* gs2m_tile_hist_ptr(void* front_temp, size_t n);
-void gs2m_front_zero_region(void* front_temp, size_t n, uint32_t** ptr, size_t* words);
+
+// words the host reads back through a mapped pinned block (api.hip): [0] num_rendered, [1] prefiltered violation flag,
+// [2] longest tile list + 1 (0 = not landed yet), [3] dense gradient rows + 1 (0 = not landed yet)
+#define GS2M_LAND_R 0
+#define GS2M_LAND_PREFILTERED 1
+#define GS2M_LAND_MAXTILE 2
+#define GS2M_LAND_ROWS 3
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -273,12 +262,17 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, uint32_t* tile_hist, const uint32_t* block_sums, const uint32_t* super_sums, const GeomState& g, const BinningState& b, const ZeroJobs& zero, hipStream_t s);
-void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s);
+// binning.hip: count (tile histogram; publishes num_rendered), scan (tile ranges, block prefixes; publishes the longest list),
+// fill (instances into their tiles' spans, quadrant masks, gradient-row numbering)
+void gs2m_launch_count(int P, int tiles_x, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s);
+void gs2m_launch_scan(int P, size_t tiles, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s);
+void gs2m_launch_fill(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ImageState& im, uint32_t* landing,
+                      hipStream_t s);
+// tile_sort.hip: every tile's span sorted by (depth, id) on chip, then split into the four quadrant lists.  max_tile = the longest
+// tile list (selects the kernel: one wave per tile with the span in registers up to 1024 entries, a workgroup per tile beyond)
+void gs2m_launch_tile_sort(size_t tiles, uint32_t max_tile, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
-void gs2m_launch_quad_lists(int W, int H, int tiles_x, int tiles_y, const GeomState& g, const BinningState& b,
-                            const ImageState& im, hipStream_t s);
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,
                              const BinningState& b, const ImageState& im, float* out_color, float* out_buffer,
                              int* out_observe, hipStream_t s);
@@ -291,7 +285,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
-                              int fc, const GeomState& g, const float* rows, int rowf,
+                              int fc, const GeomState& g, const float* rows, int rowf, bool have_rows,
                               float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s);

@@ -1,5 +1,6 @@
-// Per-Gaussian backward for gfx950: one pass that (1) sums the Gaussian's contiguous
-// partial-gradient rows written by blend_bwd.hip, (2) back-propagates conic -> 2D covariance ->
+// Per-Gaussian backward for gfx950: ONE kernel (round 5: the row sum was a kernel of its own while the rows lay in depth
+// order and the tensors in index order; both are in index order now) that (1) sums the Gaussian's contiguous
+// partial-gradient rows written by blend_bwd_q.hip, (2) back-propagates conic -> 2D covariance ->
 // 3D covariance and view-space mean, (3) the projection of the 2D mean, (4) SH colour and
 // (5) scale / rotation, and writes EVERY element of every gradient tensor (zeros for culled
 // Gaussians), so the caller does not have to pre-zero 344 B per Gaussian as the reference's
@@ -48,28 +49,218 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f
 
-template <bool SH_LDS>
+// Phase 1 of the kernel below: the sum of the partial-gradient rows of each of the workgroup's 256 Gaussians, into LDS.
+// The backward blend (blend_bwd_q.hip) numbers its rows DENSELY in index order: wave w of this workgroup (the same 64
+// consecutive Gaussians fill_kernel's wave w owned) has its rows from wave_rowbase[w] on, Gaussian by Gaussian
+// (gauss_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows per window as RQ
+// fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked in LDS, then RQ lanes per
+// Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance gather.  Fixed summation order
+// (the dense numbering: quadrants ascending within an instance, instances in emission order): bitwise reproducible.
+template <int RQ>  // float4 per row (rowf / 4: 3, 4, 5 or 6)
+struct ReduceLds {
+    float4 s_row[4][GS2M_WAVE * RQ];  // one window per wave: 64 rows x RQ float4, row-major
+    float4 s_sum[256 * RQ];           // the result: RQ float4 per Gaussian of the workgroup
+    uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE];
+    uint32_t s_bigrow[4][GS2M_WAVE], s_bigcnt[4][GS2M_WAVE];
+    unsigned long long s_bigmask[4];
+    float4 s_part[256];
+};
+template <int RQ>
+__device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase,
+                                                   const float* __restrict__ rows, ReduceLds<RQ>& L) {
+    constexpr int MAXQ = RQ, rq = RQ;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t cnt = 0, bigcnt = 0;
+    if (i < P) cnt = gauss_rows[i];
+    // big Gaussians (binning.hip: GS2M_ROWS_BIG): their rows follow the wave's small rows; this wave's stream leaves them out
+    // and the whole workgroup sums them afterwards
+    const bool big = (cnt & GS2M_ROWS_BIG) != 0u;
+    if (big) {
+        bigcnt = cnt & ~GS2M_ROWS_BIG;
+        cnt = 0;
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
+    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's (small) Gaussians
+    const uint32_t bincl = wave_inclusive_scan_u32(bigcnt, lane);
+    const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
+    const uint32_t wb = wave_id * GS2M_WAVE < (size_t)P ? wave_rowbase[wave_id] : 0u;  // the wave's first row (binning.hip: rowscan_kernel)
+    L.s_excl[wave][lane] = incl - cnt;
+    L.s_cnt[wave][lane] = cnt;
+    L.s_bigrow[wave][lane] = big ? wb + total + (bincl - bigcnt) : 0u;  // first row of a big Gaussian
+    L.s_bigcnt[wave][lane] = bigcnt;
+    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
+    if (lane == 0) L.s_bigmask[wave] = bigmask;
+    const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
+    const bool worker = g < G;
+    uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nwin = (total + GS2M_WAVE - 1) / GS2M_WAVE;
+    const float4* r4 = reinterpret_cast<const float4*>(rows) + (size_t)wb * rq;  // the wave's rows as one float4 stream
+    const uint32_t nq = total * (uint32_t)rq;
+    float4* const s_row = L.s_row[wave];
+    auto load_window = [&](uint32_t w, float4* a) {
+#pragma unroll
+        for (int e = 0; e < MAXQ; e++) {
+            const uint32_t q = w * (GS2M_WAVE * (uint32_t)rq) + (uint32_t)e * GS2M_WAVE + lane;
+            a[e] = q < nq ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // One window: park the loaded rows in LDS, then every group adds the rows of its Gaussians that lie in the window.
+    // LDS operations of one wave execute in order: the reads see the writes above them.
+    // A Gaussian that covers WHOLE windows (a splat over a few hundred tiles owns thousands of rows): its group alone would add
+    // 64 rows per window from LDS, window after window, while the rest of the wave waits.  Such windows never go through LDS:
+    // float4 number e * 64 + lane of every window belongs to channel quad (e * 64 + lane) mod rq whatever the window, so every
+    // lane adds the windows into rq accumulators of its own, and when the run of covered windows ends the owner's lanes add
+    // the 64 rq accumulators of their channel in index order -- a fixed order as well.
+    float4 hacc[MAXQ];
+#pragma unroll
+    for (int e = 0; e < MAXQ; e++) hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int heavy_owner = -1;  // group whose Gaussian the accumulators belong to (wave-uniform); -1: none
+    auto consume = [&](uint32_t w, const float4* a) {
+        const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
+        bool mine = false;
+        if (w < nwin && j < GS2M_WAVE) {
+            const uint32_t ex = L.s_excl[wave][j], cn = L.s_cnt[wave][j];
+            mine = ex <= k0 && ex + cn >= k1;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine && c == 0);
+        const int cover = m != 0ull ? (__ffsll((long long)m) - 1) / rq : -1;  // group whose Gaussian owns the whole window (wave-uniform)
+        if (heavy_owner >= 0 && cover != heavy_owner) {  // the run of covered windows has ended: hand the accumulators to their owner
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++) {
+                s_row[e * GS2M_WAVE + lane] = hacc[e];
+                hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (worker && g == heavy_owner) {
+                for (int q = c; q < GS2M_WAVE * rq; q += rq) {
+                    const float4 v = s_row[q];
+                    racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            heavy_owner = -1;
+        }
+        if (cover >= 0) {  // registers only; the owner writes its sum once a later window takes the ordinary path
+            heavy_owner = cover;
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++) { hacc[e].x += a[e].x; hacc[e].y += a[e].y; hacc[e].z += a[e].z; hacc[e].w += a[e].w; }
+            return;
+        }
+        if (w < nwin) {
+#pragma unroll
+            for (int e = 0; e < MAXQ; e++) s_row[e * GS2M_WAVE + lane] = a[e];
+        }
+        while (j < GS2M_WAVE) {
+            const uint32_t ex = L.s_excl[wave][j], cn = L.s_cnt[wave][j];
+            if (ex >= k1 && cn > 0) break;  // starts in a later window
+            // rows of this Gaussian inside the window; those of windows it covered entirely are in racc already
+            const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
+            for (uint32_t t = t0; t < t1; t++) {
+                const float4 v = s_row[(t - k0) * rq + c];
+                racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
+            }
+            if (ex + cn > k1) break;  // continues in the next window
+            L.s_sum[(wave * GS2M_WAVE + (int)j) * rq + c] = racc;  // (a big Gaussian's entry: zeros here, its sum below)
+            racc = make_float4(0.f, 0.f, 0.f, 0.f);
+            j += (uint32_t)G;
+        }
+    };
+    // THREE windows in flight: the windows of a wave are a serial chain (load -> LDS -> sum); with one window in flight every
+    // one of them cost a full memory round trip.  One extra pass (w == nwin, an empty window) lets every group finish and
+    // write its remaining Gaussians.
+    float4 a0[MAXQ], a1[MAXQ], a2[MAXQ];
+    load_window(0, a0);
+    load_window(1, a1);
+    load_window(2, a2);
+    for (uint32_t w = 0; w <= nwin; w += 3) {
+        consume(w, a0);
+        load_window(w + 3, a0);
+        if (w + 1 <= nwin) consume(w + 1, a1);
+        load_window(w + 4, a1);
+        if (w + 2 <= nwin) consume(w + 2, a2);
+        load_window(w + 5, a2);
+    }
+    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case); the barrier publishes s_sum
+    // ---- big Gaussians: thousands of rows each (a splat over hundreds of tiles).  The whole workgroup sums one such run, NT
+    // threads x 8 float4 in flight.  Thread t < NT takes float4 t, t + NT, ... of the run -- NT is a multiple of the row's
+    // float4 count, so a thread stays on one channel quad -- and the partials are added in thread order: a fixed order.
+    constexpr int NT = (256 / rq) * rq;  // threads that take part (255 at rq = 5)
+    const int tid = threadIdx.x;
+    for (int w2 = 0; w2 < 4; w2++) {
+        unsigned long long m = L.s_bigmask[w2];
+        while (m != 0ull) {
+            const int lo = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t nrows = L.s_bigcnt[w2][lo];
+            const float4* r4b = reinterpret_cast<const float4*>(rows) + (size_t)L.s_bigrow[w2][lo] * rq;
+            const uint32_t nq4 = nrows * (uint32_t)rq;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < NT) {
+                for (uint32_t q0 = (uint32_t)tid; q0 < nq4; q0 += 8u * NT) {
+                    float4 v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint32_t q = q0 + (uint32_t)e * NT;
+                        v[e] = q < nq4 ? r4b[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+                }
+            }
+            L.s_part[tid] = acc;
+            gs2m_sync();
+            if (tid < rq) {  // channel quad tid: the partials of threads tid, tid + rq, ... in that order
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = tid; k < NT; k += rq) {
+                    const float4 v = L.s_part[k];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                L.s_sum[(w2 * GS2M_WAVE + lo) * rq + tid] = t;
+            }
+            gs2m_sync();
+        }
+    }
+}
+
+template <bool SH_LDS, int RQ>
 __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ vm,
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
-    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float* __restrict__ sh_dir,
-    const float* __restrict__ rows,
-    int rowf, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
+    const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ sh_dir, const float* __restrict__ rows /* nullptr: nothing was rendered, every sum is zero */,
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
     // dL/dSH rows go out through LDS so that every global access of the (P,16,3) tensor is a coalesced stream (see
     // preprocess.hip); row stride 49 floats.  The coefficients themselves are not read here: all the backward needs of them is
     // d(colour)/d(direction), 9 floats per Gaussian that the forward's preprocess kernel left in GeomState::sh_dir.
-    __shared__ float s_sh[SH_LDS ? 256 * 49 : 1];
+    // one LDS block, two lives: the row sums (phase 1), then the block's dL/dSH rows on their way out
+    constexpr size_t kShBytes = SH_LDS ? 256 * 49 * sizeof(float) : 16, kRedBytes = sizeof(ReduceLds<RQ>);
+    __shared__ __align__(16) unsigned char s_raw[kShBytes > kRedBytes ? kShBytes : kRedBytes];
+    float* const s_sh = reinterpret_cast<float*>(s_raw);
+    ReduceLds<RQ>& red = *reinterpret_cast<ReduceLds<RQ>*>(s_raw);
+    float acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0.f;
+    if (rows != nullptr) {
+        reduce_rows_to_lds<RQ>(P, gauss_rows, wave_rowbase, rows, red);
+        gs2m_sync();
+#pragma unroll
+        for (int q = 0; q < RQ; q++) {
+            const float4 v = red.s_sum[threadIdx.x * RQ + q];
+            acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+        }
+        gs2m_sync();  // the sums are in registers: the LDS block may be overwritten
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;
     const int li = in_range ? idx : 0;
-    // The thread's own inputs and its reduced gradient row are requested BEFORE the block stages its SH rows (the staging
-    // ends in a barrier: loads issued behind it would cost a second exposed memory round trip).
     const bool visible = in_range && radii[li] > 0;
     const float mx = means3D[3 * li], my = means3D[3 * li + 1], mz = means3D[3 * li + 2];
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -82,16 +273,6 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     if (visible && shs != nullptr && D > 0) {
 #pragma unroll
         for (int k = 0; k < 9; k++) sdv[k] = sh_dir[9 * (size_t)li + k];
-    }
-    float acc[24];
-    {   // `rows` holds one reduced row per Gaussian (row_reduce_dense_kernel below): P x rowf floats
-        const int rq = rowf >> 2;
-        const float4* s4 = reinterpret_cast<const float4*>(rows + (size_t)li * rowf);
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const float4 v = q < rq ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
-        }
     }
     if (!SH_LDS && !in_range) return;
     if (in_range) {
@@ -311,224 +492,35 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     }
 }
 
-// Sum of the partial-gradient rows of every Gaussian, ahead of gaussian_bwd_kernel.  The backward blend
-// (blend_bwd_q.hip) numbers its rows DENSELY: emit wave
-// w (the same 64 depth-sorted Gaussians this kernel's wave w owns) has its rows from 4 x its first emission offset on, Gaussian
-// by Gaussian (sorted_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows
-// per window as five fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked
-// in LDS, then rq lanes per Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance
-// gather.  Fixed summation order (the dense numbering: quadrants ascending within an instance, instances in emission
-// order): bitwise reproducible.
-template <int RQ>  // float4 per row (rowf / 4: 3, 4, 5 or 6): sizes the three window register sets and the covered-run accumulators
-__global__ void __launch_bounds__(256) row_reduce_dense_kernel(int P, const uint32_t* __restrict__ sorted_gid,
-                                                               const uint32_t* __restrict__ sorted_rows,
-                                                               const uint32_t* __restrict__ sorted_off,
-                                                               const float* __restrict__ rows, int rowf, float* __restrict__ sums) {
-    constexpr int MAXQ = RQ;
-    __shared__ float4 s_row[4][GS2M_WAVE * MAXQ];  // one window: 64 rows x rq float4, row-major
-    __shared__ uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE], s_gidw[4][GS2M_WAVE];
-    __shared__ uint32_t s_bigrow[4][GS2M_WAVE], s_bigcnt[4][GS2M_WAVE], s_biggid[4][GS2M_WAVE];
-    __shared__ unsigned long long s_bigmask[4];
-    __shared__ float4 s_part[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t cnt = 0, gid = 0xFFFFFFFFu, bigcnt = 0;
-    if (i < P) {
-        cnt = sorted_rows[i];
-        gid = sorted_gid[i];
-    }
-    // big Gaussians (binning.hip: GS2M_ROWS_BIG): their rows follow the wave's small rows; this wave's stream leaves them out
-    // and the whole workgroup sums them afterwards
-    const bool big = (cnt & GS2M_ROWS_BIG) != 0u;
-    if (big) {
-        bigcnt = cnt & ~GS2M_ROWS_BIG;
-        cnt = 0;
-    }
-    const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's (small) Gaussians
-    const uint32_t bincl = wave_inclusive_scan_u32(bigcnt, lane);
-    // the wave's rows start at 4 x the emission offset of its first Gaussian (binning.hip: emit_kernel)
-    const uint32_t wb = (i >> 6) <= ((P - 1) >> 6) ? 4u * sorted_off[(i >> 6) << 6] : 0u;
-    s_excl[wave][lane] = incl - cnt;
-    s_cnt[wave][lane] = cnt;
-    s_gidw[wave][lane] = big ? 0xFFFFFFFFu : gid;  // a big Gaussian's sum is not written by the stream below
-    s_bigrow[wave][lane] = big ? wb + total + (bincl - bigcnt) : 0u;  // first row of a big Gaussian
-    s_bigcnt[wave][lane] = bigcnt;
-    s_biggid[wave][lane] = gid;
-    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
-    if (lane == 0) s_bigmask[wave] = bigmask;
-    constexpr int rq = RQ;
-    const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
-    const bool worker = g < G;
-    uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
-    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t nwin = (total + GS2M_WAVE - 1) / GS2M_WAVE;
-    const float4* r4 = reinterpret_cast<const float4*>(rows) + (size_t)wb * rq;  // the wave's rows as one float4 stream
-    const uint32_t nq = total * (uint32_t)rq;
-    auto load_window = [&](uint32_t w, float4* a) {
-#pragma unroll
-        for (int e = 0; e < MAXQ; e++) {
-            const uint32_t q = w * (GS2M_WAVE * (uint32_t)rq) + (uint32_t)e * GS2M_WAVE + lane;
-            a[e] = (e < rq && q < nq) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    // One window: park the loaded rows in LDS, then every group adds the rows of its Gaussians that lie in the window.
-    // LDS operations of one wave execute in order: the reads see the writes above them.
-    // A Gaussian that covers WHOLE windows (a splat over hundreds of tiles owns thousands of rows: a close-up, a background
-    // blob): its group alone would add 64 rows per window from LDS, window after window, while the rest of the wave
-    // waits -- six such splats in a view tripled this kernel's time.  Such windows never go through LDS: float4 number
-    // e * 64 + lane of every window belongs to channel quad (e * 64 + lane) mod rq whatever the window, so every lane adds
-    // the windows into rq accumulators of its own, and when the run of covered windows ends the owner's lanes add the
-    // 64 rq accumulators of their channel in index order -- a fixed order as well.
-    float4 hacc[MAXQ];
-#pragma unroll
-    for (int e = 0; e < MAXQ; e++) hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int heavy_owner = -1;  // group whose Gaussian the accumulators belong to (wave-uniform); -1: none
-    auto consume = [&](uint32_t w, const float4* a) {
-        const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
-        bool mine = false;
-        if (w < nwin && j < GS2M_WAVE) {
-            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
-            mine = ex <= k0 && ex + cn >= k1;
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine && c == 0);
-        const int cover = m != 0ull ? (__ffsll((long long)m) - 1) / rq : -1;  // group whose Gaussian owns the whole window (wave-uniform)
-        if (heavy_owner >= 0 && cover != heavy_owner) {  // the run of covered windows has ended: hand the accumulators to their owner
-#pragma unroll
-            for (int e = 0; e < MAXQ; e++) {
-                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = hacc[e];
-                hacc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (worker && g == heavy_owner) {
-                for (int q = c; q < GS2M_WAVE * rq; q += rq) {
-                    const float4 v = s_row[wave][q];
-                    racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            heavy_owner = -1;
-        }
-        if (cover >= 0) {  // registers only; the owner writes its sum once a later window takes the ordinary path
-            heavy_owner = cover;
-#pragma unroll
-            for (int e = 0; e < MAXQ; e++)
-                if (e < rq) { hacc[e].x += a[e].x; hacc[e].y += a[e].y; hacc[e].z += a[e].z; hacc[e].w += a[e].w; }
-            return;
-        }
-        if (w < nwin) {
-#pragma unroll
-            for (int e = 0; e < MAXQ; e++)
-                if (e < rq) s_row[wave][e * GS2M_WAVE + lane] = a[e];
-        }
-        while (j < GS2M_WAVE) {
-            const uint32_t ex = s_excl[wave][j], cn = s_cnt[wave][j];
-            if (ex >= k1 && cn > 0) break;  // starts in a later window
-            // rows of this Gaussian inside the window; those of windows it covered entirely are in racc already
-            const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
-            for (uint32_t t = t0; t < t1; t++) {
-                const float4 v = s_row[wave][(t - k0) * rq + c];
-                racc.x += v.x; racc.y += v.y; racc.z += v.z; racc.w += v.w;
-            }
-            if (ex + cn > k1) break;  // continues in the next window
-            const uint32_t gj = s_gidw[wave][j];
-            if (gj != 0xFFFFFFFFu) reinterpret_cast<float4*>(sums + (size_t)gj * rowf)[c] = racc;
-            racc = make_float4(0.f, 0.f, 0.f, 0.f);
-            j += (uint32_t)G;
-        }
-    };
-    // THREE windows in flight: the windows of a wave are a serial chain (load -> LDS -> sum), and the nearest Gaussians
-    // (the first waves in depth order) own tens of instances each -- up to 36 windows in one wave on the bench scene; with
-    // one window in flight every one of them cost a full memory round trip.  One extra pass (w == nwin, an empty window)
-    // lets every group finish and write its remaining Gaussians.
-    float4 a0[MAXQ], a1[MAXQ], a2[MAXQ];
-    load_window(0, a0);
-    load_window(1, a1);
-    load_window(2, a2);
-    for (uint32_t w = 0; w <= nwin; w += 3) {
-        consume(w, a0);
-        load_window(w + 3, a0);
-        if (w + 1 <= nwin) consume(w + 1, a1);
-        load_window(w + 4, a1);
-        if (w + 2 <= nwin) consume(w + 2, a2);
-        load_window(w + 5, a2);
-    }
-    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case)
-    // ---- big Gaussians: thousands of rows each (a splat over hundreds of tiles).  One wave streaming such a run with three
-    // windows in flight took 75 us per Gaussian (a thousand of them: +0.16 ms on this kernel); here the whole workgroup sums
-    // it, NT threads x 8 float4 in flight.  Thread t < NT takes float4 t, t + NT, ... of the run -- NT is a multiple of the
-    // row's float4 count, so a thread stays on one channel quad -- and the partials are added in thread order: a fixed order.
-    constexpr int NT = (256 / rq) * rq;  // threads that take part (255 at rq = 5)
-    const int tid = threadIdx.x;
-    for (int w2 = 0; w2 < 4; w2++) {
-        unsigned long long m = s_bigmask[w2];
-        while (m != 0ull) {
-            const int lo = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const uint32_t nrows = s_bigcnt[w2][lo];
-            const float4* r4b = reinterpret_cast<const float4*>(rows) + (size_t)s_bigrow[w2][lo] * rq;
-            const uint32_t nq4 = nrows * (uint32_t)rq;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < NT) {
-                for (uint32_t q0 = (uint32_t)tid; q0 < nq4; q0 += 8u * NT) {
-                    float4 v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const uint32_t q = q0 + (uint32_t)e * NT;
-                        v[e] = q < nq4 ? r4b[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; e++) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
-                }
-            }
-            s_part[tid] = acc;
-            gs2m_sync();
-            if (tid < rq) {  // channel quad tid: the partials of threads tid, tid + rq, ... in that order
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = tid; k < NT; k += rq) {
-                    const float4 v = s_part[k];
-                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                }
-                reinterpret_cast<float4*>(sums + (size_t)s_biggid[w2][lo] * rowf)[tid] = t;
-            }
-            gs2m_sync();
-        }
-    }
-}
-
 }  // namespace
-
-void gs2m_launch_row_reduce_dense(int P, const GeomState& g, const float* rows, int rowf, float* sums, hipStream_t s) {
-    switch (rowf >> 2) {
-        case 3: row_reduce_dense_kernel<3><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
-        case 4: row_reduce_dense_kernel<4><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
-        case 5: row_reduce_dense_kernel<5><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
-        default: row_reduce_dense_kernel<6><<<(P + 255) / 256, 256, 0, s>>>(P, g.sorted_gid, g.sorted_rows, g.sorted_off, rows, rowf, sums); break;
-    }
-}
 
 void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                               const float* colors_precomp,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, int W, int H, float tan_fovx, float tan_fovy, const int* radii,
-                              int fc, const GeomState& g, const float* rows, int rowf,
+                              int fc, const GeomState& g, const float* rows, int rowf, bool have_rows,
                               float* dL_dmeans2D, float* dL_dconics, float* dL_dopacities, float* dL_dcolors,
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
-#define GS2M_GB(LDS)                                                                                                    \
-    gaussian_bwd_kernel<LDS><<<(P + 255) / 256, 256, 0, s>>>(                                                           \
+#define GS2M_GB(LDS, RQ)                                                                                                \
+    gaussian_bwd_kernel<LDS, RQ><<<(P + 255) / 256, 256, 0, s>>>(                                                       \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
-        projmatrix,                                                                                                     \
-        campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.tiles_touched, g.clamped, g.sh_dir, rows, rowf,                 \
-        dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dshs, dL_dshs_rest, dL_dscales,  \
-        dL_drots,                                                                                                       \
-        dL_dfeatures)
+        projmatrix, campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.gauss_rows, g.wave_rowbase, g.clamped,     \
+        g.sh_dir, have_rows ? rows : nullptr, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, \
+        dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures)
+#define GS2M_GBQ(LDS)                                                                                                   \
+    switch (rowf >> 2) {                                                                                                \
+        case 3: GS2M_GB(LDS, 3); break;                                                                                 \
+        case 4: GS2M_GB(LDS, 4); break;                                                                                 \
+        case 5: GS2M_GB(LDS, 5); break;                                                                                 \
+        default: GS2M_GB(LDS, 6); break;                                                                                \
+    }
     const bool lds = shs != nullptr && M == 16 &&
                      (shs_rest ? ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15) == 0
                                : ((((uintptr_t)shs) | ((uintptr_t)dL_dshs)) & 15) == 0);
-    if (lds) GS2M_GB(true);
-    else GS2M_GB(false);
+    if (lds) { GS2M_GBQ(true) } else { GS2M_GBQ(false) }
+#undef GS2M_GBQ
 #undef GS2M_GB
 }

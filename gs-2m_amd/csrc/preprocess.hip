@@ -6,7 +6,7 @@
 // computeCov2D :70-104, computeColorFromSH :20-67, in_frustum auxiliary.h:140-162,
 // ndc2Pix/getRect auxiliary.h:40-53) but the data layout is different: instead of six SoA
 // arrays it emits ONE aligned 128-B record per visible Gaussian (common.h) plus the
-// fp32-bit depth key used by the depth sort.  This file is compiled with
+// fp32-bit depth key the tiles' lists are ordered by.  This file is compiled with
 // -ffp-contract=off: the values that decide integers (radius, tile rect, depth key) are
 // evaluated in exactly the written order.
 #include "common.h"
@@ -58,12 +58,13 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, int* __restrict__ observe_zero, float4* __restrict__ rec,
-    uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint32_t* __restrict__ block_tt,
     uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, float* __restrict__ sh_dir, ZeroJobs zero) {
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     // (the block's blend records are parked in the same LDS afterwards: 256 x 36 floats)
     __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 45];  // (afterwards: 256 x 36 floats of records + 256 x 9 of sh_dir)
     __shared__ uint8_t s_seen[256];  // the thread's Gaussian has a radius: its record is stored
+    __shared__ uint32_t s_tt[4];     // tiles_touched summed per wave: the block's total is the binning's block sum (binning.hip)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
     // issued behind it would cost a second exposed memory round trip (the kernel is latency bound at 12 waves per CU).
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float sd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d(SH colour)/d(direction): the backward's only use of the coefficients
     uint32_t out_tt = 0;
     uint32_t out_key = 0xFFFFFFFFu;
+    uint2 out_rect = make_uint2(0u, 0u);
 
     // view-space point (transformPoint4x3), near-plane cull at 0.2
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
@@ -281,6 +283,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 r4[REC_CH + 3] = make_float4(f[9], 0.f, 0.f, 0.f);
                 out_radius = mr;
                 out_tt = ew * eh;  // 0 is possible: visible (radii > 0) but nothing to emit
+                if (out_tt != 0u) out_rect = make_uint2((uint32_t)ex0 | ((uint32_t)ey0 << 16), ew | (eh << 16));
                 out_key = f2u(vz);
             }
         }
@@ -289,7 +292,12 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         radii[idx] = out_radius;
         if (observe_zero) observe_zero[idx] = 0;  // the forward adds its counts with integer atomics
         tiles_touched[idx] = out_tt;
+        rect[idx] = out_rect;
         depth_key[idx] = out_key;
+    }
+    {   // the block's instance count: what the binning adds up in front of a block instead of running a scan over P
+        const uint32_t ws = wave_inclusive_scan_u32(out_tt, (int)(threadIdx.x & 63));
+        if ((threadIdx.x & 63) == 63) s_tt[threadIdx.x >> 6] = ws;
     }
     // The block's 256 records are one contiguous 32-KB run of `rec`: they leave through LDS (row stride 36 floats:
     // conflict-free 16-B writes) as fully coalesced float4 stores -- a thread storing its own record writes seven 16-B
@@ -301,6 +309,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) s_rec[threadIdx.x * 9 + k] = rq[k];
     s_seen[threadIdx.x] = out_radius > 0 ? 1 : 0;
+    if (threadIdx.x == 0) block_tt[blockIdx.x] = s_tt[0] + s_tt[1] + s_tt[2] + s_tt[3];  // (a barrier lies between the writes and this read)
     float* s_sd = s_sh + 256 * 36;  // the block's 256 x 9 direction derivatives: one contiguous 9-KB run of `sh_dir`
     if (colors_precomp == nullptr) {
 #pragma unroll
@@ -372,7 +381,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                                                            shs, shs_rest, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, observe_zero, g.rec,             \
-                                                           g.tiles_touched, g.depth_key, g.clamped, g.sh_dir, zero)
+                                                           g.tiles_touched, g.rect, g.block_tt, g.depth_key, g.clamped, g.sh_dir, zero)
     // split SH (shs = DC, shs_rest = the other 15 coefficients) exists in the LDS-staged form only: api.hip checks
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 &&
                      (shs_rest ? (((uintptr_t)shs_rest) & 15) == 0 : (((uintptr_t)shs) & 15) == 0);

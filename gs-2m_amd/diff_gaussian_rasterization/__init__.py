@@ -84,10 +84,13 @@ def _stream():
 
 
 class _ScratchCache(_Alloc):
-    """Backward scratch (partial-gradient rows: ~1 GB at 1M Gaussians / 1080p), kept per (device, stream) and only
-    ever grown.  The scratch is dead once the backward's kernels have run, and calls on one stream are ordered, so
-    the next backward may reuse it; handing a block of that size back to the caching allocator every step only
-    invites it to split the block for smaller requests and to hipMalloc a new one the step after."""
+    """Backward scratch (partial-gradient rows: ~0.4 GB at 1M Gaussians / 1080p), kept per (device, stream).  The scratch
+    is dead once the backward's kernels have run, and calls on one stream are ordered, so the next backward may reuse it;
+    handing a block of that size back to the caching allocator every step only invites it to split the block for smaller
+    requests and to hipMalloc a new one the step after.  Grown on demand (10 % head room: the row count moves with the
+    camera); given back when the last SHRINK_AFTER backwards all asked for less than half of it (evaluation at another
+    resolution after training, a pruned model)."""
+    SHRINK_AFTER = 32
     _cache = {}
     _cache_lock = threading.Lock()  # autograd runs backwards on its own threads: two devices' backwards may get() at once
 
@@ -107,11 +110,21 @@ class _ScratchCache(_Alloc):
         with cls._cache_lock:
             cls._cache.clear()
 
+    recent_max = 0
+    window = 0
+
     def _alloc(self, nbytes, _user):
-        if self.tensor is not None and self.tensor.numel() >= int(nbytes):
+        nbytes = int(nbytes)
+        self.recent_max = max(self.recent_max, nbytes)
+        self.window += 1
+        if self.window >= self.SHRINK_AFTER:
+            if self.tensor is not None and self.tensor.numel() > 2 * self.recent_max + (1 << 20):
+                self.tensor = None
+            self.recent_max, self.window = nbytes, 0
+        if self.tensor is not None and self.tensor.numel() >= nbytes:
             return self.tensor.data_ptr()
         self.tensor = None  # drop the old block before growing
-        return super()._alloc(nbytes, _user)
+        return super()._alloc(nbytes + nbytes // 10, _user)
 
 
 # forwards of the autograd path / of them: the cached binning buffer was leased to another graph ("busy": allocated through
@@ -120,21 +133,39 @@ BINNING_CACHE_STATS = {"calls": 0, "busy": 0, "grown": 0}
 
 
 class _BinningLease:
-    """Exclusive use of one cache entry's buffer; given back when this object dies or -- sooner -- when nothing but the
-    cache references the buffer any more (_BinningCache.acquire).  The autograd Function keeps it on `ctx`: a training loop
-    that still holds the previous iteration's outputs when it renders again (train.py's `out = render(...)`) keeps that
-    graph node, hence this object, alive into the next forward although the backward has long released its saved tensors."""
+    """Exclusive use of one cache entry's buffer by ONE forward and the graph node it created.  The cache entry holds the
+    lease (strongly); the lease holds a weak reference to the autograd node (`attach`), the node holds the lease.  The
+    lease has ended when (a) the node has died, or (b) autograd has freed the node's saved tensors -- a backward without
+    retain_graph has run -- which the PUBLIC `ctx.saved_tensors` property reports by raising (the check every second
+    `.backward()` on a freed graph trips); a training loop that still holds the previous iteration's outputs when it
+    renders again (train.py's `out = render(...)`) keeps the node alive but not its saved tensors.  No finalizer, no
+    use-count: rounds 3-4 asked `Tensor._use_count()` (a private counter of C++ references) and cleared the entry from a
+    lock-free `__del__` that could run after another thread had taken the entry over."""
 
-    def __init__(self, entry):
-        self.entry = entry
+    def __init__(self):
+        self.node = None      # weakref to the autograd node, set by attach()
+        self.ended = False    # set explicitly when the forward that took the lease did not end up using the cached buffer
 
-    def __del__(self):
-        # no lock: a cyclic-GC run inside acquire() (which allocates while holding the lock) may finalise a lease, and the
-        # lock is not re-entrant.  A stale lease (the entry has been taken over, `owner` is another lease) does nothing.
-        e, self.entry = self.entry, None
-        if e is not None and e.owner is self:
-            e.owner = None
-            e.busy = False
+    def attach(self, ctx):
+        import weakref
+        self.node = weakref.ref(ctx)
+
+    def over(self):
+        """True once nothing can read the leased buffer any more."""
+        if self.ended:
+            return True
+        if self.node is None:
+            return False      # the forward that took the lease is still running (or never attached a node): in use
+        ctx = self.node()
+        if ctx is None:
+            return True       # the graph node is gone
+        try:
+            ctx.saved_tensors  # raises once the saved tensors have been freed (backward ran, graph not retained)
+        except RuntimeError:
+            return True
+        except Exception:
+            return False
+        return False          # the graph is alive and may still run its backward (again: retain_graph)
 
 
 class _BinningCache:
@@ -146,32 +177,41 @@ class _BinningCache:
     that finds the entry leased -- two views rendered before either backward, a retained graph -- allocates as before.
     Entries are per stream because the buffer bypasses the caching allocator's stream tracking: work queued on one
     stream is ordered, so the next forward on THAT stream may overwrite what the previous backward has finished with.
-    Retained memory: 1.25 x the largest binning buffer per (device, stream) until release_scratch()."""
+    Retained memory: 1.25 x the largest binning buffer per (device, stream) until release_scratch(); an entry whose buffer
+    is more than twice what the last SHRINK_AFTER forwards asked for (a change of resolution, evaluation after training)
+    is given back to the allocator and grown afresh."""
     _cache = {}
     _lock = threading.RLock()
+    SHRINK_AFTER = 32
 
     def __init__(self):
         self.tensor = None
-        self.busy = False
-        self.owner = None  # the lease that set `busy`
+        self.owner = None   # the lease in force, if any
+        self.recent_max = 0  # largest request of the current window of SHRINK_AFTER forwards
+        self.window = 0
 
     @classmethod
     def acquire(cls, device, stream):
-        """-> (entry, lease); lease is None when the entry is in use.  In use = leased AND the buffer still referenced by
-        something other than the cache (the saved tensors of a graph whose backward has not run, or a retained graph): once
-        the backward has released them the entry is free again even if the old graph node -- and its lease -- lives on."""
+        """-> (entry, lease); lease is None when the entry is in use (see _BinningLease.over)."""
         key = (torch.device(device).index, stream)
-        lease = _BinningLease(None)  # allocated outside the lock
+        lease = _BinningLease()
         with cls._lock:
             e = cls._cache.get(key)
             if e is None:
                 e = cls._cache[key] = cls()
-            if e.busy and not (e.tensor is not None and e.tensor._use_count() == 1):
+            if e.owner is not None and not e.owner.over():
                 return e, None
-            e.busy = True
             e.owner = lease
-            lease.entry = e
         return e, lease
+
+    def note_request(self, nbytes):
+        """Shrink policy: called once per forward that holds the lease, with the bytes the library asked for."""
+        self.recent_max = max(self.recent_max, int(nbytes))
+        self.window += 1
+        if self.window >= self.SHRINK_AFTER:
+            if self.tensor is not None and self.tensor.numel() > 2 * max(self.recent_max, 1) + 8192:
+                self.tensor = None  # regrown (1.25 x the request) by the next forward
+            self.recent_max, self.window = 0, 0
 
     @classmethod
     def release(cls):
@@ -217,7 +257,7 @@ class _CModule:
         cache, lease = _BinningCache.acquire(device, _stream()) if _cached_binning else (None, None)
         pre = None
         if lease is not None and cache.tensor is not None:
-            pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0)
+            pre = _native.Prealloc(cache.tensor.data_ptr(), cache.tensor.numel(), binning.cb, None, 0, 0)
             if _CModule._prealloc_cb is None:
                 _CModule._prealloc_cb = C.cast(L.gs2m_prealloc_alloc, _native.ALLOC_FN)
             bin_cb, bin_user = _CModule._prealloc_cb, C.byref(pre)
@@ -241,13 +281,17 @@ class _CModule:
                 BINNING_CACHE_STATS["grown"] += 1
         if pre is not None and not pre.used_fallback:
             bin_tensor = cache.tensor
+            cache.note_request(pre.requested)
             if _lease_out is not None:
-                _lease_out.append(lease)  # the caller keeps the buffer leased for as long as it needs it
+                _lease_out.append(lease)  # the caller attaches its graph node: leased for as long as that node can run a backward
+            else:
+                lease.ended = True        # nobody to tell us when the buffer is dead: the caller got a cached buffer it must copy or use at once
         else:
             bin_tensor = binning.take()
             if lease is not None:  # the entry is ours but empty or too small: a buffer 25 % larger than this request for the next call
                 cache.tensor = torch.empty(int(bin_tensor.numel() * 1.25) + 4096, dtype=torch.uint8, device=device)
-        del lease
+                cache.recent_max, cache.window = 0, 0
+                lease.ended = True  # this call's buffer is its own allocation: the cached one is free
         return rendered, out_color, radii, observe, out_buffer, geom.take(), bin_tensor, img.take()
 
     @staticmethod
@@ -365,7 +409,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         lease = []
         num_rendered, color, radii, observe, buffer, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
             *args, sh_rest=shs_rest, _cached_binning=True, _lease_out=lease)
-        ctx.binning_lease = lease[0] if lease else None  # given back when this graph node dies
+        # names this forward's landing slot: the backward sizes its scratch by the dense gradient-row count the GPU leaves there
+        ctx.forward_token = _native.lib().gs2m_raster_forward_token()
+        ctx.binning_lease = lease[0] if lease else None
+        if lease:
+            lease[0].attach(ctx)  # over once this node has died or autograd has freed its saved tensors (_BinningLease.over)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         # radii and observe carry no gradient: without this autograd materialises a zero tensor for each of them in front
@@ -391,6 +439,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
                 grad_out_buffer, shs, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
                 binningBuffer, imgBuffer, raster_settings.feature_count)
+        L = _native.lib()
+        dense_rows = L.gs2m_raster_dense_rows(ctx.forward_token)  # -1: no longer available (worst-case sizing: 4 rows per instance)
+        if dense_rows >= 0:
+            L.gs2m_raster_backward_rows_hint(dense_rows)  # consumed by this thread's next backward call, i.e. the one below
         res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest, unused_input_grads=False)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_features) = res[:9]

@@ -24,6 +24,20 @@ def _dist_up():
     return d.is_available() and d.is_initialized()
 
 
+def set_keep(n):
+    """Arenas kept registered per producer and device (default 2: the current step's and the previous one's).  A step that
+    ACCUMULATES the gradients of V views in the first view's arena (train(views_per_rank=V), bench.py --views-per-rank V)
+    produces V arenas before it reduces the first: it asks for V + 1, so that the first is still registered -- hence still
+    summed in place -- when the reduction runs."""
+    global _KEEP
+    n = max(2, int(n))
+    with _lock:
+        if n != _KEEP:
+            _KEEP = n
+            for k in list(_registry):
+                _registry[k] = collections.deque(_registry[k], maxlen=n)
+
+
 def enable(on=True):
     """Start (stop) registering new arenas.  Called by gs2m_dp.GradReducer: only a reducer ever looks an arena up, and a
     registered arena outlives its gradients (`_KEEP` per producer: ~0.65 GB at 1M Gaussians for the rasterizer's), which

@@ -15,12 +15,12 @@ LIB_PATH = os.environ.get("GS2M_LIB", os.path.join(CSRC, "libgs2m_raster.so"))  
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visible", "gs2m_raster_forward_split_sh", "gs2m_raster_backward_split_sh", "gs2m_knn_dist2",
-           "gs2m_debug_layout", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
+           "gs2m_debug_layout", "gs2m_debug_tile_sort", "gs2m_raster_forward_token", "gs2m_raster_dense_rows", "gs2m_raster_backward_rows_hint", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_spin_wait", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_sampling", "gs2m_profile_collect", "gs2m_version",
            # include/gs2m_loss.h (round 3: the loss tail of the training iteration)
            "gs2m_affine_mean", "gs2m_densification_stats", "gs2m_edge_gradient", "gs2m_image_loss_backward", "gs2m_image_loss_forward", "gs2m_loss_workspace_bytes", "gs2m_mv_geo_loss_backward", "gs2m_mv_geo_loss_forward", "gs2m_pbr_inputs_backward", "gs2m_pbr_inputs_forward", "gs2m_plane_loss_backward", "gs2m_plane_loss_forward", "gs2m_ssim_backward_uniform", "gs2m_tv_loss_backward", "gs2m_tv_loss_forward")
 
-STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "observe", "blend_bwd",
+STAGES = ("preprocess", "count", "scan", "fill", "tile_sort", "unused5", "blend_fwd", "unused7", "blend_bwd",
           "gaussian_bwd")
 
 _lib = None
@@ -29,14 +29,14 @@ _lib = None
 class Prealloc(C.Structure):
     """include/gs2m_raster.h: gs2m_prealloc (user block of gs2m_prealloc_alloc)"""
     _fields_ = [("ptr", C.c_void_p), ("capacity", C.c_size_t), ("fallback", ALLOC_FN), ("fallback_user", C.c_void_p),
-                ("used_fallback", C.c_int)]
+                ("used_fallback", C.c_int), ("requested", C.c_size_t)]
 
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
-        "geom_bytes", "rec", "tiles_touched", "depth_key", "sorted_gid", "sorted_off", "clamped",
-        "binning_bytes", "point_list", "tile_keys", "inst_obs",
-        "image_bytes", "final_T", "n_contrib", "ranges")]
+        "geom_bytes", "rec", "tiles_touched", "depth_key", "rect", "gauss_rows", "clamped", "wave_rowbase", "counters",
+        "binning_bytes", "point_list", "tile_keys", "qlist", "qrow",
+        "image_bytes", "final_T", "n_contrib", "ranges", "qcount")]
 
 
 def build(jobs=8, force=False):
@@ -76,6 +76,14 @@ def lib():
     L.gs2m_knn_dist2.argtypes = [i, p, p, ALLOC_FN, p, p]
     L.gs2m_debug_layout.restype = i
     L.gs2m_debug_layout.argtypes = [i, i, i, i, C.POINTER(Layout)]
+    L.gs2m_raster_forward_token.restype = C.c_ulonglong
+    L.gs2m_raster_forward_token.argtypes = []
+    L.gs2m_raster_dense_rows.restype = C.c_longlong
+    L.gs2m_raster_dense_rows.argtypes = [C.c_ulonglong]
+    L.gs2m_raster_backward_rows_hint.restype = i
+    L.gs2m_raster_backward_rows_hint.argtypes = [C.c_longlong]
+    L.gs2m_debug_tile_sort.restype = i
+    L.gs2m_debug_tile_sort.argtypes = [i, C.c_uint] + [p] * 11
     L.gs2m_set_debug.restype = i
     L.gs2m_set_debug.argtypes = [i]
     L.gs2m_set_markers.restype = i

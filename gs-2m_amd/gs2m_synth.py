@@ -138,10 +138,16 @@ def algo_bytes(P, V, R, N, Tn, fc, M=16):
                 blend_bwd=blend_b, gaussian_bwd=gauss_b, forward=fwd, backward=bwd, total=fwd + bwd)
 
 
-def make_surface_scene(n, seed=0, centre=(0.0, 0.0, 6.0), sh_degree=3):
+def make_surface_scene(n, seed=0, centre=(0.0, 0.0, 6.0), sh_degree=3, detail=0.0, splat=0.05, grain=0.0):
     """A compact synthetic object for the train.py-level configuration (SURVEY.md 8(d) C4 substitute: no dataset on the
     GPU box): n flat Gaussians on a unit-and-a-half sphere plus a ground disc, smoothly varying colours, normals
-    known.  -> dict(points, normals, colors [0,1], scales, rotations (w,x,y,z), opacities, shs (n,16,3))."""
+    known.  `detail` > 0 adds a fine colour texture of that spatial frequency (radians per unit) on top of the smooth
+    field -- a model initialised from a sparse subsample then has to densify to reproduce it, as on a real scan --
+    `grain` > 0 adds an independent random colour offset of that standard deviation to every true Gaussian (content at
+    the scale of the true splats themselves, the way sensor noise and fine surface texture fill a photograph),
+    and `splat` is the in-plane size of the true Gaussians (0.05: the small-scene default; use ~1.5 / sqrt(n) x 20 for
+    a dense cover by many small splats).  -> dict(points, normals, colors [0,1], scales, rotations (w,x,y,z),
+    opacities, shs (n,16,3))."""
     g = torch.Generator().manual_seed(seed)
     ns = int(n * 0.7)
     d = torch.nn.functional.normalize(torch.randn(ns, 3, generator=g), dim=1)
@@ -153,12 +159,18 @@ def make_surface_scene(n, seed=0, centre=(0.0, 0.0, 6.0), sh_degree=3):
     normals = torch.cat([d, torch.tensor([0.0, -1.0, 0.0]).expand(n - ns, 3)], dim=0)
     colors = 0.5 + 0.45 * torch.stack([torch.sin(2.1 * pts[:, 0] + 0.3), torch.sin(1.7 * pts[:, 1] + 1.1) * torch.cos(1.3 * pts[:, 2]),
                                        torch.cos(2.3 * pts[:, 2] - 0.4)], dim=1)
+    if detail > 0.0:
+        tex = torch.sin(detail * pts[:, 0]) * torch.sin(detail * pts[:, 1] + 0.7) * torch.sin(detail * pts[:, 2] + 1.9)
+        tex2 = torch.sin(detail * pts[:, 0] + 2.1) * torch.sin(1.3 * detail * pts[:, 2] + 0.3) * torch.cos(0.8 * detail * pts[:, 1])
+        colors = 0.5 + (colors - 0.5) * 0.55 + 0.2 * torch.stack([tex, tex2, -tex], dim=1)
+    if grain > 0.0:
+        colors = colors + grain * torch.randn(n, 3, generator=g)
     # rotation taking +z to the normal: q = normalize(1 + n_z, z x n)
     w = 1.0 + normals[:, 2]
     q = torch.stack([w, -normals[:, 1], normals[:, 0], torch.zeros(n)], dim=1)
     q[w < 1e-6] = torch.tensor([0.0, 1.0, 0.0, 0.0])
     q = torch.nn.functional.normalize(q, dim=1)
-    scales = torch.tensor([0.05, 0.05, 0.005]).expand(n, 3) * (0.7 + 0.6 * torch.rand(n, 1, generator=g))
+    scales = torch.tensor([splat, splat, 0.1 * splat]).expand(n, 3) * (0.7 + 0.6 * torch.rand(n, 1, generator=g))
     shs = torch.zeros(n, (sh_degree + 1) ** 2, 3)
     shs[:, 0] = (colors - 0.5) / 0.28209479177387814
     c = torch.tensor(centre)

@@ -38,19 +38,20 @@ def psnr(a, b):
     return (-10.0 * torch.log10(((a - b) ** 2).mean().clamp_min(1e-12))).item()
 
 
-def synthetic_scene(n_true=60_000, n_views=12, W=640, H=360, init_frac=0.15, seed=0, device="cuda"):
+def synthetic_scene(n_true=60_000, n_views=12, W=640, H=360, init_frac=0.15, seed=0, device="cuda", detail=0.0, splat=0.05,
+                    init_noise=0.02, grain=0.0, fx_scale=1.1):
     """-> (cameras, gt_images, init_points, init_colors, cameras_extent)."""
-    sc = S.make_surface_scene(n_true, seed=seed)
+    sc = S.make_surface_scene(n_true, seed=seed, detail=detail, splat=splat, grain=grain)
     t = {k: v.to(device) for k, v in sc.items()}
     truth = GaussianParams(t["points"], t["shs"][:, :1].contiguous(), t["shs"][:, 1:].contiguous(), torch.log(t["scales"]),
                            t["rotations"], inverse_sigmoid(t["opacities"]), *(inverse_sigmoid(torch.full((n_true, c), 0.5, device=device)) for c in (3, 1, 1)))
-    cams = [Camera(c, device) for c in S.orbit_cameras(n_views, W, H, radius=6.0, centre=(0.0, -0.8, 6.0), fx=1.1 * W)]
+    cams = [Camera(c, device) for c in S.orbit_cameras(n_views, W, H, radius=6.0, centre=(0.0, -0.8, 6.0), fx=fx_scale * W)]
     pipe, bg = PipelineParams(), torch.zeros(3, device=device)
     with torch.no_grad():
         gts = [render(c, truth, pipe, bg)["render"].clamp(0, 1) for c in cams]
     g = torch.Generator().manual_seed(seed + 1)
     pick = torch.randperm(n_true, generator=g)[: max(1, int(init_frac * n_true))]
-    pts = sc["points"][pick] + 0.02 * torch.randn(len(pick), 3, generator=g)
+    pts = sc["points"][pick] + init_noise * torch.randn(len(pick), 3, generator=g)
     cols = (sc["colors"][pick] + 0.05 * torch.randn(len(pick), 3, generator=g)).clamp(0, 1)
     centers = torch.stack([c.camera_center for c in cams])
     extent = 1.1 * (centers - centers.mean(0)).norm(dim=1).max().item()  # scene/dataset_readers.py getNerfppNorm
@@ -153,6 +154,77 @@ def load_colmap_dataset(folder, images="images", device="cuda", resolution=1):
     return cams, gts, xyz.astype(np.float32), (rgb / 255.0).astype(np.float32), C.nerf_normalization(infos)["radius"]
 
 
+# ---- BASELINE.json configs[3] ("C4"): DTU scan24 through the full train.py loop --------------------------------------
+# scripts/run_dtu.py:21-22 runs `train.py -s dtu/scan24 -r 2 --lambda_depth_normal 0.015`: 49 images of 1554 x 1162 read at
+# half resolution (777 x 581), ~30 k COLMAP points densified past 300 k, geometry stage with the multi-view term.  The
+# dataset is not on the GPU box (no network), so the scene is a SUBSTITUTE, and every line that reports it says so: a
+# synthetic object of `n_true` surface-aligned Gaussians with a fine colour texture, rendered by this rasterizer from 49
+# orbit cameras at 1554 x 1162, WRITTEN as a COLMAP-format dataset (sparse/0/*.bin + images/*.png) and read back through
+# the COLMAP loader at `-r 2` exactly as the reference reads a scan.
+C4 = dict(n_views=49, full_W=1554, full_H=1162, resolution=2, n_true=1_500_000, init_points=30_000, detail=60.0, splat=0.008, grain=0.4,
+          fx_scale=3.0, lambda_depth_normal=0.015)
+
+
+def c4_scene(folder, n_true=None, init_points=None, seed=0, device="cuda"):
+    """-> the `scene` tuple of `train()` for the C4 substitute, through a COLMAP-format dataset written to `folder`."""
+    n_true = n_true or C4["n_true"]
+    init_points = init_points or C4["init_points"]
+    full = synthetic_scene(n_true, C4["n_views"], C4["full_W"], C4["full_H"], init_frac=init_points / n_true, seed=seed, device=device,
+                           detail=C4["detail"], splat=C4["splat"], init_noise=0.01, grain=C4["grain"], fx_scale=C4["fx_scale"])
+    export_colmap_dataset(folder, full)
+    del full
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()
+    return load_colmap_dataset(folder, resolution=C4["resolution"], device=device)
+
+
+def c4_options(iterations):
+    """The reference's schedule (arguments/__init__.py:81-134: densify 500-15000 every 100, opacity reset every 3000, geometry
+    stage from 5000 of 30000 iterations) compressed onto `iterations` with the same proportions, `--lambda_depth_normal 0.015`
+    as scripts/run_dtu.py:21 passes it.  -> (OptimizationParams, geometry_from_iter, MultiViewParams)"""
+    import gs2m_mvs
+    opt = OptimizationParams()
+    k = iterations / 30_000.0
+    opt.lambda_depth_normal = C4["lambda_depth_normal"]
+    opt.densify_from_iter = max(100, int(round(500 * k)))
+    opt.densify_until_iter = int(round(15_000 * k))
+    opt.densification_interval = max(25, int(round(100 * k)))
+    opt.opacity_reset_interval = max(200, int(round(3000 * k)))
+    opt.position_lr_max_steps = iterations
+    mv = gs2m_mvs.MultiViewParams()
+    # 49 orbit cameras 6 units from the object: neighbours 7.3 degrees / 0.77 units apart (DTU's cameras sit ~0.1-0.2 of
+    # the scene radius apart: the reference's 1.5 / 30 degrees default bounds already admit them)
+    return opt, int(round(5000 * k)), mv
+
+
+def c4_run(folder, iterations=5000, seed=0, callback=None, log=None, multi_view=True, n_true=None, init_points=None, scene=None,
+           schedule_iterations=None):
+    """One C4 training run on the substitute scene: RGB stage, then the geometry stage with the depth-normal term at 0.015 and
+    the multi-view consistency term, densify / prune / opacity reset / observe trim on the reference's (compressed) schedule.
+    `schedule_iterations`: the run length the schedule is laid out for when only its first `iterations` are run (a test that
+    repeats the beginning of a longer run).  -> (model, stats); stats also carries `points_max` and the scene's description."""
+    import random
+    scene = scene or c4_scene(folder, n_true=n_true, init_points=init_points, seed=seed)
+    opt, geometry_from, mv = c4_options(schedule_iterations or iterations)
+    random.seed(seed)  # the multi-view term picks its neighbour view with `random` (utils/loss_utils.py multi_view_loss)
+    peak = [0]
+
+    def cb(it, g, cams, gts):
+        peak[0] = max(peak[0], g.get_xyz.shape[0])
+        if callback is not None:
+            callback(it, g, cams, gts)
+
+    model, st = train(iterations=iterations, geometry_from_iter=geometry_from, opt=opt, scene=scene, seed=seed, log=log,
+                      lambda_multi_view=OptimizationParams.lambda_multi_view if multi_view else 0.0, mv_opt=mv,
+                      trim_interval=max(250, (schedule_iterations or iterations) // 4), callback=cb)
+    st["points_max"] = peak[0]
+    st["workload"] = (f"C4 SUBSTITUTE for DTU scan24 (dataset absent): synthetic COLMAP-format scene, {len(scene[0])} views "
+                      f"{scene[0][0].image_width}x{scene[0][0].image_height} (written at {C4['full_W']}x{C4['full_H']}, read at -r {C4['resolution']}), "
+                      f"{st['points_start']} initial points, geometry stage from iteration {geometry_from} with lambda_depth_normal "
+                      f"{C4['lambda_depth_normal']}" + (" and the multi-view term" if multi_view else "") + f", {iterations} iterations")
+    return model, st
+
+
 def load_blender_dataset(folder, transforms="transforms_train.json", extension=".png", white_background=False, n_points=100_000, seed=0,
                          device="cuda"):
     """NeRF-synthetic ("Blender") dataset -> the `scene` tuple `train()` takes (readCamerasFromTransforms / readNerfSyntheticInfo,
@@ -189,7 +261,8 @@ def load_blender_dataset(folder, transforms="transforms_train.json", extension="
 def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geometry_from_iter=None, opt=None, log=None,
           device="cuda", scene=None, material_from_iter=None, light_res=128, lambda_smooth=0.0, lambda_normal=0.1,
           lambda_multi_view=0.0, mv_opt=None, lambda_rough=0.0, trim_interval=1000, alpha_masks=None,
-          white_background=False, dp=False, dp_mode="auto", ssim_fn=None, optimizer_cls=None, pipe=None, views_per_rank=1):
+          white_background=False, dp=False, dp_mode="auto", ssim_fn=None, optimizer_cls=None, pipe=None, views_per_rank=1,
+          callback=None):
     """`dp=True`: view-parallel data parallelism over the initialised torch.distributed group: every
     rank holds the full model, an iteration renders `world_size` different views (rank r takes the r-th of the next
     `world_size` entries of the shared random view order), the parameter gradients are SUMMED over the ranks with one
@@ -205,7 +278,9 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     collective is paid once per `views_per_rank` views, which is what lets the view-parallel form scale past the point
     where one view's gradients cost as much wire time as the view costs compute.
     `dp_mode`: "allreduce", "rs_ag" (reduce-scatter + all-gather: every link of the xGMI mesh busy) or "auto" = rs_ag from 4
-    ranks on."""
+    ranks on.
+    `callback(it, gaussians, cams, gts)`: called under no_grad at the end of every iteration (after the optimizer step): a
+    test's window on the run (mid-run parity spot checks, snapshots for determinism checks)."""
     opt = opt or OptimizationParams()
     ssim = ssim_fn or fused_ssim
     rank, world, reducer = 0, 1, None
@@ -215,6 +290,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
         assert dist.is_initialized(), "train(dp=True) needs an initialised torch.distributed process group"
         rank, world = dist.get_rank(), dist.get_world_size()
         reducer = GradReducer(mode=("rs_ag" if world >= 4 else "allreduce") if dp_mode == "auto" else dp_mode)
+        import gs2m_arena
+        gs2m_arena.set_keep(views_per_rank + 1)  # the first view's arena (the accumulated gradients) stays registered until the reduction
     geometry_from_iter = iterations // 2 if geometry_from_iter is None else geometry_from_iter
     material_from_iter = iterations + 1 if material_from_iter is None else material_from_iter
     cams, gts, pts, cols, extent = scene or synthetic_scene(n_true, n_views, W, H, seed=seed, device=device)
@@ -378,6 +455,9 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                     lighting.light_optimizer.step()
                     lighting.light_optimizer.zero_grad(set_to_none=True)
                     lighting.cubemap.clamp_(min=0.0)
+        if callback is not None:
+            with torch.no_grad():
+                callback(it, gaussians, cams, gts)
         if log and it % log == 0:
             print(f"[{it:6d}] loss {loss.item():.5f}  points {gaussians.get_xyz.shape[0]}", flush=True)
     if torch.device(device).type == "cuda":
@@ -413,7 +493,27 @@ if __name__ == "__main__":
     ap.add_argument("--resolution", "-r", type=int, default=1, help="down-scale factor for a COLMAP dataset's images")
     ap.add_argument("--blender", action="store_true", help="--source-path is a NeRF-synthetic (transforms_train.json) dataset")
     ap.add_argument("--export-colmap", default=None, help="write the synthetic scene as a COLMAP-format dataset to this folder and exit")
+    ap.add_argument("--c4", default=None, metavar="FOLDER", help="BASELINE configs[3] substitute (see C4 above): write the scene to FOLDER, train --iterations on it")
+    ap.add_argument("--c4-detail", type=float, default=None, help="experiment: texture frequency of the C4 substitute scene")
+    ap.add_argument("--c4-true", type=int, default=None, help="experiment: true Gaussians of the C4 substitute scene")
+    ap.add_argument("--c4-splat", type=float, default=None)
+    ap.add_argument("--c4-grain", type=float, default=None)
+    ap.add_argument("--c4-fx", type=float, default=None)
     a = ap.parse_args()
+    if a.c4:
+        if a.c4_detail is not None:
+            C4["detail"] = a.c4_detail
+        if a.c4_true is not None:
+            C4["n_true"] = a.c4_true
+        if a.c4_splat is not None:
+            C4["splat"] = a.c4_splat
+        if a.c4_grain is not None:
+            C4["grain"] = a.c4_grain
+        if a.c4_fx is not None:
+            C4["fx_scale"] = a.c4_fx
+        model, st = c4_run(a.c4, iterations=a.iterations, log=max(1, a.iterations // 20))
+        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items() if k not in ("pbr_loss", "lighting", "mv_loss")})
+        sys.exit(0)
     if a.export_colmap:
         export_colmap_dataset(a.export_colmap, synthetic_scene(a.true_gaussians, a.views, a.width, a.height))
         sys.exit(0)

@@ -154,19 +154,23 @@ typedef struct gs2m_layout {
     uint64_t rec;           /* P x 32 floats: blend records, see DESIGN.md */
     uint64_t tiles_touched; /* P u32 */
     uint64_t depth_key;     /* P u32: fp32 bits of view-space depth, 0xFFFFFFFF if culled */
-    uint64_t sorted_gid;    /* P u32: Gaussian ids in (depth, id) order */
-    uint64_t sorted_off;    /* P u32: exclusive scan of tiles_touched in that order */
+    uint64_t rect;          /* P x uint2: emitted tile rectangle {min x | min y << 16, w | h << 16} */
+    uint64_t gauss_rows;    /* P u32: partial-gradient rows of the Gaussian (bit 31: summed by a whole workgroup) */
     uint64_t clamped;       /* P u8 bit mask (bit c = SH channel c clamped) */
+    uint64_t wave_rowbase;  /* ceil(P / 64) u32: first gradient row of every wave of 64 consecutive Gaussians */
+    uint64_t counters;      /* 64 u32: [0] num_rendered, [1] the same from the block sums, [2] dense gradient rows */
     /* binning buffer */
     uint64_t binning_bytes;
-    uint64_t point_list;    /* R u32: Gaussian ids sorted by (tile, depth, id) */
+    uint64_t point_list;    /* R u32: Gaussian ids (| quadrant mask << 28) sorted by (tile, depth, id) */
     uint64_t tile_keys;     /* R u32: tile id of each sorted instance */
-    uint64_t inst_obs;      /* R u32: per-instance observe partial counts (emission order) */
+    uint64_t qlist;         /* 4R x uint2: the per-(tile, quadrant) lists {id | mask << 28, position in the tile list} */
+    uint64_t qrow;          /* 4R u32: gradient row of each list entry */
     /* image buffer */
     uint64_t image_bytes;
     uint64_t final_T;       /* W*H f32 */
     uint64_t n_contrib;     /* W*H u32 */
     uint64_t ranges;        /* tiles x uint2 */
+    uint64_t qcount;        /* tiles x 4 u32: entries of each quadrant list */
 } gs2m_layout;
 
 int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out);
@@ -282,6 +286,7 @@ typedef struct gs2m_prealloc {
     gs2m_alloc_fn fallback;
     void* fallback_user;
     int used_fallback;
+    size_t requested; /* out: bytes of the last request (a caller that keeps `ptr` from call to call sizes / shrinks it by this) */
 } gs2m_prealloc;
 char* gs2m_prealloc_alloc(size_t bytes, void* user);
 
@@ -294,15 +299,34 @@ int gs2m_set_debug(int on);
 int gs2m_set_markers(int on);
 const char* gs2m_stage_name(int stage);
 
-/* Limits: num_rendered (the emitted instance count) must stay below 2^30 -- the look-back status words of the scan
- * and sort kernels carry 30 value bits; gs2m_raster_forward returns GS2M_ERR_UNSUPPORTED beyond that. */
+/* Limits: num_rendered (the emitted instance count) must stay below 2^30 -- slots, gradient rows (up to 4 per instance)
+ * and list offsets are 32-bit; P below 2^28 (a 4-bit quadrant mask rides above the Gaussian id); at most 2^28 tiles.
+ * gs2m_raster_forward returns GS2M_ERR_UNSUPPORTED beyond that. */
+
+/* ---- backward scratch sized by what the forward actually binned -------------------------------------------------------
+ * The blend backward writes one partial-gradient row (11 + feature_count floats, padded to a multiple of 4) per
+ * (tile instance, 8x8 quadrant the splat reaches); the rows are numbered densely, and their number -- 1.8 per instance on
+ * the bench scene, 4 at most -- is known on the device shortly after the forward's binning.  A caller that wants the scratch
+ * sized by it (instead of the worst case 4 x num_rendered):
+ *   token = gs2m_raster_forward_token()       right after a forward, on the calling thread (no wait);
+ *   rows  = gs2m_raster_dense_rows(token)     any time later, from any thread (waits for the count if the GPU has not
+ *                                             produced it yet; -1 when it is no longer available: size for the worst case);
+ *   gs2m_raster_backward_rows_hint(rows)      on the thread that calls gs2m_raster_backward* next (consumed by that call). */
+unsigned long long gs2m_raster_forward_token(void);
+long long gs2m_raster_dense_rows(unsigned long long token);
+int gs2m_raster_backward_rows_hint(long long dense_rows);
+
+/* Test hook (tests/test_tile_sort_gpu.py): the per-tile (depth, id) sort + quadrant-list split on caller-made spans. */
+int gs2m_debug_tile_sort(int tiles, unsigned max_tile, const unsigned* ranges, unsigned* u_depth, const unsigned* u_val,
+                         const unsigned* u_row, const unsigned* wave_rowbase, unsigned* point_list, unsigned* tile_keys,
+                         unsigned* qlist, unsigned* qrow, unsigned* qcount, void* stream);
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage, 3 = the backward blend kernel only.  Setting the mode clears
  * the records.  gs2m_profile_collect waits for the recorded events and returns, per
  * stage, the summed milliseconds and the number of launches since the last collect.
- * Stage order: preprocess, depth_sort, scan, emit, tile_sort, ranges, blend_fwd, observe,
- * blend_bwd, gaussian_bwd. */
+ * Stage order: preprocess, count, scan, fill (+ row scan), tile_sort (+ quadrant lists), -, blend_fwd, -,
+ * blend_bwd, gaussian_bwd (row sums + per-Gaussian chain). */
 #define GS2M_NUM_STAGES 10
 int gs2m_profile_mode(int mode);
 /* mode 3 brackets every `every`-th launch of the backward blend (default 1: each one).  An event pair leaves ~6 us of bubble on

@@ -393,6 +393,15 @@ def check_sweep_case(reference, case, precomputed=False):
                                                        torch.full((P, 3), 0.5), torch.full((P, 1), 0.5), torch.full((P, 1), 0.5))
         kw = dict(colors_precomp=torch.rand(P, 3, generator=torch.Generator().manual_seed(case)), cov3D_precomp=prm.get_covariance().contiguous())
         tag += " precomputed"
+    check_scene_against(reference, sc, tag, refbin=refbin, **kw)
+    return tag
+
+
+def check_scene_against(reference, sc, tag="", refbin=False, **kw):
+    """The HIP path (through the drop-in op) against the reference build `reference` (oracle/_ref) on scene `sc`: radii exact,
+    observe and images with threshold proofs, blend sums and the well-conditioned gradients element-wise (every element outside
+    1e-3 relative beyond the counted budget needs its proof).  Raises AssertionError."""
+    import gs2m_native
     r, rg = run_oracle(reference, sc, **kw)
     try:
         gs2m_native.set_reference_binning(refbin)
@@ -411,7 +420,7 @@ def check_sweep_case(reference, case, precomputed=False):
     for k in ("shs", "opacities", "features", "means2D", "colors"):
         if k in g and g[k] is not None:
             assert_sum_close(k + " " + tag, g[k], rg[k], r)
-    return tag
+    return r, rg, out, g, sums
 
 
 def cov2d_anisotropy(f):

@@ -16,7 +16,7 @@ def _declared_functions():
             continue
         src = open(os.path.join(ROOT, "include", fn)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names += re.findall(r"^\s*(?:const\s+)?(?:int|char\s*\*|void)\s*\*?\s*(gs2m_\w+)\s*\(", src, flags=re.M)
+        names += re.findall(r"^\s*(?:const\s+)?(?:unsigned\s+long\s+long|long\s+long|int|char\s*\*|void)\s*\*?\s*(gs2m_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

@@ -4,7 +4,7 @@ with the oracle in tests/test_configs_gpu.py::test_config_c3_full_size_against_o
     colour(bg = 1) - colour(bg = 0) equals that transmittance (compositing identity);
   * the backward is linear in the upstream gradients;
   * structural invariants of the private tile lists (sorted by tile, depth order inside a tile, ranges
-    partition [0, R)) on both tile-id paths of the radix sort;
+    partition [0, R), quadrant lists = the order-preserving split of the tile list by the quadrant masks);
   * bitwise reproducibility;
   * `observe` and `radii` consistency (observe > 0 only where radii > 0)."""
 import numpy as np
@@ -74,8 +74,7 @@ def test_backward_linear_in_upstream_gradients(big):
 
 @pytest.mark.parametrize("reference_binning", [False, True])
 def test_tile_list_invariants(big, reference_binning):
-    """reference binning emits 3.8 M instances here: more sort tiles than are resident at once, i.e. the ticketed tile
-    ids of the radix sort (radix_sort.hip); the default 2.7 M take the blockIdx path."""
+    """the per-tile (depth, id) order, the tile ranges and the quadrant lists of both binning modes (2.7 M / 3.8 M instances)"""
     import gs2m_native
     import diff_gaussian_rasterization as dgr
     gs2m_native.set_reference_binning(reference_binning)
@@ -87,7 +86,6 @@ def test_tile_list_invariants(big, reference_binning):
         st.projmatrix, st.tanfovx, st.tanfovy, H, W, g["shs"], 3, st.campos, False, FC)
     torch.cuda.synchronize()
     gs2m_native.set_reference_binning(False)
-    assert (R > 768 * 4096) == reference_binning, "the two modes are meant to sit on either side of the ticket threshold"
     lay = gs2m_native.debug_layout(P, R, W, H)
     al = lambda t: (-t.data_ptr()) % 256
     view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
@@ -109,3 +107,31 @@ def test_tile_list_invariants(big, reference_binning):
     lens = (rg[:, 1] - rg[:, 0]).reshape((H + 15) // 16, (W + 15) // 16).repeat(16, 0).repeat(16, 1)[:H, :W]
     assert np.all(nc <= lens)
     assert np.array_equal(radii.cpu().numpy() > 0, dk != 0xFFFFFFFF)
+    # the four quadrant lists of every tile: the tile list's entries whose mask holds the quadrant, in list order, with the
+    # position in the tile list; the gradient rows: dense over the view, one per set mask bit, a Gaussian's rows contiguous
+    plm = view(binB, lay.point_list, R, np.uint32)
+    ql = view(binB, lay.qlist, 8 * R, np.uint32).reshape(4 * R, 2)
+    qr = view(binB, lay.qrow, 4 * R, np.uint32)
+    qc = view(imgB, lay.qcount, 4 * Tn, np.uint32).reshape(Tn, 4)
+    total_rows = int(view(geomB, lay.counters, 64, np.uint32)[2])
+    masks = plm >> 28
+    assert total_rows == int(sum(((masks >> q) & 1).sum() for q in range(4)))
+    rng = np.random.default_rng(3)
+    for t in rng.choice(np.nonzero(t)[0], 40, replace=False):
+        lo, hi = int(rg[t, 0]), int(rg[t, 1])
+        n = hi - lo
+        for q in range(4):
+            sel = np.nonzero((masks[lo:hi] >> q) & 1)[0]
+            assert qc[t, q] == len(sel)
+            ent = ql[4 * lo + q * n: 4 * lo + q * n + len(sel)]
+            assert np.array_equal(ent[:, 0], plm[lo:hi][sel]) and np.array_equal(ent[:, 1], sel)
+    rows_all = np.concatenate([qr[4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]): 4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]) + int(qc[t, q])]
+                               for t in range(Tn) for q in range(4)])
+    assert len(rows_all) == total_rows and np.array_equal(np.sort(rows_all), np.arange(total_rows)), "rows: a permutation of 0 .. total - 1"
+    gids_all = np.concatenate([ql[4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]): 4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]) + int(qc[t, q]), 0]
+                               for t in range(Tn) for q in range(4)]) & np.uint32(0x0FFFFFFF)
+    o = np.argsort(rows_all)
+    gr = view(geomB, lay.gauss_rows, P, np.uint32) & np.uint32(0x7FFFFFFF)
+    runs = 1 + int(np.count_nonzero(np.diff(gids_all[o].astype(np.int64))))
+    assert runs == len(np.unique(gids_all)), "every Gaussian's rows are ONE contiguous run"
+    assert np.array_equal(np.bincount(gids_all, minlength=P), gr), "gauss_rows = rows per Gaussian"
