@@ -16,6 +16,18 @@
 
 namespace {
 
+// getHigherMsb (rasterizer_impl.cu:31-44): number of key bits that cover the tile ids
+uint32_t higher_msb(uint32_t n) {
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
 // Landing zones: mapped pinned words the GPU publishes a forward's counts into (common.h: GS2M_LAND_*), a ring of slots per
 // device (never freed: the HIP runtime may already be gone when static destructors run).  A forward takes the next slot; the
 // token it leaves behind (gs2m_raster_forward_token) names the slot and its generation, so that the dense-row count of THAT
@@ -37,7 +49,7 @@ thread_local long long t_rows_hint = -1;  // gs2m_raster_backward_rows_hint: con
 // mode 0: off; 1: the two blend kernels only; 2: every stage; 3: the backward blend kernel only (an event pair costs
 // ~6 us of stream bubble around the kernel it brackets: bench.py's timed region brackets the dominant kernel alone).
 static_assert(GS2M_NUM_STAGES == 10, "stage table");
-enum Stage { ST_PREPROCESS = 0, ST_COUNT_TILES, ST_SCAN, ST_FILL, ST_TILE_SORT, ST_UNUSED5, ST_BLEND_FWD, ST_UNUSED7,
+enum Stage { ST_PREPROCESS = 0, ST_UNUSED1, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_LISTS, ST_BLEND_FWD, ST_UNUSED7,
              ST_BLEND_BWD, ST_GAUSSIAN_BWD, ST_COUNT };
 constexpr int kMaxRecords = 8192;
 struct Prof {
@@ -58,7 +70,7 @@ std::atomic<int> g_spin_wait{1};  // forward: poll the pinned num_rendered inste
 std::atomic<int> g_debug{0};      // gs2m_set_debug: synchronize + check after every stage
 std::atomic<int> g_markers{0};    // gs2m_set_markers: roctx ranges around the stages
 
-const char* const kStageNames[ST_COUNT] = {"preprocess", "count", "scan", "fill", "tile_sort", "-", "blend_fwd", "-", "blend_bwd", "gaussian_bwd"};
+const char* const kStageNames[ST_COUNT] = {"preprocess", "-", "scan", "emit", "tile_sort", "depth_order+quad_lists", "blend_fwd", "-", "blend_bwd", "gaussian_bwd"};
 
 // roctx ranges (rocprofv3 --marker-trace): resolved at run time so that the library has no link-time dependency
 struct Roctx {
@@ -205,27 +217,22 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (P > 0) {
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
-            // the preprocess kernel zeroes the tile histogram the count kernel adds into
-            ZeroJobs zj = {{im.tile_count, nullptr, nullptr}, {tiles, 0, 0}};
+            // the preprocess kernel zeroes the digit histograms the emit kernel counts the tile sort's keys into
+            ZeroJobs zj = {{g.tile_hist, nullptr, nullptr}, {(size_t)GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS, 0, 0}};
             gs2m_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                                    colors_precomp, features, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                                    tan_fovy, focal_x, focal_y, tiles_x, tiles_y, out_radii, out_observe, g,
                                    reference_binning ? 0 : 1, zj, s);
         }
-        // `prefiltered`: honoured as a checked promise (preprocess.hip); the check runs ahead of the count kernel, whose first
-        // workgroup publishes num_rendered, so its flag has landed when the wait below returns
+        // `prefiltered`: honoured as a checked promise (preprocess.hip); the check runs ahead of the kernel that publishes
+        // num_rendered, so its flag has landed when the wait below returns
         if (prefiltered) gs2m_launch_prefiltered_check(P, means3D, viewmatrix, land_dev + GS2M_LAND_PREFILTERED, s);
         // The reference waits for num_rendered after its scan (rasterizer_impl.cu:269-270) and the GPU idles until the host
-        // has seen the value, sized the binning buffer and launched the next kernel.  Here the value is published by the
-        // FIRST workgroup of the count kernel (the sum of the per-block counts the preprocess kernel left), and the host has
-        // the fill kernel queued while the count and scan kernels -- which need no binning memory -- still run.
-        {
-            StageTimer t(ST_COUNT_TILES, s, &failed_stage);
-            gs2m_launch_count(P, tiles_x, g, im, land_dev, s);
-        }
+        // has seen the value, sized the binning buffer and launched the next kernel.  Here the value -- the sum of the
+        // per-block counts the preprocess kernel left -- is the first thing the one-workgroup scan kernel publishes.
         {
             StageTimer t(ST_SCAN, s, &failed_stage);
-            gs2m_launch_scan(P, tiles, g, im, land_dev, s);
+            gs2m_launch_blockscan(P, g, land_dev, s);
         }
         HIP_TRY(hipGetLastError());
         DEBUG_CHECK();
@@ -242,49 +249,47 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             HIP_TRY(hipStreamSynchronize(s));  // nothing of this call is left in flight when the caller frees its buffers
             return GS2M_ERR_PREFILTERED;
         }
-        if (land[GS2M_LAND_R] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // slots, rows (4 per instance at most) and list offsets are 32-bit
+        if (land[GS2M_LAND_R] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // slots, rows (4 per instance at most), list offsets, look-back words
         R = (int)land[GS2M_LAND_R];
-    } else {
-        HIP_TRY(gs2m_zero_async(im.tile_count, tiles * sizeof(uint32_t), s));
-        gs2m_launch_scan(0, tiles, g, im, land_dev, s);
     }
 
+    const int tile_bits = (int)higher_msb((uint32_t)tiles);
     const size_t Rn = R > 0 ? (size_t)R : 1;
-    BinningState bsz = gs2m_carve_binning(nullptr, Rn);
+    const size_t btemp = gs2m_binning_temp_bytes(Rn, tile_bits);
+    BinningState bsz = gs2m_carve_binning(nullptr, Rn, btemp);
     char* bbase = binning_alloc(bsz.total_bytes, binning_user);
     if (!bbase) return GS2M_ERR_ALLOC;
-    BinningState b = gs2m_carve_binning(bbase, Rn);
+    BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
 
-    uint32_t max_tile = 0;
     if (R > 0) {
-        {
-            StageTimer t(ST_FILL, s, &failed_stage);
-            gs2m_launch_fill(P, width, height, tiles_x, g, b, im, land_dev, s);
+        {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the long-tile queue's counter
+            StageTimer t(ST_EMIT, s, &failed_stage);
+            ZeroJobs zj = {{nullptr, im.ranges_raw, im.bigq}, {0, tiles * 2, 1}};
+            gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
+            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, land_dev, zj, s);
         }
-        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: what the host was told against the fill kernel's own offsets
+        if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: what the host was told against the emit kernel's own offsets
             uint32_t total = 0;
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(&total, g.counters, sizeof(total), hipMemcpyDeviceToHost));
-            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_FILL);
+            if (total != (uint32_t)R) return GS2M_ERR_STAGE(ST_EMIT);
         }
-        // the longest tile list selects the sort kernel; the scan kernel published it before the fill kernel could start
         {
-            const auto t0 = std::chrono::steady_clock::now();
-            uint32_t spins = 0;
-            while (land[GS2M_LAND_MAXTILE] == 0u) {
-                __builtin_ia32_pause();
-                if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-            }
-            if (land[GS2M_LAND_MAXTILE] == 0u) HIP_TRY(hipStreamSynchronize(s));
-            max_tile = land[GS2M_LAND_MAXTILE] != 0u ? land[GS2M_LAND_MAXTILE] - 1u : 0xFFFFFFFFu;
+            StageTimer t(ST_TILE_SORT, s, &failed_stage);
+            // stable sort of (tile id, emission slot) on the tile bits: every tile's span comes out in index order; the last pass
+            // also records every tile's range (identifyTileRanges, rasterizer_impl.cu:108-129)
+            HIP_TRY(gs2m_radix_sort_pairs(b.temp, b.temp_bytes, b.keys_unsorted, nullptr, b.sort_keyA, b.sort_valA, b.tile_keys, b.slot_sorted,
+                                          (size_t)R, tile_bits, true, s, SideSum{nullptr, nullptr, nullptr}, im.ranges_raw, g.tile_hist));
         }
     } else {
+        HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
+        HIP_TRY(gs2m_zero_async(im.bigq, sizeof(uint32_t), s));
         land[GS2M_LAND_ROWS] = 1u;  // no instance, no row
     }
     DEBUG_CHECK();
     {
-        StageTimer t(ST_TILE_SORT, s, &failed_stage);  // per-tile (depth, id) order + the quadrant lists (empty tiles get their zero counts)
-        gs2m_launch_tile_sort(tiles, max_tile, b, im, g, s);
+        StageTimer t(ST_LISTS, s, &failed_stage);  // per-tile (depth, id) order, ranges, the quadrant lists
+        gs2m_launch_tile_sort(tiles, b, im, g, s);
     }
     {
         StageTimer t(ST_BLEND_FWD, s, &failed_stage);
@@ -323,7 +328,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Rn = R > 0 ? (size_t)R : 1;
     GeomState g = gs2m_carve_geom(geom_buffer, (size_t)P);
-    BinningState b = gs2m_carve_binning(binning_buffer, Rn);
+    BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
     // one partial-gradient row per (instance, quadrant), numbered densely over the view (binning.hip): `dense_rows` of them when
@@ -479,7 +484,7 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out) {
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Pn = P > 0 ? (size_t)P : 1, Rn = R > 0 ? (size_t)R : 1;
     GeomState g = gs2m_carve_geom(nullptr, Pn);
-    BinningState b = gs2m_carve_binning(nullptr, Rn);
+    BinningState b = gs2m_carve_binning(nullptr, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
     ImageState im = gs2m_carve_image(nullptr, N, tiles);
     out->geom_bytes = g.total_bytes;
     out->rec = (uint64_t)(uintptr_t)g.rec;
@@ -528,21 +533,26 @@ int gs2m_raster_backward_rows_hint(long long dense_rows) {
     return GS2M_OK;
 }
 
-// Test hook: tile_sort.hip on caller-made spans (no rasterization): ranges (tiles x uint2), unsorted depth / value / row arrays of
-// n entries and a per-wave row base table -> sorted values, tile ids, the four quadrant lists and their rows and counts.
-int gs2m_debug_tile_sort(int tiles, unsigned max_tile, const unsigned* ranges, unsigned* u_depth, const unsigned* u_val, const unsigned* u_row,
-                         const unsigned* wave_rowbase, unsigned* point_list, unsigned* tile_keys, unsigned* qlist, unsigned* qrow,
-                         unsigned* qcount, void* stream_) {
-    if (tiles < 0 || !ranges || !u_depth || !u_val || !u_row || !wave_rowbase || !point_list || !tile_keys || !qlist || !qrow || !qcount) return GS2M_ERR_INVALID_ARG;
+// Test hook: tile_sort.hip on caller-made spans (no rasterization): per tile {~first, last + 1} as the tile sort records them, the
+// emission slots of every span in index order, {id | mask, relative row} per slot, the depth keys by id and a per-wave row base
+// table -> ranges, sorted values, the four quadrant lists and their rows and counts.
+int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_vr,
+                         const unsigned* depth_key, const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp, unsigned* qlist,
+                         unsigned* qrow, unsigned* qcount, unsigned* bigq, void* stream_) {
+    if (tiles < 0 || !ranges_raw || !ranges || !slot_sorted || !e_vr || !depth_key || !wave_rowbase || !point_list || !row_tmp || !qlist || !qrow || !qcount || !bigq) return GS2M_ERR_INVALID_ARG;
     BinningState b = {};
-    b.u_depth = u_depth; b.u_val = const_cast<uint32_t*>(u_val); b.u_row = const_cast<uint32_t*>(u_row);
-    b.point_list = point_list; b.tile_keys = tile_keys; b.qlist = reinterpret_cast<uint2*>(qlist); b.qrow = qrow;
+    b.slot_sorted = const_cast<uint32_t*>(slot_sorted); b.e_vr = reinterpret_cast<uint2*>(const_cast<unsigned*>(e_vr));
+    b.point_list = point_list; b.sort_valA = row_tmp; b.qlist = reinterpret_cast<uint2*>(qlist); b.qrow = qrow;
     ImageState im = {};
-    im.ranges = reinterpret_cast<uint2*>(const_cast<unsigned*>(ranges));
+    im.ranges_raw = const_cast<uint32_t*>(ranges_raw);
+    im.ranges = reinterpret_cast<uint2*>(ranges);
     im.qcount = qcount;
+    im.bigq = bigq;
     GeomState g = {};
     g.wave_rowbase = const_cast<uint32_t*>(wave_rowbase);
-    gs2m_launch_tile_sort((size_t)tiles, max_tile, b, im, g, (hipStream_t)stream_);
+    g.depth_key = const_cast<uint32_t*>(depth_key);
+    HIP_TRY(gs2m_zero_async(bigq, sizeof(uint32_t), (hipStream_t)stream_));
+    gs2m_launch_tile_sort((size_t)tiles, b, im, g, (hipStream_t)stream_);
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
 }

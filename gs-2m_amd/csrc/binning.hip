@@ -1,25 +1,22 @@
-// Tile binning for gfx950 (round 5: no global sort).
+// Tile binning for gfx950 (round 5: no sort of the Gaussians; index-order emission).
 //
 // The reference (cuda_rasterizer/rasterizer_impl.cu:63-103, 265-305) scans tiles_touched, expands every visible Gaussian into
 // (tile << 32 | depth) u64 keys and runs one 45-bit radix sort over all R instances, then finds the tile ranges in the sorted
-// keys.  Rounds 1-4 here sorted the P Gaussians by depth (4 radix passes), emitted instances in depth order and sorted them
-// stably by tile (2 passes): six dependent sort launches whose cost is look-back latency, not bytes.  Now the instances are
-// BUCKETED by tile -- a counting sort whose counts, offsets and placement are three small kernels -- and each tile's span is
-// ordered by (depth, Gaussian id) ON CHIP (tile_sort.hip):
-//   count_kernel  per Gaussian (index order): one integer atomic per tile of its rectangle into tile_count[]; its first
-//                 workgroup publishes num_rendered (the sum of the per-block counts the preprocess kernel left) to the host,
-//                 which sizes the binning buffer while this kernel and the next run;
-//   scan_kernel   two workgroups: tile_count -> ranges[] / cursor[] (identifyTileRanges, rasterizer_impl.cu:108-129, before
-//                 anything is placed) and the longest list (selects the sort kernel); block_tt -> block_pref (the reference's
-//                 InclusiveSum, at block granularity);
-//   fill_kernel   load-balanced expansion as before (a wave owns 64 Gaussians and places 64 instances per step; Gaussians over
-//                 hundreds of tiles are expanded by the whole workgroup): exact ellipse-vs-8x8 test per instance -> 4-bit
-//                 quadrant mask; slot = atomic bump of the tile's cursor; {depth, id | mask, first gradient row} stored there;
-//                 gradient rows numbered densely per wave in index order;
+// keys.  Rounds 1-4 here sorted the P Gaussians by depth first (a histogram kernel + 4 radix passes whose cost is look-back
+// latency), emitted instances in depth order and sorted them stably by tile.  Round 5 drops the depth sort:
+//   blockscan_kernel  one workgroup: num_rendered = the sum of the per-block instance counts the preprocess kernel left,
+//                 published to the host at once; their exclusive prefix (the reference's InclusiveSum at block granularity);
+//   emit_kernel   load-balanced expansion in INDEX order (a wave owns 64 consecutive Gaussians and writes 64 consecutive
+//                 slots per step; Gaussians over hundreds of tiles are expanded by the whole workgroup): tile id per slot,
+//                 exact ellipse-vs-8x8 test per instance -> 4-bit quadrant mask above the id, gradient rows numbered densely per
+//                 wave; counts the tile sort's digits;
 //   rowscan_kernel  exclusive prefix of the waves' row counts: rows are dense over the whole view (the backward's scratch is
-//                 sized by their number, published to the host).
-// The order inside a tile's span is the arrival order of the atomics -- arbitrary -- and irrelevant: the span is sorted by
-// (depth, id) afterwards, which is exactly the reference's order within a tile (ties in id order).
+//                 sized by their number, published to the host);
+//   the stable 13-bit radix sort of (tile, slot) pairs (radix_sort.hip, two passes; its last pass records the tile ranges:
+//                 identifyTileRanges, rasterizer_impl.cu:108-129) leaves every tile's span in index order;
+//   tile_sort.hip orders each span by (depth, id) ON CHIP -- ties fall back on the span's own order, i.e. the Gaussian id:
+//                 exactly the reference's order within a tile -- and splits it into the quadrant lists.
+// A counting sort by tile with global atomics (count -> scan -> fill) was built first and measured: profiles/r05_frontend_ab.md.
 #include "common.h"
 
 GeomState gs2m_carve_geom(char* base, size_t P) {
@@ -43,11 +40,12 @@ GeomState gs2m_carve_geom(char* base, size_t P) {
     g.block_pref = (uint32_t*)take(nb * 4);
     g.wave_rows = (uint32_t*)take(nw * 4);
     g.wave_rowbase = (uint32_t*)take(nw * 4);
+    g.tile_hist = (uint32_t*)take(GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS * 4);
     g.total_bytes = off + GS2M_ALIGN;
     return g;
 }
 
-BinningState gs2m_carve_binning(char* base, size_t R) {
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
     BinningState b;
     size_t off = base ? (gs2m_align_up((size_t)(uintptr_t)base) - (size_t)(uintptr_t)base) : 0;
     auto take = [&](size_t bytes) {
@@ -55,16 +53,22 @@ BinningState gs2m_carve_binning(char* base, size_t R) {
         off = gs2m_align_up(off + bytes);
         return p;
     };
-    b.u_depth = (uint32_t*)take(R * 4);
-    b.u_val = (uint32_t*)take(R * 4);
-    b.u_row = (uint32_t*)take(R * 4);
-    b.point_list = (uint32_t*)take(R * 4);
+    b.keys_unsorted = (uint32_t*)take(R * 4);
+    b.e_vr = (uint2*)take(R * sizeof(uint2));
+    b.sort_keyA = (uint32_t*)take(R * 4);
+    b.sort_valA = (uint32_t*)take(R * 4);
     b.tile_keys = (uint32_t*)take(R * 4);
+    b.slot_sorted = (uint32_t*)take(R * 4);
+    b.point_list = (uint32_t*)take(R * 4);
     b.qlist = (uint2*)take(R * 4 * sizeof(uint2));
     b.qrow = (uint32_t*)take(R * 4 * 4);
+    b.temp = take(temp_bytes);
+    b.temp_bytes = temp_bytes;
     b.total_bytes = off + GS2M_ALIGN;
     return b;
 }
+
+size_t gs2m_binning_temp_bytes(size_t R, int tile_bits) { return gs2m_align_up(gs2m_radix_temp_bytes(R, tile_bits)) + GS2M_ALIGN; }
 
 ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     ImageState im;
@@ -77,8 +81,8 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     im.final_T = (float*)take(N * 4);
     im.n_contrib = (uint32_t*)take(N * 4);
     im.ranges = (uint2*)take(tiles * sizeof(uint2));
-    im.tile_count = (uint32_t*)take(tiles * 4);
-    im.cursor = (uint32_t*)take(tiles * 4);
+    im.ranges_raw = (uint32_t*)take(tiles * 2 * sizeof(uint32_t));
+    im.bigq = (uint32_t*)take((tiles + 1) * sizeof(uint32_t));
     im.qcount = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.qlast = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.total_bytes = off + GS2M_ALIGN;
@@ -106,50 +110,7 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     return t;
 }
 
-// ---- count: tile histogram --------------------------------------------------------------------------------------------
-// One thread per Gaussian in index order, one fire-and-forget integer atomic per tile of its rectangle (8 bytes of input per
-// Gaussian: the rectangle the preprocess kernel left in GeomState::rect).  Rectangles of GS2M_BIG_TILES tiles and more are
-// walked by the whole wave afterwards.  Workgroup 0 first adds up the per-block instance counts and publishes num_rendered:
-// the host sizes the binning buffer and queues the fill kernel while this kernel and the scan run.
-__global__ void __launch_bounds__(256) count_kernel(int P, int tiles_x, const uint2* __restrict__ rect,
-                                                    const uint32_t* __restrict__ block_tt, int nblocks,
-                                                    uint32_t* __restrict__ tile_count, uint32_t* landing) {
-    __shared__ unsigned long long s_part[16];
-    if (blockIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) t += block_tt[b];
-        t = block_sum_u64(t, s_part);
-        // saturated: a count beyond 2^32 cannot wrap past the caller's range check
-        if (threadIdx.x == 0) publish(landing, GS2M_LAND_R, t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t);
-    }
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    uint2 r = make_uint2(0u, 0u);
-    if (i < P) r = rect[i];
-    const uint32_t w = r.y & 0xFFFFu, h = r.y >> 16, cnt = w * h;
-    const bool big = cnt >= GS2M_BIG_TILES;
-    if (cnt != 0u && !big) {
-        uint32_t t = (r.x >> 16) * (uint32_t)tiles_x + (r.x & 0xFFFFu), tx = 0;
-        for (uint32_t k = 0; k < cnt; k++) {
-            __hip_atomic_fetch_add(&tile_count[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t++;
-            if (++tx == w) { tx = 0; t += (uint32_t)tiles_x - w; }
-        }
-    }
-    unsigned long long m = __builtin_amdgcn_ballot_w64(big);
-    while (m != 0ull) {  // a splat over hundreds of tiles: all 64 lanes on its rectangle
-        const int src = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t rx = __shfl(r.x, src, 64), ry = __shfl(r.y, src, 64);
-        const uint32_t bw = ry & 0xFFFFu, n = bw * (ry >> 16);
-        const uint32_t t0 = (rx >> 16) * (uint32_t)tiles_x + (rx & 0xFFFFu);
-        for (uint32_t k = lane; k < n; k += GS2M_WAVE) {
-            const uint32_t yy = k / bw, xx = k - yy * bw;
-            __hip_atomic_fetch_add(&tile_count[t0 + yy * (uint32_t)tiles_x + xx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// ---- scan: tile ranges and block prefixes ------------------------------------------------------------------------------
+// ---- prefix sums by one workgroup ---------------------------------------------------------------------------------------
 // Exclusive prefix sum of in[0, n) by ONE workgroup of 1024 threads: a thread owns a contiguous segment (a serial sum, a
 // workgroup-wide scan of the 1024 segment sums, a serial write-out).  The arrays are a few thousand words (8160 tiles at
 // 1080p, 3907 blocks at 1M Gaussians): latency, not bandwidth.  `emit(i, exclusive, value)` receives every element.
@@ -185,21 +146,18 @@ __device__ __forceinline__ unsigned long long scan_segments(const uint32_t* __re
     return total;
 }
 
-__global__ void __launch_bounds__(1024) scan_kernel(const uint32_t* __restrict__ tile_count, size_t tiles, uint2* __restrict__ ranges,
-                                                    uint32_t* __restrict__ cursor, const uint32_t* __restrict__ block_tt, size_t nblocks,
-                                                    uint32_t* __restrict__ block_pref, uint32_t* __restrict__ counters, uint32_t* landing) {
+// num_rendered and the block prefixes.  The total leaves for the host first (one read of the block sums), the prefix follows.
+__global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restrict__ block_tt, size_t nblocks, uint32_t* __restrict__ block_pref,
+                                                         uint32_t* __restrict__ counters, uint32_t* landing) {
     __shared__ uint32_t s_w[32];
-    if (blockIdx.x == 0) {
-        uint32_t gmax = 0;
-        scan_segments(tile_count, tiles, s_w, [&](size_t t, uint32_t excl, uint32_t v) {
-            ranges[t] = v != 0u ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // (0, 0) for an untouched tile, as the reference's memset leaves it
-            cursor[t] = excl;
-        }, &gmax);
-        if (threadIdx.x == 0) publish(landing, GS2M_LAND_MAXTILE, gmax + 1u);  // + 1: 0 means "not landed"
-    } else {
-        const unsigned long long total = scan_segments(block_tt, nblocks, s_w, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; }, nullptr);
-        if (threadIdx.x == 0) counters[1] = (uint32_t)total;
-    }
+    __shared__ unsigned long long s_part[16];
+    unsigned long long t = 0;
+    for (size_t b = threadIdx.x; b < nblocks; b += 1024) t += block_tt[b];
+    t = block_sum_u64(t, s_part);
+    // saturated: a count beyond 2^32 cannot wrap past the caller's range check
+    if (threadIdx.x == 0) publish(landing, GS2M_LAND_R, t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t);
+    scan_segments(block_tt, nblocks, s_w, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; }, nullptr);
+    if (threadIdx.x == 0) counters[1] = (uint32_t)t;
 }
 
 // exclusive prefix of the waves' gradient-row counts -> first row of every wave; the total goes to the host
@@ -213,31 +171,34 @@ __global__ void __launch_bounds__(1024) rowscan_kernel(const uint32_t* __restric
     }
 }
 
-// ---- fill: instances into their tiles' spans ---------------------------------------------------------------------------
-// Load-balanced expansion (replaces duplicateWithKeys, rasterizer_impl.cu:63-103).  One wave owns 64 consecutive Gaussians;
-// each step the wave places 64 instances, each lane locating its source Gaussian by binary search in the wave's prefix sums.
-// Every instance is tested against the four 8x8 quadrants of its tile with the exact ellipse-vs-rectangle test (common.h) --
-// here the Gaussian's geometry is loaded once per Gaussian -- and the 4-bit hit mask travels above the Gaussian id.  The
-// backward writes one gradient row per set bit; the rows of a wave's 64 Gaussians are numbered densely in emission order
-// (Gaussian by Gaussian, instance by instance, quadrant by quadrant), relative to the wave's first row, which rowscan_kernel
-// supplies afterwards (wave_rowbase) and tile_sort.hip adds: all rows of a Gaussian are one dense run and the per-Gaussian
-// backward streams them (gaussian_bwd.hip).
+// ---- emit: instances in index order ---------------------------------------------------------------------------------------
+// Load-balanced expansion (replaces duplicateWithKeys, rasterizer_impl.cu:63-103).  One wave owns 64 consecutive Gaussians
+// whose instances occupy one contiguous slot range (first slot of the workgroup = block_pref[] + a scan of its own 256 counts);
+// each step the wave writes 64 consecutive slots, each lane locating its source Gaussian by binary search in the wave's
+// prefix sums.  Every instance is tested against the four 8x8 quadrants of its tile with the exact ellipse-vs-rectangle test
+// (common.h) -- here the Gaussian's geometry is loaded once per Gaussian -- and the 4-bit hit mask travels above the Gaussian
+// id.  The backward writes one gradient row per set bit; the rows of a wave's 64 Gaussians are numbered densely in emission
+// order (Gaussian by Gaussian, instance by instance, quadrant by quadrant), relative to the wave's first row, which
+// rowscan_kernel supplies afterwards (wave_rowbase) and tile_sort.hip adds: all rows of a Gaussian are one dense run and the
+// per-Gaussian backward streams them (gaussian_bwd.hip).  The digits of the tile ids are counted here for the tile sort
+// (radix_sort.hip: ext_hist), and the kernel zeroes that sort's scratch and the tile ranges on the side.
 // BIG SPLATS.  Gaussians with at least GS2M_BIG_TILES tiles are left out of the wave's own loop and expanded afterwards by
-// ALL FOUR waves of the workgroup together (64-instance chunks dealt round the waves: a first pass counts the rows per chunk,
-// the chunk totals are scanned in LDS, a second pass repeats the tests and places the instances).  Their rows follow the
-// wave's small rows -- small Gaussians in lane order, then the big ones in lane order -- and gauss_rows carries
-// GS2M_ROWS_BIG for them, which the per-Gaussian backward reads the same way.
-__global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tiles_x, const uint2* __restrict__ rect,
-                                                   const uint32_t* __restrict__ depth_key, const uint32_t* __restrict__ block_pref,
-                                                   const float4* __restrict__ rec, uint32_t* __restrict__ cursor,
-                                                   uint32_t* __restrict__ u_depth, uint32_t* __restrict__ u_val, uint32_t* __restrict__ u_row,
+// ALL FOUR waves of the workgroup together (64-instance chunks dealt round the waves: tests, keys and values in a first pass,
+// chunk totals scanned in LDS, row numbers in a second pass that reads the masks back).  Their rows follow the wave's small
+// rows -- small Gaussians in lane order, then the big ones in lane order -- and gauss_rows carries GS2M_ROWS_BIG for them,
+// which the per-Gaussian backward reads the same way.
+__global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint2* __restrict__ rect,
+                                                   const uint32_t* __restrict__ block_pref, const float4* __restrict__ rec,
+                                                   uint32_t* __restrict__ keys_out, uint2* __restrict__ e_vr,
                                                    uint32_t* __restrict__ gauss_rows, uint32_t* __restrict__ wave_rows,
-                                                   uint32_t* __restrict__ counters) {
+                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_hist, int npass, int4 hbits,
+                                                   int4 hshift, ZeroJobs zero) {
+    __shared__ uint32_t s_th[4][256];  // digit counts of this workgroup's keys, for the tile sort
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
-    __shared__ uint32_t s_cnt[4][GS2M_WAVE];    // instances of the Gaussian
-    __shared__ uint32_t s_depth[4][GS2M_WAVE];
+    __shared__ uint32_t s_off[4][GS2M_WAVE];    // first emission slot of the Gaussian
+    __shared__ uint32_t s_cnt[4][GS2M_WAVE];    // its instances
     __shared__ float4 s_geo[4][GS2M_WAVE];      // x, y, A, B
     __shared__ float2 s_ct[4][GS2M_WAVE];       // C, t2
     __shared__ uint32_t s_rc[4][GS2M_WAVE];     // gradient rows per Gaussian
@@ -247,6 +208,18 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_round_total;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch, the tile ranges, the long-tile queue
+#pragma unroll
+    for (int p = 0; p < 4; p++) s_th[p][threadIdx.x] = 0u;
+    const int hb[4] = {hbits.x, hbits.y, hbits.z, hbits.w}, hs[4] = {hshift.x, hshift.y, hshift.z, hshift.w};
+    // this workgroup's counts into one of GS2M_HIST_COPIES copies of the global histogram (one add per non-empty bin)
+    auto flush_hist = [&]() {
+        uint32_t* dst = tile_hist + (blockIdx.x & (GS2M_HIST_COPIES - 1)) * GS2M_HIST_COPY_WORDS;
+        for (int p = 0; p < npass; p++) {
+            const uint32_t c = s_th[p][threadIdx.x];
+            if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
+        }
+    };
     uint32_t cnt = 0, rmin = 0, rw = 1;
     if (i < P) {
         const uint2 r = rect[i];
@@ -261,7 +234,6 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
         const float4* r = rec + (size_t)i * REC_Q;
         s_geo[wave][lane] = r[REC_GEO0];
         s_ct[wave][lane] = make_float2(r[REC_GEO1].x, r[REC_BIN].w);
-        s_depth[wave][lane] = depth_key[i];
     }
     const bool big = cnt >= GS2M_BIG_TILES && cnt < (1u << 29);  // (4 rows per instance at most: the row count must stay below the GS2M_ROWS_BIG bit)
     const uint32_t lcnt = big ? 0u : cnt;  // instances the wave expands itself
@@ -275,11 +247,18 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
     const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
     if (lane == 0) s_bigmask[wave] = bigmask;
     gs2m_sync();
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)  // num_rendered as the offsets add up (debug mode compares it with what the host was told)
-        counters[0] = block_pref[blockIdx.x] + s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    // ---- emission offsets: the exclusive prefix sum of tiles_touched in index order (the reference's InclusiveSum,
+    // rasterizer_impl.cu:265-266) = the block's prefix + the waves in front + the lanes in front
+    uint32_t off = block_pref[blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (w < wave) off += s_wtot[w];
+    off += incl_all - cnt;
+    s_off[wave][lane] = off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) counters[0] = off + cnt;  // num_rendered (debug mode compares it with what the host was told)
     const uint32_t gid0 = (uint32_t)blockIdx.x * 256u;
-    // tile and quadrant-hit mask of instance t of the Gaussian parked at [w][lo]
-    auto expand = [&](int w, int lo, uint32_t t, uint32_t& tile) -> uint32_t {
+    // tile and quadrant-hit mask of instance t of the Gaussian parked at [w][lo]; writes its key at `slot` and counts its digits
+    auto expand = [&](int w, int lo, uint32_t t, uint32_t slot) -> uint32_t {
         const uint32_t rwid = s_rw[w][lo];
         const uint32_t ry = t / rwid, rx = t - ry * rwid;
         const uint32_t rm = s_rmin[w][lo];
@@ -291,31 +270,30 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
         // quadrants outside the image have no pixels: no list entry, no gradient row
         if (px0 + 8 >= W) mask &= 0x5u;
         if (py0 + 8 >= H) mask &= 0x3u;
-        tile = ty * (uint32_t)tiles_x + tx;
+        const uint32_t key = ty * (uint32_t)tiles_x + tx;
+        keys_out[slot] = key;
+        for (int p = 0; p < npass; p++) atomicAdd(&s_th[p][(key >> hs[p]) & ((1u << hb[p]) - 1u)], 1u);
         return mask;
     };
-    // the instance takes the next free slot of its tile's span
-    auto place = [&](int w, int lo, uint32_t tile, uint32_t mask, uint32_t row) {
-        const uint32_t slot = __hip_atomic_fetch_add(&cursor[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u_depth[slot] = s_depth[w][lo];
-        u_val[slot] = (gid0 + (uint32_t)(w * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS);
-        u_row[slot] = row;
-    };
+    gs2m_sync();  // s_off of the other waves' Gaussians (the big path reads them)
     uint32_t rows_run = 0;  // gradient rows of the wave's own (small) instances so far
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
         const uint32_t j = k + lane;
-        uint32_t pc = 0, tile = 0, mask = 0;
+        uint32_t pc = 0, slot = 0, mask = 0;
         int lo = 0;
         if (j < total) {
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
                 if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always (a big Gaussian has an empty range: never found)
-            mask = expand(wave, lo, j - s_pref[wave][lo], tile);
+            const uint32_t t = j - s_pref[wave][lo];
+            slot = s_off[wave][lo] + t;
+            mask = expand(wave, lo, t, slot);
             pc = (uint32_t)__popc(mask);
             if (pc) atomicAdd(&s_rc[wave][lo], pc);
         }
         const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
-        if (j < total) place(wave, lo, tile, mask, rows_run + pin - pc);  // the instance's first gradient row, relative to the wave's first
+        // value = id | mask, and the instance's first gradient row relative to the wave's first row
+        if (j < total) e_vr[slot] = make_uint2((gid0 + (uint32_t)(wave * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), rows_run + pin - pc);
         rows_run += __shfl(pin, 63, 64);
     }
     if (i < P && !big) gauss_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
@@ -323,6 +301,7 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
     const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
     if (gs2m_sync_or(bigmask != 0ull) == 0) {  // no big Gaussian in this workgroup (the common case)
         if (lane == 0 && (size_t)wave_id * GS2M_WAVE < (size_t)P) wave_rows[wave_id] = rows_run;
+        flush_hist();
         return;
     }
     // ---- the workgroup's big Gaussians, one after the other, all four waves on each ----
@@ -332,16 +311,20 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
         while (m != 0ull) {
             const int lo = __builtin_ctzll(m);
             m &= m - 1ull;
-            const uint32_t bcnt = s_cnt[w][lo];
+            const uint32_t bcnt = s_cnt[w][lo], boff = s_off[w][lo];
             const uint32_t first_row = s_smallrows[w] + bigrows;
             const uint32_t chunks = (bcnt + GS2M_WAVE - 1) / GS2M_WAVE;
             uint32_t done_rows = 0;  // rows of the rounds before this one
             for (uint32_t c0 = 0; c0 < chunks; c0 += 1024) {  // rounds of at most 1024 chunks (s_ctot)
                 const uint32_t c1 = min(chunks, c0 + 1024u);
-                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // first pass: rows per chunk
+                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // first pass: tests, keys and values, rows per chunk
                     const uint32_t t = c * GS2M_WAVE + lane;
-                    uint32_t tile;
-                    uint32_t pc = t < bcnt ? (uint32_t)__popc(expand(w, lo, t, tile)) : 0u;
+                    uint32_t pc = 0;
+                    if (t < bcnt) {
+                        const uint32_t mask = expand(w, lo, t, boff + t);
+                        e_vr[boff + t] = make_uint2((gid0 + (uint32_t)(w * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), 0u);
+                        pc = (uint32_t)__popc(mask);
+                    }
                     pc = wave_inclusive_scan_u32(pc, lane);
                     if (lane == 63) s_ctot[c - c0] = pc;
                 }
@@ -365,13 +348,11 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
                     if (lane == 63) s_round_total = inc;
                 }
                 gs2m_sync();
-                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // second pass: the tests again, placement with the row numbers
+                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // second pass: first rows (the masks are read back: this thread wrote them)
                     const uint32_t t = c * GS2M_WAVE + lane;
-                    uint32_t tile = 0, mask = 0;
-                    if (t < bcnt) mask = expand(w, lo, t, tile);
-                    const uint32_t pc = (uint32_t)__popc(mask);
+                    const uint32_t pc = t < bcnt ? (uint32_t)__popc(e_vr[boff + t].x >> GS2M_GID_BITS) : 0u;
                     const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
-                    if (t < bcnt) place(w, lo, tile, mask, first_row + done_rows + s_ctot[c - c0] + pin - pc);
+                    if (t < bcnt) reinterpret_cast<uint32_t*>(e_vr + boff + t)[1] = first_row + done_rows + s_ctot[c - c0] + pin - pc;
                 }
                 done_rows += s_round_total;
                 gs2m_sync();  // s_ctot is rewritten by the next round / the next Gaussian
@@ -381,22 +362,22 @@ __global__ void __launch_bounds__(256) fill_kernel(int P, int W, int H, int tile
         }
         if (threadIdx.x == 0 && ((size_t)blockIdx.x * 4 + w) * GS2M_WAVE < (size_t)P) wave_rows[(size_t)blockIdx.x * 4 + w] = s_smallrows[w] + bigrows;
     }
+    flush_hist();  // (a barrier closes the last round above: every count is in)
 }
 
 }  // namespace
 
-void gs2m_launch_count(int P, int tiles_x, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s) {
-    count_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, tiles_x, g.rect, g.block_tt, (P + 255) / 256, im.tile_count, landing);
+void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s) {
+    blockscan_kernel<<<1, 1024, 0, s>>>(g.block_tt, (size_t)(P + 255) / 256, g.block_pref, g.counters, landing);
 }
 
-void gs2m_launch_scan(int P, size_t tiles, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s) {
-    scan_kernel<<<2, 1024, 0, s>>>(im.tile_count, tiles, im.ranges, im.cursor, g.block_tt, (size_t)(P + 255) / 256, g.block_pref, g.counters, landing);
-}
-
-void gs2m_launch_fill(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ImageState& im, uint32_t* landing,
-                      hipStream_t s) {
-    fill_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.depth_key, g.block_pref, g.rec, im.cursor, b.u_depth, b.u_val, b.u_row,
-                                                g.gauss_rows, g.wave_rows, g.counters);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t* landing,
+                      const ZeroJobs& zero, hipStream_t s) {
+    int npass = 0, bits[4], shift[4];
+    gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.rec, b.keys_unsorted, b.e_vr, g.gauss_rows, g.wave_rows,
+                                                g.counters, g.tile_hist, npass, make_int4(bits[0], bits[1], bits[2], bits[3]),
+                                                make_int4(shift[0], shift[1], shift[2], shift[3]), zero);
     rowscan_kernel<<<1, 1024, 0, s>>>(g.wave_rows, (size_t)(P + 63) / 64, g.wave_rowbase, g.counters, landing);
 }
 

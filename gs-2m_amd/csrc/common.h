@@ -56,26 +56,30 @@ struct GeomState {
     uint32_t* block_pref;    // ceil(P / 256): exclusive prefix of block_tt (scan kernel): first emission offset of a block
     uint32_t* wave_rows;     // ceil(P / 64): gradient rows of each wave of 64 consecutive Gaussians (fill_kernel)
     uint32_t* wave_rowbase;  // ceil(P / 64): exclusive prefix of wave_rows (rowscan_kernel): first gradient row of the wave
+    uint32_t* tile_hist;     // GS2M_HIST_COPIES x 1024: the tile sort's digit histograms, counted by emit_kernel (zeroed by the preprocess kernel)
     size_t total_bytes;      // including alignment slack
 };
 struct BinningState {
-    uint32_t* u_depth;       // R: depth key of the instance binned at this slot (slots of a tile are contiguous: ranges[tile]; order
-                             //    inside a tile's span = arrival order of fill_kernel's atomics, i.e. arbitrary)
-    uint32_t* u_val;         // R: Gaussian id | quadrant-hit mask << 28
-    uint32_t* u_row;         // R: first gradient row of the instance
-    uint32_t* point_list;    // R: u_val sorted by (tile, depth, id) -- the reference's point_list (+ mask bits)
-    uint32_t* tile_keys;     // R: tile id of each sorted instance
+    uint32_t* keys_unsorted; // R: tile id of the instance at each emission slot (index order)
+    uint2* e_vr;             // R: per emission slot {Gaussian id | quadrant-hit mask << 28, first gradient row relative to the emit wave's}
+    uint32_t* sort_keyA;     // R (radix sort ping buffer)
+    uint32_t* sort_valA;     // R
+    uint32_t* tile_keys;     // R: sorted tile ids
+    uint32_t* slot_sorted;   // R: emission slots in (tile, index) order -- the stable tile sort's values
+    uint32_t* point_list;    // R: Gaussian id | mask << 28 sorted by (tile, depth, id) -- the reference's point_list (+ mask bits)
     uint2* qlist;            // 4R: per (tile, 8x8 quadrant) compacted lists {Gaussian id | mask << 28, position in the tile list};
                              //     the list of (tile, q) starts at 4 * ranges[tile].x + q * (tile list length)
     uint32_t* qrow;          // 4R: gradient row of each list entry (parallel to qlist)
+    char* temp;              // radix sort scratch
+    size_t temp_bytes;
     size_t total_bytes;
 };
 struct ImageState {
     float* final_T;      // N
     uint32_t* n_contrib; // N
-    uint2* ranges;       // tiles: [first, last + 1) slot of the tile (scan kernel)
-    uint32_t* tile_count; // tiles: instances per tile (count kernel; zeroed by the preprocess kernel)
-    uint32_t* cursor;    // tiles: next free slot of the tile while fill_kernel runs
+    uint2* ranges;       // tiles (written by the tile-sort kernel from ranges_raw)
+    uint32_t* ranges_raw; // tiles * 2: per tile {~first position, last position + 1} as atomicMax targets of the tile sort's last pass; 0, 0 = untouched
+    uint32_t* bigq;      // 1 + tiles: [0] = number of tiles with more than 1024 instances, then their ids (tile_sort.hip)
     uint32_t* qcount;    // tiles * 4: entries in each quadrant list
     uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;
@@ -222,7 +226,8 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
 
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
 GeomState gs2m_carve_geom(char* base, size_t P);
-BinningState gs2m_carve_binning(char* base, size_t R);
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
+size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
 ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 
 // hand-written onesweep radix sort (radix_sort.hip).  Rounds 1-4 sorted the Gaussians by depth and the instances by tile with
@@ -249,7 +254,7 @@ void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]);
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 
 // words the host reads back through a mapped pinned block (api.hip): [0] num_rendered, [1] prefiltered violation flag,
-// [2] longest tile list + 1 (0 = not landed yet), [3] dense gradient rows + 1 (0 = not landed yet)
+// [2] unused, [3] dense gradient rows + 1 (0 = not landed yet)
 #define GS2M_LAND_R 0
 #define GS2M_LAND_PREFILTERED 1
 #define GS2M_LAND_MAXTILE 2
@@ -262,15 +267,14 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                             float tan_fovx, float tan_fovy, float focal_x, float focal_y, int tiles_x, int tiles_y,
                             int* radii, int* observe_zero, const GeomState& g, int shrink, const ZeroJobs& zero, hipStream_t s);
-// binning.hip: count (tile histogram; publishes num_rendered), scan (tile ranges, block prefixes; publishes the longest list),
-// fill (instances into their tiles' spans, quadrant masks, gradient-row numbering)
-void gs2m_launch_count(int P, int tiles_x, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s);
-void gs2m_launch_scan(int P, size_t tiles, const GeomState& g, const ImageState& im, uint32_t* landing, hipStream_t s);
-void gs2m_launch_fill(int P, int W, int H, int tiles_x, const GeomState& g, const BinningState& b, const ImageState& im, uint32_t* landing,
-                      hipStream_t s);
-// tile_sort.hip: every tile's span sorted by (depth, id) on chip, then split into the four quadrant lists.  max_tile = the longest
-// tile list (selects the kernel: one wave per tile with the span in registers up to 1024 entries, a workgroup per tile beyond)
-void gs2m_launch_tile_sort(size_t tiles, uint32_t max_tile, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
+// binning.hip: blockscan (publishes num_rendered; block prefixes of tiles_touched), emit (instances in index order: tile keys,
+// quadrant masks, gradient-row numbering, the tile sort's digit counts) + rowscan (first gradient row of every wave)
+void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t* landing,
+                      const ZeroJobs& zero, hipStream_t s);
+// tile_sort.hip: every tile's span (stable radix sort by tile: index order) sorted by (depth, id) on chip, then split into the four
+// quadrant lists; writes ranges[] from ranges_raw
+void gs2m_launch_tile_sort(size_t tiles, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

@@ -20,7 +20,7 @@ EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visi
            # include/gs2m_loss.h (round 3: the loss tail of the training iteration)
            "gs2m_affine_mean", "gs2m_densification_stats", "gs2m_edge_gradient", "gs2m_image_loss_backward", "gs2m_image_loss_forward", "gs2m_loss_workspace_bytes", "gs2m_mv_geo_loss_backward", "gs2m_mv_geo_loss_forward", "gs2m_pbr_inputs_backward", "gs2m_pbr_inputs_forward", "gs2m_plane_loss_backward", "gs2m_plane_loss_forward", "gs2m_ssim_backward_uniform", "gs2m_tv_loss_backward", "gs2m_tv_loss_forward")
 
-STAGES = ("preprocess", "count", "scan", "fill", "tile_sort", "unused5", "blend_fwd", "unused7", "blend_bwd",
+STAGES = ("preprocess", "unused1", "scan", "emit", "tile_sort", "lists", "blend_fwd", "unused7", "blend_bwd",
           "gaussian_bwd")
 
 _lib = None
@@ -83,7 +83,7 @@ def lib():
     L.gs2m_raster_backward_rows_hint.restype = i
     L.gs2m_raster_backward_rows_hint.argtypes = [C.c_longlong]
     L.gs2m_debug_tile_sort.restype = i
-    L.gs2m_debug_tile_sort.argtypes = [i, C.c_uint] + [p] * 11
+    L.gs2m_debug_tile_sort.argtypes = [i] + [p] * 13
     L.gs2m_set_debug.restype = i
     L.gs2m_set_debug.argtypes = [i]
     L.gs2m_set_markers.restype = i

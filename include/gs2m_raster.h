@@ -317,16 +317,17 @@ long long gs2m_raster_dense_rows(unsigned long long token);
 int gs2m_raster_backward_rows_hint(long long dense_rows);
 
 /* Test hook (tests/test_tile_sort_gpu.py): the per-tile (depth, id) sort + quadrant-list split on caller-made spans. */
-int gs2m_debug_tile_sort(int tiles, unsigned max_tile, const unsigned* ranges, unsigned* u_depth, const unsigned* u_val,
-                         const unsigned* u_row, const unsigned* wave_rowbase, unsigned* point_list, unsigned* tile_keys,
-                         unsigned* qlist, unsigned* qrow, unsigned* qcount, void* stream);
+int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_vr,
+                         const unsigned* depth_key, const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp,
+                         unsigned* qlist, unsigned* qrow, unsigned* qcount, unsigned* bigq, void* stream);
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage, 3 = the backward blend kernel only.  Setting the mode clears
  * the records.  gs2m_profile_collect waits for the recorded events and returns, per
  * stage, the summed milliseconds and the number of launches since the last collect.
- * Stage order: preprocess, count, scan, fill (+ row scan), tile_sort (+ quadrant lists), -, blend_fwd, -,
- * blend_bwd, gaussian_bwd (row sums + per-Gaussian chain). */
+ * Stage order: preprocess, -, scan (num_rendered + block prefixes), emit (+ row scan), tile_sort (stable radix sort by tile),
+ * depth_order+quad_lists (per-tile sort on chip, ranges, quadrant lists), blend_fwd, -, blend_bwd, gaussian_bwd (row sums +
+ * per-Gaussian chain). */
 #define GS2M_NUM_STAGES 10
 int gs2m_profile_mode(int mode);
 /* mode 3 brackets every `every`-th launch of the backward blend (default 1: each one).  An event pair leaves ~6 us of bubble on

@@ -117,7 +117,7 @@ def test_tile_list_invariants(big, reference_binning):
     masks = plm >> 28
     assert total_rows == int(sum(((masks >> q) & 1).sum() for q in range(4)))
     rng = np.random.default_rng(3)
-    for t in rng.choice(np.nonzero(t)[0], 40, replace=False):
+    for t in rng.choice(np.nonzero(t)[0], 40, replace=False):  # (`t` was the touched-tiles mask)
         lo, hi = int(rg[t, 0]), int(rg[t, 1])
         n = hi - lo
         for q in range(4):

@@ -2,8 +2,6 @@
 order -- the order the reference's 45-bit radix sort of id-ordered keys produces inside a tile (rasterizer_impl.cu:288-296) --
 and the four quadrant lists / gradient rows must be the order-preserving split of it.  Spans of every length class (one wave
 with 8 or 16 elements per lane, a workgroup over LDS, a workgroup over global memory), with many exactly equal depths."""
-import ctypes as C
-
 import numpy as np
 import pytest
 import torch
@@ -12,49 +10,57 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(lengths, max_tile, seed, tie_levels):
+    """spans as the stable tile sort leaves them: per tile the emission slots of its instances in Gaussian-index order"""
     import gs2m_native
     rng = np.random.default_rng(seed)
     tiles = len(lengths)
     starts = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint32)
     n = int(starts[-1])
-    ranges = np.stack([starts[:-1], starts[1:]], 1).astype(np.uint32)
-    ranges[np.asarray(lengths) == 0] = 0
+    raw = np.zeros((tiles, 2), np.uint32)
+    for t, L in enumerate(lengths):
+        if L:
+            raw[t] = (~np.uint32(starts[t]), starts[t + 1])
     P = 1 << 20
-    depth = np.empty(max(n, 1), np.uint32); val = np.empty(max(n, 1), np.uint32); row = np.empty(max(n, 1), np.uint32)
+    nn = max(n, 1)
+    depth_key = rng.integers(0x40000000, 0x41000000, P).astype(np.uint32)
+    if tie_levels:
+        depth_key = (np.float32(2.0) + rng.integers(0, tie_levels, P).astype(np.float32) * np.float32(0.001)).view(np.uint32)
+    val = np.zeros(nn, np.uint32); row = np.zeros(nn, np.uint32)
     for t, L in enumerate(lengths):
         if L == 0:
             continue
         lo = int(starts[t])
-        d = rng.integers(0, tie_levels, L) if tie_levels else rng.integers(0, 1 << 31, L)
-        depth[lo:lo + L] = (np.float32(2.0) + d.astype(np.float32) * np.float32(0.001)).view(np.uint32) if tie_levels else (d.astype(np.uint32) | np.uint32(0x40000000))
-        gid = rng.choice(P, L, replace=False).astype(np.uint32)          # a Gaussian appears once per tile
+        gid = np.sort(rng.choice(P, L, replace=False)).astype(np.uint32)   # a Gaussian appears once per tile; index order
         val[lo:lo + L] = gid | (rng.integers(0, 16, L).astype(np.uint32) << np.uint32(28))
         row[lo:lo + L] = rng.integers(0, 1 << 20, L)
+    slot = rng.permutation(nn).astype(np.uint32)          # the emission slots the sorted values point at
+    e_vr = np.zeros((nn, 2), np.uint32)
+    e_vr[slot, 0] = val; e_vr[slot, 1] = row
     wave_rowbase = rng.integers(0, 1 << 24, P // 64).astype(np.uint32)
     dev = "cuda"
-    T = lambda a: torch.from_numpy(a.astype(np.uint32).view(np.int32).copy()).to(dev)
-    t_ranges, t_depth, t_val, t_row, t_wrb = T(ranges.reshape(-1)), T(depth), T(val), T(row), T(wave_rowbase)
-    nn = max(n, 1)
-    o_pl, o_tk = torch.zeros(nn, dtype=torch.int32, device=dev), torch.zeros(nn, dtype=torch.int32, device=dev)
-    o_ql = torch.zeros(8 * nn, dtype=torch.int32, device=dev)
-    o_qr = torch.zeros(4 * nn, dtype=torch.int32, device=dev)
-    o_qc = torch.full((4 * tiles,), -1, dtype=torch.int32, device=dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.uint32).view(np.int32).reshape(-1).copy()).to(dev)
+    t_raw, t_slot, t_evr, t_dk, t_wrb = T(raw), T(slot), T(e_vr), T(depth_key), T(wave_rowbase)
+    Z = lambda k, fill=0: torch.full((k,), fill, dtype=torch.int32, device=dev)
+    o_rg, o_pl, o_tmp, o_ql, o_qr, o_qc, o_bq = Z(2 * tiles, -1), Z(nn), Z(nn), Z(8 * nn), Z(4 * nn), Z(4 * tiles, -1), Z(tiles + 1)
     L = gs2m_native.lib()
-    rc = L.gs2m_debug_tile_sort(tiles, int(max_tile), t_ranges.data_ptr(), t_depth.data_ptr(), t_val.data_ptr(), t_row.data_ptr(), t_wrb.data_ptr(),
-                                o_pl.data_ptr(), o_tk.data_ptr(), o_ql.data_ptr(), o_qr.data_ptr(), o_qc.data_ptr(), gs2m_native.stream_ptr())
+    rc = L.gs2m_debug_tile_sort(tiles, t_raw.data_ptr(), o_rg.data_ptr(), t_slot.data_ptr(), t_evr.data_ptr(), t_dk.data_ptr(), t_wrb.data_ptr(),
+                                o_pl.data_ptr(), o_tmp.data_ptr(), o_ql.data_ptr(), o_qr.data_ptr(), o_qc.data_ptr(), o_bq.data_ptr(),
+                                gs2m_native.stream_ptr())
     gs2m_native.check(rc, "gs2m_debug_tile_sort")
     torch.cuda.synchronize()
     U = lambda t: t.cpu().numpy().view(np.uint32)
-    pl, tk, ql, qr, qc = U(o_pl), U(o_tk), U(o_ql).reshape(-1, 2), U(o_qr), U(o_qc).reshape(tiles, 4)
+    rg, pl, ql, qr, qc = U(o_rg).reshape(tiles, 2), U(o_pl), U(o_ql).reshape(-1, 2), U(o_qr), U(o_qc).reshape(tiles, 4)
+    assert int(U(o_bq)[0]) == sum(1 for L_ in lengths if L_ > 1024)
     for t, Ln in enumerate(lengths):
         lo = int(starts[t])
         if Ln == 0:
-            assert np.all(qc[t] == 0), t
+            assert np.all(qc[t] == 0) and np.all(rg[t] == 0), t
             continue
-        d, v, r = depth[lo:lo + Ln], val[lo:lo + Ln], row[lo:lo + Ln]
+        assert rg[t, 0] == lo and rg[t, 1] == lo + Ln, t
+        v, r = val[lo:lo + Ln], row[lo:lo + Ln]
+        d = depth_key[v & np.uint32(0x0FFFFFFF)]
         order = np.lexsort((v & np.uint32(0x0FFFFFFF), d))   # by depth, ties by Gaussian id
         assert np.array_equal(pl[lo:lo + Ln], v[order]), f"tile {t} (length {Ln}): sorted values"
-        assert np.all(tk[lo:lo + Ln] == t)
         sv, sr = v[order], r[order] + wave_rowbase[(v[order] & np.uint32(0x0FFFFFFF)) >> 6]
         m = sv >> 28
         for q in range(4):
