@@ -264,7 +264,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     if (R > 0) {
         {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the long-tile queue's counter
             StageTimer t(ST_EMIT, s, &failed_stage);
-            ZeroJobs zj = {{nullptr, im.ranges_raw, im.bigq}, {0, tiles * 2, 1}};
+            ZeroJobs zj = {{nullptr, im.ranges_raw, im.bigq}, {0, tiles * 2, tiles + 2}};  // (the two queue heads: words 0 and tiles + 1)
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
             gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, land_dev, zj, s);
         }
@@ -283,13 +283,13 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
-        HIP_TRY(gs2m_zero_async(im.bigq, sizeof(uint32_t), s));
+        HIP_TRY(gs2m_zero_async(im.bigq, (tiles + 2) * sizeof(uint32_t), s));
         land[GS2M_LAND_ROWS] = 1u;  // no instance, no row
     }
     DEBUG_CHECK();
     {
         StageTimer t(ST_LISTS, s, &failed_stage);  // per-tile (depth, id) order, ranges, the quadrant lists
-        gs2m_launch_tile_sort(tiles, b, im, g, s);
+        gs2m_launch_tile_sort(tiles, tiles_x, tiles_y, b, im, g, s);
     }
     {
         StageTimer t(ST_BLEND_FWD, s, &failed_stage);
@@ -534,14 +534,14 @@ int gs2m_raster_backward_rows_hint(long long dense_rows) {
 }
 
 // Test hook: tile_sort.hip on caller-made spans (no rasterization): per tile {~first, last + 1} as the tile sort records them, the
-// emission slots of every span in index order, {id | mask, relative row} per slot, the depth keys by id and a per-wave row base
+// emission slots of every span in index order, {id | mask, relative row, depth key, -} per slot and a per-wave row base
 // table -> ranges, sorted values, the four quadrant lists and their rows and counts.
-int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_vr,
-                         const unsigned* depth_key, const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp, unsigned* qlist,
+int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_rec,
+                         const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp, unsigned* qlist,
                          unsigned* qrow, unsigned* qcount, unsigned* bigq, void* stream_) {
-    if (tiles < 0 || !ranges_raw || !ranges || !slot_sorted || !e_vr || !depth_key || !wave_rowbase || !point_list || !row_tmp || !qlist || !qrow || !qcount || !bigq) return GS2M_ERR_INVALID_ARG;
+    if (tiles < 0 || !ranges_raw || !ranges || !slot_sorted || !e_rec || !wave_rowbase || !point_list || !row_tmp || !qlist || !qrow || !qcount || !bigq) return GS2M_ERR_INVALID_ARG;
     BinningState b = {};
-    b.slot_sorted = const_cast<uint32_t*>(slot_sorted); b.e_vr = reinterpret_cast<uint2*>(const_cast<unsigned*>(e_vr));
+    b.slot_sorted = const_cast<uint32_t*>(slot_sorted); b.e_rec = reinterpret_cast<uint4*>(const_cast<unsigned*>(e_rec));
     b.point_list = point_list; b.sort_valA = row_tmp; b.qlist = reinterpret_cast<uint2*>(qlist); b.qrow = qrow;
     ImageState im = {};
     im.ranges_raw = const_cast<uint32_t*>(ranges_raw);
@@ -550,9 +550,8 @@ int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges
     im.bigq = bigq;
     GeomState g = {};
     g.wave_rowbase = const_cast<uint32_t*>(wave_rowbase);
-    g.depth_key = const_cast<uint32_t*>(depth_key);
-    HIP_TRY(gs2m_zero_async(bigq, sizeof(uint32_t), (hipStream_t)stream_));
-    gs2m_launch_tile_sort((size_t)tiles, b, im, g, (hipStream_t)stream_);
+    HIP_TRY(gs2m_zero_async(bigq, (size_t)(tiles + 2) * sizeof(uint32_t), (hipStream_t)stream_));
+    gs2m_launch_tile_sort((size_t)tiles, tiles, 1, b, im, g, (hipStream_t)stream_);  // (a one-row tile grid)
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
 }

@@ -54,7 +54,7 @@ BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
         return p;
     };
     b.keys_unsorted = (uint32_t*)take(R * 4);
-    b.e_vr = (uint2*)take(R * sizeof(uint2));
+    b.e_rec = (uint4*)take(R * sizeof(uint4));
     b.sort_keyA = (uint32_t*)take(R * 4);
     b.sort_valA = (uint32_t*)take(R * 4);
     b.tile_keys = (uint32_t*)take(R * 4);
@@ -82,7 +82,7 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     im.n_contrib = (uint32_t*)take(N * 4);
     im.ranges = (uint2*)take(tiles * sizeof(uint2));
     im.ranges_raw = (uint32_t*)take(tiles * 2 * sizeof(uint32_t));
-    im.bigq = (uint32_t*)take((tiles + 1) * sizeof(uint32_t));
+    im.bigq = (uint32_t*)take(2 * (tiles + 1) * sizeof(uint32_t));
     im.qcount = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.qlast = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.total_bytes = off + GS2M_ALIGN;
@@ -93,8 +93,9 @@ namespace {
 
 __device__ __forceinline__ void publish(uint32_t* landing, int word, uint32_t v) {
     // one aligned system-scope 32-bit store into the mapped pinned block the host polls (a 4-byte hipMemcpyAsync may be
-    // carried out byte by byte: torn counts were seen)
-    __hip_atomic_store(landing + word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // carried out byte by byte: torn counts were seen).  RELAXED: the host needs this word and nothing else of the kernel's
+    // output -- a release at system scope writes the whole L2 back first (10 us behind a kernel that left tens of MB dirty)
+    __hip_atomic_store(landing + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Sum over the workgroup (any size that is a multiple of 64, up to 1024 threads); valid in every thread.
@@ -111,61 +112,63 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 }
 
 // ---- prefix sums by one workgroup ---------------------------------------------------------------------------------------
-// Exclusive prefix sum of in[0, n) by ONE workgroup of 1024 threads: a thread owns a contiguous segment (a serial sum, a
-// workgroup-wide scan of the 1024 segment sums, a serial write-out).  The arrays are a few thousand words (8160 tiles at
-// 1080p, 3907 blocks at 1M Gaussians): latency, not bandwidth.  `emit(i, exclusive, value)` receives every element.
+// Exclusive prefix sums of a few thousand words (3907 block counts / 15625 wave row counts at 1M Gaussians) WITHOUT a chain between
+// workgroups and without a serial pass: workgroup b owns elements [1024 b, 1024 b + 1024) and adds up everything in front of them
+// itself (coalesced, all loads requested together: one memory round trip; the whole array is tens of KB, read from L2 by every
+// workgroup).  A single workgroup walking the array in rounds took 16 us for 15625 words: two dependent round trips behind a
+// kernel that has just left tens of MB dirty in the L2s.  Beyond 64 workgroups (65536 elements: 16 M Gaussians for the block
+// counts, 4 M for the wave rows) the part in front is read in rounds.
 template <typename F>
-__device__ __forceinline__ unsigned long long scan_segments(const uint32_t* __restrict__ in, size_t n, uint32_t* s_w /* [16] */, F emit,
-                                                            uint32_t* out_max) {
-    const size_t seg = (n + 1023) / 1024, lo = min(n, (size_t)threadIdx.x * seg), hi = min(n, lo + seg);
-    uint32_t sum = 0, mx = 0;
-    for (size_t i = lo; i < hi; i++) {
-        const uint32_t v = in[i];
-        sum += v;
-        mx = max(mx, v);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_scan_u32(sum, lane);
+__device__ __forceinline__ unsigned long long scan_1024_per_block(const uint32_t* __restrict__ in, size_t n, uint32_t* s_w /* [16] */,
+                                                                  unsigned long long* s_part /* [16] */, F emit) {
+    const size_t first = (size_t)blockIdx.x * 1024;
+    unsigned long long before = 0;
+    for (size_t base = 0; base < first; base += 16 * 1024) {  // the elements in front, 16 per thread and round
+        uint32_t v[16];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        for (int k = 0; k < 16; k++) {
+            const size_t i = base + (size_t)k * 1024 + threadIdx.x;
+            v[k] = i < first ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) before += v[k];
+    }
+    const size_t i = first + threadIdx.x;
+    const uint32_t mine = i < n ? in[i] : 0u;
+    before = block_sum_u64(before, s_part);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_scan_u32(mine, lane);
+    if (lane == 63) s_w[wave] = incl;
     gs2m_sync();
-    if (lane == 63) { s_w[wave] = incl; s_w[16 + wave] = mx; }
-    gs2m_sync();
-    uint32_t run = incl - sum, total = 0, gmax = 0;
+    uint32_t run = incl - mine, total = 0;
     for (int w = 0; w < 16; w++) {
         if (w < wave) run += s_w[w];
         total += s_w[w];
-        gmax = max(gmax, s_w[16 + w]);
     }
-    for (size_t i = lo; i < hi; i++) {
-        const uint32_t v = in[i];
-        emit(i, run, v);
-        run += v;
-    }
-    if (out_max) *out_max = gmax;
-    return total;
+    if (i < n) emit(i, (uint32_t)before + run, mine);
+    return before + total;  // everything up to the end of this workgroup's elements
 }
 
-// num_rendered and the block prefixes.  The total leaves for the host first (one read of the block sums), the prefix follows.
+// num_rendered and the block prefixes.  The workgroup that owns the last elements has the grand total: it tells the host.
 __global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restrict__ block_tt, size_t nblocks, uint32_t* __restrict__ block_pref,
                                                          uint32_t* __restrict__ counters, uint32_t* landing) {
-    __shared__ uint32_t s_w[32];
+    __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_part[16];
-    unsigned long long t = 0;
-    for (size_t b = threadIdx.x; b < nblocks; b += 1024) t += block_tt[b];
-    t = block_sum_u64(t, s_part);
-    // saturated: a count beyond 2^32 cannot wrap past the caller's range check
-    if (threadIdx.x == 0) publish(landing, GS2M_LAND_R, t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t);
-    scan_segments(block_tt, nblocks, s_w, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; }, nullptr);
-    if (threadIdx.x == 0) counters[1] = (uint32_t)t;
+    const unsigned long long t = scan_1024_per_block(block_tt, nblocks, s_w, s_part, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; });
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        // saturated: a count beyond 2^32 cannot wrap past the caller's range check
+        publish(landing, GS2M_LAND_R, t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t);
+        counters[1] = (uint32_t)t;
+    }
 }
 
 // exclusive prefix of the waves' gradient-row counts -> first row of every wave; the total goes to the host
 __global__ void __launch_bounds__(1024) rowscan_kernel(const uint32_t* __restrict__ wave_rows, size_t nwaves, uint32_t* __restrict__ wave_rowbase,
                                                        uint32_t* __restrict__ counters, uint32_t* landing) {
-    __shared__ uint32_t s_w[32];
-    const unsigned long long total = scan_segments(wave_rows, nwaves, s_w, [&](size_t w, uint32_t excl, uint32_t) { wave_rowbase[w] = excl; }, nullptr);
-    if (threadIdx.x == 0) {
+    __shared__ uint32_t s_w[16];
+    __shared__ unsigned long long s_part[16];
+    const unsigned long long total = scan_1024_per_block(wave_rows, nwaves, s_w, s_part, [&](size_t w, uint32_t excl, uint32_t) { wave_rowbase[w] = excl; });
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         counters[2] = (uint32_t)total;
         publish(landing, GS2M_LAND_ROWS, (uint32_t)total + 1u);
     }
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(1024) rowscan_kernel(const uint32_t* __restric
 // which the per-Gaussian backward reads the same way.
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint2* __restrict__ rect,
                                                    const uint32_t* __restrict__ block_pref, const float4* __restrict__ rec,
-                                                   uint32_t* __restrict__ keys_out, uint2* __restrict__ e_vr,
+                                                   const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ keys_out, uint4* __restrict__ e_rec,
                                                    uint32_t* __restrict__ gauss_rows, uint32_t* __restrict__ wave_rows,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_hist, int npass, int4 hbits,
                                                    int4 hshift, ZeroJobs zero) {
@@ -199,6 +202,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
     __shared__ uint32_t s_off[4][GS2M_WAVE];    // first emission slot of the Gaussian
     __shared__ uint32_t s_cnt[4][GS2M_WAVE];    // its instances
+    __shared__ uint32_t s_depth[4][GS2M_WAVE];  // its depth key
     __shared__ float4 s_geo[4][GS2M_WAVE];      // x, y, A, B
     __shared__ float2 s_ct[4][GS2M_WAVE];       // C, t2
     __shared__ uint32_t s_rc[4][GS2M_WAVE];     // gradient rows per Gaussian
@@ -234,6 +238,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         const float4* r = rec + (size_t)i * REC_Q;
         s_geo[wave][lane] = r[REC_GEO0];
         s_ct[wave][lane] = make_float2(r[REC_GEO1].x, r[REC_BIN].w);
+        s_depth[wave][lane] = depth_key[i];
     }
     const bool big = cnt >= GS2M_BIG_TILES && cnt < (1u << 29);  // (4 rows per instance at most: the row count must stay below the GS2M_ROWS_BIG bit)
     const uint32_t lcnt = big ? 0u : cnt;  // instances the wave expands itself
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         }
         const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
         // value = id | mask, and the instance's first gradient row relative to the wave's first row
-        if (j < total) e_vr[slot] = make_uint2((gid0 + (uint32_t)(wave * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), rows_run + pin - pc);
+        if (j < total) e_rec[slot] = make_uint4((gid0 + (uint32_t)(wave * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), rows_run + pin - pc, s_depth[wave][lo], 0u);
         rows_run += __shfl(pin, 63, 64);
     }
     if (i < P && !big) gauss_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
@@ -322,7 +327,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                     uint32_t pc = 0;
                     if (t < bcnt) {
                         const uint32_t mask = expand(w, lo, t, boff + t);
-                        e_vr[boff + t] = make_uint2((gid0 + (uint32_t)(w * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), 0u);
+                        e_rec[boff + t] = make_uint4((gid0 + (uint32_t)(w * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), 0u, s_depth[w][lo], 0u);
                         pc = (uint32_t)__popc(mask);
                     }
                     pc = wave_inclusive_scan_u32(pc, lane);
@@ -350,9 +355,9 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                 gs2m_sync();
                 for (uint32_t c = c0 + wave; c < c1; c += 4) {  // second pass: first rows (the masks are read back: this thread wrote them)
                     const uint32_t t = c * GS2M_WAVE + lane;
-                    const uint32_t pc = t < bcnt ? (uint32_t)__popc(e_vr[boff + t].x >> GS2M_GID_BITS) : 0u;
+                    const uint32_t pc = t < bcnt ? (uint32_t)__popc(e_rec[boff + t].x >> GS2M_GID_BITS) : 0u;
                     const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
-                    if (t < bcnt) reinterpret_cast<uint32_t*>(e_vr + boff + t)[1] = first_row + done_rows + s_ctot[c - c0] + pin - pc;
+                    if (t < bcnt) reinterpret_cast<uint32_t*>(e_rec + boff + t)[1] = first_row + done_rows + s_ctot[c - c0] + pin - pc;
                 }
                 done_rows += s_round_total;
                 gs2m_sync();  // s_ctot is rewritten by the next round / the next Gaussian
@@ -368,17 +373,19 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
 }  // namespace
 
 void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s) {
-    blockscan_kernel<<<1, 1024, 0, s>>>(g.block_tt, (size_t)(P + 255) / 256, g.block_pref, g.counters, landing);
+    const size_t nb = (size_t)(P + 255) / 256;
+    blockscan_kernel<<<(unsigned)((nb + 1023) / 1024 > 0 ? (nb + 1023) / 1024 : 1), 1024, 0, s>>>(g.block_tt, nb, g.block_pref, g.counters, landing);
 }
 
 void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t* landing,
                       const ZeroJobs& zero, hipStream_t s) {
     int npass = 0, bits[4], shift[4];
     gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
-    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.rec, b.keys_unsorted, b.e_vr, g.gauss_rows, g.wave_rows,
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.rec, g.depth_key, b.keys_unsorted, b.e_rec, g.gauss_rows, g.wave_rows,
                                                 g.counters, g.tile_hist, npass, make_int4(bits[0], bits[1], bits[2], bits[3]),
                                                 make_int4(shift[0], shift[1], shift[2], shift[3]), zero);
-    rowscan_kernel<<<1, 1024, 0, s>>>(g.wave_rows, (size_t)(P + 63) / 64, g.wave_rowbase, g.counters, landing);
+    const size_t nw = (size_t)(P + 63) / 64;
+    rowscan_kernel<<<(unsigned)((nw + 1023) / 1024 > 0 ? (nw + 1023) / 1024 : 1), 1024, 0, s>>>(g.wave_rows, nw, g.wave_rowbase, g.counters, landing);
 }
 
 // Zero fill as an ordinary kernel.  hipMemsetAsync goes through the runtime's blit path, which on this stack

@@ -61,7 +61,8 @@ struct GeomState {
 };
 struct BinningState {
     uint32_t* keys_unsorted; // R: tile id of the instance at each emission slot (index order)
-    uint2* e_vr;             // R: per emission slot {Gaussian id | quadrant-hit mask << 28, first gradient row relative to the emit wave's}
+    uint4* e_rec;            // R: per emission slot {Gaussian id | quadrant-hit mask << 28, first gradient row relative to the emit wave's,
+                             //    depth key, 0}: ONE 16-byte gather per instance in the per-tile sort
     uint32_t* sort_keyA;     // R (radix sort ping buffer)
     uint32_t* sort_valA;     // R
     uint32_t* tile_keys;     // R: sorted tile ids
@@ -79,7 +80,8 @@ struct ImageState {
     uint32_t* n_contrib; // N
     uint2* ranges;       // tiles (written by the tile-sort kernel from ranges_raw)
     uint32_t* ranges_raw; // tiles * 2: per tile {~first position, last position + 1} as atomicMax targets of the tile sort's last pass; 0, 0 = untouched
-    uint32_t* bigq;      // 1 + tiles: [0] = number of tiles with more than 1024 instances, then their ids (tile_sort.hip)
+    uint32_t* bigq;      // 2 x (1 + tiles): two queues of tile ids, each headed by its length: tiles of 513 .. 1024 instances (a wave
+                         //     with 16 elements per lane sorts one), tiles beyond (a workgroup each) -- tile_sort.hip
     uint32_t* qcount;    // tiles * 4: entries in each quadrant list
     uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;
@@ -274,7 +276,7 @@ void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const Geo
                       const ZeroJobs& zero, hipStream_t s);
 // tile_sort.hip: every tile's span (stable radix sort by tile: index order) sorted by (depth, id) on chip, then split into the four
 // quadrant lists; writes ranges[] from ranges_raw
-void gs2m_launch_tile_sort(size_t tiles, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
+void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

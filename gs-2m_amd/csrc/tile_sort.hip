@@ -19,6 +19,7 @@
 //   * longer spans are queued and sorted by a workgroup each: the same network over LDS (up to 4096 entries) or, beyond, over
 //     the tile's own (still unused) quadrant-list region in global memory -- slow, correct, exercised by the dense-scene tests.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,46 +28,68 @@ template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
 }
+// a full permutation inside the row: every lane has a source, `old` is never used (bound_ctrl: no tied operand, no copy)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
 // value of lane ^ (1 << B)
 template <int B>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
-    if constexpr (B == 0) return dpp_u32<DPP_QUAD_PERM(1, 0, 3, 2)>(v, v);
-    else if constexpr (B == 1) return dpp_u32<DPP_QUAD_PERM(2, 3, 0, 1)>(v, v);
+    if constexpr (B == 0) return dpp_perm<DPP_QUAD_PERM(1, 0, 3, 2)>(v);
+    else if constexpr (B == 1) return dpp_perm<DPP_QUAD_PERM(2, 3, 0, 1)>(v);
     else if constexpr (B == 2) {
         // banks (groups of 4 lanes) 0 and 2 of every row read 4 lanes up, banks 1 and 3 read 4 lanes down
         const uint32_t t = dpp_u32<0x104 /* row_shl:4 */, 0xF, 0x5>(v, v);
         return dpp_u32<0x114 /* row_shr:4 */, 0xF, 0xA>(t, v);
-    } else if constexpr (B == 3) return dpp_u32<0x128 /* row_ror:8 */>(v, v);
+    } else if constexpr (B == 3) return dpp_perm<0x128 /* row_ror:8 */>(v);
     else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ (1 << B)) << 2, (int)v);
 }
 // value of lane ^ ((1 << T) - 1): mirrored inside groups of 2^T lanes
 template <int T>
 __device__ __forceinline__ uint32_t lane_flip(uint32_t v, int lane) {
-    if constexpr (T == 1) return dpp_u32<DPP_QUAD_PERM(1, 0, 3, 2)>(v, v);
-    else if constexpr (T == 2) return dpp_u32<DPP_QUAD_PERM(3, 2, 1, 0)>(v, v);
-    else if constexpr (T == 3) return dpp_u32<DPP_ROW_HALF_MIRROR>(v, v);
-    else if constexpr (T == 4) return dpp_u32<DPP_ROW_MIRROR>(v, v);
+    if constexpr (T == 1) return dpp_perm<DPP_QUAD_PERM(1, 0, 3, 2)>(v);
+    else if constexpr (T == 2) return dpp_perm<DPP_QUAD_PERM(3, 2, 1, 0)>(v);
+    else if constexpr (T == 3) return dpp_perm<DPP_ROW_HALF_MIRROR>(v);
+    else if constexpr (T == 4) return dpp_perm<DPP_ROW_MIRROR>(v);
     else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ ((1 << T) - 1)) << 2, (int)v);
 }
 
 // ---- the network, element i = lane * E + e --------------------------------------------------------------------------------
-template <int E, bool TIE>  // TIE: equal keys are ordered by x (the span position)
-__device__ __forceinline__ void ce(uint32_t (&k)[E], uint32_t (&x)[E], int a, int b) {  // a < b: the smaller key to a
-    const bool sw = TIE ? (k[b] < k[a] || (k[b] == k[a] && x[b] < x[a])) : (k[b] < k[a]);
-    const uint32_t ka = sw ? k[b] : k[a], kb = sw ? k[a] : k[b], xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
-    k[a] = ka; k[b] = kb; x[a] = xa; x[b] = xb;
+// compile-time loop: register-array indices must be constants (a run-time index becomes a chain of compares and selects)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int E, bool TIE, int a, int b>  // TIE: equal keys are ordered by x (the span position)
+__device__ __forceinline__ void ce(uint32_t (&k)[E], uint32_t (&x)[E]) {  // a < b: the smaller key to a
+    if constexpr (TIE) {
+        const bool sw = k[b] < k[a] || (k[b] == k[a] && x[b] < x[a]);
+        const uint32_t ka = sw ? k[b] : k[a], kb = sw ? k[a] : k[b], xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
+        k[a] = ka; k[b] = kb; x[a] = xa; x[b] = xb;
+    } else {  // min / max for the keys, one compare for the two payload selects: 5 vector instructions, no mask arithmetic
+        const bool sw = k[b] < k[a];
+        const uint32_t mn = min(k[a], k[b]), mx = max(k[a], k[b]);
+        const uint32_t xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
+        k[a] = mn; k[b] = mx; x[a] = xa; x[b] = xb;
+    }
 }
 template <int E, int KB, bool TIE>  // mirrored compare inside blocks of 2^KB elements of one lane
 __device__ __forceinline__ void inlane_flip(uint32_t (&k)[E], uint32_t (&x)[E]) {
-#pragma unroll
-    for (int e = 0; e < E; e++)
-        if (((e >> (KB - 1)) & 1) == 0) ce<E, TIE>(k, x, e, e ^ ((1 << KB) - 1));
+    static_for<0, E>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (((e >> (KB - 1)) & 1) == 0) ce<E, TIE, e, (e ^ ((1 << KB) - 1))>(k, x);
+    });
 }
 template <int E, int JB, bool TIE>
 __device__ __forceinline__ void inlane_xor(uint32_t (&k)[E], uint32_t (&x)[E]) {
-#pragma unroll
-    for (int e = 0; e < E; e++)
-        if (((e >> JB) & 1) == 0) ce<E, TIE>(k, x, e, e | (1 << JB));
+    static_for<0, E>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (((e >> JB) & 1) == 0) ce<E, TIE, e, (e | (1 << JB))>(k, x);
+    });
 }
 // Across lanes: the lane with the lower number keeps the smaller keys.  On equal keys both keep their own (consistent on
 // both sides; the order of equal depths is settled by a second run with TIE).
@@ -77,10 +100,15 @@ __device__ __forceinline__ void cross_flip(uint32_t (&k)[E], uint32_t (&x)[E], i
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t ok = lane_flip<T>(k[E - 1 - e], lane), ox = lane_flip<T>(x[E - 1 - e], lane);
-        const bool take = TIE ? (lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e])))
-                              : (lower ? (ok < k[e]) : (ok > k[e]));
-        nk[e] = take ? ok : k[e];
-        nx[e] = take ? ox : x[e];
+        if constexpr (TIE) {
+            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
+            nk[e] = take ? ok : k[e];
+            nx[e] = take ? ox : x[e];
+        } else {  // the lower lane keeps the minimum, the upper one the maximum; the payload follows the key (equal keys: each keeps its own)
+            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+            nk[e] = lower ? mn : mx;
+            nx[e] = nk[e] == k[e] ? x[e] : ox;
+        }
     }
 #pragma unroll
     for (int e = 0; e < E; e++) { k[e] = nk[e]; x[e] = nx[e]; }
@@ -91,10 +119,16 @@ __device__ __forceinline__ void cross_xor(uint32_t (&k)[E], uint32_t (&x)[E], in
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t ok = lane_xor<B>(k[e], lane), ox = lane_xor<B>(x[e], lane);
-        const bool take = TIE ? (lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e])))
-                              : (lower ? (ok < k[e]) : (ok > k[e]));
-        k[e] = take ? ok : k[e];
-        x[e] = take ? ox : x[e];
+        if constexpr (TIE) {
+            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
+            k[e] = take ? ok : k[e];
+            x[e] = take ? ox : x[e];
+        } else {
+            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+            const uint32_t nk = lower ? mn : mx;
+            x[e] = nk == k[e] ? x[e] : ox;
+            k[e] = nk;
+        }
     }
 }
 template <int E, int LE, int JB, bool TIE>  // compare-exchange steps with strides 2^JB ... 2^0
@@ -119,38 +153,55 @@ __device__ __forceinline__ void levels(uint32_t (&k)[E], uint32_t (&x)[E], int l
 
 __device__ __forceinline__ int skew(int p) { return p + (p >> 5); }  // LDS index of element p: conflict-free lane-major AND position-major access
 
-// One tile by one wave: sort, order ties, emit the sorted list and the four quadrant lists.
-template <int E, int LE>
-__device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
-                                               const uint2* __restrict__ e_vr, const uint32_t* __restrict__ depth_key,
-                                               const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
-                                               uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                               uint32_t* __restrict__ qcount, uint32_t* s_v, uint32_t* s_r) {
-    const int lane = threadIdx.x;
-    uint32_t key[E], idx[E];
-    {
-        uint32_t slot[E];
-        uint2 vr[E];
+// One tile by one wave, in two halves so that a wave can have the NEXT tile's records in flight while it sorts this one:
+//   tile_fetch    the span's emission slots (coalesced: span position p = e * 64 + lane sits in register e of lane `lane` -- the
+//                 network sorts whatever arrangement it is given) and, through them, the 16-byte records (one gather each);
+//   tile_finish   staging in LDS, the network, ties, the sorted list and the four quadrant lists.
+template <int E>
+__device__ __forceinline__ void tile_fetch(uint4 (&rc)[E], const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
+                                           const uint4* __restrict__ e_rec, const int lane) {
+    uint32_t slot[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t p = (uint32_t)(lane * E + e);
-            slot[e] = p < n ? slot_sorted[start + p] : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < E; e++) vr[e] = (uint32_t)(lane * E + e) < n ? e_vr[slot[e]] : make_uint2(0u, 0u);
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t p = (uint32_t)(lane * E + e);
-            const uint32_t gid = vr[e].x & GS2M_GID_MASK;
-            key[e] = p < n ? depth_key[gid] : 0xFFFFFFFFu;  // (a real key is the bit pattern of a depth > 0.2: never all ones)
-            idx[e] = p;
-            // id | mask and the absolute first row wait in LDS under their span position
-            s_v[skew((int)p)] = vr[e].x;
-            s_r[skew((int)p)] = p < n ? vr[e].y + wave_rowbase[gid >> 6] : 0u;
-        }
+    for (int e = 0; e < E; e++) {
+        const uint32_t p = (uint32_t)(e * GS2M_WAVE + lane);
+        slot[e] = p < n ? slot_sorted[start + p] : 0u;
     }
-    levels<E, LE, 1, false>(key, idx, lane, n);
+#pragma unroll
+#ifdef GS2M_KO_TS_GATHER  // timing only: the records read in span order (coalesced) instead of gathered by slot
+    for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * GS2M_WAVE + lane) < n ? e_rec[start + e * GS2M_WAVE + lane + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+#else
+    for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * GS2M_WAVE + lane) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+#endif
+}
+template <int E, int LE>
+__device__ __forceinline__ void tile_finish(const uint4 (&rc)[E], const int tile, const uint32_t start, const uint32_t n,
+                                            const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
+                                            uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
+                                            uint32_t* s_v, uint32_t* s_r, const int lane) {
+    uint32_t key[E], idx[E], rb[E];  // rb: first row of the emit wave that owns the element at span position e * 64 + lane
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t p = (uint32_t)(e * GS2M_WAVE + lane);
+        key[e] = rc[e].z;  // (a real key is the bit pattern of a depth > 0.2: never all ones, the padding's key)
+        idx[e] = p;
+        // id | mask and the first row wait in LDS under their span position; the row's base (a dependent gather) is asked
+        // for now and added behind the sort: its latency disappears behind the network
+        s_v[skew((int)p)] = rc[e].x;
+        s_r[skew((int)p)] = rc[e].y;
+#ifndef GS2M_KO_TS_ROWBASE
+        rb[e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
+#else
+        rb[e] = rc[e].x >> 6;
+#endif
+    }
+#ifndef GS2M_KO_TS_SORT
+    // (the padding is spread over the lanes in this arrangement: every level runs)
+    levels<E, LE, 1, false>(key, idx, lane, 0xFFFFFFFFu);
+#endif
+#pragma unroll
+    for (int e = 0; e < E; e++) s_r[skew(e * GS2M_WAVE + lane)] += rb[e];
     // ---- equal depths: span order = Gaussian-id order (rasterizer_impl.cu:288-296 sorts id-ordered keys stably) ----
+    // sorted element i = lane * E + e (the network's index space)
     bool tie = false;
 #pragma unroll
     for (int e = 0; e + 1 < E; e++) tie |= (uint32_t)(lane * E + e + 1) < n && key[e] == key[e + 1];
@@ -158,7 +209,7 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
         const uint32_t nxt = (uint32_t)__shfl_down((int)key[0], 1, 64);
         tie |= lane < 63 && (uint32_t)(lane * E + E) < n && key[E - 1] == nxt;
     }
-    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) levels<E, LE, 1, true>(key, idx, lane, n);  // (depth, position): a total order
+    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) levels<E, LE, 1, true>(key, idx, lane, 0xFFFFFFFFu);  // (depth, position): a total order
     // ---- ids and rows of the sorted elements: picked up by position, parked again lane-major, read position-major ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint32_t sv[E], sr[E];
@@ -192,53 +243,116 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
         for (int q = 0; q < 4; q++) {
             const bool hit = ((mask >> q) & 1u) != 0u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+#ifndef GS2M_KO_TS_LISTS
             if (hit) {
                 const size_t o = (size_t)q * n + run[q] + (uint32_t)__popcll(m & lt);
                 out[o] = make_uint2(v, k);
                 orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
             }
+#endif
             run[q] += (uint32_t)__popcll(m);
         }
     }
     if (lane < 4) qcount[tile * 4 + lane] = lane == 0 ? run[0] : (lane == 1 ? run[1] : (lane == 2 ? run[2] : run[3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS arrays are the next tile's from here on
 }
 
-__global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
-                                                            const uint32_t* __restrict__ slot_sorted, const uint2* __restrict__ e_vr,
-                                                            const uint32_t* __restrict__ depth_key, const uint32_t* __restrict__ wave_rowbase,
-                                                            uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
-                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, uint32_t* bigq) {
-    constexpr int M = 64 * 16;
-    __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
-    const int tile = blockIdx.x;
-    // identifyTileRanges (rasterizer_impl.cu:108-129): the tile sort's last pass recorded where the tile's run of instances starts
-    // and ends (radix_sort.hip: range_raw); (0, 0) for an untouched tile, as the reference's memset leaves it
+// identifyTileRanges (rasterizer_impl.cu:108-129): the tile sort's last pass recorded where the tile's run of instances starts
+// and ends (radix_sort.hip: range_raw); (0, 0) for an untouched tile, as the reference's memset leaves it
+__device__ __forceinline__ uint2 tile_range(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, int tile, int lane) {
     const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
     const uint2 range = raw.y != 0u ? make_uint2(~raw.x, raw.y) : make_uint2(0u, 0u);
-    if (threadIdx.x == 0) ranges[tile] = range;
-    const uint32_t n = range.y - range.x;
-    if (n == 0u) {
-        if (threadIdx.x < 4) qcount[tile * 4 + threadIdx.x] = 0u;
-        return;
-    }
-    if (n <= 512u) sort_tile_wave<8, 3>(tile, range.x, n, slot_sorted, e_vr, depth_key, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r);
-    else if (n <= 1024u) sort_tile_wave<16, 4>(tile, range.x, n, slot_sorted, e_vr, depth_key, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r);
-    else if (threadIdx.x == 0) bigq[1u + atomicAdd(&bigq[0], 1u)] = (uint32_t)tile;  // a workgroup's (tile_sort_big_kernel)
+    if (lane == 0) ranges[tile] = range;
+    return range;
 }
 
-// ---- long spans: a workgroup per queued tile ---------------------------------------------------------------------------------
+#ifndef GS2M_TS_TILES_PER_WAVE
+#define GS2M_TS_TILES_PER_WAVE 1
+#endif
+// One wave per GS2M_TS_TILES_PER_WAVE neighbouring tiles (1: measured -- with 2 or 3 the later tiles' records are in flight while the
+// first is sorted, but the 32 more registers per tile cost more occupancy than the overlap returns: 127 / 122 us against 83);
+// spans of up to 512 entries are sorted here (8 elements per lane), longer ones are queued for tile_sort_rest_kernel.
+__global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ slot_sorted, const uint4* __restrict__ e_rec,
+                                                            const uint32_t* __restrict__ wave_rowbase,
+                                                            uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
+                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, uint32_t* q16,
+                                                            uint32_t* qbig, int tiles, int tiles_x, int tiles_y) {
+    constexpr int M = 64 * 8, TPW = GS2M_TS_TILES_PER_WAVE;
+    __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
+    const int lane = threadIdx.x;
+    // Which tile: workgroup ids go round the 8 XCDs (each with its own L2), and the records a tile gathers are 16 bytes out of a
+    // 64-byte sector whose other three records usually belong to the SAME Gaussian's instances in the neighbouring tiles
+    // (emit_kernel writes a Gaussian's instances to consecutive slots).  So the four tiles of a 2 x 2 block run back to back
+    // on ONE XCD: the sector one of them pulls in is in that L2 when the others ask for it.
+    int my_tile;
+    {
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, sub = j & 3;
+        const int stx = (tiles_x + 1) >> 1, nsuper = stx * ((tiles_y + 1) >> 1);
+        const int S = (j >> 2) * 8 + xcd;
+        if (S >= nsuper) return;
+        const int tx = 2 * (S % stx) + (sub & 1), ty = 2 * (S / stx) + (sub >> 1);
+        if (tx >= tiles_x || ty >= tiles_y) return;
+        my_tile = ty * tiles_x + tx;
+    }
+    uint2 range[TPW];
+    uint32_t n[TPW];
+    uint4 rc[TPW][8];
+    static_for<0, TPW>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int tile = my_tile * TPW + t;
+        range[t] = make_uint2(0u, 0u);
+        n[t] = 0u;
+        if (tile < tiles) {
+            range[t] = tile_range(ranges_raw, ranges, tile, lane);
+            n[t] = range[t].y - range[t].x;
+            if (n[t] > 512u) {  // a longer span: another kernel's
+                if (lane == 0) {
+                    uint32_t* q = n[t] <= 1024u ? q16 : qbig;
+                    q[1u + atomicAdd(&q[0], 1u)] = (uint32_t)tile;
+                }
+                n[t] = 0u;
+            } else if (n[t] == 0u && lane < 4) {
+                qcount[tile * 4 + lane] = 0u;
+            }
+        }
+        tile_fetch<8>(rc[t], range[t].x, n[t], slot_sorted, e_rec, lane);  // (n == 0: nothing is read)
+    });
+    static_for<0, TPW>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (n[t] != 0u)
+            tile_finish<8, 3>(rc[t], my_tile * TPW + t, range[t].x, n[t], wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
+    });
+}
+
+// ---- the queued tiles: spans of 513 .. 1024 entries by one wave each (16 elements per lane), longer spans by a workgroup each ----
 constexpr int BIG_LDS = 4096;
-__global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
-                                                            const uint2* __restrict__ e_vr, const uint32_t* __restrict__ depth_key,
-                                                            const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
-                                                            uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
-                                                            uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                                            uint32_t* __restrict__ qcount, const uint32_t* __restrict__ bigq) {
-    __shared__ uint32_t s_key[BIG_LDS], s_idx[BIG_LDS];
-    const int tid = threadIdx.x;
-    const uint32_t nbig = bigq[0];
+__global__ void __launch_bounds__(256) tile_sort_rest_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
+                                                             const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
+                                                             uint32_t* __restrict__ point_list,
+                                                             uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
+                                                             uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
+                                                             uint32_t* __restrict__ qcount, const uint32_t* __restrict__ q16,
+                                                             const uint32_t* __restrict__ qbig) {
+    constexpr int M16 = 64 * 16, W16 = M16 + M16 / 32;
+    __shared__ uint32_t s_all[8 * W16 > 2 * BIG_LDS ? 8 * W16 : 2 * BIG_LDS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        const uint32_t n16 = q16[0];
+        uint32_t* s_v = s_all + wave * 2 * W16;
+        for (uint32_t k = blockIdx.x * 4 + wave; k < n16; k += gridDim.x * 4) {
+            const int tile = (int)q16[1u + k];
+            const uint2 range = ranges[tile];
+            uint4 rc[16];
+            tile_fetch<16>(rc, range.x, range.y - range.x, slot_sorted, e_rec, lane);
+            tile_finish<16, 4>(rc, tile, range.x, range.y - range.x, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_v + W16, lane);
+        }
+    }
+    uint32_t* const s_key = s_all;
+    uint32_t* const s_idx = s_all + BIG_LDS;
+    const uint32_t nbig = qbig[0];
     for (uint32_t bq = blockIdx.x; bq < nbig; bq += gridDim.x) {
-        const int tile = (int)bigq[1u + bq];
+        const int tile = (int)qbig[1u + bq];
         const uint2 range = ranges[tile];
         const uint32_t n = range.y - range.x, start = range.x;
         // working arrays: LDS, or -- beyond its capacity -- the tile's own quadrant-list region (32 n bytes, written only at the end)
@@ -249,9 +363,9 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint2* __restr
             if (glob) __threadfence_block();
             gs2m_sync();
         };
-        barrier();  // the previous tile's LDS reads are done
+        barrier();  // the previous tile's (and the wave phase's) LDS accesses are done
         for (uint32_t p = tid; p < n; p += 256) {
-            K[p] = depth_key[e_vr[slot_sorted[start + p]].x & GS2M_GID_MASK];
+            K[p] = e_rec[slot_sorted[start + p]].z;
             I[p] = p;
         }
         barrier();
@@ -283,14 +397,14 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint2* __restr
         }
         // sorted ids -> point_list (final), absolute rows -> row_tmp
         for (uint32_t p = tid; p < n; p += 256) {
-            const uint2 vr = e_vr[slot_sorted[start + I[p]]];
-            point_list[start + p] = vr.x;
-            row_tmp[start + p] = vr.y + wave_rowbase[(vr.x & GS2M_GID_MASK) >> 6];
+            const uint4 rc = e_rec[slot_sorted[start + I[p]]];
+            point_list[start + p] = rc.x;
+            row_tmp[start + p] = rc.y + wave_rowbase[(rc.x & GS2M_GID_MASK) >> 6];
         }
         __threadfence_block();
         gs2m_sync();
         // quadrant lists: wave q compacts quadrant q (the scratch in the list region is dead behind the barrier above)
-        const int q = tid >> 6, lane = tid & 63;
+        const int q = wave;
         uint2* out = qlist + (size_t)4 * start + (size_t)q * n;
         uint32_t* orow = qrow + (size_t)4 * start + (size_t)q * n;
         uint32_t run = 0;
@@ -315,12 +429,16 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint2* __restr
 
 }  // namespace
 
-void gs2m_launch_tile_sort(size_t tiles, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
+void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
+    static_assert(GS2M_TS_TILES_PER_WAVE == 1, "the 2 x 2 tile-to-workgroup mapping below is one tile per wave");
     if (tiles == 0) return;
-    tile_sort_wave_kernel<<<(unsigned)tiles, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_vr, g.depth_key, g.wave_rowbase, b.point_list,
-                                                         b.qlist, b.qrow, im.qcount, im.bigq);
-    // tiles of more than 1024 instances were queued (none on the bench scenes: the workgroups find an empty queue)
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    tile_sort_big_kernel<<<grid, 256, 0, s>>>(im.ranges, b.slot_sorted, b.e_vr, g.depth_key, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                              im.qcount, im.bigq);
+    uint32_t* q16 = im.bigq;
+    uint32_t* qbig = im.bigq + tiles + 1;
+    const size_t nsuper = (size_t)((tiles_x + 1) / 2) * ((tiles_y + 1) / 2);
+    tile_sort_wave_kernel<<<(unsigned)(((nsuper + 7) / 8) * 32), 64, 0, s>>>(
+        im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, q16, qbig, (int)tiles, tiles_x, tiles_y);
+    // tiles of more than 512 instances were queued (none on the bench scene: the workgroups find two empty queues)
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    tile_sort_rest_kernel<<<grid, 256, 0, s>>>(im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
+                                               im.qcount, q16, qbig);
 }
