@@ -2,20 +2,24 @@
 """bench.py -- train views/s (fwd+bwd raster) at 1M Gaussians 1080p on N MI355X.
 
 One "step" = one view per GPU: GaussianRasterizer forward + backward with dense upstream gradients on colour and
-the G-buffer, timed at the op boundary.  At N > 1 every rank renders its own camera of the same
-replicated scene and the step ENDS with the blocking RCCL sum of the view's per-Gaussian gradients -- one collective
-over the binding's gradient arena -- plus the densification side channels (gs2m_dp); the pipelined form (the sum of
-step k overlapping step k + 1) is timed as well and reported beside it.  Prints ONE JSON line on rank 0.
+the G-buffer, timed at the op boundary.  At N > 1 (north_star / BASELINE configs[4]) every rank renders ONE
+camera of the same replicated scene -- rank r: position r of SURVEY.md 8(d)'s 8-position ring -- and the step ENDS with the
+blocking RCCL sum of the view's per-Gaussian gradients -- one collective over the binding's gradient arena -- plus the
+densification side channels (gs2m_dp): that is `value`.  Beside it, timed in the same run and labelled: the same step on
+equal-work cameras (`equal_work_*`), with two views per rank whose gradients accumulate before ONE reduction
+(`accumulate_v2_*`), with the reduction of step k overlapping step k + 1 (`pipelined_*`), and without any collective
+(`compute_only_*`: what N independent GPUs would deliver -- the reference point for scaling efficiency on THIS workload).
+Prints ONE JSON line on rank 0.
 
 Order inside a run: W warm-up steps, K steps timed "at start" (`clock_ramp`: the GPU's clock governor is still ramping
 there), the auxiliary passes of the same step (pipelined / one-view forms at N > 1, the reference-binning pass), then W warm-up
 steps again and the K timed steps `value` is computed from, then the per-stage pass (`stages_ms`).
 
-  --config c3 (default)  BASELINE.json configs[2]: 1M Gaussians, 1920x1080, feature_count 9 (material G-buffers) -- the
-                         configuration the metric is quoted on; kept at every N so that the driver's scaling efficiency
-                         compares equal per-GPU work
+  --config c3            BASELINE.json configs[2]: 1M Gaussians, 1920x1080, feature_count 9 (material G-buffers) -- the
+                         configuration the metric is quoted on; the default at N = 1
   --config c2            configs[1]: 500k Gaussians, 1080p, feature_count 5 (colour + depth + normal)
-  --config c5            configs[4]'s per-GPU shape: 2M Gaussians, 1080p, feature_count 9
+  --config c5            configs[4]: 2M Gaussians, 1080p, feature_count 9, one view per GPU -- the default at N > 1 (the data-
+                         parallel configuration BASELINE names; `--config c3` keeps the single-GPU workload at every N)
   --config c1            configs[0]: 10k Gaussians, 256x256, feature_count 10 (the CPU-runnable case)
   --config c4            configs[3]: the full train.py loop at DTU scan24's size on a SUBSTITUTE scene (the dataset is not on the
                          box): 49 views 777x581 through the COLMAP loader at -r 2, ~30 k -> past 300 k points, geometry stage with
@@ -301,7 +305,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"], help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS) + ["c4"], help="BASELINE.json configuration (see the module docstring); default c3 on one GPU, c5 on several")
     ap.add_argument("--c4-iterations", type=int, default=5000, help="--config c4: training iterations (the reference runs 30000; the schedule is compressed)")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -312,10 +316,10 @@ def main():
     ap.add_argument("--no-caller-levels", action="store_true", help="skip render_level_ms / train_step_ms / material_step_ms")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "rs_ag"],
                     help="auto: reduce-scatter + all-gather from 4 ranks on (every link of the xGMI mesh busy), all-reduce below")
-    ap.add_argument("--camera-ring", action="store_true",
-                    help="N > 1: the 8-position camera ring of SURVEY.md 8(d) (45 degrees apart: the views differ in work by up to 1.6x, "
-                         "position k costs 1.24-2.03 ms) instead of the default equal-work arc (the single-GPU camera moved 0.4 degrees per "
-                         "view around the cloud centre: per-GPU work stays what it is at N = 1, i.e. weak scaling)")
+    ap.add_argument("--equal-work", action="store_true",
+                    help="N > 1: `value` on the equal-work arc (the single-GPU camera moved 0.4 degrees per view around the cloud centre: per-GPU "
+                         "work stays what it is at N = 1) instead of the default, the 8-position camera ring of SURVEY.md 8(d) (45 degrees apart: "
+                         "the views differ in work by up to 1.6x); the other one is timed beside it either way")
     ap.add_argument("--ring-position", type=int, default=None,
                     help="N = 1 only: render the camera rank k of an N-GPU run takes (position k of the 8-camera ring, SURVEY.md 8(d)) "
                          "-- the per-view times the multi-GPU model in DESIGN.md section 6 is built from; not the metric's workload")
@@ -324,15 +328,17 @@ def main():
     ap.add_argument("--heavy-tail", default=None, metavar="F:K",
                     help="not the metric's workload: a fraction F of the Gaussians K times larger (splats over hundreds of tiles, as "
                          "close-ups and background blobs of real scenes have them) -- how the stages hold up off the uniform scene")
-    ap.add_argument("--views-per-rank", type=int, default=None,
-                    help="views every rank renders per step; with more than one their gradients ACCUMULATE and one reduction follows the "
-                         "last view (exact sums, no stale gradients; the collective is paid once per that many views).  Default: 1 on one "
-                         "GPU (the metric's step), 2 on several")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="views every rank renders per step of the HEADLINE (default 1: the metric's step, north_star's form); with more "
+                         "than one their gradients ACCUMULATE and one reduction follows the last view (exact sums, no stale gradients; the "
+                         "collective is paid once per that many views).  The two-view form is timed beside the headline at N > 1 anyway")
     ap.add_argument("--no-reference-binning", action="store_true", help="skip the second timing of the same workload in reference-binning mode")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if a.config is None:
+        a.config = "c3" if world == 1 else "c5"
     # watchdog: a rank that hangs (a peer died inside a collective, a stuck kernel) dumps every thread's stack and exits
     # instead of holding the GPU until the caller's limit
     import faulthandler
@@ -383,12 +389,16 @@ def main():
         import math
         th = math.radians(0.4 * k)
         return S.look_at_camera(W, H, (6.0 * math.sin(th), 0.0, 6.0 - 6.0 * math.cos(th)), (0.0, 0.0, 6.0))
-    Vn = a.views_per_rank or (1 if world == 1 else 2)
-    # rank r, view v of a step: camera r + v * world of the arc (default) or of the ring; world == 1: the single-GPU camera first
-    use_ring = a.camera_ring or (world == 1 and a.ring_position is not None)
+    Vn = max(1, a.views_per_rank)
+    # rank r, view v of a step: camera r + v * world of the ring (default at N > 1) or of the arc; world == 1: the single-GPU camera
+    # first.  The headline's cameras and, at N > 1, the other family beside it; two views per rank for the accumulate form.
+    head_ring = (world > 1 and not a.equal_work) or (world == 1 and a.ring_position is not None)
     first = rank if world > 1 else (a.ring_position or 0)
-    cams_v = [(ring_camera if use_ring else arc_camera)(first + v * world) for v in range(Vn)]
-    cam = cams_v[0]
+    nviews = max(Vn, 2) if world > 1 else Vn
+    fam = {"ring": [ring_camera(first + v * world) for v in range(nviews)] if (world > 1 or head_ring) else None,
+           "arc": [arc_camera(first + v * world) for v in range(nviews)] if (world > 1 or not head_ring) else None}
+    head = "ring" if head_ring else "arc"
+    cam = fam[head][0]
     ref_cam = S.make_camera(W, H)
     g = S.make_gaussians(P, ref_cam, seed=a.seed)
     if a.heavy_tail:
@@ -400,10 +410,11 @@ def main():
     Gc, Gb = Gc.to(dev), Gb.to(dev)
     prm = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
     means2D = torch.zeros(P, 4, device=dev, requires_grad=True)
-    sts = [GaussianRasterizationSettings(
+    mk = lambda c: GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=torch.zeros(3, device=dev),
         scale_modifier=1.0, viewmatrix=c["viewmatrix"].to(dev), projmatrix=c["projmatrix"].to(dev), sh_degree=3,
-        campos=c["campos"].to(dev), prefiltered=False, feature_count=fc) for c in cams_v]
+        campos=c["campos"].to(dev), prefiltered=False, feature_count=fc)
+    sts_f = {k: [mk(c) for c in v] for k, v in fam.items() if v is not None}
     empty = torch.Tensor([])
     sh_in, sh_rest = prm["shs"], None
     if a.split_sh:
@@ -414,7 +425,11 @@ def main():
         leaves.append(sh_rest)
     dp_mode = ("rs_ag" if world >= 4 else "allreduce") if a.dp_mode == "auto" else a.dp_mode
     reducer = GradReducer(mode=dp_mode)
-    VPR = Vn  # views per rank and step
+    VPR = Vn  # views per rank and step of the headline
+    import gs2m_arena
+    gs2m_arena.set_keep(max(VPR, 2) + 1)  # accumulate mode: the first view's arena (the accumulated gradients) stays registered until the reduction
+    if world > 1:
+        gs2m_native.set_sort_tickets(True)  # RCCL's kernels share the device: the tile sort must not assume it has the GPU to itself
     if os.environ.get("GS2M_SPIN_WAIT") is not None:  # debugging aid: 0 = hipStreamSynchronize instead of polling the pinned count
         gs2m_native.set_spin_wait(int(os.environ["GS2M_SPIN_WAIT"]))
     info = {}
@@ -424,23 +439,23 @@ def main():
         while pending:
             pending.pop(0).wait()
 
-    vv = [VPR]  # views per rank of the step being timed
-
-    def step(pipelined=False):
+    def step(pipelined=False, family=None, views=None, reduce=True):
+        sts = sts_f[family or head]
+        nv = views or VPR
         for t in leaves:
             t.grad = None
         local = None
-        for v in range(vv[0]):
+        for v in range(nv):
             if v:  # dL/dmeans2D is per view (densification accumulates NORMS of it, train.py:223-227): not accumulated
                 means2D.grad = None
             color, radii, observe, buffer = rasterize_gaussians(
                 prm["means3D"], means2D, sh_in, empty, prm["opacities"], prm["scales"], prm["rotations"], empty,
                 prm["features"], sts[v], sh_rest)
             torch.autograd.backward([color, buffer], [Gc, Gb])  # v > 0: autograd ADDS to the first view's gradients, in its arena
-            if world > 1 and vv[0] > 1:
+            if world > 1 and nv > 1 and reduce:
                 with torch.no_grad():
                     local = reducer.local_densification_stats(means2D.grad, radii, observe, into=local)
-        if world > 1:
+        if world > 1 and reduce:
             # The sum of this step's gradients: ONE collective over the arena the binding allocated them in (the leaves'
             # .grad are views of it; with several views per rank they hold the views' accumulated sums), plus the
             # densification side channels.  Blocking form (the metric): the step ends when the sums have landed.
@@ -465,11 +480,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(pipelined):
+    def timed(pipelined=False, **kw):
         fence()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            step(pipelined)
+            step(pipelined, **kw)
         fence()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         if world > 1:
@@ -485,14 +500,14 @@ def main():
     # slower until then).  Kept as `ms_per_step_at_start`; the auxiliary passes below all run the same step, and the headline
     # region is timed after them, again behind W warm-up steps, at the clock a training run of 30k steps spends its time at.
     ms_start = timed(False)
-    ms_pipelined = timed(True) if world > 1 else None
-    ms_single = None
-    if world > 1 and VPR > 1:  # beside the accumulate mode: north_star's plain form, one view per rank and step, blocking sum
-        vv[0] = 1
-        for _ in range(2):
-            step()
-        ms_single = timed(False)
-        vv[0] = VPR
+    beside = {}
+    if world > 1:  # beside the headline, same run, each behind two untimed steps of its own form
+        other = "arc" if head == "ring" else "ring"
+        for key, kw in (("pipelined", dict(pipelined=True)), ("equal_work" if other == "arc" else "camera_ring", dict(family=other)),
+                        ("accumulate_v2", dict(views=2)), ("compute_only", dict(reduce=False))):
+            for _ in range(2):
+                step(**kw)
+            beside[key] = (timed(**kw), kw.get("views", VPR))
         step()
 
     # The same workload with the reference's own instance list (gs2m_set_reference_binning(1): every tile of the radius
@@ -524,6 +539,17 @@ def main():
     ms = timed(False)
     blend = gs2m_native.profile_collect()
     gs2m_native.profile_mode(0)
+    # the same K steps once more with an event between them: per-step times, for the median beside the mean (an event is a
+    # marker on the launch stream; the steps run back to back as before, minus ~1 us of marker per step)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    fence()
+    evs[0].record()
+    for k in range(a.steps):
+        step()
+        evs[k + 1].record()
+    fence()
+    per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps))
+    ms_median = per_step[len(per_step) // 2] if a.steps % 2 else 0.5 * (per_step[a.steps // 2 - 1] + per_step[a.steps // 2])
 
     # untimed: per-stage breakdown of the same step, right behind the headline region (same clock).  Every stage is bracketed by
     # HIP events of its own: a bracket also sees the dispatch latency that back-to-back kernels overlap with their predecessor's
@@ -581,13 +607,13 @@ def main():
         out = {
             "metric": "train views/s (fwd+bwd raster) at 1M Gaussians 1080p",
             "value": round(world * VPR * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": round(ms, 4), "median_ms_per_step": round(ms_median, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2, 'c5': 4}[a.config]}] ({a.config}): " if preset else "custom: ")
                                    + f"{P} synthetic Gaussians (SH deg 3), 1 camera {W}x{H} per GPU, feature_count={fc}, fwd+bwd at the op boundary"
-                                   + ("" if world == 1 else (f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}: the views differ in work), " if use_ring else
+                                   + ("" if world == 1 else (f", cameras on the 8-position ring of SURVEY.md 8(d) (rank r, view v: position r + v x {world}: the views differ in work), " if head == "ring" else
                                                              f", equal-work cameras (the single-GPU camera moved 0.4 degrees per view around the cloud centre; rank r, view v: camera r + v x {world}), ")
-                                      + (f"{VPR} views per rank and step whose gradients accumulate, " if VPR > 1 else "")
+                                      + (f"{VPR} views per rank and step whose gradients accumulate, " if VPR > 1 else "one view per rank and step, ")
                                       + f"blocking RCCL sum ({dp_mode}) of the step's gradients (one in-place collective over the gradient arena) at step end")
                                    + (f" [{VPR} views per step, gradients accumulated]" if world == 1 and VPR > 1 else "")
                                    + (f" [ring position {a.ring_position}: NOT the metric's camera]" if world == 1 and a.ring_position else ""),
@@ -601,18 +627,17 @@ def main():
         if ref_binning is not None:
             out["reference_binning_ms_per_step"] = ref_binning["ms_per_step"]
             out["reference_binning"] = ref_binning
-        if ms_pipelined is not None:
-            out["pipelined_ms_per_step"] = round(ms_pipelined, 4)
-            out["pipelined_value"] = round(world * VPR * 1e3 / ms_pipelined, 3)
+        for key, (msb, nvb) in beside.items():
+            out[key + "_ms_per_step"] = round(msb, 4)
+            out[key + "_value"] = round(world * nvb * 1e3 / msb, 3)
+        if "compute_only" in beside:
+            out["scaling_efficiency_vs_compute_only"] = round(beside["compute_only"][0] / ms, 4)  # = value / (what N independent GPUs deliver on this workload)
         out["views_per_step"] = world * VPR
         # the same K steps timed right behind the first W warm-up steps (where rounds 1-3 timed): inside the governor's clock ramp
         out["clock_ramp"] = {"ms_per_step_at_start": round(ms_start, 4), "value_at_start": round(world * VPR * 1e3 / ms_start, 3),
                              "steps_before_headline": "W warm-up + K at-start + reference-binning pass (3 + K) + W warm-up",
                              "note": "sclk reaches 2400 MHz after ~0.5 s of continuous work (tools/clock_trace.py); "
                                      "`value` is timed after that, `value_at_start` before"}
-        if ms_single is not None:
-            out["one_view_per_rank_ms_per_step"] = round(ms_single, 4)
-            out["one_view_per_rank_value"] = round(world * 1e3 / ms_single, 3)
     if world == 1 and rank == 0:
         torch.cuda.empty_cache()
         if not a.no_caller_levels:

@@ -21,6 +21,13 @@
 //    tiles that were started before it (forward progress without co-residency assumptions).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
+
+static std::atomic<int> g_sort_tickets{0};
+extern "C" int gs2m_set_sort_tickets(int on) {
+    g_sort_tickets = on ? 1 : 0;
+    return GS2M_OK;
+}
 
 namespace {
 #ifndef LB2_WIN
@@ -373,8 +380,10 @@ void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t*
     // stream-ordered, and a look-back that does stall is still released by the dispatch of the earlier blocks, which
     // the hardware starts in id order); beyond that an atomic ticket hands them out in start order.  The ticket
     // serialises the starts on one address: 0.088 -> 0.074 ms for the 661-tile instance sort without it.
-    // GS2M_SORT_TICKETS=1 forces tickets (shared / CU-masked devices).
-    static const bool force_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
+    // GS2M_SORT_TICKETS=1 or gs2m_set_sort_tickets(1) forces tickets: a device shared with other resident kernels -- RCCL's, in
+    // data-parallel runs (gs2m_dp switches them on when it creates a reducer) -- or CU-masked.
+    static const bool env_tickets = getenv("GS2M_SORT_TICKETS") && atoi(getenv("GS2M_SORT_TICKETS")) != 0;
+    const bool force_tickets = env_tickets || g_sort_tickets.load(std::memory_order_relaxed) != 0;
     rs_onesweep_kernel<BITS><<<tiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, ghist,
                                                           (!force_tickets && tiles <= resident_tiles()) ? nullptr : ticket, status, range_raw, hist_copies, sb);
 }

@@ -58,6 +58,14 @@ class GradReducer:
         self.last_plan = []
         import gs2m_arena
         gs2m_arena.enable()  # from now on the producers' gradient arenas are registered (summed in place)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            try:  # the collectives' kernels share the device with the rasterizer from now on: the tile sort must not assume
+                import gs2m_native  # that every workgroup of a pass is resident at once (radix_sort.hip: launch_pass)
+                import torch
+                if torch.cuda.is_available():
+                    gs2m_native.set_sort_tickets(True)
+            except Exception:
+                pass
 
     @property
     def world_size(self):

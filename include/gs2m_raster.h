@@ -275,6 +275,12 @@ int gs2m_activate_backward(int P, const float* rotation, const float* scales, co
  * (falls back to a stream synchronize after 2 s); 0: hipStreamSynchronize.  Same results. */
 int gs2m_set_spin_wait(int on);
 
+/* 1: the tile sort hands its 4096-key tiles out by an atomic ticket instead of by workgroup id, so that a tile only ever waits for
+ * tiles that have started -- needed when other kernels may be resident on the device at the same time (RCCL's in data-parallel
+ * runs: gs2m_dp.GradReducer switches it on; a CU-masked or partitioned device).  0 (default): workgroup ids whenever every
+ * workgroup of a pass fits on the device at once.  Also: environment variable GS2M_SORT_TICKETS=1. */
+int gs2m_set_sort_tickets(int on);
+
 /* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)
  * allocated AHEAD of that wait: pass gs2m_prealloc_alloc as the callback and a gs2m_prealloc as its user pointer.  A
  * request that fits `capacity` returns `ptr` without leaving the library -- the GPU idles between the wait and the next
