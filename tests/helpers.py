@@ -308,8 +308,9 @@ def grad_stats(got, ref, rel=REL_TOL_GRADS, floor_frac=1e-5):
 # pixel's (small) term; such elements may exceed the element-wise bound, but they are few and small:
 MAX_GRAD_EXCEPTIONS = 2e-4  # fraction of a tensor's elements
 # end to end, dL/dscale and dL/drot additionally carry the conditioning of the cov2D -> cov3D -> (S, R) chain (see
-# assert_two_stage, which checks the two halves without it): measured <= 1.7e-3 of the elements on the needle scene
-MAX_GRAD_EXCEPTIONS_CHAIN = 3e-3
+# assert_two_stage, which checks the two halves without it): measured <= 1.7e-3 of the elements on the needle scene (small
+# scenes only: the full-size comparisons with the reference build ask every exception for its proof, helpers.check_full_size)
+MAX_GRAD_EXCEPTIONS_CHAIN = 2e-3
 def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS, max_exceptions=None, floor_frac=None):
     """north_star: 1e-3 relative on gradients, ELEMENT-WISE (`|a-b| <= 1e-3 |b| + floor`, see grad_stats), with a
     counted exception set (<= `max_exceptions` of the elements) that is itself bounded in the max norm
@@ -330,7 +331,7 @@ def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS, max_exceptions=None, fl
     assert worst <= rel, f"{name}: max-norm relative error {worst:.3e} > {rel:g}"
 
 
-def assert_sum_close(name, got, ref, f, rel=REL_TOL_GRADS, floor_frac=1e-5, max_proofs=48):
+def assert_sum_close(name, got, ref, f, rel=REL_TOL_GRADS, floor_frac=1e-5, max_proofs=48, budget=MAX_GRAD_EXCEPTIONS):
     """assert_grad_close for a per-Gaussian blend SUM (what the reference accumulates with atomicAdd), with the proof image
     outliers and observe mismatches get when the counted-exception budget does not cover the rows outside the bound: a
     pixel that one implementation takes and the other does not (alpha * 255 = 1.00000 at a contributor: the two exp() differ
@@ -338,12 +339,14 @@ def assert_sum_close(name, got, ref, f, rel=REL_TOL_GRADS, floor_frac=1e-5, max_
     included -- sweep case 89 of tests/ref_report.py: 11 elements of dL/dcolour, 2e-4 of them allowed.  Every Gaussian
     that owns an element outside the bound must then have, in one of its tiles, a pixel within CHAIN_EVENT_BAND of a
     threshold of the blend at or in front of its own list entry, computed from `f`'s state (the walk of observe_event);
-    the max-norm bound stays."""
+    the max-norm bound stays.  `budget`: the counted-exception fraction below which no proof is asked for; 0 = north_star's
+    "1e-3 relative, full stop": EVERY row with an element outside the bound needs its proof (the full-size comparisons with the
+    reference build: a handful of Gaussians per million)."""
     got = np.asarray(got); ref = np.asarray(ref)
     assert got.shape == ref.shape and np.all(np.isfinite(got)), name
     frac, worst, floor = grad_stats(got, ref, rel, floor_frac)
     assert worst <= rel, f"{name}: max-norm relative error {worst:.3e} > {rel:g}"
-    if frac <= max(MAX_GRAD_EXCEPTIONS, 2.0 / max(got.size, 1)):
+    if frac <= (max(budget, 2.0 / max(got.size, 1)) if budget > 0 else 0.0):
         return
     a = got.reshape(got.shape[0], -1).astype(np.float64); b = ref.reshape(ref.shape[0], -1).astype(np.float64)
     rows = np.nonzero((np.abs(a - b) > rel * np.abs(b) + floor).any(1))[0]
@@ -423,6 +426,32 @@ def check_scene_against(reference, sc, tag="", refbin=False, **kw):
     return r, rg, out, g, sums
 
 
+def check_full_size(reference, sc, refbin, tag=""):
+    """The HIP path against the reference build at a BASELINE configuration's full size with NO counted-exception budget: radii
+    exact; observe and every image outlier with its threshold proof; every blend sum and every gradient element-wise at 1e-3
+    relative, and every Gaussian owning an element outside that bound proven to sit on a threshold of the blend (sums and the
+    well-conditioned tensors) or to be needle-like / measurably amplified / on a threshold (dL/dscale, dL/drot, dL/dmean3D)."""
+    import gs2m_native
+    r, rg = run_oracle(reference, sc)
+    try:
+        gs2m_native.set_reference_binning(refbin)
+        out, g = run_hip(sc)
+        sums = run_hip_sums(sc)
+    finally:
+        gs2m_native.set_reference_binning(False)
+    assert np.array_equal(out["radii"], r.radii), "radii " + tag
+    assert_observe_close(out["observe"], r)
+    assert_image_close("color " + tag, out["color"], r.color, oracle_fwd=r)
+    for ch in range(10):
+        assert_image_close(f"buffer[{ch}] " + tag, out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
+    for k in ("means2D", "conics", "opacities", "colors", "features"):
+        assert_sum_close("sum:" + k + " " + tag, sums[k], rg[k].reshape(sums[k].shape), r, floor_frac=1e-4 if k == "conics" else 1e-5, budget=0.0)
+    for k in ("shs", "opacities", "features", "means2D"):
+        assert_sum_close(k + " " + tag, g[k], rg[k], r, budget=0.0)
+    assert_chain_exceptions_conditioned(r, g, rg, sums=sums, names=("scales", "rotations", "means3D"), tag=tag)
+    return r
+
+
 def cov2d_anisotropy(f):
     """rho = det / (a c) of the 2-D covariance the backward differentiates through (the forward's, plus 0.3 on the
     diagonal, CR/backward.cu:205-207), recovered from the oracle's conic: 1 for a round splat, -> 0 for a needle.  The
@@ -476,7 +505,11 @@ def assert_chain_exceptions_conditioned(f, g, gr, sums=None, names=("scales", "r
         # the chain at that Gaussian (screen-filling needles are often the largest entries of the tensor): measured on the
         # 400-scene sweep 1.06e-3 ... 2.7e-2 of the largest element, where round 3's flat 1e-3 failed 17 scenes whose two-stage
         # check -- the rigorous half: sums element-wise, chain bit-identical on equal sums -- passes.  CHAIN_GROSS_MAX bounds them.
-        assert d.max(initial=0.0) <= CHAIN_GROSS_MAX * (np.abs(ref).max(initial=0.0) + 1e-30), f"{k} {tag}: max-norm relative error {d.max() / (np.abs(ref).max() + 1e-30):.3e}"
+        peak = np.abs(ref).max(initial=0.0) + 1e-30
+        assert d.max(initial=0.0) <= CHAIN_GROSS_MAX * peak, f"{k} {tag}: max-norm relative error {d.max() / peak:.3e}"
+        clean = np.ones(d.shape[0], bool)
+        clean[rows] = False  # rows WITHOUT an exception keep north_star's bound in the max norm too (CHAIN_GROSS_MAX is for proven rows only)
+        assert d[clean].max(initial=0.0) <= rel * peak + floor, f"{k} {tag}: a row inside the element-wise bound exceeds {rel:g} of the largest element"
         ok = rho[rows] <= CHAIN_RHO_MAX
         if amp_in is not None and len(rows):
             with np.errstate(all="ignore"):

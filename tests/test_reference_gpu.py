@@ -238,25 +238,14 @@ def test_hip_binning_reproduces_the_reference_builds_lists(reference):
 @pytest.mark.parametrize("name,P,fc", [("c3 (the bench workload)", 1_000_000, 9), ("c2", 500_000, 5), ("c5 per-GPU shape", 2_000_000, 9)])
 def test_bench_workloads_at_full_size_against_the_reference_build(reference, name, P, fc):
     """BASELINE configs as bench.py runs them (1920x1080; C3: 1M Gaussians, feature_count 9): forward + backward of the HIP
-    path against the reference's kernels on the same device, in both binning modes"""
-    import gs2m_native
+    path against the reference's kernels on the same device, in both binning modes; gradients at 1e-3 relative element-wise with
+    a PROOF for every Gaussian that owns an element outside (a handful per million: threshold pixels, needles)"""
     sc = Hh.make_scene(P, 1920, 1080, seed=0, fc=fc)
-    r, rg = Hh.run_oracle(reference, sc)
-    assert r.num_rendered > 3 * P
     for mode in (False, True):
-        gs2m_native.set_reference_binning(mode)
-        try:
-            out, g = Hh.run_hip(sc)
-        finally:
-            gs2m_native.set_reference_binning(False)
-        assert np.array_equal(out["radii"], r.radii)
-        Hh.assert_observe_close(out["observe"], r)
-        Hh.assert_image_close("color", out["color"], r.color, oracle_fwd=r)
-        for ch in range(10):
-            Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
-        for k in GRADS:
-            Hh.assert_grad_close(k, g[k], rg[k])
-        del out, g
+        # no counted-exception budget: every element outside 1e-3 relative carries its proof (helpers.check_full_size)
+        r = Hh.check_full_size(reference, sc, mode, tag=f"{name} {'reference' if mode else 'default'} binning")
+        assert r.num_rendered > 3 * P
+        del r
 
 
 @pytest.mark.parametrize("frac,factor", [(0.002, 30.0), (0.02, 8.0)])
@@ -284,7 +273,16 @@ def test_heavy_tailed_scene_at_1080p_against_the_reference_build(reference, frac
             Hh.assert_image_close(f"buffer[{ch}]", out["buffer"][ch], r.buffer[ch], scale=max(1.0, float(np.abs(r.buffer[ch]).max())), oracle_fwd=r)
         for k in ("means2D", "opacities", "shs", "features"):
             Hh.assert_grad_close(k, g[k], rg[k])
-        del out, g
+        # the big splats' rows go through the workgroup paths of emit_kernel and of the per-Gaussian row sum: their blend SUMS
+        # element-wise against the reference's atomics, exceptions beyond the counted budget proven (not only the chain's end)
+        gs2m_native.set_reference_binning(mode)
+        try:
+            sums = Hh.run_hip_sums(sc)
+        finally:
+            gs2m_native.set_reference_binning(False)
+        for k in ("means2D", "conics", "opacities", "colors", "features"):
+            Hh.assert_sum_close("sum:" + k, sums[k], rg[k].reshape(sums[k].shape), r, floor_frac=1e-4 if k == "conics" else 1e-5)
+        del out, g, sums
 
 
 @pytest.mark.parametrize("max_degree", [0, 1, 2])
