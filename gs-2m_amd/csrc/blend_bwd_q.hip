@@ -278,7 +278,12 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
             for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
             float gAn[KK];  // A operand of the NEXT block's colour . gradient product
 #pragma unroll
+#ifdef GS2M_BWDQ_OLD_GAN
             for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * GST + 4 * k] : 0.f;  // the last block has no successor
+#else
+            // (the last block has no successor: it reads its own rows again -- an address select instead of a branch per operand)
+            for (int k = 0; k < KK; k++) gAn[k] = gA[(16 * (b < 3 ? b + 1 : 3)) * GST + 4 * k];
+#endif
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
                 const int pi = (2 * b + h) * 4 + r;
