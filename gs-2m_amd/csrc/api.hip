@@ -262,9 +262,9 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
 
     if (R > 0) {
-        {   // the emit kernel also zeroes the tile sort's scratch, the tile ranges and the long-tile queue's counter
+        {   // the emit kernel also zeroes the tile sort's scratch and the tile ranges
             StageTimer t(ST_EMIT, s, &failed_stage);
-            ZeroJobs zj = {{nullptr, im.ranges_raw, im.bigq}, {0, tiles * 2, tiles + 2}};  // (the two queue heads: words 0 and tiles + 1)
+            ZeroJobs zj = {{nullptr, im.ranges_raw, nullptr}, {0, tiles * 2, 0}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
             gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, land_dev, zj, s);
         }
@@ -283,7 +283,6 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
-        HIP_TRY(gs2m_zero_async(im.bigq, (tiles + 2) * sizeof(uint32_t), s));
         land[GS2M_LAND_ROWS] = 1u;  // no instance, no row
     }
     DEBUG_CHECK();
@@ -538,8 +537,8 @@ int gs2m_raster_backward_rows_hint(long long dense_rows) {
 // table -> ranges, sorted values, the four quadrant lists and their rows and counts.
 int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_rec,
                          const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp, unsigned* qlist,
-                         unsigned* qrow, unsigned* qcount, unsigned* bigq, void* stream_) {
-    if (tiles < 0 || !ranges_raw || !ranges || !slot_sorted || !e_rec || !wave_rowbase || !point_list || !row_tmp || !qlist || !qrow || !qcount || !bigq) return GS2M_ERR_INVALID_ARG;
+                         unsigned* qrow, unsigned* qcount, void* stream_) {
+    if (tiles < 0 || !ranges_raw || !ranges || !slot_sorted || !e_rec || !wave_rowbase || !point_list || !row_tmp || !qlist || !qrow || !qcount) return GS2M_ERR_INVALID_ARG;
     BinningState b = {};
     b.slot_sorted = const_cast<uint32_t*>(slot_sorted); b.e_rec = reinterpret_cast<uint4*>(const_cast<unsigned*>(e_rec));
     b.point_list = point_list; b.sort_valA = row_tmp; b.qlist = reinterpret_cast<uint2*>(qlist); b.qrow = qrow;
@@ -547,10 +546,8 @@ int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges
     im.ranges_raw = const_cast<uint32_t*>(ranges_raw);
     im.ranges = reinterpret_cast<uint2*>(ranges);
     im.qcount = qcount;
-    im.bigq = bigq;
     GeomState g = {};
     g.wave_rowbase = const_cast<uint32_t*>(wave_rowbase);
-    HIP_TRY(gs2m_zero_async(bigq, (size_t)(tiles + 2) * sizeof(uint32_t), (hipStream_t)stream_));
     gs2m_launch_tile_sort((size_t)tiles, tiles, 1, b, im, g, (hipStream_t)stream_);  // (a one-row tile grid)
     HIP_TRY(hipGetLastError());
     return GS2M_OK;

@@ -82,7 +82,6 @@ ImageState gs2m_carve_image(char* base, size_t N, size_t tiles) {
     im.n_contrib = (uint32_t*)take(N * 4);
     im.ranges = (uint2*)take(tiles * sizeof(uint2));
     im.ranges_raw = (uint32_t*)take(tiles * 2 * sizeof(uint32_t));
-    im.bigq = (uint32_t*)take(2 * (tiles + 1) * sizeof(uint32_t));
     im.qcount = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.qlast = (uint32_t*)take(tiles * 4 * sizeof(uint32_t));
     im.total_bytes = off + GS2M_ALIGN;
@@ -212,7 +211,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_round_total;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch, the tile ranges, the long-tile queue
+    gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
 #pragma unroll
     for (int p = 0; p < 4; p++) s_th[p][threadIdx.x] = 0u;
     const int hb[4] = {hbits.x, hbits.y, hbits.z, hbits.w}, hs[4] = {hshift.x, hshift.y, hshift.z, hshift.w};

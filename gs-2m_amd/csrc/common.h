@@ -80,8 +80,6 @@ struct ImageState {
     uint32_t* n_contrib; // N
     uint2* ranges;       // tiles (written by the tile-sort kernel from ranges_raw)
     uint32_t* ranges_raw; // tiles * 2: per tile {~first position, last position + 1} as atomicMax targets of the tile sort's last pass; 0, 0 = untouched
-    uint32_t* bigq;      // 2 x (1 + tiles): two queues of tile ids, each headed by its length: tiles of 513 .. 1024 instances (a wave
-                         //     with 16 elements per lane sorts one), tiles beyond (a workgroup each) -- tile_sort.hip
     uint32_t* qcount;    // tiles * 4: entries in each quadrant list
     uint32_t* qlast;     // tiles * 4: entries up to and including the quadrant's last contributor (forward -> backward)
     size_t total_bytes;

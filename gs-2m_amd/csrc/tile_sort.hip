@@ -153,47 +153,47 @@ __device__ __forceinline__ void levels(uint32_t (&k)[E], uint32_t (&x)[E], int l
 
 __device__ __forceinline__ int skew(int p) { return p + (p >> 5); }  // LDS index of element p: conflict-free lane-major AND position-major access
 
-// One tile by one wave, in two halves so that a wave can have the NEXT tile's records in flight while it sorts this one:
-//   tile_fetch    the span's emission slots (coalesced: span position p = e * 64 + lane sits in register e of lane `lane` -- the
-//                 network sorts whatever arrangement it is given) and, through them, the 16-byte records (one gather each);
-//   tile_finish   staging in LDS, the network, ties, the sorted list and the four quadrant lists.
-template <int E>
-__device__ __forceinline__ void tile_fetch(uint4 (&rc)[E], const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
-                                           const uint4* __restrict__ e_rec, const int lane) {
-    uint32_t slot[E];
+// One tile by one wave: the span's emission slots (coalesced: span position p = e * 64 + lane sits in register e of lane `lane` --
+// the network sorts whatever arrangement it is given) and, through them, the 16-byte records (one gather each, 8 in flight per
+// lane); staging in LDS, the network, ties, the sorted list and the four quadrant lists.
+template <int E, int LE>
+__device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
+                                               const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
+                                               uint32_t* __restrict__ point_list, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
+                                               uint32_t* __restrict__ qcount, uint32_t* s_v, uint32_t* s_r, const int lane) {
+    uint32_t key[E], idx[E], rb[E];  // rb: first row of the emit wave that owns the element at span position e * 64 + lane
+    static_for<0, E / 8>([&](auto bc) {  // batches of 8 elements per lane: 32 registers of records in flight, whatever E
+        constexpr int e0 = 8 * decltype(bc)::value;
+        uint32_t slot[8];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const uint32_t p = (uint32_t)(e * GS2M_WAVE + lane);
-        slot[e] = p < n ? slot_sorted[start + p] : 0u;
-    }
+        for (int e = 0; e < 8; e++) {
+            const uint32_t p = (uint32_t)((e0 + e) * GS2M_WAVE + lane);
+            slot[e] = p < n ? slot_sorted[start + p] : 0u;
+        }
+        uint4 rc[8];  // {id | mask, relative first row, depth key, -}
 #pragma unroll
 #ifdef GS2M_KO_TS_GATHER  // timing only: the records read in span order (coalesced) instead of gathered by slot
-    for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * GS2M_WAVE + lane) < n ? e_rec[start + e * GS2M_WAVE + lane + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        for (int e = 0; e < 8; e++) rc[e] = (uint32_t)((e0 + e) * GS2M_WAVE + lane) < n ? e_rec[start + (e0 + e) * GS2M_WAVE + lane + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
 #else
-    for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * GS2M_WAVE + lane) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        for (int e = 0; e < 8; e++) rc[e] = (uint32_t)((e0 + e) * GS2M_WAVE + lane) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
 #endif
-}
-template <int E, int LE>
-__device__ __forceinline__ void tile_finish(const uint4 (&rc)[E], const int tile, const uint32_t start, const uint32_t n,
-                                            const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
-                                            uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
-                                            uint32_t* s_v, uint32_t* s_r, const int lane) {
-    uint32_t key[E], idx[E], rb[E];  // rb: first row of the emit wave that owns the element at span position e * 64 + lane
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const uint32_t p = (uint32_t)(e * GS2M_WAVE + lane);
-        key[e] = rc[e].z;  // (a real key is the bit pattern of a depth > 0.2: never all ones, the padding's key)
-        idx[e] = p;
-        // id | mask and the first row wait in LDS under their span position; the row's base (a dependent gather) is asked
-        // for now and added behind the sort: its latency disappears behind the network
-        s_v[skew((int)p)] = rc[e].x;
-        s_r[skew((int)p)] = rc[e].y;
+        static_for<0, 8>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const uint32_t p = (uint32_t)((e0 + e) * GS2M_WAVE + lane);
+            key[e0 + e] = rc[e].z;  // (a real key is the bit pattern of a depth > 0.2: never all ones, the padding's key)
+            idx[e0 + e] = p;
+            // id | mask and the first row wait in LDS under their span position; the row's base (a dependent gather) is asked
+            // for now and added behind the sort: its latency disappears behind the network
+            s_v[skew((int)p)] = rc[e].x;
+            s_r[skew((int)p)] = rc[e].y;
 #ifndef GS2M_KO_TS_ROWBASE
-        rb[e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
+            rb[e0 + e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
 #else
-        rb[e] = rc[e].x >> 6;
+            rb[e0 + e] = 0u;
 #endif
-    }
+        });
+        asm volatile("" ::: "memory");  // the next batch's loads stay behind this batch's staging (registers: one batch in flight)
+    });
 #ifndef GS2M_KO_TS_SORT
     // (the padding is spread over the lanes in this arrangement: every level runs)
     levels<E, LE, 1, false>(key, idx, lane, 0xFFFFFFFFu);
@@ -257,6 +257,29 @@ __device__ __forceinline__ void tile_finish(const uint4 (&rc)[E], const int tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS arrays are the next tile's from here on
 }
 
+// Which tile a one-wave workgroup takes: workgroup ids go round the 8 XCDs (each with its own L2), and the records a tile gathers are
+// 16 bytes out of a 64-byte sector whose other three records usually belong to the SAME Gaussian's instances in the neighbouring
+// tiles (emit_kernel writes a Gaussian's instances to consecutive slots).  So the four tiles of a 2 x 2 block run back to back on
+// ONE XCD: the sector one of them pulls in is in that L2 when the others ask for it (4 x 4 tiles since the measurement below).  -1: no tile (grid padding).
+#ifndef GS2M_TS_SUPER_LOG
+#define GS2M_TS_SUPER_LOG 2  // the block of tiles that shares an XCD is 2^LOG x 2^LOG tiles (measured: 1x1 82 us, 2x2 80, 4x4 73, 8x8 72)
+#endif
+__device__ __forceinline__ int tile_of_block(int b, int tiles_x, int tiles_y) {
+    constexpr int L = GS2M_TS_SUPER_LOG, SIDE = 1 << L, PER = SIDE * SIDE;
+    const int xcd = b & 7, j = b >> 3, sub = j & (PER - 1);
+    const int stx = (tiles_x + SIDE - 1) >> L, nsuper = stx * ((tiles_y + SIDE - 1) >> L);
+    const int S = (j >> (2 * L)) * 8 + xcd;
+    if (S >= nsuper) return -1;
+    const int tx = SIDE * (S % stx) + (sub & (SIDE - 1)), ty = SIDE * (S / stx) + (sub >> L);
+    if (tx >= tiles_x || ty >= tiles_y) return -1;
+    return ty * tiles_x + tx;
+}
+__host__ __device__ inline unsigned tile_grid(int tiles_x, int tiles_y) {
+    constexpr int L = GS2M_TS_SUPER_LOG, SIDE = 1 << L;
+    const size_t nsuper = (size_t)((tiles_x + SIDE - 1) >> L) * ((tiles_y + SIDE - 1) >> L);
+    return (unsigned)(((nsuper + 7) / 8) * 8 * SIDE * SIDE);
+}
+
 // identifyTileRanges (rasterizer_impl.cu:108-129): the tile sort's last pass recorded where the tile's run of instances starts
 // and ends (radix_sort.hip: range_raw); (0, 0) for an untouched tile, as the reference's memset leaves it
 __device__ __forceinline__ uint2 tile_range(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, int tile, int lane) {
@@ -266,95 +289,65 @@ __device__ __forceinline__ uint2 tile_range(const uint32_t* __restrict__ ranges_
     return range;
 }
 
-#ifndef GS2M_TS_TILES_PER_WAVE
-#define GS2M_TS_TILES_PER_WAVE 1
-#endif
-// One wave per GS2M_TS_TILES_PER_WAVE neighbouring tiles (1: measured -- with 2 or 3 the later tiles' records are in flight while the
-// first is sorted, but the 32 more registers per tile cost more occupancy than the overlap returns: 127 / 122 us against 83);
-// spans of up to 512 entries are sorted here (8 elements per lane), longer ones are queued for tile_sort_rest_kernel.
+// One wave per tile; spans of up to 512 entries are sorted here (8 elements per lane: 4 KB of LDS and ~45 registers per wave, i.e.
+// a full complement of waves per SIMD), longer ones are left to the two kernels below, which look at every tile's length themselves
+// (a queue of tile ids filled with one atomic per long tile cost 97 us at 2 M Gaussians, where EVERY tile is long: 8160 atomics on
+// one word).  (Two or three tiles per wave with the later tiles' records in flight while the first is sorted: 127 / 122 us against
+// 83 -- the extra registers cost more occupancy than the overlap returns.)
 __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ slot_sorted, const uint4* __restrict__ e_rec,
                                                             const uint32_t* __restrict__ wave_rowbase,
                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
-                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, uint32_t* q16,
-                                                            uint32_t* qbig, int tiles, int tiles_x, int tiles_y) {
-    constexpr int M = 64 * 8, TPW = GS2M_TS_TILES_PER_WAVE;
+                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y) {
+    constexpr int M = 64 * 8;
     __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
     const int lane = threadIdx.x;
-    // Which tile: workgroup ids go round the 8 XCDs (each with its own L2), and the records a tile gathers are 16 bytes out of a
-    // 64-byte sector whose other three records usually belong to the SAME Gaussian's instances in the neighbouring tiles
-    // (emit_kernel writes a Gaussian's instances to consecutive slots).  So the four tiles of a 2 x 2 block run back to back
-    // on ONE XCD: the sector one of them pulls in is in that L2 when the others ask for it.
-    int my_tile;
-    {
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, sub = j & 3;
-        const int stx = (tiles_x + 1) >> 1, nsuper = stx * ((tiles_y + 1) >> 1);
-        const int S = (j >> 2) * 8 + xcd;
-        if (S >= nsuper) return;
-        const int tx = 2 * (S % stx) + (sub & 1), ty = 2 * (S / stx) + (sub >> 1);
-        if (tx >= tiles_x || ty >= tiles_y) return;
-        my_tile = ty * tiles_x + tx;
+    const int tile = tile_of_block(blockIdx.x, tiles_x, tiles_y);
+    if (tile < 0) return;
+    const uint2 range = tile_range(ranges_raw, ranges, tile, lane);
+    const uint32_t n = range.y - range.x;
+    if (n == 0u) {
+        if (lane < 4) qcount[tile * 4 + lane] = 0u;
+    } else if (n <= 512u) {
+        sort_tile_wave<8, 3>(tile, range.x, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
     }
-    uint2 range[TPW];
-    uint32_t n[TPW];
-    uint4 rc[TPW][8];
-    static_for<0, TPW>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int tile = my_tile * TPW + t;
-        range[t] = make_uint2(0u, 0u);
-        n[t] = 0u;
-        if (tile < tiles) {
-            range[t] = tile_range(ranges_raw, ranges, tile, lane);
-            n[t] = range[t].y - range[t].x;
-            if (n[t] > 512u) {  // a longer span: another kernel's
-                if (lane == 0) {
-                    uint32_t* q = n[t] <= 1024u ? q16 : qbig;
-                    q[1u + atomicAdd(&q[0], 1u)] = (uint32_t)tile;
-                }
-                n[t] = 0u;
-            } else if (n[t] == 0u && lane < 4) {
-                qcount[tile * 4 + lane] = 0u;
-            }
-        }
-        tile_fetch<8>(rc[t], range[t].x, n[t], slot_sorted, e_rec, lane);  // (n == 0: nothing is read)
-    });
-    static_for<0, TPW>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if (n[t] != 0u)
-            tile_finish<8, 3>(rc[t], my_tile * TPW + t, range[t].x, n[t], wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
-    });
 }
 
-// ---- the queued tiles: spans of 513 .. 1024 entries by one wave each (16 elements per lane), longer spans by a workgroup each ----
-constexpr int BIG_LDS = 4096;
-__global__ void __launch_bounds__(256) tile_sort_rest_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
-                                                             const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
-                                                             uint32_t* __restrict__ point_list,
-                                                             uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
-                                                             uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                                             uint32_t* __restrict__ qcount, const uint32_t* __restrict__ q16,
-                                                             const uint32_t* __restrict__ qbig) {
+// ---- longer spans ---------------------------------------------------------------------------------------------------------------
+// 513 .. 1024 entries: one wave, 16 elements per lane (8 KB of LDS, 128 registers).  Launched over all tiles: a wave whose tile is
+// shorter or longer leaves at once (on the bench scene all of them; at 2 M Gaussians / 1080p every tile is sorted here).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+tile_sort_wave16_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted, const uint4* __restrict__ e_rec,
+                        const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
+                        uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y) {
     constexpr int M16 = 64 * 16, W16 = M16 + M16 / 32;
-    __shared__ uint32_t s_all[8 * W16 > 2 * BIG_LDS ? 8 * W16 : 2 * BIG_LDS];
+    __shared__ uint32_t s_v[W16], s_r[W16];
+    const int lane = threadIdx.x;
+    const int tile = tile_of_block(blockIdx.x, tiles_x, tiles_y);
+    if (tile < 0) return;
+    const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
+    const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
+    if (n <= 512u || n > 1024u) return;
+    sort_tile_wave<16, 4>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
+}
+
+// more than 1024 entries: a workgroup each (launched over all tiles as well)
+constexpr int BIG_LDS = 4096;
+__global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted,
+                                                            const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
+                                                            uint32_t* __restrict__ point_list,
+                                                            uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
+                                                            uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
+                                                            uint32_t* __restrict__ qcount) {
+    __shared__ uint32_t s_all[2 * BIG_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    {
-        const uint32_t n16 = q16[0];
-        uint32_t* s_v = s_all + wave * 2 * W16;
-        for (uint32_t k = blockIdx.x * 4 + wave; k < n16; k += gridDim.x * 4) {
-            const int tile = (int)q16[1u + k];
-            const uint2 range = ranges[tile];
-            uint4 rc[16];
-            tile_fetch<16>(rc, range.x, range.y - range.x, slot_sorted, e_rec, lane);
-            tile_finish<16, 4>(rc, tile, range.x, range.y - range.x, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_v + W16, lane);
-        }
-    }
     uint32_t* const s_key = s_all;
     uint32_t* const s_idx = s_all + BIG_LDS;
-    const uint32_t nbig = qbig[0];
-    for (uint32_t bq = blockIdx.x; bq < nbig; bq += gridDim.x) {
-        const int tile = (int)qbig[1u + bq];
-        const uint2 range = ranges[tile];
-        const uint32_t n = range.y - range.x, start = range.x;
+    {
+        const int tile = blockIdx.x;
+        const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
+        const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
+        if (n <= 1024u) return;
         // working arrays: LDS, or -- beyond its capacity -- the tile's own quadrant-list region (32 n bytes, written only at the end)
         const bool glob = n > (uint32_t)BIG_LDS;
         uint32_t* const K = glob ? reinterpret_cast<uint32_t*>(qlist + (size_t)4 * start) : s_key;
@@ -363,7 +356,6 @@ __global__ void __launch_bounds__(256) tile_sort_rest_kernel(const uint2* __rest
             if (glob) __threadfence_block();
             gs2m_sync();
         };
-        barrier();  // the previous tile's (and the wave phase's) LDS accesses are done
         for (uint32_t p = tid; p < n; p += 256) {
             K[p] = e_rec[slot_sorted[start + p]].z;
             I[p] = p;
@@ -430,15 +422,12 @@ __global__ void __launch_bounds__(256) tile_sort_rest_kernel(const uint2* __rest
 }  // namespace
 
 void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
-    static_assert(GS2M_TS_TILES_PER_WAVE == 1, "the 2 x 2 tile-to-workgroup mapping below is one tile per wave");
     if (tiles == 0) return;
-    uint32_t* q16 = im.bigq;
-    uint32_t* qbig = im.bigq + tiles + 1;
-    const size_t nsuper = (size_t)((tiles_x + 1) / 2) * ((tiles_y + 1) / 2);
-    tile_sort_wave_kernel<<<(unsigned)(((nsuper + 7) / 8) * 32), 64, 0, s>>>(
-        im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, q16, qbig, (int)tiles, tiles_x, tiles_y);
-    // tiles of more than 512 instances were queued (none on the bench scene: the workgroups find two empty queues)
-    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
-    tile_sort_rest_kernel<<<grid, 256, 0, s>>>(im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                               im.qcount, q16, qbig);
+    const unsigned grid = tile_grid(tiles_x, tiles_y);
+    tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
+                                              tiles_x, tiles_y);
+    // tiles of more than 512 instances (none on the bench scene: the waves of the two kernels leave at once)
+    tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y);
+    tile_sort_big_kernel<<<(unsigned)tiles, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
+                                                         im.qcount);
 }

@@ -83,7 +83,7 @@ def lib():
     L.gs2m_raster_backward_rows_hint.restype = i
     L.gs2m_raster_backward_rows_hint.argtypes = [C.c_longlong]
     L.gs2m_debug_tile_sort.restype = i
-    L.gs2m_debug_tile_sort.argtypes = [i] + [p] * 12
+    L.gs2m_debug_tile_sort.argtypes = [i] + [p] * 11
     L.gs2m_set_debug.restype = i
     L.gs2m_set_debug.argtypes = [i]
     L.gs2m_set_markers.restype = i

@@ -325,7 +325,7 @@ int gs2m_raster_backward_rows_hint(long long dense_rows);
 /* Test hook (tests/test_tile_sort_gpu.py): the per-tile (depth, id) sort + quadrant-list split on caller-made spans. */
 int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges, const unsigned* slot_sorted, const unsigned* e_rec,
                          const unsigned* wave_rowbase, unsigned* point_list, unsigned* row_tmp,
-                         unsigned* qlist, unsigned* qrow, unsigned* qcount, unsigned* bigq, void* stream);
+                         unsigned* qlist, unsigned* qrow, unsigned* qcount, void* stream);
 
 /* ---- per-stage timing with HIP events recorded on the launch stream (bench.py) ----
  * mode 0 = off, 1 = the two blend kernels only, 2 = every stage, 3 = the backward blend kernel only.  Setting the mode clears

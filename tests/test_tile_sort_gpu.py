@@ -41,16 +41,15 @@ def _run(lengths, max_tile, seed, tie_levels):
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.uint32).view(np.int32).reshape(-1).copy()).to(dev)
     t_raw, t_slot, t_erec, t_wrb = T(raw), T(slot), T(e_rec), T(wave_rowbase)
     Z = lambda k, fill=0: torch.full((k,), fill, dtype=torch.int32, device=dev)
-    o_rg, o_pl, o_tmp, o_ql, o_qr, o_qc, o_bq = Z(2 * tiles, -1), Z(nn), Z(nn), Z(8 * nn), Z(4 * nn), Z(4 * tiles, -1), Z(2 * (tiles + 1))
+    o_rg, o_pl, o_tmp, o_ql, o_qr, o_qc = Z(2 * tiles, -1), Z(nn), Z(nn), Z(8 * nn), Z(4 * nn), Z(4 * tiles, -1)
     L = gs2m_native.lib()
     rc = L.gs2m_debug_tile_sort(tiles, t_raw.data_ptr(), o_rg.data_ptr(), t_slot.data_ptr(), t_erec.data_ptr(), t_wrb.data_ptr(),
-                                o_pl.data_ptr(), o_tmp.data_ptr(), o_ql.data_ptr(), o_qr.data_ptr(), o_qc.data_ptr(), o_bq.data_ptr(),
+                                o_pl.data_ptr(), o_tmp.data_ptr(), o_ql.data_ptr(), o_qr.data_ptr(), o_qc.data_ptr(),
                                 gs2m_native.stream_ptr())
     gs2m_native.check(rc, "gs2m_debug_tile_sort")
     torch.cuda.synchronize()
     U = lambda t: t.cpu().numpy().view(np.uint32)
     rg, pl, ql, qr, qc = U(o_rg).reshape(tiles, 2), U(o_pl), U(o_ql).reshape(-1, 2), U(o_qr), U(o_qc).reshape(tiles, 4)
-    assert int(U(o_bq)[0]) == sum(1 for L_ in lengths if 512 < L_ <= 1024) and int(U(o_bq)[tiles + 1]) == sum(1 for L_ in lengths if L_ > 1024)
     for t, Ln in enumerate(lengths):
         lo = int(starts[t])
         if Ln == 0:
