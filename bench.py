@@ -493,6 +493,13 @@ def main():
             ms = float(t.item())
         return ms
 
+    # Python's cyclic collector: a full (generation-2) collection walks every tracked object of the process -- 36 ms with the ~170 k
+    # objects of `import torch` + this script (tools/stall_probe.py) -- and lands wherever the allocation counters trip, i.e. now and
+    # then inside a timed region of 0.25 s.  Everything alive at this point is set-up state that stays alive: moved to the permanent
+    # generation, later collections only look at what the loop itself creates (same results; `gs2m_train.train` does the same).
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(a.warmup):
         step()
     # The position rounds 1-3 timed at: right after the warm-up, i.e. inside the clock governor's ramp (sclk takes about half

@@ -425,6 +425,12 @@ int gs2m_set_reference_binning(int on) {
     return GS2M_OK;
 }
 
+int gs2m_set_tile_sort_policy(int policy) {
+    if (policy < -1 || policy > 512) return GS2M_ERR_INVALID_ARG;
+    gs2m_set_tile_sort_policy_impl(policy);
+    return GS2M_OK;
+}
+
 int gs2m_set_debug(int on) {
     g_debug = on ? 1 : 0;
     return GS2M_OK;

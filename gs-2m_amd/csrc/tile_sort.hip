@@ -19,6 +19,8 @@
 //   * longer spans are queued and sorted by a workgroup each: the same network over LDS (up to 4096 entries) or, beyond, over
 //     the tile's own (still unused) quadrant-list region in global memory -- slow, correct, exercised by the dense-scene tests.
 #include "common.h"
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -298,7 +300,8 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ slot_sorted, const uint4* __restrict__ e_rec,
                                                             const uint32_t* __restrict__ wave_rowbase,
                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
-                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y) {
+                                                            uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y,
+                                                            uint32_t wave_max /* <= 512: longer spans are another kernel's */) {
     constexpr int M = 64 * 8;
     __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
     const int lane = threadIdx.x;
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
     const uint32_t n = range.y - range.x;
     if (n == 0u) {
         if (lane < 4) qcount[tile * 4 + lane] = 0u;
-    } else if (n <= 512u) {
+    } else if (n <= wave_max) {
         sort_tile_wave<8, 3>(tile, range.x, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
     }
 }
@@ -331,14 +334,147 @@ tile_sort_wave16_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t*
     sort_tile_wave<16, 4>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
 }
 
-// more than 1024 entries: a workgroup each (launched over all tiles as well)
+// ---- a workgroup per tile, the span still in registers -------------------------------------------------------------------------------
+// Few tiles with long lists (a 777 x 581 training view: 1813 tiles of ~500 instances; 2 M Gaussians at 1080p: 8160 tiles of ~660) leave
+// a wave-per-tile kernel one or two waves per SIMD, each a serial chain of 16 gathers per lane and a 1024-element network.  Here
+// 256 lanes share a tile: element i = tid * E + e (E = 2, 4 or 8: up to 512, 1024, 2048 entries), every wave sorts its 64 E elements
+// with the network above, and the two merge levels that span the four waves exchange registers through LDS -- three exchanges in
+// all (the mirrored compare of either level and the stride-of-one-wave step of the last), everything else stays inside a wave.
+template <int E, bool TIE>
+__device__ __forceinline__ void cross_wave(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, const int partner, const bool mirrored, const bool lower,
+                                           uint32_t* s_xk, uint32_t* s_xi) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        s_xk[skew(tid * E + e)] = k[e];
+        s_xi[skew(tid * E + e)] = x[e];
+    }
+    gs2m_sync();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int pe = mirrored ? E - 1 - e : e;
+        const uint32_t ok = s_xk[skew(partner * E + pe)], ox = s_xi[skew(partner * E + pe)];
+        if constexpr (TIE) {
+            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
+            k[e] = take ? ok : k[e];
+            x[e] = take ? ox : x[e];
+        } else {
+            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+            const uint32_t nk = lower ? mn : mx;
+            x[e] = nk == k[e] ? x[e] : ox;
+            k[e] = nk;
+        }
+    }
+    gs2m_sync();  // the exchange arrays are rewritten by the next exchange
+}
+template <int E, int LE, bool TIE>
+__device__ __forceinline__ void network_wg(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, uint32_t* s_xk, uint32_t* s_xi) {
+    const int lane = tid & 63, wave = tid >> 6;
+    levels<E, LE, 1, TIE>(k, x, lane, 0xFFFFFFFFu);                                        // sorted runs of 64 E: one per wave
+    cross_wave<E, TIE>(k, x, tid, tid ^ 127, true, (wave & 1) == 0, s_xk, s_xi);            // level LE + 7: mirrored compare across a pair of waves
+    xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
+    cross_wave<E, TIE>(k, x, tid, tid ^ 255, true, wave < 2, s_xk, s_xi);                   // level LE + 8: across all four
+    cross_wave<E, TIE>(k, x, tid, tid ^ 64, false, (wave & 1) == 0, s_xk, s_xi);            //   stride of one wave
+    xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
+}
+
+constexpr int WG_MAX = 2048, WG_WORDS = WG_MAX + WG_MAX / 32;
+template <int E, int LE>
+__device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
+                                             const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
+                                             uint32_t* __restrict__ point_list, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
+                                             uint32_t* __restrict__ qcount, uint32_t* s_v, uint32_t* s_r, uint32_t* s_xk, uint32_t* s_xi, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t key[E], idx[E], rb[E];
+    {   // span position p = e * 256 + tid: coalesced slot loads, one 16-byte gather per element, all E in flight
+        uint32_t slot[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t p = (uint32_t)(e * 256 + tid);
+            slot[e] = p < n ? slot_sorted[start + p] : 0u;
+        }
+        uint4 rc[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * 256 + tid) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        static_for<0, E>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const uint32_t p = (uint32_t)(e * 256 + tid);
+            key[e] = rc[e].z;
+            idx[e] = p;
+            s_v[skew((int)p)] = rc[e].x;
+            s_r[skew((int)p)] = rc[e].y;
+            rb[e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
+        });
+    }
+    network_wg<E, LE, false>(key, idx, tid, s_xk, s_xi);
+#pragma unroll
+    for (int e = 0; e < E; e++) s_r[skew(e * 256 + tid)] += rb[e];  // (this thread parked it: LDS operations of one wave execute in order)
+    // equal depths anywhere in the sorted span (neighbours inside a lane, across lanes, across waves): span order = id order
+    bool tie = false;
+#pragma unroll
+    for (int e = 0; e + 1 < E; e++) tie |= (uint32_t)(tid * E + e + 1) < n && key[e] == key[e + 1];
+    s_xk[tid] = key[0];
+    gs2m_sync();
+    tie |= tid < 255 && (uint32_t)(tid * E + E) < n && key[E - 1] == s_xk[tid + 1];
+    if (gs2m_sync_or(tie) != 0) network_wg<E, LE, true>(key, idx, tid, s_xk, s_xi);  // (depth, position): a total order
+    // ids and rows of the sorted elements, parked under their sorted position in the exchange arrays (free now)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const bool real = (uint32_t)(tid * E + e) < n;
+        const uint32_t v = real ? s_v[skew((int)idx[e])] : 0u, r = real ? s_r[skew((int)idx[e])] : 0u;
+        s_xk[skew(tid * E + e)] = v;
+        s_xi[skew(tid * E + e)] = r;
+    }
+    gs2m_sync();
+    for (uint32_t k = (uint32_t)tid; k < n; k += 256) point_list[start + k] = s_xk[skew((int)k)];
+    // quadrant lists: wave q compacts quadrant q
+    const int q = wave;
+    uint2* out = qlist + (size_t)4 * start + (size_t)q * n;
+    uint32_t* orow = qrow + (size_t)4 * start + (size_t)q * n;
+    uint32_t run = 0;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t base = 0; base < n; base += GS2M_WAVE) {
+        const uint32_t k = base + (uint32_t)lane;
+        uint32_t v = 0, r = 0;
+        if (k < n) { v = s_xk[skew((int)k)]; r = s_xi[skew((int)k)]; }
+        const uint32_t mask = v >> GS2M_GID_BITS;
+        const bool hit = ((mask >> q) & 1u) != 0u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) {
+            const uint32_t o = run + (uint32_t)__popcll(m & lt);
+            out[o] = make_uint2(v, k);
+            orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
+        }
+        run += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) qcount[tile * 4 + q] = run;
+}
+
+// spans of wave_max + 1 .. 2048 entries (wave_max: what tile_sort_wave_kernel takes; launched over all tiles, a workgroup whose tile is
+// shorter or longer leaves at once)
+__global__ void __launch_bounds__(256) tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted,
+                                                           const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
+                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
+                                                           uint32_t* __restrict__ qcount, int tiles_x, int tiles_y, uint32_t wave_max) {
+    __shared__ uint32_t s_v[WG_WORDS], s_r[WG_WORDS], s_xk[WG_WORDS], s_xi[WG_WORDS];
+    const int tid = threadIdx.x;
+    const int tile = tile_of_block(blockIdx.x, tiles_x, tiles_y);
+    if (tile < 0) return;
+    const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
+    const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
+    if (n <= wave_max || n > (uint32_t)WG_MAX) return;
+    if (n <= 512u) sort_tile_wg<2, 1>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
+    else if (n <= 1024u) sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
+    else sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
+}
+
+// more than 2048 (or, in the old arrangement, 1024) entries: a workgroup each (launched over all tiles as well)
 constexpr int BIG_LDS = 4096;
 __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted,
                                                             const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
                                                             uint32_t* __restrict__ point_list,
                                                             uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
                                                             uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                                            uint32_t* __restrict__ qcount) {
+                                                            uint32_t* __restrict__ qcount, uint32_t big_min /* spans of more entries than this */) {
     __shared__ uint32_t s_all[2 * BIG_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* const s_key = s_all;
@@ -347,7 +483,7 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __re
         const int tile = blockIdx.x;
         const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
         const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
-        if (n <= 1024u) return;
+        if (n <= big_min) return;
         // working arrays: LDS, or -- beyond its capacity -- the tile's own quadrant-list region (32 n bytes, written only at the end)
         const bool glob = n > (uint32_t)BIG_LDS;
         uint32_t* const K = glob ? reinterpret_cast<uint32_t*>(qlist + (size_t)4 * start) : s_key;
@@ -421,13 +557,30 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __re
 
 }  // namespace
 
+static std::atomic<int> g_ts_policy{0};
+void gs2m_set_tile_sort_policy_impl(int policy) { g_ts_policy = policy; }
+
 void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
     if (tiles == 0) return;
     const unsigned grid = tile_grid(tiles_x, tiles_y);
+    // Who sorts which span.  Many tiles (a 1080p frame: 8160): a wave per tile fills the chip, spans of up to 512 entries stay with
+    // one wave.  Few tiles: the chip is filled by giving every tile a workgroup.  policy: 0 = this rule; > 0 = the wave kernel's
+    // limit, explicitly; -1 = the round-5 arrangement (one wave up to 1024 entries, 16 per lane), kept for comparison.
+    static const int env_policy = getenv("GS2M_TS_POLICY") ? atoi(getenv("GS2M_TS_POLICY")) : 0;  // (experiments)
+    const int set_policy = g_ts_policy.load(std::memory_order_relaxed), policy = set_policy != 0 ? set_policy : env_policy;
+    if (policy < 0) {
+        tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
+                                                  tiles_x, tiles_y, 512u);
+        tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y);
+        tile_sort_big_kernel<<<(unsigned)tiles, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
+                                                             im.qcount, 1024u);
+        return;
+    }
+    const uint32_t wave_max = policy > 0 ? (uint32_t)(policy > 512 ? 512 : policy) : (tiles >= 4096 ? 512u : 128u);
     tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
-                                              tiles_x, tiles_y);
-    // tiles of more than 512 instances (none on the bench scene: the waves of the two kernels leave at once)
-    tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y);
+                                              tiles_x, tiles_y, wave_max);
+    tile_sort_wg_kernel<<<grid, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y,
+                                             wave_max);
     tile_sort_big_kernel<<<(unsigned)tiles, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                                         im.qcount);
+                                                         im.qcount, (uint32_t)WG_MAX);
 }

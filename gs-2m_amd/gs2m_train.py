@@ -320,6 +320,12 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     stack = []
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
+    # Python's cyclic collector walks every tracked object of the process on a full collection (36 ms with the ~170 k objects torch's
+    # import leaves; tools/stall_probe.py), at moments of its own choosing: the set-up state goes to the permanent generation, so the
+    # collections inside the loop only look at what the loop creates.
+    import gc
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     for it in range(1, iterations + 1):
         gaussians.update_learning_rate(it)

@@ -1,12 +1,22 @@
 """csrc/tile_sort.hip on caller-made spans (gs2m_debug_tile_sort): every tile's span must come out in (depth, Gaussian id)
 order -- the order the reference's 45-bit radix sort of id-ordered keys produces inside a tile (rasterizer_impl.cu:288-296) --
 and the four quadrant lists / gradient rows must be the order-preserving split of it.  Spans of every length class (one wave
-with 8 or 16 elements per lane, a workgroup over LDS, a workgroup over global memory), with many exactly equal depths."""
+with 8 or 16 elements per lane, a workgroup with 2, 4 or 8 per lane, a workgroup over LDS, a workgroup over global memory), with many exactly equal depths."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[0, 512, -1], ids=["auto", "wave512", "round5"], autouse=True)
+def policy(request):
+    """every arrangement of who sorts which span (gs2m_set_tile_sort_policy): few tiles -> a workgroup from 129 entries on; a wave up to
+    512 and a workgroup beyond; the round-5 kernels"""
+    import gs2m_native
+    gs2m_native.set_tile_sort_policy(request.param)
+    yield request.param
+    gs2m_native.set_tile_sort_policy(0)
 
 
 def _run(lengths, max_tile, seed, tie_levels):
@@ -73,12 +83,12 @@ def _run(lengths, max_tile, seed, tie_levels):
 
 @pytest.mark.parametrize("tie_levels", [0, 7, 300])
 def test_one_wave_per_tile_up_to_512(tie_levels):
-    _run([0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 331, 427, 511, 512, 5, 0, 400], 512, 1 + tie_levels, tie_levels)
+    _run([0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 130, 255, 256, 257, 300, 331, 427, 511, 512, 5, 0, 400], 512, 1 + tie_levels, tie_levels)
 
 
 @pytest.mark.parametrize("tie_levels", [0, 7, 300])
 def test_one_wave_per_tile_up_to_1024(tie_levels):
-    _run([513, 1, 0, 700, 1023, 1024, 64, 900, 512, 600, 33], 1024, 11 + tie_levels, tie_levels)
+    _run([513, 1, 0, 700, 1023, 1024, 64, 900, 512, 600, 33, 1025, 1500, 2047, 2048], 2048, 11 + tie_levels, tie_levels)
 
 
 @pytest.mark.parametrize("tie_levels", [0, 5, 2000])
@@ -90,3 +100,4 @@ def test_many_tiles_like_a_frame():
     rng = np.random.default_rng(5)
     _run(list(rng.integers(250, 430, 3000)), 430, 31, 0)
     _run(list(rng.integers(0, 900, 500)), 900, 32, 40)
+    _run(list(rng.integers(200, 700, 4200)), 700, 33, 25)   # a big frame: the wave kernel keeps spans of up to 512
