@@ -426,7 +426,7 @@ int gs2m_set_reference_binning(int on) {
 }
 
 int gs2m_set_tile_sort_policy(int policy) {
-    if (policy < -1 || policy > 512) return GS2M_ERR_INVALID_ARG;
+    if (policy < 0 || policy > 2) return GS2M_ERR_INVALID_ARG;
     gs2m_set_tile_sort_policy_impl(policy);
     return GS2M_OK;
 }

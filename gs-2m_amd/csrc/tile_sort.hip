@@ -155,6 +155,37 @@ __device__ __forceinline__ void levels(uint32_t (&k)[E], uint32_t (&x)[E], int l
 
 __device__ __forceinline__ int skew(int p) { return p + (p >> 5); }  // LDS index of element p: conflict-free lane-major AND position-major access
 
+// ---- equal depths ------------------------------------------------------------------------------------------------------------------
+// The network orders by depth alone; the members of a run of equal depths must follow in span order (= Gaussian-id order: what the
+// reference's stable radix sort of id-ordered keys leaves, rasterizer_impl.cu:288-296).  Trained models hold coincident Gaussians --
+// a quarter of the tiles of a 420 k-Gaussian training view have such a pair (tools/c4_ts_clock.py) -- so the runs are settled where
+// they lie: with keys and span positions parked in sorted order (s_k, s_i), element i looks along its run and goes to
+// run start + the number of members with a smaller span position.  Linear in the run's length per member: coincident Gaussians come in
+// pairs; a tile whose instances ALL share one depth (the tests build such spans) still comes out right, in ~n^2 / lanes steps.
+template <int E>
+__device__ __forceinline__ void tie_positions(const uint32_t (&key)[E], const uint32_t (&idx)[E], uint32_t (&pos)[E], const int t, const uint32_t n,
+                                              const uint32_t* s_k, const uint32_t* s_i) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t i = (uint32_t)(t * E + e);
+        pos[e] = i;
+        if (i >= n) continue;
+        const uint32_t K = key[e], X = idx[e];
+        uint32_t a = i, cnt = 0;
+        for (uint32_t j = i; j > 0u;) {
+            j--;
+            if (s_k[skew((int)j)] != K) break;
+            a = j;
+            cnt += s_i[skew((int)j)] < X ? 1u : 0u;
+        }
+        for (uint32_t j = i + 1u; j < n; j++) {
+            if (s_k[skew((int)j)] != K) break;
+            cnt += s_i[skew((int)j)] < X ? 1u : 0u;
+        }
+        pos[e] = a + cnt;
+    }
+}
+
 // One tile by one wave: the span's emission slots (coalesced: span position p = e * 64 + lane sits in register e of lane `lane` --
 // the network sorts whatever arrangement it is given) and, through them, the 16-byte records (one gather each, 8 in flight per
 // lane); staging in LDS, the network, ties, the sorted list and the four quadrant lists.
@@ -202,8 +233,27 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
 #endif
 #pragma unroll
     for (int e = 0; e < E; e++) s_r[skew(e * GS2M_WAVE + lane)] += rb[e];
-    // ---- equal depths: span order = Gaussian-id order (rasterizer_impl.cu:288-296 sorts id-ordered keys stably) ----
-    // sorted element i = lane * E + e (the network's index space)
+    // ---- ids and rows of the sorted elements: picked up by span position (sorted element i = lane * E + e, the network's index space) ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t sv[E], sr[E];
+    auto pick_up = [&]() {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool real = (uint32_t)(lane * E + e) < n;  // (padding sorts behind every real element: idx < n for the first n)
+            sv[e] = real ? s_v[skew((int)idx[e])] : 0u;
+            sr[e] = real ? s_r[skew((int)idx[e])] : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto park = [&]() {  // parked again under their sorted position, read position-major below
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            s_v[skew(lane * E + e)] = sv[e];
+            s_r[skew(lane * E + e)] = sr[e];
+        }
+    };
+    pick_up();
+    // ---- equal depths (tie_positions above) ----
     bool tie = false;
 #pragma unroll
     for (int e = 0; e + 1 < E; e++) tie |= (uint32_t)(lane * E + e + 1) < n && key[e] == key[e + 1];
@@ -211,21 +261,23 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
         const uint32_t nxt = (uint32_t)__shfl_down((int)key[0], 1, 64);
         tie |= lane < 63 && (uint32_t)(lane * E + E) < n && key[E - 1] == nxt;
     }
-    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) levels<E, LE, 1, true>(key, idx, lane, 0xFFFFFFFFu);  // (depth, position): a total order
-    // ---- ids and rows of the sorted elements: picked up by position, parked again lane-major, read position-major ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint32_t sv[E], sr[E];
+    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // (wave-uniform)
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const bool real = (uint32_t)(lane * E + e) < n;  // (padding sorts behind every real element: idx < n for the first n)
-        sv[e] = real ? s_v[skew((int)idx[e])] : 0u;
-        sr[e] = real ? s_r[skew((int)idx[e])] : 0u;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = 0; e < E; e++) {  // (the staging arrays are free: their content is in sv / sr)
+            s_v[skew(lane * E + e)] = key[e];
+            s_r[skew(lane * E + e)] = idx[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t pos[E];
+        tie_positions<E>(key, idx, pos, lane, n, s_v, s_r);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        s_v[skew(lane * E + e)] = sv[e];
-        s_r[skew(lane * E + e)] = sr[e];
+        for (int e = 0; e < E; e++) {
+            s_v[skew((int)pos[e])] = sv[e];
+            s_r[skew((int)pos[e])] = sr[e];
+        }
+    } else {
+        park();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint2* out = qlist + (size_t)4 * start;
@@ -301,7 +353,7 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ wave_rowbase,
                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
                                                             uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y,
-                                                            uint32_t wave_max /* <= 512: longer spans are another kernel's */) {
+                                                            uint32_t wave_max /* 512: longer spans are another kernel's */) {
     constexpr int M = 64 * 8;
     __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
     const int lane = threadIdx.x;
@@ -342,48 +394,60 @@ tile_sort_wave16_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t*
 // all (the mirrored compare of either level and the stride-of-one-wave step of the last), everything else stays inside a wave.
 template <int E, bool TIE>
 __device__ __forceinline__ void cross_wave(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, const int partner, const bool mirrored, const bool lower,
-                                           uint32_t* s_xk, uint32_t* s_xi) {
+                                           uint32_t* s_x) {  // one exchange array: the keys go across first, then the positions
+    uint32_t ok[E], ox[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        s_xk[skew(tid * E + e)] = k[e];
-        s_xi[skew(tid * E + e)] = x[e];
-    }
+    for (int e = 0; e < E; e++) s_x[skew(tid * E + e)] = k[e];
     gs2m_sync();
 #pragma unroll
+    for (int e = 0; e < E; e++) ok[e] = s_x[skew(partner * E + (mirrored ? E - 1 - e : e))];
+    gs2m_sync();
+#pragma unroll
+    for (int e = 0; e < E; e++) s_x[skew(tid * E + e)] = x[e];
+    gs2m_sync();
+#pragma unroll
+    for (int e = 0; e < E; e++) ox[e] = s_x[skew(partner * E + (mirrored ? E - 1 - e : e))];
+    gs2m_sync();  // the exchange array is rewritten by the next exchange
+#pragma unroll
     for (int e = 0; e < E; e++) {
-        const int pe = mirrored ? E - 1 - e : e;
-        const uint32_t ok = s_xk[skew(partner * E + pe)], ox = s_xi[skew(partner * E + pe)];
         if constexpr (TIE) {
-            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
-            k[e] = take ? ok : k[e];
-            x[e] = take ? ox : x[e];
+            const bool take = lower ? (ok[e] < k[e] || (ok[e] == k[e] && ox[e] < x[e])) : (ok[e] > k[e] || (ok[e] == k[e] && ox[e] > x[e]));
+            k[e] = take ? ok[e] : k[e];
+            x[e] = take ? ox[e] : x[e];
         } else {
-            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+            const uint32_t mn = min(k[e], ok[e]), mx = max(k[e], ok[e]);
             const uint32_t nk = lower ? mn : mx;
-            x[e] = nk == k[e] ? x[e] : ox;
+            x[e] = nk == k[e] ? x[e] : ox[e];
             k[e] = nk;
         }
     }
-    gs2m_sync();  // the exchange arrays are rewritten by the next exchange
 }
 template <int E, int LE, bool TIE>
-__device__ __forceinline__ void network_wg(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, uint32_t* s_xk, uint32_t* s_xi) {
+__device__ __forceinline__ void network_wg(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, uint32_t* s_x) {
     const int lane = tid & 63, wave = tid >> 6;
     levels<E, LE, 1, TIE>(k, x, lane, 0xFFFFFFFFu);                                        // sorted runs of 64 E: one per wave
-    cross_wave<E, TIE>(k, x, tid, tid ^ 127, true, (wave & 1) == 0, s_xk, s_xi);            // level LE + 7: mirrored compare across a pair of waves
+    cross_wave<E, TIE>(k, x, tid, tid ^ 127, true, (wave & 1) == 0, s_x);            // level LE + 7: mirrored compare across a pair of waves
     xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
-    cross_wave<E, TIE>(k, x, tid, tid ^ 255, true, wave < 2, s_xk, s_xi);                   // level LE + 8: across all four
-    cross_wave<E, TIE>(k, x, tid, tid ^ 64, false, (wave & 1) == 0, s_xk, s_xi);            //   stride of one wave
+    cross_wave<E, TIE>(k, x, tid, tid ^ 255, true, wave < 2, s_x);                   // level LE + 8: across all four
+    cross_wave<E, TIE>(k, x, tid, tid ^ 64, false, (wave & 1) == 0, s_x);            //   stride of one wave
     xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
 }
 
-constexpr int WG_MAX = 2048, WG_WORDS = WG_MAX + WG_MAX / 32;
+constexpr int WG_MAX = 2048;
 template <int E, int LE>
 __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
                                              const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
                                              uint32_t* __restrict__ point_list, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                             uint32_t* __restrict__ qcount, uint32_t* s_v, uint32_t* s_r, uint32_t* s_xk, uint32_t* s_xi, const int tid) {
+                                             uint32_t* __restrict__ qcount, uint32_t* s_v, uint32_t* s_r, uint32_t* s_x, const int tid,
+                                             uint32_t* __restrict__ clk = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
+#ifdef GS2M_TS_CLOCK  // variant builds: where a tile's time goes (100 MHz wall clock ticks of thread 0 at the phase boundaries)
+    const unsigned long long c0 = wall_clock64();
+    int cphase = 0;
+#define TS_CLK() do { if (tid == 0 && clk) clk[16 * tile + (cphase++)] = (uint32_t)(wall_clock64() - c0); } while (0)
+#else
+#define TS_CLK() do {} while (0)
+#endif
     uint32_t key[E], idx[E], rb[E];
     {   // span position p = e * 256 + tid: coalesced slot loads, one 16-byte gather per element, all E in flight
         uint32_t slot[E];
@@ -394,7 +458,11 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
         }
         uint4 rc[E];
 #pragma unroll
+#ifdef GS2M_KO_TS_GATHER  // timing only
+        for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * 256 + tid) < n ? e_rec[start + e * 256 + tid + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+#else
         for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * 256 + tid) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+#endif
         static_for<0, E>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const uint32_t p = (uint32_t)(e * 256 + tid);
@@ -405,27 +473,63 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
             rb[e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
         });
     }
-    network_wg<E, LE, false>(key, idx, tid, s_xk, s_xi);
+    TS_CLK();  // 0: records staged (loads done)
+#ifndef GS2M_KO_TS_SORT
+    network_wg<E, LE, false>(key, idx, tid, s_x);
+#else
+    gs2m_sync();
+#endif
+    TS_CLK();  // 1: sorted
 #pragma unroll
     for (int e = 0; e < E; e++) s_r[skew(e * 256 + tid)] += rb[e];  // (this thread parked it: LDS operations of one wave execute in order)
-    // equal depths anywhere in the sorted span (neighbours inside a lane, across lanes, across waves): span order = id order
+    // ids and rows of the sorted elements: picked up by span position
+    uint32_t sv[E], sr[E];
+    auto pick_up = [&]() {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool real = (uint32_t)(tid * E + e) < n;
+            sv[e] = real ? s_v[skew((int)idx[e])] : 0u;
+            sr[e] = real ? s_r[skew((int)idx[e])] : 0u;
+        }
+    };
+    auto park = [&]() {  // parked again under their sorted position
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            s_v[skew(tid * E + e)] = sv[e];
+            s_r[skew(tid * E + e)] = sr[e];
+        }
+    };
+    gs2m_sync();  // (the row bases added above)
+    pick_up();
+    // equal depths anywhere in the sorted span (neighbours inside a lane, across lanes, across waves): tie_positions above
     bool tie = false;
 #pragma unroll
     for (int e = 0; e + 1 < E; e++) tie |= (uint32_t)(tid * E + e + 1) < n && key[e] == key[e + 1];
-    s_xk[tid] = key[0];
+    s_x[tid] = key[0];
     gs2m_sync();
-    tie |= tid < 255 && (uint32_t)(tid * E + E) < n && key[E - 1] == s_xk[tid + 1];
-    if (gs2m_sync_or(tie) != 0) network_wg<E, LE, true>(key, idx, tid, s_xk, s_xi);  // (depth, position): a total order
-    // ids and rows of the sorted elements, parked under their sorted position in the exchange arrays (free now)
+    tie |= tid < 255 && (uint32_t)(tid * E + E) < n && key[E - 1] == s_x[tid + 1];
+    if (gs2m_sync_or(tie) != 0) {  // (the barrier also closes the pick-up: the staging arrays are free)
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const bool real = (uint32_t)(tid * E + e) < n;
-        const uint32_t v = real ? s_v[skew((int)idx[e])] : 0u, r = real ? s_r[skew((int)idx[e])] : 0u;
-        s_xk[skew(tid * E + e)] = v;
-        s_xi[skew(tid * E + e)] = r;
+        for (int e = 0; e < E; e++) {
+            s_v[skew(tid * E + e)] = key[e];
+            s_r[skew(tid * E + e)] = idx[e];
+        }
+        gs2m_sync();
+        uint32_t pos[E];
+        tie_positions<E>(key, idx, pos, tid, n, s_v, s_r);
+        gs2m_sync();  // every look along a run is done: the arrays take the payload
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            s_v[skew((int)pos[e])] = sv[e];
+            s_r[skew((int)pos[e])] = sr[e];
+        }
+    } else {
+        park();
     }
+    TS_CLK();  // 2: ties settled
     gs2m_sync();
-    for (uint32_t k = (uint32_t)tid; k < n; k += 256) point_list[start + k] = s_xk[skew((int)k)];
+    TS_CLK();  // 3: payload in sorted order
+    for (uint32_t k = (uint32_t)tid; k < n; k += 256) point_list[start + k] = s_v[skew((int)k)];
     // quadrant lists: wave q compacts quadrant q
     const int q = wave;
     uint2* out = qlist + (size_t)4 * start + (size_t)q * n;
@@ -435,55 +539,38 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
     for (uint32_t base = 0; base < n; base += GS2M_WAVE) {
         const uint32_t k = base + (uint32_t)lane;
         uint32_t v = 0, r = 0;
-        if (k < n) { v = s_xk[skew((int)k)]; r = s_xi[skew((int)k)]; }
+        if (k < n) { v = s_v[skew((int)k)]; r = s_r[skew((int)k)]; }
         const uint32_t mask = v >> GS2M_GID_BITS;
         const bool hit = ((mask >> q) & 1u) != 0u;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+#ifndef GS2M_KO_TS_LISTS
         if (hit) {
             const uint32_t o = run + (uint32_t)__popcll(m & lt);
             out[o] = make_uint2(v, k);
             orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
         }
+#endif
         run += (uint32_t)__popcll(m);
     }
     if (lane == 0) qcount[tile * 4 + q] = run;
+    TS_CLK();  // 4: lists written (stores issued)
+#ifdef GS2M_TS_CLOCK
+    if (tid == 0 && clk) { clk[16 * tile + 14] = n; clk[16 * tile + 15] = (uint32_t)(c0 & 0xFFFFFFFFull); }
+#endif
 }
 
-// spans of wave_max + 1 .. 2048 entries (wave_max: what tile_sort_wave_kernel takes; launched over all tiles, a workgroup whose tile is
-// shorter or longer leaves at once)
-__global__ void __launch_bounds__(256) tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted,
-                                                           const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
-                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                                           uint32_t* __restrict__ qcount, int tiles_x, int tiles_y, uint32_t wave_max) {
-    __shared__ uint32_t s_v[WG_WORDS], s_r[WG_WORDS], s_xk[WG_WORDS], s_xi[WG_WORDS];
-    const int tid = threadIdx.x;
-    const int tile = tile_of_block(blockIdx.x, tiles_x, tiles_y);
-    if (tile < 0) return;
-    const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
-    const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
-    if (n <= wave_max || n > (uint32_t)WG_MAX) return;
-    if (n <= 512u) sort_tile_wg<2, 1>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
-    else if (n <= 1024u) sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
-    else sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_xk, s_xi, tid);
-}
-
-// more than 2048 (or, in the old arrangement, 1024) entries: a workgroup each (launched over all tiles as well)
+// more than 2048 entries: the same network over LDS (up to 4096 entries) or, beyond, over the tile's own (still unused) quadrant-list
+// region in global memory -- slow, correct, exercised by the dense-scene tests
 constexpr int BIG_LDS = 4096;
-__global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted,
-                                                            const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
-                                                            uint32_t* __restrict__ point_list,
-                                                            uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
-                                                            uint2* __restrict__ qlist, uint32_t* __restrict__ qrow,
-                                                            uint32_t* __restrict__ qcount, uint32_t big_min /* spans of more entries than this */) {
-    __shared__ uint32_t s_all[2 * BIG_LDS];
+__device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
+                                              const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
+                                              uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
+                                              uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
+                                              uint32_t* s_all /* 2 * BIG_LDS words */) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* const s_key = s_all;
     uint32_t* const s_idx = s_all + BIG_LDS;
     {
-        const int tile = blockIdx.x;
-        const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
-        const uint32_t start = ~raw.x, n = raw.y != 0u ? raw.y - start : 0u;
-        if (n <= big_min) return;
         // working arrays: LDS, or -- beyond its capacity -- the tile's own quadrant-list region (32 n bytes, written only at the end)
         const bool glob = n > (uint32_t)BIG_LDS;
         uint32_t* const K = glob ? reinterpret_cast<uint32_t*>(qlist + (size_t)4 * start) : s_key;
@@ -555,6 +642,52 @@ __global__ void __launch_bounds__(256) tile_sort_big_kernel(const uint32_t* __re
     }
 }
 
+
+// A workgroup per tile, in two launches: spans of up to 1024 entries (MAXE = 4: 13 KB of LDS and 80 registers, six workgroups per CU;
+// this launch also writes ranges[] -- it is the frame's first when it runs at all) and the longer ones (MAXE = 8; launched on every
+// frame).  A fixed grid walks the tiles: on a frame without such spans a launch costs what ~1000 workgroups cost to look at a few tile
+// ranges each.
+#ifndef GS2M_TS_WG_OCC
+#define GS2M_TS_WG_OCC 6
+#endif
+template <int MAXE>
+struct WgCfg {
+    static constexpr int kMax = 256 * MAXE, kWords = kMax + kMax / 32;
+    static constexpr int kLds = MAXE >= 8 ? (3 * kWords > 2 * BIG_LDS ? 3 * kWords : 2 * BIG_LDS) : 3 * kWords;
+};
+template <int MAXE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >= 8 ? 4 : GS2M_TS_WG_OCC, 8)))
+tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
+                    const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
+                    uint32_t* __restrict__ row_tmp, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
+                    int tiles_x, int tiles_y, uint32_t nblocks) {
+    constexpr int WORDS = WgCfg<MAXE>::kWords;
+    __shared__ uint32_t s_all[WgCfg<MAXE>::kLds];
+    uint32_t* const s_v = s_all, * const s_r = s_all + WORDS, * const s_x = s_all + 2 * WORDS;
+    const int tid = threadIdx.x;
+    for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {  // (gridDim.x is a multiple of 8: a workgroup stays on its XCD's tiles)
+        const int tile = tile_of_block((int)blk, tiles_x, tiles_y);
+        if (tile < 0) continue;
+        const uint2 raw = reinterpret_cast<const uint2*>(ranges_raw)[tile];
+        const uint32_t start = raw.y != 0u ? ~raw.x : 0u, n = raw.y != 0u ? raw.y - start : 0u;
+        if constexpr (MAXE < 8) {
+            if (ranges != nullptr) {
+                if (tid == 0) ranges[tile] = raw.y != 0u ? make_uint2(start, raw.y) : make_uint2(0u, 0u);
+                if (n == 0u && tid < 4) qcount[tile * 4 + tid] = 0u;
+            }
+            if (n == 0u || n > 1024u) continue;
+            if (n <= 256u) sort_tile_wg<1, 0>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            else if (n <= 512u) sort_tile_wg<2, 1>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            else sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+        } else {
+            if (n <= 1024u) continue;
+            if (n <= (uint32_t)WG_MAX) sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            else sort_tile_big(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, row_tmp, qlist, qrow, qcount, s_all);
+        }
+        gs2m_sync();  // the LDS arrays are the next tile's
+    }
+}
+
 }  // namespace
 
 static std::atomic<int> g_ts_policy{0};
@@ -563,24 +696,25 @@ void gs2m_set_tile_sort_policy_impl(int policy) { g_ts_policy = policy; }
 void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
     if (tiles == 0) return;
     const unsigned grid = tile_grid(tiles_x, tiles_y);
-    // Who sorts which span.  Many tiles (a 1080p frame: 8160): a wave per tile fills the chip, spans of up to 512 entries stay with
-    // one wave.  Few tiles: the chip is filled by giving every tile a workgroup.  policy: 0 = this rule; > 0 = the wave kernel's
-    // limit, explicitly; -1 = the round-5 arrangement (one wave up to 1024 entries, 16 per lane), kept for comparison.
+    // Who sorts which span.  A frame of many tiles (1080p: 8160) fills the chip with one wave per tile (8 elements per lane up to 512
+    // entries, 16 up to 1024: 4096 to 8192 tiles resident, each with all its record gathers in flight -- the kernels are bound by those
+    // gathers).  A frame of few tiles (a 777 x 581 training view: 1813) leaves such a kernel one or two waves per SIMD, each a serial
+    // chain of ~40 / ~90 us: there every tile gets a workgroup (27 + 18 us instead of 40 + 99 + 55 on that view; on 8160 tiles of 400 to
+    // 900 entries the workgroup kernels lose, 315 against 173 us: 1536 tiles resident instead of 4096).  policy: 0 = by tile count,
+    // 1 = workgroups, 2 = waves.
     static const int env_policy = getenv("GS2M_TS_POLICY") ? atoi(getenv("GS2M_TS_POLICY")) : 0;  // (experiments)
     const int set_policy = g_ts_policy.load(std::memory_order_relaxed), policy = set_policy != 0 ? set_policy : env_policy;
-    if (policy < 0) {
+    const bool waves = policy == 2 || (policy == 0 && tiles >= 2560);
+    const unsigned wg_grid = grid < 2048u ? grid : 2048u;  // (both multiples of 8)
+    if (waves) {
         tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
                                                   tiles_x, tiles_y, 512u);
         tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y);
-        tile_sort_big_kernel<<<(unsigned)tiles, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                                             im.qcount, 1024u);
-        return;
+    } else {
+        tile_sort_wg_kernel<4><<<wg_grid, 256, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
+                                                       im.qcount, tiles_x, tiles_y, grid);
     }
-    const uint32_t wave_max = policy > 0 ? (uint32_t)(policy > 512 ? 512 : policy) : (tiles >= 4096 ? 512u : 128u);
-    tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
-                                              tiles_x, tiles_y, wave_max);
-    tile_sort_wg_kernel<<<grid, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y,
-                                             wave_max);
-    tile_sort_big_kernel<<<(unsigned)tiles, 256, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                                         im.qcount, (uint32_t)WG_MAX);
+    // spans of more than 1024 entries: none on the bench scenes (the workgroups look at their tiles' ranges and leave)
+    tile_sort_wg_kernel<8><<<wg_grid < 1024u ? wg_grid : 1024u, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
+                                                                             b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid);
 }

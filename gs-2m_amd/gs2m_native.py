@@ -275,7 +275,7 @@ def set_sort_tickets(on):
 
 
 def set_tile_sort_policy(policy):
-    """0: by tile count (default); n > 0: one wave per tile up to n entries, a workgroup beyond; -1: the round-5 arrangement."""
+    """0: by tile count (default); 1: a workgroup per tile; 2: a wave per tile (spans of up to 1024 entries)."""
     check(lib().gs2m_set_tile_sort_policy(int(policy)), "gs2m_set_tile_sort_policy")
 
 

@@ -281,10 +281,9 @@ int gs2m_set_spin_wait(int on);
  * workgroup of a pass fits on the device at once.  Also: environment variable GS2M_SORT_TICKETS=1. */
 int gs2m_set_sort_tickets(int on);
 
-/* Which kernel puts a tile's span into (depth, id) order (csrc/tile_sort.hip).  0 (default): by the number of tiles -- a frame of
- * at least 4096 tiles keeps spans of up to 512 entries with one wave each, a smaller frame hands every span of more than 128 entries
- * to a workgroup; n > 0: one wave up to n (<= 512) entries, a workgroup beyond; -1: one wave up to 1024 entries (16 per lane), the
- * round-5 arrangement, kept for comparison.  Same results in every setting. */
+/* Which kernels put a tile's span into (depth, id) order (csrc/tile_sort.hip).  0 (default): by the number of tiles -- a frame of at
+ * least 2560 tiles gives every tile one wave (spans of up to 1024 entries), a smaller frame gives every tile a workgroup; 1: workgroups
+ * whatever the frame; 2: waves whatever the frame.  Spans of more than 1024 entries go to a workgroup in every setting.  Same results. */
 int gs2m_set_tile_sort_policy(int policy);
 
 /* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)

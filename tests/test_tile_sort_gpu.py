@@ -9,10 +9,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 512, -1], ids=["auto", "wave512", "round5"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "workgroups", "waves"], autouse=True)
 def policy(request):
-    """every arrangement of who sorts which span (gs2m_set_tile_sort_policy): few tiles -> a workgroup from 129 entries on; a wave up to
-    512 and a workgroup beyond; the round-5 kernels"""
+    """every arrangement of who sorts which span (gs2m_set_tile_sort_policy): by tile count; a workgroup per tile; a wave per tile"""
     import gs2m_native
     gs2m_native.set_tile_sort_policy(request.param)
     yield request.param
@@ -100,4 +99,4 @@ def test_many_tiles_like_a_frame():
     rng = np.random.default_rng(5)
     _run(list(rng.integers(250, 430, 3000)), 430, 31, 0)
     _run(list(rng.integers(0, 900, 500)), 900, 32, 40)
-    _run(list(rng.integers(200, 700, 4200)), 700, 33, 25)   # a big frame: the wave kernel keeps spans of up to 512
+    _run(list(rng.integers(200, 700, 4200)), 700, 33, 25)   # a big frame: one wave per tile
