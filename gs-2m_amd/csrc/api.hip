@@ -44,6 +44,7 @@ LandRing g_land[64];
 std::mutex g_land_mutex;
 thread_local uint64_t t_last_token = 0;  // (device + 1) << 40 | generation << 8 | slot; 0: none
 thread_local long long t_rows_hint = -1;  // gs2m_raster_backward_rows_hint: consumed by this thread's next backward
+thread_local long long t_units_hint = -1, t_units_from_token = -1;  // the heavy-unit count that travels with it
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 // mode 0: off; 1: the two blend kernels only; 2: every stage; 3: the backward blend kernel only (an event pair costs
@@ -207,13 +208,14 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     const uint32_t generation = ring.gen[slot].fetch_add(1) + 1;
     volatile uint32_t* land = ring.host + slot * kLandWords;
     uint32_t* land_dev = ring.dev + slot * kLandWords;
-    land[GS2M_LAND_R] = 0xFFFFFFFFu;  // a sentinel no count can take (R < 2^30)
+    land[GS2M_LAND_R] = 0xFFFFFFFFu;  // a sentinel no count can take (R < 2^29)
+    land[GS2M_LAND_HUNITS] = 0u;
     land[GS2M_LAND_PREFILTERED] = 0u;
-    land[GS2M_LAND_MAXTILE] = 0u;
     land[GS2M_LAND_ROWS] = 0u;
     t_last_token = ((uint64_t)(dev_id + 1) << 40) | ((uint64_t)(generation & 0xFFFFFFFFu) << 8) | slot;
 
     int R = 0;
+    uint32_t U = 0;  // heavy units (common.h)
     if (P > 0) {
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
@@ -249,24 +251,27 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             HIP_TRY(hipStreamSynchronize(s));  // nothing of this call is left in flight when the caller frees its buffers
             return GS2M_ERR_PREFILTERED;
         }
-        if (land[GS2M_LAND_R] >= (1u << 30)) return GS2M_ERR_UNSUPPORTED;  // slots, rows (4 per instance at most), list offsets, look-back words
+        // slots, list offsets, look-back words; gradient rows (4 per instance, heavy units padded to 64 instances) stay below the
+        // GS2M_ROWS_BIG bit
+        if (land[GS2M_LAND_R] >= (1u << 29) || land[GS2M_LAND_HUNITS] >= (1u << 22)) return GS2M_ERR_UNSUPPORTED;
         R = (int)land[GS2M_LAND_R];
+        U = land[GS2M_LAND_HUNITS];  // (published with num_rendered in one store)
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);
     const size_t Rn = R > 0 ? (size_t)R : 1;
     const size_t btemp = gs2m_binning_temp_bytes(Rn, tile_bits);
-    BinningState bsz = gs2m_carve_binning(nullptr, Rn, btemp);
+    BinningState bsz = gs2m_carve_binning(nullptr, Rn, btemp, U);
     char* bbase = binning_alloc(bsz.total_bytes, binning_user);
     if (!bbase) return GS2M_ERR_ALLOC;
-    BinningState b = gs2m_carve_binning(bbase, Rn, btemp);
+    BinningState b = gs2m_carve_binning(bbase, Rn, btemp, U);
 
     if (R > 0) {
         {   // the emit kernel also zeroes the tile sort's scratch and the tile ranges
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, im.ranges_raw, nullptr}, {0, tiles * 2, 0}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, land_dev, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, U, land_dev, zj, s);
         }
         if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: what the host was told against the emit kernel's own offsets
             uint32_t total = 0;
@@ -327,15 +332,26 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Rn = R > 0 ? (size_t)R : 1;
     GeomState g = gs2m_carve_geom(geom_buffer, (size_t)P);
-    BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    BinningState b = gs2m_carve_binning(binning_buffer, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)), 0);  // (no offset depends on the heavy units)
     ImageState im = gs2m_carve_image(image_buffer, N, tiles);
 
     // one partial-gradient row per (instance, quadrant), numbered densely over the view (binning.hip): `dense_rows` of them when
     // the caller passed the forward's count on (gs2m_raster_backward_rows_hint), 4 per instance at most otherwise
     const int rowf = gs2m_row_floats(feature_count);
     const long long hint = t_rows_hint;
+    long long units = hint >= 0 ? t_units_hint : -1;
     t_rows_hint = -1;
-    const size_t nrows = (hint >= 0 && (size_t)hint <= Rn * 4) ? (size_t)hint : Rn * 4;
+    t_units_hint = -1;
+    size_t nrows = 0;
+    if (hint >= 0 && (size_t)hint <= Rn * 10 + 256) {
+        nrows = (size_t)hint;
+    } else if (R > 0) {  // no count from the caller: the forward left it on the device (a blocking read)
+        uint32_t c[2] = {0u, 0u};
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(c, g.counters + GS2M_CNT_ROWS, sizeof(c), hipMemcpyDeviceToHost));
+        nrows = c[0];
+        units = c[1];
+    }
     const size_t rows_bytes = gs2m_align_up((nrows > 0 ? nrows : 1) * (size_t)rowf * sizeof(float));
     char* sbase = scratch_alloc(rows_bytes + 2 * GS2M_ALIGN, scratch_user);
     if (!sbase) return GS2M_ERR_ALLOC;
@@ -348,7 +364,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     }
     DEBUG_CHECK();
     {
-        StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);  // row sums + the per-Gaussian chain: one kernel
+        StageTimer tg(ST_GAUSSIAN_BWD, s, &failed_stage);  // row sums + the per-Gaussian chain: one kernel (+ the heavy units' sums ahead of it)
+        if (R > 0) gs2m_launch_heavy_reduce(rows, rowf, b, g, units, s);
         gs2m_launch_gaussian_bwd(P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, feature_count, g,
                                  rows, rowf, R > 0, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D,
@@ -489,7 +506,7 @@ int gs2m_debug_layout(int P, int R, int width, int height, gs2m_layout* out) {
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;
     const size_t Pn = P > 0 ? (size_t)P : 1, Rn = R > 0 ? (size_t)R : 1;
     GeomState g = gs2m_carve_geom(nullptr, Pn);
-    BinningState b = gs2m_carve_binning(nullptr, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)));
+    BinningState b = gs2m_carve_binning(nullptr, Rn, gs2m_binning_temp_bytes(Rn, (int)higher_msb((uint32_t)tiles)), 0);
     ImageState im = gs2m_carve_image(nullptr, N, tiles);
     out->geom_bytes = g.total_bytes;
     out->rec = (uint64_t)(uintptr_t)g.rec;
@@ -527,7 +544,10 @@ long long gs2m_raster_dense_rows(unsigned long long token) {
     for (;;) {
         if (ring.gen[slot].load() != generation) return -1;  // the slot has been handed to a later forward
         const uint32_t v = land[GS2M_LAND_ROWS];
-        if (v != 0u) return ring.gen[slot].load() == generation ? (long long)v - 1 : -1;
+        if (v != 0u) {
+            t_units_from_token = (long long)land[GS2M_LAND_HUNITS];
+            return ring.gen[slot].load() == generation ? (long long)v - 1 : -1;
+        }
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return -1;
     }
@@ -535,6 +555,8 @@ long long gs2m_raster_dense_rows(unsigned long long token) {
 
 int gs2m_raster_backward_rows_hint(long long dense_rows) {
     t_rows_hint = dense_rows;
+    t_units_hint = dense_rows >= 0 ? t_units_from_token : -1;  // (the forward's heavy-unit count came back with its row count)
+    t_units_from_token = -1;
     return GS2M_OK;
 }
 

@@ -7,9 +7,10 @@
 //   blockscan_kernel  one workgroup: num_rendered = the sum of the per-block instance counts the preprocess kernel left,
 //                 published to the host at once; their exclusive prefix (the reference's InclusiveSum at block granularity);
 //   emit_kernel   load-balanced expansion in INDEX order (a wave owns 64 consecutive Gaussians and writes 64 consecutive
-//                 slots per step; Gaussians over hundreds of tiles are expanded by the whole workgroup): tile id per slot,
-//                 exact ellipse-vs-8x8 test per instance -> 4-bit quadrant mask above the id, gradient rows numbered densely per
-//                 wave; counts the tile sort's digits;
+//                 slots per step): tile id per slot, exact ellipse-vs-8x8 test per instance -> 4-bit quadrant mask above the id,
+//                 gradient rows numbered densely per wave; counts the tile sort's digits;
+//   emit_heavy_kernel  the instances of HEAVY Gaussians (common.h: GS2M_HEAVY_TILES), a wave per unit of 64 instances: balanced
+//                 whatever the index order of the big splats;
 //   rowscan_kernel  exclusive prefix of the waves' row counts: rows are dense over the whole view (the backward's scratch is
 //                 sized by their number, published to the host);
 //   the stable 13-bit radix sort of (tile, slot) pairs (radix_sort.hip, two passes; its last pass records the tile ranges:
@@ -38,6 +39,8 @@ GeomState gs2m_carve_geom(char* base, size_t P) {
     g.gauss_rows = (uint32_t*)take(P * 4);
     g.block_tt = (uint32_t*)take(nb * 4);
     g.block_pref = (uint32_t*)take(nb * 4);
+    g.block_hu = (uint32_t*)take(nb * 4);
+    g.block_hupref = (uint32_t*)take(nb * 4);
     g.wave_rows = (uint32_t*)take(nw * 4);
     g.wave_rowbase = (uint32_t*)take(nw * 4);
     g.tile_hist = (uint32_t*)take(GS2M_HIST_COPIES * GS2M_HIST_COPY_WORDS * 4);
@@ -45,7 +48,7 @@ GeomState gs2m_carve_geom(char* base, size_t P) {
     return g;
 }
 
-BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes, size_t heavy_units) {
     BinningState b;
     size_t off = base ? (gs2m_align_up((size_t)(uintptr_t)base) - (size_t)(uintptr_t)base) : 0;
     auto take = [&](size_t bytes) {
@@ -64,6 +67,7 @@ BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes) {
     b.qrow = (uint32_t*)take(R * 4 * 4);
     b.temp = take(temp_bytes);
     b.temp_bytes = temp_bytes;
+    b.hrec = (HeavyUnit*)take(heavy_units * sizeof(HeavyUnit));
     b.total_bytes = off + GS2M_ALIGN;
     return b;
 }
@@ -149,15 +153,22 @@ __device__ __forceinline__ unsigned long long scan_1024_per_block(const uint32_t
 }
 
 // num_rendered and the block prefixes.  The workgroup that owns the last elements has the grand total: it tells the host.
-__global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restrict__ block_tt, size_t nblocks, uint32_t* __restrict__ block_pref,
+__global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restrict__ block_tt, const uint32_t* __restrict__ block_hu, size_t nblocks,
+                                                         uint32_t* __restrict__ block_pref, uint32_t* __restrict__ block_hupref,
                                                          uint32_t* __restrict__ counters, uint32_t* landing) {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_part[16];
     const unsigned long long t = scan_1024_per_block(block_tt, nblocks, s_w, s_part, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; });
+    gs2m_sync();
+    const unsigned long long u = scan_1024_per_block(block_hu, nblocks, s_w, s_part, [&](size_t b, uint32_t excl, uint32_t) { block_hupref[b] = excl; });
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        // saturated: a count beyond 2^32 cannot wrap past the caller's range check
-        publish(landing, GS2M_LAND_R, t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t);
-        counters[1] = (uint32_t)t;
+        // saturated: a count beyond 2^32 cannot wrap past the caller's range check.  num_rendered and the heavy units leave in ONE
+        // 8-byte store: the host that sees the first has the second
+        const uint32_t r32 = t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)t, u32 = u > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)u;
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(landing + GS2M_LAND_R), (unsigned long long)r32 | ((unsigned long long)u32 << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        counters[1] = r32;
+        counters[GS2M_CNT_HUNITS] = u32;
     }
 }
 
@@ -166,9 +177,11 @@ __global__ void __launch_bounds__(1024) rowscan_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ counters, uint32_t* landing) {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_part[16];
-    const unsigned long long total = scan_1024_per_block(wave_rows, nwaves, s_w, s_part, [&](size_t w, uint32_t excl, uint32_t) { wave_rowbase[w] = excl; });
+    // the heavy units' rows come first (4 x 64 per unit), the waves' dense rows behind them
+    const uint32_t heavy_rows = 4u * GS2M_UNIT * counters[GS2M_CNT_HUNITS];
+    const unsigned long long total = heavy_rows + scan_1024_per_block(wave_rows, nwaves, s_w, s_part, [&](size_t w, uint32_t excl, uint32_t) { wave_rowbase[w] = heavy_rows + excl; });
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        counters[2] = (uint32_t)total;
+        counters[GS2M_CNT_ROWS] = (uint32_t)total;
         publish(landing, GS2M_LAND_ROWS, (uint32_t)total + 1u);
     }
 }
@@ -184,14 +197,27 @@ __global__ void __launch_bounds__(1024) rowscan_kernel(const uint32_t* __restric
 // rowscan_kernel supplies afterwards (wave_rowbase) and tile_sort.hip adds: all rows of a Gaussian are one dense run and the
 // per-Gaussian backward streams them (gaussian_bwd.hip).  The digits of the tile ids are counted here for the tile sort
 // (radix_sort.hip: ext_hist), and the kernel zeroes that sort's scratch and the tile ranges on the side.
-// BIG SPLATS.  Gaussians with at least GS2M_BIG_TILES tiles are left out of the wave's own loop and expanded afterwards by
-// ALL FOUR waves of the workgroup together (64-instance chunks dealt round the waves: tests, keys and values in a first pass,
-// chunk totals scanned in LDS, row numbers in a second pass that reads the masks back).  Their rows follow the wave's small
-// rows -- small Gaussians in lane order, then the big ones in lane order -- and gauss_rows carries GS2M_ROWS_BIG for them,
-// which the per-Gaussian backward reads the same way.
+// HEAVY Gaussians (common.h: at least GS2M_HEAVY_TILES instances) are left out of the wave's loop: the wave only writes where their
+// units start (gauss_rows) and whose the units are (HeavyUnit), emit_heavy_kernel below expands them.
+
+// tile and quadrant-hit mask of instance t of a Gaussian: {tile id, mask}
+__device__ __forceinline__ uint2 expand_instance(uint32_t rmin, uint32_t rwid, uint32_t t, const float4 a /* x, y, A, B */, const float2 ct /* C, t2 */,
+                                                 int W, int H, int tiles_x) {
+    const uint32_t ry = t / rwid, rx = t - ry * rwid;
+    const uint32_t tx = (rmin & 0xFFFFu) + rx, ty = (rmin >> 16) + ry;
+    const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
+    uint32_t mask = gs2m_reaches_quads(a.x, a.y, a.z, a.w, ct.x, ct.y, (float)px0, (float)py0);
+    // quadrants outside the image have no pixels: no list entry, no gradient row
+    if (px0 + 8 >= W) mask &= 0x5u;
+    if (py0 + 8 >= H) mask &= 0x3u;
+    return make_uint2(ty * (uint32_t)tiles_x + tx, mask);
+}
+
 __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tiles_x, const uint2* __restrict__ rect,
-                                                   const uint32_t* __restrict__ block_pref, const float4* __restrict__ rec,
+                                                   const uint32_t* __restrict__ block_pref, const uint32_t* __restrict__ block_hupref,
+                                                   const float4* __restrict__ rec,
                                                    const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ keys_out, uint4* __restrict__ e_rec,
+                                                   HeavyUnit* __restrict__ hrec,
                                                    uint32_t* __restrict__ gauss_rows, uint32_t* __restrict__ wave_rows,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_hist, int npass, int4 hbits,
                                                    int4 hshift, ZeroJobs zero) {
@@ -200,29 +226,17 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
     __shared__ uint32_t s_rw[4][GS2M_WAVE];
     __shared__ uint32_t s_off[4][GS2M_WAVE];    // first emission slot of the Gaussian
-    __shared__ uint32_t s_cnt[4][GS2M_WAVE];    // its instances
     __shared__ uint32_t s_depth[4][GS2M_WAVE];  // its depth key
     __shared__ float4 s_geo[4][GS2M_WAVE];      // x, y, A, B
     __shared__ float2 s_ct[4][GS2M_WAVE];       // C, t2
     __shared__ uint32_t s_rc[4][GS2M_WAVE];     // gradient rows per Gaussian
-    __shared__ unsigned long long s_bigmask[4];  // per wave: lanes whose Gaussian is big
-    __shared__ uint32_t s_smallrows[4], s_wtot[4];
-    __shared__ uint32_t s_ctot[1024];  // rows per 64-instance chunk of the big Gaussian being expanded, then their exclusive prefix
-    __shared__ uint32_t s_round_total;
+    __shared__ uint32_t s_wtot[4], s_whu[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     gs2m_zero_jobs(zero, (size_t)i, (size_t)gridDim.x * 256);  // tile-sort scratch and the tile ranges
 #pragma unroll
     for (int p = 0; p < 4; p++) s_th[p][threadIdx.x] = 0u;
     const int hb[4] = {hbits.x, hbits.y, hbits.z, hbits.w}, hs[4] = {hshift.x, hshift.y, hshift.z, hshift.w};
-    // this workgroup's counts into one of GS2M_HIST_COPIES copies of the global histogram (one add per non-empty bin)
-    auto flush_hist = [&]() {
-        uint32_t* dst = tile_hist + (blockIdx.x & (GS2M_HIST_COPIES - 1)) * GS2M_HIST_COPY_WORDS;
-        for (int p = 0; p < npass; p++) {
-            const uint32_t c = s_th[p][threadIdx.x];
-            if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
-        }
-    };
     uint32_t cnt = 0, rmin = 0, rw = 1;
     if (i < P) {
         const uint2 r = rect[i];
@@ -231,56 +245,43 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         cnt = rw * (r.y >> 16);
         if (rw == 0u) rw = 1u;
     }
-    const uint32_t incl_all = wave_inclusive_scan_u32(cnt, lane);
-    if (lane == 63) s_wtot[wave] = incl_all;
-    if (cnt > 0) {
+    const bool heavy = cnt >= GS2M_HEAVY_TILES && cnt < (1u << 29);
+    const uint32_t hu = heavy ? (cnt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+    const uint32_t incl_all = wave_inclusive_scan_u32(cnt, lane), incl_hu = wave_inclusive_scan_u32(hu, lane);
+    if (lane == 63) { s_wtot[wave] = incl_all; s_whu[wave] = incl_hu; }
+    const uint32_t lcnt = heavy ? 0u : cnt;  // instances the wave expands itself
+    if (lcnt > 0) {
         const float4* r = rec + (size_t)i * REC_Q;
         s_geo[wave][lane] = r[REC_GEO0];
         s_ct[wave][lane] = make_float2(r[REC_GEO1].x, r[REC_BIN].w);
         s_depth[wave][lane] = depth_key[i];
     }
-    const bool big = cnt >= GS2M_BIG_TILES && cnt < (1u << 29);  // (4 rows per instance at most: the row count must stay below the GS2M_ROWS_BIG bit)
-    const uint32_t lcnt = big ? 0u : cnt;  // instances the wave expands itself
     const uint32_t incl = wave_inclusive_scan_u32(lcnt, lane);
     const uint32_t total = __shfl(incl, 63, 64);
     s_pref[wave][lane] = incl - lcnt;
     s_rmin[wave][lane] = rmin;
     s_rw[wave][lane] = rw;
-    s_cnt[wave][lane] = cnt;
     s_rc[wave][lane] = 0u;
-    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
-    if (lane == 0) s_bigmask[wave] = bigmask;
     gs2m_sync();
     // ---- emission offsets: the exclusive prefix sum of tiles_touched in index order (the reference's InclusiveSum,
-    // rasterizer_impl.cu:265-266) = the block's prefix + the waves in front + the lanes in front
-    uint32_t off = block_pref[blockIdx.x];
+    // rasterizer_impl.cu:265-266) = the block's prefix + the waves in front + the lanes in front; the heavy units likewise
+    uint32_t off = block_pref[blockIdx.x], ustart = block_hupref[blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; w++)
-        if (w < wave) off += s_wtot[w];
+        if (w < wave) { off += s_wtot[w]; ustart += s_whu[w]; }
     off += incl_all - cnt;
+    ustart += incl_hu - hu;
     s_off[wave][lane] = off;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) counters[0] = off + cnt;  // num_rendered (debug mode compares it with what the host was told)
+    if (heavy) {
+        gauss_rows[i] = GS2M_ROWS_BIG | ustart;
+        for (uint32_t j = 0; j < hu; j++) {
+            hrec[ustart + j].gid = (uint32_t)i;
+            hrec[ustart + j].off = off;
+        }
+    }
     const uint32_t gid0 = (uint32_t)blockIdx.x * 256u;
-    // tile and quadrant-hit mask of instance t of the Gaussian parked at [w][lo]; writes its key at `slot` and counts its digits
-    auto expand = [&](int w, int lo, uint32_t t, uint32_t slot) -> uint32_t {
-        const uint32_t rwid = s_rw[w][lo];
-        const uint32_t ry = t / rwid, rx = t - ry * rwid;
-        const uint32_t rm = s_rmin[w][lo];
-        const uint32_t tx = (rm & 0xFFFFu) + rx, ty = (rm >> 16) + ry;
-        const float4 a = s_geo[w][lo];
-        const float2 ct = s_ct[w][lo];
-        const int px0 = (int)tx * GS2M_TILE, py0 = (int)ty * GS2M_TILE;
-        uint32_t mask = gs2m_reaches_quads(a.x, a.y, a.z, a.w, ct.x, ct.y, (float)px0, (float)py0);
-        // quadrants outside the image have no pixels: no list entry, no gradient row
-        if (px0 + 8 >= W) mask &= 0x5u;
-        if (py0 + 8 >= H) mask &= 0x3u;
-        const uint32_t key = ty * (uint32_t)tiles_x + tx;
-        keys_out[slot] = key;
-        for (int p = 0; p < npass; p++) atomicAdd(&s_th[p][(key >> hs[p]) & ((1u << hb[p]) - 1u)], 1u);
-        return mask;
-    };
-    gs2m_sync();  // s_off of the other waves' Gaussians (the big path reads them)
-    uint32_t rows_run = 0;  // gradient rows of the wave's own (small) instances so far
+    uint32_t rows_run = 0;  // gradient rows of the wave's own instances so far
     for (uint32_t k = 0; k < total; k += GS2M_WAVE) {
         const uint32_t j = k + lane;
         uint32_t pc = 0, slot = 0, mask = 0;
@@ -288,10 +289,13 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         if (j < total) {
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
-                if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always (a big Gaussian has an empty range: never found)
+                if (s_pref[wave][lo + step] <= j) lo += step;  // lo + step <= 63 always (a heavy Gaussian has an empty range: never found)
             const uint32_t t = j - s_pref[wave][lo];
             slot = s_off[wave][lo] + t;
-            mask = expand(wave, lo, t, slot);
+            const uint2 km = expand_instance(s_rmin[wave][lo], s_rw[wave][lo], t, s_geo[wave][lo], s_ct[wave][lo], W, H, tiles_x);
+            mask = km.y;
+            keys_out[slot] = km.x;
+            for (int p = 0; p < npass; p++) atomicAdd(&s_th[p][(km.x >> hs[p]) & ((1u << hb[p]) - 1u)], 1u);
             pc = (uint32_t)__popc(mask);
             if (pc) atomicAdd(&s_rc[wave][lo], pc);
         }
@@ -300,89 +304,78 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         if (j < total) e_rec[slot] = make_uint4((gid0 + (uint32_t)(wave * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), rows_run + pin - pc, s_depth[wave][lo], 0u);
         rows_run += __shfl(pin, 63, 64);
     }
-    if (i < P && !big) gauss_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
-    if (lane == 0) s_smallrows[wave] = rows_run;
+    if (i < P && !heavy) gauss_rows[i] = s_rc[wave][lane];  // LDS operations of one wave execute in order: the adds are done
     const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
-    if (gs2m_sync_or(bigmask != 0ull) == 0) {  // no big Gaussian in this workgroup (the common case)
-        if (lane == 0 && (size_t)wave_id * GS2M_WAVE < (size_t)P) wave_rows[wave_id] = rows_run;
-        flush_hist();
-        return;
+    if (lane == 0 && (size_t)wave_id * GS2M_WAVE < (size_t)P) wave_rows[wave_id] = rows_run;
+    gs2m_sync();
+    // this workgroup's digit counts into one of GS2M_HIST_COPIES copies of the global histogram (one add per non-empty bin)
+    uint32_t* dst = tile_hist + (blockIdx.x & (GS2M_HIST_COPIES - 1)) * GS2M_HIST_COPY_WORDS;
+    for (int p = 0; p < npass; p++) {
+        const uint32_t c = s_th[p][threadIdx.x];
+        if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
     }
-    // ---- the workgroup's big Gaussians, one after the other, all four waves on each ----
-    for (int w = 0; w < 4; w++) {
-        unsigned long long m = s_bigmask[w];
-        uint32_t bigrows = 0;  // rows of wave w's earlier big Gaussians
-        while (m != 0ull) {
-            const int lo = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const uint32_t bcnt = s_cnt[w][lo], boff = s_off[w][lo];
-            const uint32_t first_row = s_smallrows[w] + bigrows;
-            const uint32_t chunks = (bcnt + GS2M_WAVE - 1) / GS2M_WAVE;
-            uint32_t done_rows = 0;  // rows of the rounds before this one
-            for (uint32_t c0 = 0; c0 < chunks; c0 += 1024) {  // rounds of at most 1024 chunks (s_ctot)
-                const uint32_t c1 = min(chunks, c0 + 1024u);
-                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // first pass: tests, keys and values, rows per chunk
-                    const uint32_t t = c * GS2M_WAVE + lane;
-                    uint32_t pc = 0;
-                    if (t < bcnt) {
-                        const uint32_t mask = expand(w, lo, t, boff + t);
-                        e_rec[boff + t] = make_uint4((gid0 + (uint32_t)(w * GS2M_WAVE + lo)) | (mask << GS2M_GID_BITS), 0u, s_depth[w][lo], 0u);
-                        pc = (uint32_t)__popc(mask);
-                    }
-                    pc = wave_inclusive_scan_u32(pc, lane);
-                    if (lane == 63) s_ctot[c - c0] = pc;
-                }
-                gs2m_sync();
-                if (wave == 0) {  // exclusive prefix over the round's chunk totals, 16 per lane
-                    uint32_t v[16], sum = 0;
+}
+
+// One wave per heavy unit: instances 64 (u - first unit) .. + 63 of the Gaussian the unit belongs to.  Slot = the Gaussian's first
+// slot + the instance number (index order, as everything else); gradient row of the instance = GS2M_ROWS_BIG | 256 u + 4 lane (four
+// rows reserved per instance; HeavyUnit::pop says how many are used).
+__global__ void __launch_bounds__(256) emit_heavy_kernel(uint32_t units, int W, int H, int tiles_x, const uint2* __restrict__ rect, const float4* __restrict__ rec,
+                                                         const uint32_t* __restrict__ depth_key, const uint32_t* __restrict__ gauss_rows,
+                                                         uint32_t* __restrict__ keys_out, uint4* __restrict__ e_rec, HeavyUnit* __restrict__ hrec,
+                                                         uint32_t* __restrict__ tile_hist, int npass, int4 hbits, int4 hshift) {
+    __shared__ uint32_t s_th[4][256];
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const uint32_t idx = lane * 16 + e;
-                        v[e] = idx < c1 - c0 ? s_ctot[idx] : 0u;
-                        sum += v[e];
-                    }
-                    const uint32_t inc = wave_inclusive_scan_u32(sum, lane);
-                    uint32_t run = inc - sum;
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const uint32_t idx = lane * 16 + e;
-                        if (idx < c1 - c0) s_ctot[idx] = run;
-                        run += v[e];
-                    }
-                    if (lane == 63) s_round_total = inc;
-                }
-                gs2m_sync();
-                for (uint32_t c = c0 + wave; c < c1; c += 4) {  // second pass: first rows (the masks are read back: this thread wrote them)
-                    const uint32_t t = c * GS2M_WAVE + lane;
-                    const uint32_t pc = t < bcnt ? (uint32_t)__popc(e_rec[boff + t].x >> GS2M_GID_BITS) : 0u;
-                    const uint32_t pin = wave_inclusive_scan_u32(pc, lane);
-                    if (t < bcnt) reinterpret_cast<uint32_t*>(e_rec + boff + t)[1] = first_row + done_rows + s_ctot[c - c0] + pin - pc;
-                }
-                done_rows += s_round_total;
-                gs2m_sync();  // s_ctot is rewritten by the next round / the next Gaussian
-            }
-            if (threadIdx.x == 0) gauss_rows[blockIdx.x * 256 + w * GS2M_WAVE + lo] = done_rows | GS2M_ROWS_BIG;
-            bigrows += done_rows;
+    for (int p = 0; p < 4; p++) s_th[p][threadIdx.x] = 0u;
+    gs2m_sync();
+    const int hb[4] = {hbits.x, hbits.y, hbits.z, hbits.w}, hs[4] = {hshift.x, hshift.y, hshift.z, hshift.w};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x * 4u + (uint32_t)wave;
+    if (u < units) {
+        const uint32_t gid = hrec[u].gid, off = hrec[u].off;  // (wave-uniform)
+        const uint32_t ustart = gauss_rows[gid] & ~GS2M_ROWS_BIG;
+        const uint2 r = rect[gid];
+        const uint32_t rw = r.y & 0xFFFFu, cnt = rw * (r.y >> 16);
+        const float4* rq = rec + (size_t)gid * REC_Q;
+        const float4 geo = rq[REC_GEO0];
+        const float2 ct = make_float2(rq[REC_GEO1].x, rq[REC_BIN].w);
+        const uint32_t dk = depth_key[gid];
+        const uint32_t t = (u - ustart) * GS2M_UNIT + (uint32_t)lane;
+        uint32_t pc = 0;
+        if (t < cnt) {
+            const uint2 km = expand_instance(r.x, rw, t, geo, ct, W, H, tiles_x);
+            keys_out[off + t] = km.x;
+            for (int p = 0; p < npass; p++) atomicAdd(&s_th[p][(km.x >> hs[p]) & ((1u << hb[p]) - 1u)], 1u);
+            e_rec[off + t] = make_uint4(gid | (km.y << GS2M_GID_BITS), GS2M_ROWS_BIG | (4u * (u * GS2M_UNIT + (uint32_t)lane)), dk, 0u);
+            pc = (uint32_t)__popc(km.y);
         }
-        if (threadIdx.x == 0 && ((size_t)blockIdx.x * 4 + w) * GS2M_WAVE < (size_t)P) wave_rows[(size_t)blockIdx.x * 4 + w] = s_smallrows[w] + bigrows;
+        hrec[u].pop[lane] = (uint8_t)pc;
     }
-    flush_hist();  // (a barrier closes the last round above: every count is in)
+    gs2m_sync();
+    uint32_t* dst = tile_hist + (blockIdx.x & (GS2M_HIST_COPIES - 1)) * GS2M_HIST_COPY_WORDS;
+    for (int p = 0; p < npass; p++) {
+        const uint32_t c = s_th[p][threadIdx.x];
+        if (c) atomicAdd(&dst[p * 256 + threadIdx.x], c);
+    }
 }
 
 }  // namespace
 
 void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s) {
     const size_t nb = (size_t)(P + 255) / 256;
-    blockscan_kernel<<<(unsigned)((nb + 1023) / 1024 > 0 ? (nb + 1023) / 1024 : 1), 1024, 0, s>>>(g.block_tt, nb, g.block_pref, g.counters, landing);
+    blockscan_kernel<<<(unsigned)((nb + 1023) / 1024 > 0 ? (nb + 1023) / 1024 : 1), 1024, 0, s>>>(g.block_tt, g.block_hu, nb, g.block_pref, g.block_hupref, g.counters,
+                                                                                                  landing);
 }
 
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t* landing,
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t heavy_units, uint32_t* landing,
                       const ZeroJobs& zero, hipStream_t s) {
     int npass = 0, bits[4], shift[4];
     gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
-    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.rec, g.depth_key, b.keys_unsorted, b.e_rec, g.gauss_rows, g.wave_rows,
-                                                g.counters, g.tile_hist, npass, make_int4(bits[0], bits[1], bits[2], bits[3]),
-                                                make_int4(shift[0], shift[1], shift[2], shift[3]), zero);
+    const int4 hbits = make_int4(bits[0], bits[1], bits[2], bits[3]), hshift = make_int4(shift[0], shift[1], shift[2], shift[3]);
+    emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.block_hupref, g.rec, g.depth_key, b.keys_unsorted, b.e_rec, b.hrec,
+                                                g.gauss_rows, g.wave_rows, g.counters, g.tile_hist, npass, hbits, hshift, zero);
+    if (heavy_units > 0u)
+        emit_heavy_kernel<<<(heavy_units + 3u) / 4u, 256, 0, s>>>(heavy_units, W, H, tiles_x, g.rect, g.rec, g.depth_key, g.gauss_rows, b.keys_unsorted, b.e_rec,
+                                                                  b.hrec, g.tile_hist, npass, hbits, hshift);
     const size_t nw = (size_t)(P + 63) / 64;
     rowscan_kernel<<<(unsigned)((nw + 1023) / 1024 > 0 ? (nw + 1023) / 1024 : 1), 1024, 0, s>>>(g.wave_rows, nw, g.wave_rowbase, g.counters, landing);
 }

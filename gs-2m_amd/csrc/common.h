@@ -27,11 +27,23 @@
 // the binned values carry the instance's quadrant-hit mask above the Gaussian id
 #define GS2M_GID_BITS 28
 #define GS2M_GID_MASK 0x0FFFFFFFu
-// A Gaussian with at least this many tile instances is "big": fill_kernel expands it with the whole workgroup and the
-// per-Gaussian backward sums its rows with the whole workgroup; its entry of GeomState::gauss_rows carries GS2M_ROWS_BIG
-// (rows < 2^31: a big Gaussian has fewer than 2^29 instances, fill_kernel's test)
-#define GS2M_BIG_TILES 512u
+// HEAVY Gaussians: at least this many tile instances.  A wave of the emit kernel and of the per-Gaussian backward owns 64 consecutive
+// Gaussians; trained models keep their big splats together in index order (the initial points, whole densification generations), so
+// one wave would expand thousands of instances and add up tens of thousands of gradient rows while the rest of the chip waits.
+// Heavy Gaussians are taken out of those waves: their instances are cut into UNITS of 64 (a Gaussian owns ceil(instances / 64) whole
+// units, numbered in index order through the block scan), a wave per unit expands them (emit_heavy_kernel), every instance of a unit
+// has 4 gradient rows reserved (rows 256 u .. 256 u + 255: the heavy rows come first, the waves' dense rows follow), a wave per unit
+// adds the rows up in the backward (heavy_reduce_kernel) and the Gaussian's thread adds its units' sums.  GeomState::gauss_rows of a
+// heavy Gaussian = GS2M_ROWS_BIG | its first unit.  (48: above every Gaussian of the bench clouds, whose largest covers 36 tiles.)
+#define GS2M_HEAVY_TILES 48u
 #define GS2M_ROWS_BIG 0x80000000u
+#define GS2M_UNIT 64u
+struct HeavyUnit {      // 80 bytes per unit, at the end of the binning buffer
+    uint32_t gid;       // the Gaussian the unit belongs to
+    uint32_t off;       // first emission slot of that Gaussian
+    uint32_t pad[2];
+    uint8_t pop[GS2M_UNIT];  // gradient rows (set quadrant bits) of each instance of the unit: rows 256 u + 4 k .. + pop[k] - 1 are written
+};
 
 // per (instance, quadrant) partial-gradient row produced by the blend backward (floats):
 // 0 mx, 1 my, 2 |mx|, 3 |my|, 4 cxx, 5 cxy, 6 cyy, 7 dopacity, 8..10 dcolor, 11.. dfeature
@@ -51,9 +63,11 @@ struct GeomState {
     uint8_t* clamped;        // P
     float* sh_dir;           // P * 9: d(SH colour)/d(view direction) of a visible Gaussian, {dRdx, dRdy, dRdz}[rgb] (preprocess -> gaussian_bwd)
     uint32_t* counters;      // 64 u32 (counters[0] = num_rendered as fill_kernel's offsets add up: debug mode compares)
-    uint32_t* gauss_rows;    // P: gradient rows of each Gaussian (| GS2M_ROWS_BIG), written by fill_kernel
+    uint32_t* gauss_rows;    // P: gradient rows of each Gaussian, or GS2M_ROWS_BIG | first unit of a heavy one (emit_kernel)
     uint32_t* block_tt;      // ceil(P / 256): tiles_touched summed over blocks of 256 Gaussians (preprocess kernel)
     uint32_t* block_pref;    // ceil(P / 256): exclusive prefix of block_tt (scan kernel): first emission offset of a block
+    uint32_t* block_hu;      // ceil(P / 256): heavy units of the block's Gaussians (preprocess kernel)
+    uint32_t* block_hupref;  // ceil(P / 256): exclusive prefix of block_hu (scan kernel)
     uint32_t* wave_rows;     // ceil(P / 64): gradient rows of each wave of 64 consecutive Gaussians (fill_kernel)
     uint32_t* wave_rowbase;  // ceil(P / 64): exclusive prefix of wave_rows (rowscan_kernel): first gradient row of the wave
     uint32_t* tile_hist;     // GS2M_HIST_COPIES x 1024: the tile sort's digit histograms, counted by emit_kernel (zeroed by the preprocess kernel)
@@ -73,6 +87,7 @@ struct BinningState {
     uint32_t* qrow;          // 4R: gradient row of each list entry (parallel to qlist)
     char* temp;              // radix sort scratch
     size_t temp_bytes;
+    HeavyUnit* hrec;         // U heavy units (behind everything else: no other offset depends on U)
     size_t total_bytes;
 };
 struct ImageState {
@@ -226,7 +241,7 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
 
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
 GeomState gs2m_carve_geom(char* base, size_t P);
-BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes);
+BinningState gs2m_carve_binning(char* base, size_t R, size_t temp_bytes, size_t heavy_units);
 size_t gs2m_binning_temp_bytes(size_t R, int tile_bits);
 ImageState gs2m_carve_image(char* base, size_t N, size_t tiles);
 
@@ -253,12 +268,15 @@ hipError_t gs2m_radix_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* 
 void gs2m_radix_plan(int total_bits, int* npass, int bits[4], int shift[4]);
 void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr, size_t* words);
 
-// words the host reads back through a mapped pinned block (api.hip): [0] num_rendered, [1] prefiltered violation flag,
-// [2] unused, [3] dense gradient rows + 1 (0 = not landed yet)
+// words the host reads back through a mapped pinned block (api.hip): [0] num_rendered and [1] heavy units (ONE 8-byte store: the
+// second is there when the first is), [2] prefiltered violation flag, [3] gradient rows + 1 (0 = not landed yet)
 #define GS2M_LAND_R 0
-#define GS2M_LAND_PREFILTERED 1
-#define GS2M_LAND_MAXTILE 2
+#define GS2M_LAND_HUNITS 1
+#define GS2M_LAND_PREFILTERED 2
 #define GS2M_LAND_ROWS 3
+// GeomState::counters: [0] num_rendered as the emit kernel's offsets add up (debug mode), [1] num_rendered, [2] gradient rows, [3] heavy units
+#define GS2M_CNT_ROWS 2
+#define GS2M_CNT_HUNITS 3
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -270,8 +288,11 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
 // binning.hip: blockscan (publishes num_rendered; block prefixes of tiles_touched), emit (instances in index order: tile keys,
 // quadrant masks, gradient-row numbering, the tile sort's digit counts) + rowscan (first gradient row of every wave)
 void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s);
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t* landing,
-                      const ZeroJobs& zero, hipStream_t s);
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t heavy_units,
+                      uint32_t* landing, const ZeroJobs& zero, hipStream_t s);
+// gaussian_bwd.hip: the rows of every heavy unit added up into the unit's first row (before gaussian_bwd_kernel); heavy_units < 0:
+// not known on the host (a fixed grid reads the count on the device)
+void gs2m_launch_heavy_reduce(float* rows, int rowf, const BinningState& b, const GeomState& g, long long heavy_units, hipStream_t s);
 // tile_sort.hip: every tile's span (stable radix sort by tile: index order) sorted by (depth, id) on chip, then split into the four
 // quadrant lists; writes ranges[] from ranges_raw
 void gs2m_set_tile_sort_policy_impl(int policy);

@@ -61,9 +61,6 @@ struct ReduceLds {
     float4 s_row[4][GS2M_WAVE * RQ];  // one window per wave: 64 rows x RQ float4, row-major
     float4 s_sum[256 * RQ];           // the result: RQ float4 per Gaussian of the workgroup
     uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE];
-    uint32_t s_bigrow[4][GS2M_WAVE], s_bigcnt[4][GS2M_WAVE];
-    unsigned long long s_bigmask[4];
-    float4 s_part[256];
 };
 template <int RQ>
 __device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase,
@@ -71,26 +68,17 @@ __device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __rest
     constexpr int MAXQ = RQ, rq = RQ;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t cnt = 0, bigcnt = 0;
+    uint32_t cnt = 0;
     if (i < P) cnt = gauss_rows[i];
-    // big Gaussians (binning.hip: GS2M_ROWS_BIG): their rows follow the wave's small rows; this wave's stream leaves them out
-    // and the whole workgroup sums them afterwards
-    const bool big = (cnt & GS2M_ROWS_BIG) != 0u;
-    if (big) {
-        bigcnt = cnt & ~GS2M_ROWS_BIG;
-        cnt = 0;
-    }
+    // heavy Gaussians (common.h: GS2M_ROWS_BIG | first unit): their rows are not part of the wave's run; heavy_reduce_kernel below
+    // has added them up per unit, the Gaussian's thread adds the units' sums (gaussian_bwd_kernel)
+    if ((cnt & GS2M_ROWS_BIG) != 0u) cnt = 0;
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's (small) Gaussians
-    const uint32_t bincl = wave_inclusive_scan_u32(bigcnt, lane);
+    const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's Gaussians
     const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
     const uint32_t wb = wave_id * GS2M_WAVE < (size_t)P ? wave_rowbase[wave_id] : 0u;  // the wave's first row (binning.hip: rowscan_kernel)
     L.s_excl[wave][lane] = incl - cnt;
     L.s_cnt[wave][lane] = cnt;
-    L.s_bigrow[wave][lane] = big ? wb + total + (bincl - bigcnt) : 0u;  // first row of a big Gaussian
-    L.s_bigcnt[wave][lane] = bigcnt;
-    const unsigned long long bigmask = __builtin_amdgcn_ballot_w64(big);
-    if (lane == 0) L.s_bigmask[wave] = bigmask;
     const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
     const bool worker = g < G;
     uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
@@ -182,45 +170,49 @@ __device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __rest
         if (w + 2 <= nwin) consume(w + 2, a2);
         load_window(w + 5, a2);
     }
-    if (gs2m_sync_or(bigmask != 0ull) == 0) return;  // no big Gaussian in this workgroup (the common case); the barrier publishes s_sum
-    // ---- big Gaussians: thousands of rows each (a splat over hundreds of tiles).  The whole workgroup sums one such run, NT
-    // threads x 8 float4 in flight.  Thread t < NT takes float4 t, t + NT, ... of the run -- NT is a multiple of the row's
-    // float4 count, so a thread stays on one channel quad -- and the partials are added in thread order: a fixed order.
-    constexpr int NT = (256 / rq) * rq;  // threads that take part (255 at rq = 5)
-    const int tid = threadIdx.x;
-    for (int w2 = 0; w2 < 4; w2++) {
-        unsigned long long m = L.s_bigmask[w2];
-        while (m != 0ull) {
-            const int lo = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const uint32_t nrows = L.s_bigcnt[w2][lo];
-            const float4* r4b = reinterpret_cast<const float4*>(rows) + (size_t)L.s_bigrow[w2][lo] * rq;
-            const uint32_t nq4 = nrows * (uint32_t)rq;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < NT) {
-                for (uint32_t q0 = (uint32_t)tid; q0 < nq4; q0 += 8u * NT) {
-                    float4 v[8];
+}
+
+// ---- heavy Gaussians: one wave per unit of 64 instances = 256 reserved rows, of which HeavyUnit::pop says which are written ----
+// Lane l < NT takes float4 l, l + NT, ... of the unit's rows -- NT is a multiple of the row's float4 count, so a lane stays on one
+// channel quad -- and the lanes' partials are added in lane order: a fixed order.  The unit's sum replaces its first row.
+template <int RQ>
+__global__ void __launch_bounds__(256) heavy_reduce_kernel(float* __restrict__ rows, const HeavyUnit* __restrict__ hrec, const uint32_t* __restrict__ counters) {
+    constexpr int NT = (GS2M_WAVE / RQ) * RQ, RPL = NT / RQ /* rows per load */, NLOAD = (4 * (int)GS2M_UNIT + RPL - 1) / RPL;
+    __shared__ float4 s_part[4][GS2M_WAVE];
+    __shared__ uint8_t s_pop[4][GS2M_UNIT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t units = counters[GS2M_CNT_HUNITS];
+    for (uint32_t u = blockIdx.x * 4u + (uint32_t)wave; u < units; u += gridDim.x * 4u) {
+        s_pop[wave][lane] = hrec[u].pop[lane];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (one wave: LDS operations execute in order)
+        float4* const r4 = reinterpret_cast<float4*>(rows) + (size_t)u * (4 * GS2M_UNIT) * RQ;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < NT) {
+            const int c = lane % RQ, r0 = lane / RQ;
+#pragma unroll 1
+            for (int l0 = 0; l0 < NLOAD; l0 += 8) {
+                float4 v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const uint32_t q = q0 + (uint32_t)e * NT;
-                        v[e] = q < nq4 ? r4b[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                for (int e = 0; e < 8; e++) {
+                    const int r = (l0 + e) * RPL + r0;  // row of the unit: instance r >> 2, its (r & 3)-th row
+                    const bool ok = l0 + e < NLOAD && r < 4 * (int)GS2M_UNIT && (uint32_t)(r & 3) < (uint32_t)s_pop[wave][r >> 2];
+                    v[e] = ok ? r4[r * RQ + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
-                }
+                for (int e = 0; e < 8; e++) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
             }
-            L.s_part[tid] = acc;
-            gs2m_sync();
-            if (tid < rq) {  // channel quad tid: the partials of threads tid, tid + rq, ... in that order
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = tid; k < NT; k += rq) {
-                    const float4 v = L.s_part[k];
-                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                }
-                L.s_sum[(w2 * GS2M_WAVE + lo) * rq + tid] = t;
-            }
-            gs2m_sync();
         }
+        s_part[wave][lane] = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < RQ) {  // channel quad `lane`: the partials of lanes lane, lane + RQ, ... in that order
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = lane; k < NT; k += RQ) {
+                const float4 v = s_part[wave][k];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            r4[lane] = t;  // (every load of this wave has returned: the partials depend on them)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -231,7 +223,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ vm,
     const float* __restrict__ proj, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
-    const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase, const uint8_t* __restrict__ clamped,
+    const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ wave_rowbase,
+    const uint8_t* __restrict__ clamped,
     const float* __restrict__ sh_dir, const float* __restrict__ rows /* nullptr: nothing was rendered, every sum is zero */,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
@@ -257,6 +250,19 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
         }
         gs2m_sync();  // the sums are in registers: the LDS block may be overwritten
+        const int hi = blockIdx.x * 256 + threadIdx.x;
+        const uint32_t gr = hi < P ? gauss_rows[hi] : 0u;
+        if ((gr & GS2M_ROWS_BIG) != 0u) {  // a heavy Gaussian: the sums of its units (heavy_reduce_kernel), in unit order
+            const uint32_t u0 = gr & ~GS2M_ROWS_BIG, nu = (tiles_touched[hi] + GS2M_UNIT - 1u) / GS2M_UNIT;
+            const float4* r4 = reinterpret_cast<const float4*>(rows);
+            for (uint32_t j = 0; j < nu; j++) {
+#pragma unroll
+                for (int q = 0; q < RQ; q++) {
+                    const float4 v = r4[(size_t)(u0 + j) * (4 * GS2M_UNIT) * RQ + q];
+                    acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                }
+            }
+        }
     }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;
@@ -507,7 +513,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
 #define GS2M_GB(LDS, RQ)                                                                                                \
     gaussian_bwd_kernel<LDS, RQ><<<(P + 255) / 256, 256, 0, s>>>(                                                       \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
-        projmatrix, campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.gauss_rows, g.wave_rowbase, g.clamped,     \
+        projmatrix, campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.gauss_rows, g.tiles_touched, g.wave_rowbase, g.clamped, \
         g.sh_dir, have_rows ? rows : nullptr, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, \
         dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures)
 #define GS2M_GBQ(LDS)                                                                                                   \
@@ -523,4 +529,16 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
     if (lds) { GS2M_GBQ(true) } else { GS2M_GBQ(false) }
 #undef GS2M_GBQ
 #undef GS2M_GB
+}
+
+void gs2m_launch_heavy_reduce(float* rows, int rowf, const BinningState& b, const GeomState& g, long long heavy_units, hipStream_t s) {
+    if (heavy_units == 0 || rows == nullptr) return;
+    // known on the host: a wave per unit; otherwise a fixed grid that reads the count on the device (and leaves at once without units)
+    const unsigned grid = heavy_units > 0 ? (unsigned)((heavy_units + 3) / 4 < 8192 ? (heavy_units + 3) / 4 : 8192) : 512u;
+    switch (rowf >> 2) {
+        case 3: heavy_reduce_kernel<3><<<grid, 256, 0, s>>>(rows, b.hrec, g.counters); break;
+        case 4: heavy_reduce_kernel<4><<<grid, 256, 0, s>>>(rows, b.hrec, g.counters); break;
+        case 5: heavy_reduce_kernel<5><<<grid, 256, 0, s>>>(rows, b.hrec, g.counters); break;
+        default: heavy_reduce_kernel<6><<<grid, 256, 0, s>>>(rows, b.hrec, g.counters); break;
+    }
 }

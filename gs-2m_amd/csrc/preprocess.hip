@@ -58,13 +58,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float* __restrict__ features, const float* __restrict__ vm, const float* __restrict__ pm,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int tiles_x, int tiles_y, int shrink, int* __restrict__ radii, int* __restrict__ observe_zero, float4* __restrict__ rec,
-    uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint32_t* __restrict__ block_tt,
+    uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint32_t* __restrict__ block_tt, uint32_t* __restrict__ block_hu,
     uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clamped, float* __restrict__ sh_dir, ZeroJobs zero) {
     // SH rows go through LDS (common.h: gs2m_stage_sh); other M fall back to direct per-thread loads.
     // (the block's blend records are parked in the same LDS afterwards: 256 x 36 floats)
     __shared__ __align__(16) float s_sh[SH_LDS ? 256 * 49 : 256 * 45];  // (afterwards: 256 x 36 floats of records + 256 x 9 of sh_dir)
     __shared__ uint8_t s_seen[256];  // the thread's Gaussian has a radius: its record is stored
     __shared__ uint32_t s_tt[4];     // tiles_touched summed per wave: the block's total is the binning's block sum (binning.hip)
+    __shared__ uint32_t s_hu[4];     // heavy units per wave (common.h: GS2M_HEAVY_TILES)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // The thread's own inputs are requested BEFORE the block stages its SH rows: the staging ends in a barrier, and loads
     // issued behind it would cost a second exposed memory round trip (the kernel is latency bound at 12 waves per CU).
@@ -298,6 +299,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     {   // the block's instance count: what the binning adds up in front of a block instead of running a scan over P
         const uint32_t ws = wave_inclusive_scan_u32(out_tt, (int)(threadIdx.x & 63));
         if ((threadIdx.x & 63) == 63) s_tt[threadIdx.x >> 6] = ws;
+        uint32_t hu = out_tt >= GS2M_HEAVY_TILES && out_tt < (1u << 29) ? (out_tt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) hu += __shfl_xor(hu, d, 64);
+        if ((threadIdx.x & 63) == 0) s_hu[threadIdx.x >> 6] = hu;
     }
     // The block's 256 records are one contiguous 32-KB run of `rec`: they leave through LDS (row stride 36 floats:
     // conflict-free 16-B writes) as fully coalesced float4 stores -- a thread storing its own record writes seven 16-B
@@ -309,7 +314,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
     for (int k = 0; k < REC_Q; k++) s_rec[threadIdx.x * 9 + k] = rq[k];
     s_seen[threadIdx.x] = out_radius > 0 ? 1 : 0;
-    if (threadIdx.x == 0) block_tt[blockIdx.x] = s_tt[0] + s_tt[1] + s_tt[2] + s_tt[3];  // (a barrier lies between the writes and this read)
+    if (threadIdx.x == 0) {  // (a barrier lies between the writes and these reads)
+        block_tt[blockIdx.x] = s_tt[0] + s_tt[1] + s_tt[2] + s_tt[3];
+        block_hu[blockIdx.x] = s_hu[0] + s_hu[1] + s_hu[2] + s_hu[3];
+    }
     float* s_sd = s_sh + 256 * 36;  // the block's 256 x 9 direction derivatives: one contiguous 9-KB run of `sh_dir`
     if (colors_precomp == nullptr) {
 #pragma unroll
@@ -381,7 +389,7 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
                                                            shs, shs_rest, cov3D_precomp, colors_precomp, features, viewmatrix,      \
                                                            projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x,        \
                                                            focal_y, tiles_x, tiles_y, shrink, radii, observe_zero, g.rec,             \
-                                                           g.tiles_touched, g.rect, g.block_tt, g.depth_key, g.clamped, g.sh_dir, zero)
+                                                           g.tiles_touched, g.rect, g.block_tt, g.block_hu, g.depth_key, g.clamped, g.sh_dir, zero)
     // split SH (shs = DC, shs_rest = the other 15 coefficients) exists in the LDS-staged form only: api.hip checks
     const bool lds = colors_precomp == nullptr && shs != nullptr && M == 16 &&
                      (shs_rest ? (((uintptr_t)shs_rest) & 15) == 0 : (((uintptr_t)shs) & 15) == 0);

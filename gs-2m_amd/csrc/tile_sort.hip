@@ -15,7 +15,8 @@
 //     equal neighbours (rare, wave-uniform) it is run again with (depth, position) as the key -- positions are in id order;
 //   * ids and rows wait in LDS under their span position and are picked up in sorted order, then ballots give every instance
 //     its place in each of the four quadrant lists with coalesced stores; the gradient row of a list entry = the instance's
-//     first row (relative to its emit wave, emit_kernel) + the wave's base (rowscan_kernel) + its quadrants before this one;
+//     first row (relative to its emit wave, emit_kernel; absolute and flagged GS2M_ROWS_BIG for a heavy Gaussian's) + the wave's base
+//     (rowscan_kernel) + its quadrants before this one;
 //   * longer spans are queued and sorted by a workgroup each: the same network over LDS (up to 4096 entries) or, beyond, over
 //     the tile's own (still unused) quadrant-list region in global memory -- slow, correct, exercised by the dense-scene tests.
 #include "common.h"
@@ -218,9 +219,9 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
             // id | mask and the first row wait in LDS under their span position; the row's base (a dependent gather) is asked
             // for now and added behind the sort: its latency disappears behind the network
             s_v[skew((int)p)] = rc[e].x;
-            s_r[skew((int)p)] = rc[e].y;
+            s_r[skew((int)p)] = rc[e].y & ~GS2M_ROWS_BIG;
 #ifndef GS2M_KO_TS_ROWBASE
-            rb[e0 + e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
+            rb[e0 + e] = p < n && (rc[e].y & GS2M_ROWS_BIG) == 0u ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;  // (a heavy instance's row is absolute)
 #else
             rb[e0 + e] = 0u;
 #endif
@@ -469,8 +470,8 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
             key[e] = rc[e].z;
             idx[e] = p;
             s_v[skew((int)p)] = rc[e].x;
-            s_r[skew((int)p)] = rc[e].y;
-            rb[e] = p < n ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;
+            s_r[skew((int)p)] = rc[e].y & ~GS2M_ROWS_BIG;
+            rb[e] = p < n && (rc[e].y & GS2M_ROWS_BIG) == 0u ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;  // (a heavy instance's row is absolute)
         });
     }
     TS_CLK();  // 0: records staged (loads done)
@@ -614,7 +615,7 @@ __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t sta
         for (uint32_t p = tid; p < n; p += 256) {
             const uint4 rc = e_rec[slot_sorted[start + I[p]]];
             point_list[start + p] = rc.x;
-            row_tmp[start + p] = rc.y + wave_rowbase[(rc.x & GS2M_GID_MASK) >> 6];
+            row_tmp[start + p] = (rc.y & GS2M_ROWS_BIG) != 0u ? (rc.y & ~GS2M_ROWS_BIG) : rc.y + wave_rowbase[(rc.x & GS2M_GID_MASK) >> 6];
         }
         __threadfence_block();
         gs2m_sync();

@@ -113,9 +113,10 @@ def test_tile_list_invariants(big, reference_binning):
     ql = view(binB, lay.qlist, 8 * R, np.uint32).reshape(4 * R, 2)
     qr = view(binB, lay.qrow, 4 * R, np.uint32)
     qc = view(imgB, lay.qcount, 4 * Tn, np.uint32).reshape(Tn, 4)
-    total_rows = int(view(geomB, lay.counters, 64, np.uint32)[2])
+    cnts = view(geomB, lay.counters, 64, np.uint32)
+    total_rows, U = int(cnts[2]), int(cnts[3])  # the row space; heavy units (256 reserved rows each, in front of the dense rows)
     masks = plm >> 28
-    assert total_rows == int(sum(((masks >> q) & 1).sum() for q in range(4)))
+    set_bits = int(sum(((masks >> q) & 1).sum() for q in range(4)))
     rng = np.random.default_rng(3)
     for t in rng.choice(np.nonzero(t)[0], 40, replace=False):  # (`t` was the touched-tiles mask)
         lo, hi = int(rg[t, 0]), int(rg[t, 1])
@@ -127,11 +128,28 @@ def test_tile_list_invariants(big, reference_binning):
             assert np.array_equal(ent[:, 0], plm[lo:hi][sel]) and np.array_equal(ent[:, 1], sel)
     rows_all = np.concatenate([qr[4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]): 4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]) + int(qc[t, q])]
                                for t in range(Tn) for q in range(4)])
-    assert len(rows_all) == total_rows and np.array_equal(np.sort(rows_all), np.arange(total_rows)), "rows: a permutation of 0 .. total - 1"
     gids_all = np.concatenate([ql[4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]): 4 * int(rg[t, 0]) + q * int(rg[t, 1] - rg[t, 0]) + int(qc[t, q]), 0]
                                for t in range(Tn) for q in range(4)]) & np.uint32(0x0FFFFFFF)
-    o = np.argsort(rows_all)
-    gr = view(geomB, lay.gauss_rows, P, np.uint32) & np.uint32(0x7FFFFFFF)
-    runs = 1 + int(np.count_nonzero(np.diff(gids_all[o].astype(np.int64))))
-    assert runs == len(np.unique(gids_all)), "every Gaussian's rows are ONE contiguous run"
-    assert np.array_equal(np.bincount(gids_all, minlength=P), gr), "gauss_rows = rows per Gaussian"
+    gr_raw = view(geomB, lay.gauss_rows, P, np.uint32)
+    tt = view(geomB, lay.tiles_touched, P, np.uint32).astype(np.int64)
+    heavy = ((gr_raw & np.uint32(0x80000000)) != 0) & (tt > 0)
+    assert np.array_equal(heavy, tt >= 48), "heavy = at least 48 instances (common.h)"
+    assert len(rows_all) == set_bits and len(np.unique(rows_all)) == set_bits and int(rows_all.max()) < total_rows, "one row per set mask bit, all different"
+    is_h = heavy[gids_all]
+    lr, lg = rows_all[~is_h].astype(np.int64), gids_all[~is_h]
+    assert total_rows == 256 * U + len(lr) and np.array_equal(np.sort(lr), np.arange(256 * U, total_rows)), "the waves' rows: dense behind the heavy units"
+    o = np.argsort(lr)
+    runs = 1 + int(np.count_nonzero(np.diff(lg[o].astype(np.int64))))
+    assert runs == len(np.unique(lg)), "every Gaussian's rows are ONE contiguous run"
+    cnt = np.bincount(lg, minlength=P)
+    assert np.array_equal(cnt[~heavy], gr_raw[~heavy] * (tt[~heavy] > 0)), "gauss_rows = rows per Gaussian"
+    if reference_binning:
+        assert U > 0, "the reference's rectangles hold Gaussians of 48 tiles and more on this scene"
+    if U > 0:
+        u0 = (gr_raw & np.uint32(0x7FFFFFFF)).astype(np.int64)
+        nu = (tt + 63) // 64
+        hg = np.nonzero(heavy)[0]
+        assert int(nu[hg].sum()) == U and np.array_equal(u0[hg], np.concatenate([[0], np.cumsum(nu[hg])[:-1]])), "units: whole, in index order"
+        hr, hgid = rows_all[is_h].astype(np.int64), gids_all[is_h]
+        assert np.all(hr >= 256 * u0[hgid]) and np.all(hr < 256 * (u0[hgid] + nu[hgid])), "a heavy Gaussian's rows lie in its own units"
+        assert np.all((hr - 256 * u0[hgid]) // 4 < tt[hgid]), "four reserved rows per instance"
