@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         cnt = rw * (r.y >> 16);
         if (rw == 0u) rw = 1u;
     }
-    const bool heavy = cnt >= GS2M_HEAVY_TILES && cnt < (1u << 29);
+    const bool heavy = gs2m_heavy(cnt);
     const uint32_t hu = heavy ? (cnt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
     const uint32_t incl_all = wave_inclusive_scan_u32(cnt, lane), incl_hu = wave_inclusive_scan_u32(hu, lane);
     if (lane == 63) { s_wtot[wave] = incl_all; s_whu[wave] = incl_hu; }

@@ -35,7 +35,13 @@
 // has 4 gradient rows reserved (rows 256 u .. 256 u + 255: the heavy rows come first, the waves' dense rows follow), a wave per unit
 // adds the rows up in the backward (heavy_reduce_kernel) and the Gaussian's thread adds its units' sums.  GeomState::gauss_rows of a
 // heavy Gaussian = GS2M_ROWS_BIG | its first unit.  (48: above every Gaussian of the bench clouds, whose largest covers 36 tiles.)
+// In a CROWDED wave -- the 64 Gaussians hold more than GS2M_CROWDED_WAVE instances between them, heavy ones not counted: a run of
+// medium-sized splats -- the bar drops to GS2M_HEAVY_TILES_CROWDED, so that what a wave keeps for itself stays below ~512 instances
+// (8 steps of the emit loop, ~32 windows of rows in the backward).  gs2m_heavy() below: the preprocess and the emit kernel decide
+// alike (same waves), the backward reads the decision off gauss_rows.
 #define GS2M_HEAVY_TILES 48u
+#define GS2M_HEAVY_TILES_CROWDED 8u
+#define GS2M_CROWDED_WAVE 512u
 #define GS2M_ROWS_BIG 0x80000000u
 #define GS2M_UNIT 64u
 struct HeavyUnit {      // 80 bytes per unit, at the end of the binning buffer
@@ -365,6 +371,14 @@ __device__ __forceinline__ int gs2m_sync_count(bool pred) {
 __device__ __forceinline__ int gs2m_sync_or(bool pred) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return __syncthreads_or(pred);
+}
+
+// Is the Gaussian of this lane heavy?  `cnt`: its tile instances; called by all 64 lanes of a wave of 64 consecutive Gaussians.
+__device__ __forceinline__ bool gs2m_heavy(uint32_t cnt) {
+    uint32_t light = cnt < GS2M_HEAVY_TILES ? cnt : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) light += (uint32_t)__shfl_xor((int)light, d, 64);
+    return cnt >= (light > GS2M_CROWDED_WAVE ? GS2M_HEAVY_TILES_CROWDED : GS2M_HEAVY_TILES) && cnt < (1u << 29);
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave (u32).

@@ -250,17 +250,47 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
         }
         gs2m_sync();  // the sums are in registers: the LDS block may be overwritten
+        // heavy Gaussians: the sums of their units (heavy_reduce_kernel).  Up to four units: the Gaussian's own thread adds them, in unit
+        // order (a crowded wave holds dozens of one-unit Gaussians: all of them at once).  More (a splat over hundreds of tiles): the
+        // wave's 64 lanes fetch them together, lane l units l, l + 64, ..., and a butterfly adds the lanes up -- a fixed order as well.
         const int hi = blockIdx.x * 256 + threadIdx.x;
         const uint32_t gr = hi < P ? gauss_rows[hi] : 0u;
-        if ((gr & GS2M_ROWS_BIG) != 0u) {  // a heavy Gaussian: the sums of its units (heavy_reduce_kernel), in unit order
-            const uint32_t u0 = gr & ~GS2M_ROWS_BIG, nu = (tiles_touched[hi] + GS2M_UNIT - 1u) / GS2M_UNIT;
-            const float4* r4 = reinterpret_cast<const float4*>(rows);
+        const bool hv = (gr & GS2M_ROWS_BIG) != 0u;
+        const uint32_t u0 = gr & ~GS2M_ROWS_BIG, nu = hv ? (tiles_touched[hi] + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+        const float4* r4 = reinterpret_cast<const float4*>(rows);
+        if (hv && nu <= 4u) {
             for (uint32_t j = 0; j < nu; j++) {
 #pragma unroll
                 for (int q = 0; q < RQ; q++) {
                     const float4 v = r4[(size_t)(u0 + j) * (4 * GS2M_UNIT) * RQ + q];
                     acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
                 }
+            }
+        }
+        unsigned long long many = __builtin_amdgcn_ballot_w64(hv && nu > 4u);
+        const int lane = threadIdx.x & 63;
+        while (many != 0ull) {
+            const int L = __builtin_ctzll(many);
+            many &= many - 1ull;
+            const uint32_t u0L = (uint32_t)__shfl((int)u0, L, 64), nuL = (uint32_t)__shfl((int)nu, L, 64);
+            float part[4 * RQ];
+#pragma unroll
+            for (int k = 0; k < 4 * RQ; k++) part[k] = 0.f;
+            for (uint32_t j = (uint32_t)lane; j < nuL; j += GS2M_WAVE) {
+#pragma unroll
+                for (int q = 0; q < RQ; q++) {
+                    const float4 v = r4[(size_t)(u0L + j) * (4 * GS2M_UNIT) * RQ + q];
+                    part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4 * RQ; k++) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part[k] += __shfl_xor(part[k], d, 64);
+            }
+            if (lane == L) {
+#pragma unroll
+                for (int k = 0; k < 4 * RQ; k++) acc[k] += part[k];
             }
         }
     }
