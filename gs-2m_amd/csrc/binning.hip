@@ -152,15 +152,52 @@ __device__ __forceinline__ unsigned long long scan_1024_per_block(const uint32_t
     return before + total;  // everything up to the end of this workgroup's elements
 }
 
+// the same for two arrays at once (block instance counts and block heavy-unit counts): one pass, one set of barriers
+template <typename F>
+__device__ __forceinline__ void scan2_1024_per_block(const uint32_t* __restrict__ in0, const uint32_t* __restrict__ in1, size_t n, uint32_t* s_w /* [32] */,
+                                                     unsigned long long* s_part /* [32] */, F emit, unsigned long long& total0, unsigned long long& total1) {
+    const size_t first = (size_t)blockIdx.x * 1024;
+    unsigned long long b0 = 0, b1 = 0;
+    for (size_t base = 0; base < first; base += 8 * 1024) {  // the elements in front, 8 of either array per thread and round
+        uint32_t v[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t i = base + (size_t)k * 1024 + threadIdx.x;
+            v[k] = i < first ? in0[i] : 0u;
+            w[k] = i < first ? in1[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { b0 += v[k]; b1 += w[k]; }
+    }
+    const size_t i = first + threadIdx.x;
+    const uint32_t m0 = i < n ? in0[i] : 0u, m1 = i < n ? in1[i] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { b0 += __shfl_xor(b0, d, 64); b1 += __shfl_xor(b1, d, 64); }
+    const uint32_t i0 = wave_inclusive_scan_u32(m0, lane), i1 = wave_inclusive_scan_u32(m1, lane);
+    if (lane == 0) { s_part[wave] = b0; s_part[16 + wave] = b1; }
+    if (lane == 63) { s_w[wave] = i0; s_w[16 + wave] = i1; }
+    gs2m_sync();
+    unsigned long long f0 = 0, f1 = 0;
+    uint32_t r0 = i0 - m0, r1 = i1 - m1, t0 = 0, t1 = 0;
+    for (int w = 0; w < 16; w++) {
+        f0 += s_part[w]; f1 += s_part[16 + w];
+        if (w < wave) { r0 += s_w[w]; r1 += s_w[16 + w]; }
+        t0 += s_w[w]; t1 += s_w[16 + w];
+    }
+    if (i < n) emit(i, (uint32_t)f0 + r0, (uint32_t)f1 + r1);
+    total0 = f0 + t0;
+    total1 = f1 + t1;
+}
+
 // num_rendered and the block prefixes.  The workgroup that owns the last elements has the grand total: it tells the host.
 __global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restrict__ block_tt, const uint32_t* __restrict__ block_hu, size_t nblocks,
                                                          uint32_t* __restrict__ block_pref, uint32_t* __restrict__ block_hupref,
                                                          uint32_t* __restrict__ counters, uint32_t* landing) {
-    __shared__ uint32_t s_w[16];
-    __shared__ unsigned long long s_part[16];
-    const unsigned long long t = scan_1024_per_block(block_tt, nblocks, s_w, s_part, [&](size_t b, uint32_t excl, uint32_t) { block_pref[b] = excl; });
-    gs2m_sync();
-    const unsigned long long u = scan_1024_per_block(block_hu, nblocks, s_w, s_part, [&](size_t b, uint32_t excl, uint32_t) { block_hupref[b] = excl; });
+    __shared__ uint32_t s_w[32];
+    __shared__ unsigned long long s_part[32];
+    unsigned long long t = 0, u = 0;
+    scan2_1024_per_block(block_tt, block_hu, nblocks, s_w, s_part, [&](size_t b, uint32_t e0, uint32_t e1) { block_pref[b] = e0; block_hupref[b] = e1; }, t, u);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         // saturated: a count beyond 2^32 cannot wrap past the caller's range check.  num_rendered and the heavy units leave in ONE
         // 8-byte store: the host that sees the first has the second

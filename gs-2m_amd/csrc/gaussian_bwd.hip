@@ -62,14 +62,15 @@ struct ReduceLds {
     float4 s_sum[256 * RQ];           // the result: RQ float4 per Gaussian of the workgroup
     uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE];
 };
-template <int RQ>
-__device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase,
-                                                   const float* __restrict__ rows, ReduceLds<RQ>& L) {
+template <int RQ>  // -> the thread's own gauss_rows entry
+__device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase,
+                                                       const float* __restrict__ rows, ReduceLds<RQ>& L) {
     constexpr int MAXQ = RQ, rq = RQ;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t cnt = 0;
     if (i < P) cnt = gauss_rows[i];
+    const uint32_t own = cnt;
     // heavy Gaussians (common.h: GS2M_ROWS_BIG | first unit): their rows are not part of the wave's run; heavy_reduce_kernel below
     // has added them up per unit, the Gaussian's thread adds the units' sums (gaussian_bwd_kernel)
     if ((cnt & GS2M_ROWS_BIG) != 0u) cnt = 0;
@@ -170,6 +171,7 @@ __device__ __forceinline__ void reduce_rows_to_lds(int P, const uint32_t* __rest
         if (w + 2 <= nwin) consume(w + 2, a2);
         load_window(w + 5, a2);
     }
+    return own;
 }
 
 // ---- heavy Gaussians: one wave per unit of 64 instances = 256 reserved rows, of which HeavyUnit::pop says which are written ----
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 24; k++) acc[k] = 0.f;
     if (rows != nullptr) {
-        reduce_rows_to_lds<RQ>(P, gauss_rows, wave_rowbase, rows, red);
+        const uint32_t gr = reduce_rows_to_lds<RQ>(P, gauss_rows, wave_rowbase, rows, red);
         gs2m_sync();
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
@@ -254,43 +256,44 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
         // order (a crowded wave holds dozens of one-unit Gaussians: all of them at once).  More (a splat over hundreds of tiles): the
         // wave's 64 lanes fetch them together, lane l units l, l + 64, ..., and a butterfly adds the lanes up -- a fixed order as well.
         const int hi = blockIdx.x * 256 + threadIdx.x;
-        const uint32_t gr = hi < P ? gauss_rows[hi] : 0u;
         const bool hv = (gr & GS2M_ROWS_BIG) != 0u;
-        const uint32_t u0 = gr & ~GS2M_ROWS_BIG, nu = hv ? (tiles_touched[hi] + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
-        const float4* r4 = reinterpret_cast<const float4*>(rows);
-        if (hv && nu <= 4u) {
-            for (uint32_t j = 0; j < nu; j++) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hv) != 0ull, 0)) {  // (wave-uniform; no heavy Gaussian in most waves)
+            const uint32_t u0 = gr & ~GS2M_ROWS_BIG, nu = hv ? (tiles_touched[hi] + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+            const float4* r4 = reinterpret_cast<const float4*>(rows);
+            if (hv && nu <= 4u) {
+                for (uint32_t j = 0; j < nu; j++) {
 #pragma unroll
-                for (int q = 0; q < RQ; q++) {
-                    const float4 v = r4[(size_t)(u0 + j) * (4 * GS2M_UNIT) * RQ + q];
-                    acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                    for (int q = 0; q < RQ; q++) {
+                        const float4 v = r4[(size_t)(u0 + j) * (4 * GS2M_UNIT) * RQ + q];
+                        acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                    }
                 }
             }
-        }
-        unsigned long long many = __builtin_amdgcn_ballot_w64(hv && nu > 4u);
-        const int lane = threadIdx.x & 63;
-        while (many != 0ull) {
-            const int L = __builtin_ctzll(many);
-            many &= many - 1ull;
-            const uint32_t u0L = (uint32_t)__shfl((int)u0, L, 64), nuL = (uint32_t)__shfl((int)nu, L, 64);
-            float part[4 * RQ];
+            unsigned long long many = __builtin_amdgcn_ballot_w64(hv && nu > 4u);
+            const int lane = threadIdx.x & 63;
+            while (many != 0ull) {
+                const int L = __builtin_ctzll(many);
+                many &= many - 1ull;
+                const uint32_t u0L = (uint32_t)__shfl((int)u0, L, 64), nuL = (uint32_t)__shfl((int)nu, L, 64);
+                float part[4 * RQ];
 #pragma unroll
-            for (int k = 0; k < 4 * RQ; k++) part[k] = 0.f;
-            for (uint32_t j = (uint32_t)lane; j < nuL; j += GS2M_WAVE) {
+                for (int k = 0; k < 4 * RQ; k++) part[k] = 0.f;
+                for (uint32_t j = (uint32_t)lane; j < nuL; j += GS2M_WAVE) {
 #pragma unroll
-                for (int q = 0; q < RQ; q++) {
-                    const float4 v = r4[(size_t)(u0L + j) * (4 * GS2M_UNIT) * RQ + q];
-                    part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w;
+                    for (int q = 0; q < RQ; q++) {
+                        const float4 v = r4[(size_t)(u0L + j) * (4 * GS2M_UNIT) * RQ + q];
+                        part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w;
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 4 * RQ; k++) {
+                for (int k = 0; k < 4 * RQ; k++) {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) part[k] += __shfl_xor(part[k], d, 64);
-            }
-            if (lane == L) {
+                    for (int d = 32; d > 0; d >>= 1) part[k] += __shfl_xor(part[k], d, 64);
+                }
+                if (lane == L) {
 #pragma unroll
-                for (int k = 0; k < 4 * RQ; k++) acc[k] += part[k];
+                    for (int k = 0; k < 4 * RQ; k++) acc[k] += part[k];
+                }
             }
         }
     }

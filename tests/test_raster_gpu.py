@@ -86,11 +86,12 @@ def test_many_instances_per_gaussian(oracle_lib):
 
 
 @pytest.mark.parametrize("refbin", [False, True])
-def test_big_splats_take_the_workgroup_paths(oracle_lib, refbin):
-    """Gaussians with at least GS2M_BIG_TILES = 512 tile instances (here: screen-filling splats on a 48 x 27 tile image, several
-    per emit wave, next to thousands of small ones): expanded by the whole workgroup in emit_kernel, their rows after the
-    wave's small rows, summed by the whole workgroup in row_reduce_dense_kernel -- every check of the ordinary scenes, in both
-    binning modes, plus bitwise reproducibility of the gradients (fixed summation orders in the cooperative paths too)."""
+def test_big_splats_take_the_heavy_unit_paths(oracle_lib, refbin):
+    """Gaussians with hundreds of tile instances (here: screen-filling splats on a 48 x 27 tile image, several per emit wave, next to
+    thousands of small ones): HEAVY (common.h: GS2M_HEAVY_TILES) -- expanded a unit of 64 instances per wave by emit_heavy_kernel, four
+    gradient rows reserved per instance, added up per unit by heavy_reduce_kernel, the units' sums fetched by the whole wave in
+    gaussian_bwd_kernel -- every check of the ordinary scenes, in both binning modes, plus bitwise reproducibility of the gradients
+    (fixed summation orders in these paths too)."""
     _require_gpu()
     import gs2m_native
     sc = Hh.make_scene(6000, 768, 432, seed=31, fc=9, scale_lo=0.003, scale_hi=0.03, bg=(0.05, 0.1, 0.2))
@@ -99,6 +100,37 @@ def test_big_splats_take_the_workgroup_paths(oracle_lib, refbin):
     gs2m_native.set_reference_binning(refbin)
     f, out = _check(oracle_lib, sc)
     assert (f.tiles_touched >= 512).sum() >= 20, "the scene is meant to hold big Gaussians"
+    a = Hh.run_hip_sums(sc)
+    b = Hh.run_hip_sums(sc)
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+def test_crowded_waves_hand_medium_splats_to_the_heavy_units(oracle_lib):
+    """A trained model keeps its medium-sized splats together in index order (a densification generation): a wave of 64 consecutive
+    Gaussians holding more than 512 instances between them is CROWDED and hands everything from 8 tiles on to the heavy units
+    (common.h: gs2m_heavy).  Here: the first 1500 of 8000 Gaussians cover 8 to 47 tiles each."""
+    _require_gpu()
+    import gs2m_native
+    import diff_gaussian_rasterization as dgr
+    sc = Hh.make_scene(8000, 640, 400, seed=41, fc=9, scale_lo=0.003, scale_hi=0.02, bg=(0.0, 0.1, 0.0))
+    sc["g"]["scales"][:1500] *= 6.0
+    f, out = _check(oracle_lib, sc)
+    tt = np.asarray(f.tiles_touched).astype(np.int64)
+    g = {k: v.cuda() for k, v in sc["g"].items()}
+    st = Hh.settings_for(sc, "cuda")
+    e = torch.Tensor([])
+    R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
+        st.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
+        st.projmatrix, st.tanfovx, st.tanfovy, sc["H"], sc["W"], g["shs"], sc["sh_degree"], st.campos, False, sc["fc"])
+    torch.cuda.synchronize()
+    lay = gs2m_native.debug_layout(8000, R, sc["W"], sc["H"])
+    al = (-geomB.data_ptr()) % 256
+    gr = geomB[al + lay.gauss_rows: al + lay.gauss_rows + 4 * 8000].cpu().numpy().view(np.uint32)
+    ttd = geomB[al + lay.tiles_touched: al + lay.tiles_touched + 4 * 8000].cpu().numpy().view(np.uint32).astype(np.int64)
+    heavy = ((gr & np.uint32(0x80000000)) != 0) & (ttd > 0)
+    assert int((heavy & (ttd < 48)).sum()) > 200, "the scene is meant to hold crowded waves"
+    assert int((~heavy & (ttd >= 8))[1600:].sum()) > 0, "... next to ordinary ones that keep their medium splats"
     a = Hh.run_hip_sums(sc)
     b = Hh.run_hip_sums(sc)
     for k in a:
