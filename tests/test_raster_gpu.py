@@ -114,7 +114,8 @@ def test_crowded_waves_hand_medium_splats_to_the_heavy_units(oracle_lib):
     import gs2m_native
     import diff_gaussian_rasterization as dgr
     sc = Hh.make_scene(8000, 640, 400, seed=41, fc=9, scale_lo=0.003, scale_hi=0.02, bg=(0.0, 0.1, 0.0))
-    sc["g"]["scales"][:1500] *= 6.0
+    sc["g"]["scales"][:1500] *= 10.0
+    sc["g"]["scales"][2000::97] *= 8.0  # lone medium splats in ordinary waves
     f, out = _check(oracle_lib, sc)
     tt = np.asarray(f.tiles_touched).astype(np.int64)
     g = {k: v.cuda() for k, v in sc["g"].items()}
