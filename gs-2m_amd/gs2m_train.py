@@ -381,7 +381,8 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                     Lmv = gs2m_mvs.multi_view_loss(mv_scene, cam, mv_opt, out, pipe, bg, material_stage, render,
                                                    fused=os.environ.get("GS2M_MV_OP_BY_OP") is None)  # debugging aid: the op-by-op formulation
                     loss = loss + lambda_multi_view * Lmv
-                    stats.setdefault("mv_loss", []).append(float(Lmv.detach()) if torch.is_tensor(Lmv) else float(Lmv))
+                    # (kept on the device: a float() here would make the host wait for the whole forward before it queues the backward)
+                    stats.setdefault("mv_loss", []).append(Lmv.detach() if torch.is_tensor(Lmv) else float(Lmv))
             if material_stage:  # train.py:132-196
                 if k not in rays:
                     rays[k] = F.normalize(cam.get_rays().view(-1, 3), p=2, dim=-1)
@@ -412,7 +413,7 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
                 loss = loss + Lpbr + Lsm
                 if mv_scene is not None and lambda_rough > 0:  # train.py:194-195
                     loss = loss + lambda_rough * gs2m_mvs.roughness_loss(mv_scene, cam, mv_opt, out, pipe, bg, render)
-                stats["pbr_loss"].append(Lpbr_log.item())
+                stats["pbr_loss"].append(Lpbr_log.detach())  # (on the device until the run ends: no host wait per iteration)
             loss.backward()
             return loss, out, vis, radii, fused_tail
 
@@ -469,6 +470,9 @@ def train(iterations=1000, W=640, H=360, n_views=12, n_true=60_000, seed=0, geom
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for name in ("mv_loss", "pbr_loss"):  # the per-iteration loss values waited on the device
+        if stats.get(name):
+            stats[name] = [float(v) for v in stats[name]]
     stats.update(psnr_end=evaluate(), points_end=gaussians.get_xyz.shape[0], seconds=dt, it_per_s=iterations / dt, loss_end=loss.item())
     if lighting is not None:  # the material stage supervises the PBR image, not the SH colours (train.py:111-113): report that one too
         with torch.no_grad():

@@ -59,3 +59,24 @@ def test_multi_view_helpers_reproduce_the_reference_functions():
     zz, n, valid = M._sample_depth_normal(t("sdn_pts"), cam, {"depth_map": t("sdn_depth_map"), "normal_map": t("sn_normal_map")}, fused=False)
     assert torch.equal(valid, t("sdn_valid"))
     assert torch.allclose(zz, t("sdn_z"), rtol=1e-6, atol=1e-6) and torch.allclose(n, t("sdn_n"), rtol=1e-5, atol=1e-6)
+
+
+def test_random_subset_is_an_exact_uniform_draw():
+    """gs2m_mvs.random_subset: exactly min(k, count) indices of set mask elements, no duplicates, every set element equally likely"""
+    import gs2m_mvs
+    torch.manual_seed(0)
+    mask = torch.rand(20000) < 0.6
+    n = int(mask.sum())
+    hits = torch.zeros(20000)
+    for _ in range(200):
+        idx = gs2m_mvs.random_subset(mask, 3000)
+        assert idx.numel() == 3000 and len(torch.unique(idx)) == 3000 and bool(mask[idx].all())
+        hits[idx] += 1
+    freq = hits[mask] / 200.0
+    assert abs(float(freq.mean()) - 3000.0 / n) < 1e-6 and float(freq.std()) < 1.5 * (3000.0 / n * (1 - 3000.0 / n) / 200.0) ** 0.5
+    few = torch.zeros(5000, dtype=torch.bool); few[::50] = True
+    idx = gs2m_mvs.random_subset(few, 3000)
+    assert idx.numel() == 100 and bool(few[idx].all())
+    assert gs2m_mvs.random_subset(torch.zeros(100, dtype=torch.bool), 10).numel() == 0
+    near = torch.ones(3100, dtype=torch.bool)  # count within 4 sigma of k: everything is kept by the thinning
+    assert gs2m_mvs.random_subset(near, 3000).numel() == 3000
