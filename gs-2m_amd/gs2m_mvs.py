@@ -428,6 +428,29 @@ def _sample_normal_map(pixels, normal_map, fused=True):
     return F.grid_sample(normal_map.unsqueeze(0), grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
 
 
+class _TakeDistinct(torch.autograd.Function):
+    """x[idx] along dim 0 for DISTINCT indices (random_subset's): the backward is a plain scatter into zeros.  torch's indexing backward
+    cannot know the indices are distinct and sorts them first to add duplicates up deterministically: two 100 k-key merge sorts per
+    iteration for the normals and distances the NCC patches start from."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return x[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_copy_(0, idx, g.contiguous())
+        return out, None
+
+
+def take_distinct(x, idx):
+    return _TakeDistinct.apply(x, idx) if x.requires_grad else x[idx]
+
+
 def random_subset(mask, k):
     """-> indices of a uniformly random subset of exactly min(k, count) set elements of the flat bool `mask` -- what the reference's
     `idx[torch.randperm(idx.numel())[:k]]` draws (utils/loss_utils.py:283-286, 172-175), without sorting one random key per VALID PIXEL
@@ -482,8 +505,8 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
         if material_stage:
             w_ncc = w_ncc * (render_pkg["roughness_map"].squeeze().clamp(0, 1) ** 2.0).reshape(-1)[idx]
         pixels = scene.pixels.reshape(-1, 2)[idx]
-    local_n = render_pkg["local_normal_map"].permute(1, 2, 0).reshape(-1, 3)[idx]
-    local_d = render_pkg["distance_map"].reshape(-1)[idx]
+    local_n = take_distinct(render_pkg["local_normal_map"].permute(1, 2, 0).reshape(-1, 3), idx)
+    local_d = take_distinct(render_pkg["distance_map"].reshape(-1), idx)
     ncc, mask = (patch_ncc if fused else patch_ncc_torch)(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size)
     m = mask.reshape(-1)
     ncc_loss = (ncc.reshape(-1) * w_ncc * m).sum() / m.sum().clamp(min=1)
@@ -514,6 +537,6 @@ def roughness_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, render
         else:
             ncc_gray, ncc_grad, std_mask = patch_ncc_torch(pixels, local_n, local_d, viewpoint_cam, near, scene.ncc_scale, opt.multi_view_patch_size, roughness=True)
         err = torch.tanh(8.0 * (torch.where(std_mask, ncc_grad, ncc_gray).reshape(-1) - opt.reflection_threshold))
-    rough = render_pkg["roughness_map"].reshape(-1)[idx]       # grid_sample at integer pixel positions = the pixel itself
+    rough = take_distinct(render_pkg["roughness_map"].reshape(-1), idx)       # grid_sample at integer pixel positions = the pixel itself
     m = ((err < 0.0) & (rough <= 0.8).detach()) | ((err > 0.0) & (rough > 0.08).detach())
     return (err * rough * m).sum() / m.sum().clamp(min=1)

@@ -80,3 +80,15 @@ def test_random_subset_is_an_exact_uniform_draw():
     assert gs2m_mvs.random_subset(torch.zeros(100, dtype=torch.bool), 10).numel() == 0
     near = torch.ones(3100, dtype=torch.bool)  # count within 4 sigma of k: everything is kept by the thinning
     assert gs2m_mvs.random_subset(near, 3000).numel() == 3000
+
+
+def test_take_distinct_matches_indexing():
+    import gs2m_mvs
+    torch.manual_seed(1)
+    for shape in ((5000,), (5000, 3)):
+        x = torch.randn(*shape, requires_grad=True)
+        idx = torch.randperm(5000)[:1200]
+        w = torch.randn(1200, *shape[1:])
+        (ga,) = torch.autograd.grad((x[idx] * w).sum(), x)
+        (gb,) = torch.autograd.grad((gs2m_mvs.take_distinct(x, idx) * w).sum(), x)
+        assert torch.equal(x[idx], gs2m_mvs.take_distinct(x, idx)) and torch.equal(ga, gb)
