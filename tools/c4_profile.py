@@ -82,7 +82,8 @@ def run(path, steps):
             tt = view(geomB, lay.tiles_touched, P, np.uint32).astype(np.int64)
             rows = view(geomB, lay.gauss_rows, P, np.uint32).astype(np.int64)
             rows[tt == 0] = 0  # (written for emitting Gaussians only)
-            rows &= 0x7FFFFFFF  # (the big-splat flag)
+            heavy = (rows & 0x80000000) != 0  # (heavy Gaussians: the entry is their first unit, common.h)
+            rows[heavy] = 0
             Tn = ((W + 15) // 16) * ((H + 15) // 16)
             rg = view(imgB, lay.ranges, Tn * 2, np.uint32).reshape(Tn, 2).astype(np.int64)
             ll = rg[:, 1] - rg[:, 0]
@@ -95,7 +96,7 @@ def run(path, steps):
             print("  per wave of 64 Gaussians (index order): mean of max %.1f, mean of sum %.1f, max of sum %d" % (w.max(1).mean(), w.sum(1).mean(), w.sum(1).max()))
             print("  tile list length: mean %.1f percentiles %s %s; tiles <= 512: %d, 513..1024: %d, > 1024: %d, > 4096: %d" % (
                 ll.mean(), q, np.percentile(ll, q).tolist(), int((ll <= 512).sum()), int(((ll > 512) & (ll <= 1024)).sum()), int((ll > 1024).sum()), int((ll > 4096).sum())))
-            print("  gradient rows: total %d = %.2f per instance; per Gaussian mean %.2f percentiles %s %s; Gaussians with >= 64 / 256 / 1024 rows: %d / %d / %d holding %.1f / %.1f / %.1f %% of the rows" % (
+            print("  gradient rows of the waves' own (not heavy) Gaussians: total %d = %.2f per instance of the frame; per Gaussian mean %.2f percentiles %s %s; Gaussians with >= 64 / 256 / 1024 rows: %d / %d / %d holding %.1f / %.1f / %.1f %% of the rows" % (
                 rows.sum(), rows.sum() / max(R, 1), rows[rows > 0].mean(), q, np.percentile(rows[rows > 0], q).tolist(),
                 int((rows >= 64).sum()), int((rows >= 256).sum()), int((rows >= 1024).sum()),
                 100.0 * rows[rows >= 64].sum() / rows.sum(), 100.0 * rows[rows >= 256].sum() / rows.sum(), 100.0 * rows[rows >= 1024].sum() / rows.sum()))
