@@ -209,7 +209,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     volatile uint32_t* land = ring.host + slot * kLandWords;
     uint32_t* land_dev = ring.dev + slot * kLandWords;
     land[GS2M_LAND_R] = 0xFFFFFFFFu;  // a sentinel no count can take (R < 2^29)
-    land[GS2M_LAND_HUNITS] = 0u;
+    land[GS2M_LAND_HUNITS] = 0xFFFFFFFFu;  // (likewise: the two leave the GPU in one 8-byte store, the host still waits for both words)
     land[GS2M_LAND_PREFILTERED] = 0u;
     land[GS2M_LAND_ROWS] = 0u;
     t_last_token = ((uint64_t)(dev_id + 1) << 40) | ((uint64_t)(generation & 0xFFFFFFFFu) << 8) | slot;
@@ -241,12 +241,12 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         if (spin_wait) {
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t spins = 0;
-            while (land[GS2M_LAND_R] == 0xFFFFFFFFu) {
+            while (land[GS2M_LAND_R] == 0xFFFFFFFFu || land[GS2M_LAND_HUNITS] == 0xFFFFFFFFu) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
             }
         }
-        if (land[GS2M_LAND_R] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
+        if (land[GS2M_LAND_R] == 0xFFFFFFFFu || land[GS2M_LAND_HUNITS] == 0xFFFFFFFFu) HIP_TRY(hipStreamSynchronize(s));  // polling disabled or timed out (e.g. a faulted stream)
         if (prefiltered && land[GS2M_LAND_PREFILTERED] != 0u) {  // a Gaussian behind the near plane: the reference traps the device here
             HIP_TRY(hipStreamSynchronize(s));  // nothing of this call is left in flight when the caller frees its buffers
             return GS2M_ERR_PREFILTERED;
@@ -289,6 +289,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     } else {
         HIP_TRY(gs2m_zero_async(im.ranges_raw, tiles * 2 * sizeof(uint32_t), s));
         land[GS2M_LAND_ROWS] = 1u;  // no instance, no row
+        if (land[GS2M_LAND_HUNITS] == 0xFFFFFFFFu) land[GS2M_LAND_HUNITS] = 0u;  // (P == 0: nothing was launched)
     }
     DEBUG_CHECK();
     {
