@@ -452,18 +452,28 @@ def take_distinct(x, idx):
 
 
 def random_subset(mask, k):
-    """-> indices of a uniformly random subset of exactly min(k, count) set elements of the flat bool `mask` -- what the reference's
-    `idx[torch.randperm(idx.numel())[:k]]` draws (utils/loss_utils.py:283-286, 172-175), without sorting one random key per VALID PIXEL
-    (450 k keys per iteration at DTU's size: 0.18 ms of merge-sort kernels): the mask is thinned to k + 4 sqrt(k) expected survivors
-    first (one fused compare), and the permutation prefix is drawn among those ~1 % more than k.  A uniform k-subset of a uniformly
-    thinned set is a uniform k-subset.  (One host wait, as `nonzero` always had.)"""
+    """-> indices of a random subset of exactly min(k, count) set elements of the flat bool `mask`, every set element equally likely --
+    what the reference draws with `idx[torch.randperm(idx.numel())[:k]]` (utils/loss_utils.py:283-286, 172-175), without sorting one
+    random key per VALID PIXEL (450 k keys per iteration at DTU's size: 0.18 ms of merge-sort kernels; the sort's ~12 launches cost
+    nearly as much for 100 k keys).  Two steps, no sort: the mask is thinned to k + 4 sqrt(k) expected survivors (one fused compare
+    against uniform numbers), then the ~1 % in excess are removed one per stratum of the survivor list (position (j + U_j) m / e for
+    the j-th of e removals: distinct, increasing, uniform over the list), and the kept positions follow from a searchsorted.  Not the
+    uniform distribution over k-subsets (the removals are stratified), but uniform inclusion probabilities and exactly k samples.
+    (One host wait, as `nonzero` always had.)"""
     flat = mask.reshape(-1)
     n = flat.sum()
     p = ((k + 4.0 * math.sqrt(k)) / n.clamp(min=1).to(torch.float32)).clamp(max=1.0)
     idx = torch.nonzero(flat & (torch.rand(flat.shape[0], device=flat.device) < p)).squeeze(1)
     m = idx.numel()
     if m > k:
-        return idx[torch.randperm(m, device=idx.device)[:k]]
+        e = m - k
+        if 4 * e > m:  # many to remove (a small k out of a short list): the plain way
+            return idx[torch.randperm(m, device=idx.device)[:k]]
+        j = torch.arange(e, device=idx.device, dtype=torch.float64)
+        removed = ((j + torch.rand(e, device=idx.device, dtype=torch.float64)) * (m / e)).long().clamp_(max=m - 1)  # strictly increasing: m / e >= 4
+        out = torch.arange(k, device=idx.device)
+        # the j-th kept element sits at old position j + #{i : removed_i - i <= j}
+        return idx[out + torch.searchsorted(removed - torch.arange(e, device=idx.device), out, right=True)]
     if m < k and int(n) > m:  # the thinning came out short (4 sigma): the plain way
         idx = torch.nonzero(flat).squeeze(1)
         if idx.numel() > k:
