@@ -34,14 +34,15 @@
 // units, numbered in index order through the block scan), a wave per unit expands them (emit_heavy_kernel), every instance of a unit
 // has 4 gradient rows reserved (rows 256 u .. 256 u + 255: the heavy rows come first, the waves' dense rows follow), a wave per unit
 // adds the rows up in the backward (heavy_reduce_kernel) and the Gaussian's thread adds its units' sums.  GeomState::gauss_rows of a
-// heavy Gaussian = GS2M_ROWS_BIG | its first unit.  (48: above every Gaussian of the bench clouds, whose largest covers 36 tiles.)
+// heavy Gaussian = GS2M_ROWS_BIG | its first unit.  (40: above every Gaussian of the bench clouds, whose largest covers 36 tiles.)
 // In a CROWDED wave -- the 64 Gaussians hold more than GS2M_CROWDED_WAVE instances between them, heavy ones not counted: a run of
-// medium-sized splats -- the bar drops to GS2M_HEAVY_TILES_CROWDED, so that what a wave keeps for itself stays below ~512 instances
-// (8 steps of the emit loop, ~32 windows of rows in the backward).  gs2m_heavy() below: the preprocess and the emit kernel decide
+// medium-sized splats -- the bar drops to GS2M_HEAVY_TILES_CROWDED, so that what a wave keeps for itself stays below ~450 instances
+// (7 steps of the emit loop, ~28 windows of rows in the backward; the waves of the bench clouds hold 173 on average, 296 at most:
+// tools/wave_sums.py; on the C4 view 48 / 512 -> 40 / 320 took the per-Gaussian backward from 110 to 88 us).  gs2m_heavy() below: the preprocess and the emit kernel decide
 // alike (same waves), the backward reads the decision off gauss_rows.
-#define GS2M_HEAVY_TILES 48u
+#define GS2M_HEAVY_TILES 40u
 #define GS2M_HEAVY_TILES_CROWDED 8u
-#define GS2M_CROWDED_WAVE 512u
+#define GS2M_CROWDED_WAVE 320u
 #define GS2M_ROWS_BIG 0x80000000u
 #define GS2M_UNIT 64u
 struct HeavyUnit {      // 80 bytes per unit, at the end of the binning buffer

@@ -134,8 +134,8 @@ def test_tile_list_invariants(big, reference_binning):
     tt = view(geomB, lay.tiles_touched, P, np.uint32).astype(np.int64)
     heavy = ((gr_raw & np.uint32(0x80000000)) != 0) & (tt > 0)
     ttw = np.concatenate([tt, np.zeros((-P) % 64, np.int64)]).reshape(-1, 64)
-    crowded = np.repeat((ttw * (ttw < 48)).sum(1) > 512, 64)[:P]
-    assert np.array_equal(heavy, (tt >= 48) | (crowded & (tt >= 8))), "heavy = at least 48 instances, 8 in a crowded wave (common.h)"
+    crowded = np.repeat((ttw * (ttw < 40)).sum(1) > 320, 64)[:P]
+    assert np.array_equal(heavy, (tt >= 40) | (crowded & (tt >= 8))), "heavy = at least 40 instances, 8 in a crowded wave (common.h)"
     assert len(rows_all) == set_bits and len(np.unique(rows_all)) == set_bits and int(rows_all.max()) < total_rows, "one row per set mask bit, all different"
     is_h = heavy[gids_all]
     lr, lg = rows_all[~is_h].astype(np.int64), gids_all[~is_h]
@@ -146,7 +146,7 @@ def test_tile_list_invariants(big, reference_binning):
     cnt = np.bincount(lg, minlength=P)
     assert np.array_equal(cnt[~heavy], gr_raw[~heavy] * (tt[~heavy] > 0)), "gauss_rows = rows per Gaussian"
     if reference_binning:
-        assert U > 0, "the reference's rectangles hold Gaussians of 48 tiles and more on this scene"
+        assert U > 0, "the reference's rectangles hold Gaussians of 40 tiles and more on this scene"
     if U > 0:
         u0 = (gr_raw & np.uint32(0x7FFFFFFF)).astype(np.int64)
         nu = (tt + 63) // 64
