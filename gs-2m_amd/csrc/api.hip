@@ -215,7 +215,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     t_last_token = ((uint64_t)(dev_id + 1) << 40) | ((uint64_t)(generation & 0xFFFFFFFFu) << 8) | slot;
 
     int R = 0;
-    uint32_t U = 0;  // heavy units (common.h)
+    uint32_t U = 0, crowded = GS2M_CROWDED_WAVE;  // heavy units and the crowded-wave bar in force (common.h)
     if (P > 0) {
         {
             StageTimer t(ST_PREPROCESS, s, &failed_stage);
@@ -256,6 +256,21 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         if (land[GS2M_LAND_R] >= (1u << 29) || land[GS2M_LAND_HUNITS] >= (1u << 22)) return GS2M_ERR_UNSUPPORTED;
         R = (int)land[GS2M_LAND_R];
         U = land[GS2M_LAND_HUNITS];  // (published with num_rendered in one store)
+        // The crowded-wave rule (common.h) repairs IMBALANCE between waves.  A frame whose Gaussians all cover a dozen tiles has every
+        // wave crowded and nothing to repair -- but each of its Gaussians would reserve a unit of 256 rows for its dozen instances.
+        // When the units ask for more than 6 rows per instance of the frame, they are counted again without the rule (Gaussians of
+        // GS2M_HEAVY_TILES and more only: at most 64/40 x 4 = 6.4 rows per heavy instance) and the emit kernel is told.
+        if ((size_t)U * 4 * GS2M_UNIT > (size_t)6 * (size_t)R + 65536) {
+            crowded = GS2M_CROWDED_OFF;
+            land[GS2M_LAND_R] = 0xFFFFFFFFu;
+            land[GS2M_LAND_HUNITS] = 0xFFFFFFFFu;
+            gs2m_launch_recount_heavy(P, g, s);
+            gs2m_launch_blockscan(P, g, land_dev, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));  // (the rare path: no polling)
+            if (land[GS2M_LAND_R] != (uint32_t)R || land[GS2M_LAND_HUNITS] >= (1u << 22)) return GS2M_ERR_STAGE(ST_SCAN);
+            U = land[GS2M_LAND_HUNITS];
+        }
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -271,7 +286,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             StageTimer t(ST_EMIT, s, &failed_stage);
             ZeroJobs zj = {{nullptr, im.ranges_raw, nullptr}, {0, tiles * 2, 0}};
             gs2m_radix_zero_region(b.temp, (size_t)R, tile_bits, &zj.p[0], &zj.words[0]);
-            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, U, land_dev, zj, s);
+            gs2m_launch_emit(P, width, height, tiles_x, tile_bits, g, b, U, crowded, land_dev, zj, s);
         }
         if (g_debug.load(std::memory_order_relaxed)) {  // debug mode: what the host was told against the emit kernel's own offsets
             uint32_t total = 0;

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
                                                    HeavyUnit* __restrict__ hrec,
                                                    uint32_t* __restrict__ gauss_rows, uint32_t* __restrict__ wave_rows,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_hist, int npass, int4 hbits,
-                                                   int4 hshift, ZeroJobs zero) {
+                                                   int4 hshift, uint32_t crowded, ZeroJobs zero) {
     __shared__ uint32_t s_th[4][256];  // digit counts of this workgroup's keys, for the tile sort
     __shared__ uint32_t s_pref[4][GS2M_WAVE];
     __shared__ uint32_t s_rmin[4][GS2M_WAVE];
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
         cnt = rw * (r.y >> 16);
         if (rw == 0u) rw = 1u;
     }
-    const bool heavy = gs2m_heavy(cnt);
+    const bool heavy = gs2m_heavy(cnt, crowded);
     const uint32_t hu = heavy ? (cnt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
     const uint32_t incl_all = wave_inclusive_scan_u32(cnt, lane), incl_hu = wave_inclusive_scan_u32(hu, lane);
     if (lane == 63) { s_wtot[wave] = incl_all; s_whu[wave] = incl_hu; }
@@ -353,6 +353,24 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int W, int H, int tile
     }
 }
 
+// block_hu once more, with the crowded-wave rule off (common.h: gs2m_heavy; api.hip launches this when the rule would reserve more rows
+// than the frame can justify, then scans again)
+__global__ void __launch_bounds__(256) recount_heavy_kernel(int P, const uint2* __restrict__ rect, uint32_t* __restrict__ block_hu) {
+    __shared__ uint32_t s_hu[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t cnt = 0;
+    if (i < P) {
+        const uint2 r = rect[i];
+        cnt = (r.y & 0xFFFFu) * (r.y >> 16);
+    }
+    uint32_t hu = gs2m_heavy(cnt, GS2M_CROWDED_OFF) ? (cnt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) hu += (uint32_t)__shfl_xor((int)hu, d, 64);
+    if ((threadIdx.x & 63) == 0) s_hu[threadIdx.x >> 6] = hu;
+    gs2m_sync();
+    if (threadIdx.x == 0) block_hu[blockIdx.x] = s_hu[0] + s_hu[1] + s_hu[2] + s_hu[3];
+}
+
 // One wave per heavy unit: instances 64 (u - first unit) .. + 63 of the Gaussian the unit belongs to.  Slot = the Gaussian's first
 // slot + the instance number (index order, as everything else); gradient row of the instance = GS2M_ROWS_BIG | 256 u + 4 lane (four
 // rows reserved per instance; HeavyUnit::pop says how many are used).
@@ -403,13 +421,17 @@ void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStre
                                                                                                   landing);
 }
 
-void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t heavy_units, uint32_t* landing,
-                      const ZeroJobs& zero, hipStream_t s) {
+void gs2m_launch_recount_heavy(int P, const GeomState& g, hipStream_t s) {
+    recount_heavy_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.rect, g.block_hu);
+}
+
+void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t heavy_units, uint32_t crowded,
+                      uint32_t* landing, const ZeroJobs& zero, hipStream_t s) {
     int npass = 0, bits[4], shift[4];
     gs2m_radix_plan(tile_bits, &npass, bits, shift);  // the digits the tile sort will use: counted here, where the keys are made
     const int4 hbits = make_int4(bits[0], bits[1], bits[2], bits[3]), hshift = make_int4(shift[0], shift[1], shift[2], shift[3]);
     emit_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, W, H, tiles_x, g.rect, g.block_pref, g.block_hupref, g.rec, g.depth_key, b.keys_unsorted, b.e_rec, b.hrec,
-                                                g.gauss_rows, g.wave_rows, g.counters, g.tile_hist, npass, hbits, hshift, zero);
+                                                g.gauss_rows, g.wave_rows, g.counters, g.tile_hist, npass, hbits, hshift, crowded, zero);
     if (heavy_units > 0u)
         emit_heavy_kernel<<<(heavy_units + 3u) / 4u, 256, 0, s>>>(heavy_units, W, H, tiles_x, g.rect, g.rec, g.depth_key, g.gauss_rows, b.keys_unsorted, b.e_rec,
                                                                   b.hrec, g.tile_hist, npass, hbits, hshift);

@@ -296,7 +296,9 @@ void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const flo
 // quadrant masks, gradient-row numbering, the tile sort's digit counts) + rowscan (first gradient row of every wave)
 void gs2m_launch_blockscan(int P, const GeomState& g, uint32_t* landing, hipStream_t s);
 void gs2m_launch_emit(int P, int W, int H, int tiles_x, int tile_bits, const GeomState& g, const BinningState& b, uint32_t heavy_units,
-                      uint32_t* landing, const ZeroJobs& zero, hipStream_t s);
+                      uint32_t crowded, uint32_t* landing, const ZeroJobs& zero, hipStream_t s);
+// the blocks' heavy-unit counts once more with the crowded-wave rule off (the preprocess kernel counted them with it on)
+void gs2m_launch_recount_heavy(int P, const GeomState& g, hipStream_t s);
 // gaussian_bwd.hip: the rows of every heavy unit added up into the unit's first row (before gaussian_bwd_kernel); heavy_units < 0:
 // not known on the host (a fixed grid reads the count on the device)
 void gs2m_launch_heavy_reduce(float* rows, int rowf, const BinningState& b, const GeomState& g, long long heavy_units, hipStream_t s);
@@ -375,11 +377,14 @@ __device__ __forceinline__ int gs2m_sync_or(bool pred) {
 }
 
 // Is the Gaussian of this lane heavy?  `cnt`: its tile instances; called by all 64 lanes of a wave of 64 consecutive Gaussians.
-__device__ __forceinline__ bool gs2m_heavy(uint32_t cnt) {
+// `crowded`: GS2M_CROWDED_WAVE, or GS2M_CROWDED_OFF when the forward found that the crowded-wave rule would reserve more rows than
+// the frame can justify (api.hip: a frame whose waves are ALL crowded has no imbalance to repair).
+#define GS2M_CROWDED_OFF 0xFFFFFFFFu
+__device__ __forceinline__ bool gs2m_heavy(uint32_t cnt, uint32_t crowded) {
     uint32_t light = cnt < GS2M_HEAVY_TILES ? cnt : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) light += (uint32_t)__shfl_xor((int)light, d, 64);
-    return cnt >= (light > GS2M_CROWDED_WAVE ? GS2M_HEAVY_TILES_CROWDED : GS2M_HEAVY_TILES) && cnt < (1u << 29);
+    return cnt >= (light > crowded ? GS2M_HEAVY_TILES_CROWDED : GS2M_HEAVY_TILES) && cnt < (1u << 29);
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave (u32).

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     {   // the block's instance count: what the binning adds up in front of a block instead of running a scan over P
         const uint32_t ws = wave_inclusive_scan_u32(out_tt, (int)(threadIdx.x & 63));
         if ((threadIdx.x & 63) == 63) s_tt[threadIdx.x >> 6] = ws;
-        uint32_t hu = gs2m_heavy(out_tt) ? (out_tt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
+        uint32_t hu = gs2m_heavy(out_tt, GS2M_CROWDED_WAVE) ? (out_tt + GS2M_UNIT - 1u) / GS2M_UNIT : 0u;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) hu += __shfl_xor(hu, d, 64);
         if ((threadIdx.x & 63) == 0) s_hu[threadIdx.x >> 6] = hu;

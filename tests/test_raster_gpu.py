@@ -138,6 +138,34 @@ def test_crowded_waves_hand_medium_splats_to_the_heavy_units(oracle_lib):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
+def test_uniformly_medium_scene_switches_the_crowded_rule_off(oracle_lib):
+    """Every Gaussian covers a dozen tiles and more: every wave is crowded, there is no imbalance to repair, and a unit of 256 rows per
+    Gaussian would be 10x the rows the frame needs.  The forward notices (heavy units x 256 > 6 x num_rendered), counts the units again
+    without the crowded-wave rule and tells the emit kernel (api.hip): only Gaussians of 40 tiles and more stay heavy."""
+    _require_gpu()
+    import gs2m_native
+    import diff_gaussian_rasterization as dgr
+    sc = Hh.make_scene(3000, 640, 400, seed=43, fc=9, scale_lo=0.04, scale_hi=0.09, bg=(0.0, 0.0, 0.1))
+    f, out = _check(oracle_lib, sc)
+    g = {k: v.cuda() for k, v in sc["g"].items()}
+    st = Hh.settings_for(sc, "cuda")
+    e = torch.Tensor([])
+    R, color, radii, observe, buffer, geomB, binB, imgB = dgr._C.rasterize_gaussians(
+        st.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, g["features"], st.viewmatrix,
+        st.projmatrix, st.tanfovx, st.tanfovy, sc["H"], sc["W"], g["shs"], sc["sh_degree"], st.campos, False, sc["fc"])
+    torch.cuda.synchronize()
+    lay = gs2m_native.debug_layout(3000, R, sc["W"], sc["H"])
+    al = (-geomB.data_ptr()) % 256
+    gr = geomB[al + lay.gauss_rows: al + lay.gauss_rows + 4 * 3000].cpu().numpy().view(np.uint32)
+    ttd = geomB[al + lay.tiles_touched: al + lay.tiles_touched + 4 * 3000].cpu().numpy().view(np.uint32).astype(np.int64)
+    U = int(geomB[al + lay.counters: al + lay.counters + 16].cpu().numpy().view(np.uint32)[3])
+    heavy = ((gr & np.uint32(0x80000000)) != 0) & (ttd > 0)
+    w = np.concatenate([ttd, np.zeros((-3000) % 64, np.int64)]).reshape(-1, 64)
+    assert ((w * (w < 40)).sum(1) > 320).mean() > 0.5, "the scene is meant to have most waves crowded"
+    assert np.array_equal(heavy, ttd >= 40) and U == int(((ttd[heavy] + 63) // 64).sum()), "the crowded-wave rule is off for this frame"
+    assert 256 * U <= 6 * R + 65536
+
+
 def test_dense_scene_terminates(oracle_lib):
     """many opaque layers: exercises T < 1e-4 termination, n_contrib < list length, block early-out."""
     _require_gpu()
