@@ -14,5 +14,16 @@ r, rg = Hh.run_oracle(reference, sc)
 r2, rg2 = Hh.run_oracle(reference, sc)
 o, og = Hh.run_oracle(oracle, sc)
 out, g = Hh.run_hip(sc)
+sums = Hh.run_hip_sums(sc)
+for k in ("means2D", "conics", "opacities", "colors"):
+    a, b = np.asarray(sums[k][gid], np.float64).reshape(-1), np.asarray(og[k][gid], np.float64).reshape(-1)
+    print("sum", k, "oracle", b, "hip - oracle", a - b, "reference - oracle", np.asarray(rg[k][gid], np.float64).reshape(-1) - b)
+# over all visible Gaussians: the relative error of the blend sums against the oracle's (double accumulators), HIP path and reference build
+for k in ("means2D", "conics", "colors"):
+    b = np.asarray(og[k], np.float64).reshape(len(og[k]), -1)
+    sc_ = np.abs(b).max(1) + 1e-30
+    eh = (np.abs(np.asarray(sums[k], np.float64).reshape(b.shape) - b).max(1) / sc_)[np.abs(b).max(1) > 1e-3]
+    er = (np.abs(np.asarray(rg[k], np.float64).reshape(b.shape) - b).max(1) / sc_)[np.abs(b).max(1) > 1e-3]
+    print(f"row-relative error of sum:{k} vs oracle: hip median {np.median(eh):.2e} p99 {np.percentile(eh, 99):.2e} p99.99 {np.percentile(eh, 99.99):.2e} | reference median {np.median(er):.2e} p99 {np.percentile(er, 99):.2e} p99.99 {np.percentile(er, 99.99):.2e}")
 for k in ("scales", "rotations", "means3D"):
     print(k, "oracle", og[k][gid], "\n   hip - oracle", g[k][gid] - og[k][gid], "\n   reference - oracle", rg[k][gid] - og[k][gid], "\n   reference run 2 - reference run 1", rg2[k][gid] - rg[k][gid])
