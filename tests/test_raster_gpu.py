@@ -85,6 +85,17 @@ def test_many_instances_per_gaussian(oracle_lib):
     assert f.tiles_touched.max() > 128 and f.num_rendered > 20000
 
 
+@pytest.mark.parametrize("fc", [1, 5, 10])
+def test_heavy_units_at_every_row_width(oracle_lib, fc):
+    """the heavy units' row sums (heavy_reduce_kernel<3, 4, 6>: rows of 12, 16 and 24 floats; 20 floats: the test below)"""
+    _require_gpu()
+    sc = Hh.make_scene(3000, 512, 320, seed=50 + fc, fc=fc, scale_lo=0.003, scale_hi=0.03, bg=(0.1, 0.1, 0.0))
+    big = torch.rand(3000, generator=torch.Generator().manual_seed(6)) < 0.03
+    sc["g"]["scales"] = torch.where(big[:, None], sc["g"]["scales"] * 40.0, sc["g"]["scales"])
+    f, out = _check(oracle_lib, sc)
+    assert (f.tiles_touched >= 64).sum() >= 20, "the scene is meant to hold heavy Gaussians"
+
+
 @pytest.mark.parametrize("refbin", [False, True])
 def test_big_splats_take_the_heavy_unit_paths(oracle_lib, refbin):
     """Gaussians with hundreds of tile instances (here: screen-filling splats on a 48 x 27 tile image, several per emit wave, next to
