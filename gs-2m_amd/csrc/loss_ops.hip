@@ -471,6 +471,63 @@ __global__ void __launch_bounds__(LB) tv_loss_bwd_kernel(TvArgs a, const float* 
     }
 }
 
+// The photometric part of multi_view_loss around patch_ncc (utils/loss_utils.py:293-300, 345-349), without the framework's gathers and
+// its reduction chain.  (a) mv_take: what the sampled pixels `idx` (distinct indices into the frame) hand the NCC kernel -- pixel
+// coordinates, the plane normal and distance at the pixel, the sample's weight -- in one launch instead of a (3,H,W)->(HW,3) copy and four
+// index kernels; the backward scatters the normals' and distances' gradients into zero-filled maps (no sort: the indices are distinct).
+// (b) ncc_tail: mask = ncc < 0.9, loss = sum(ncc w mask) / max(#mask, 1), one launch each way instead of ~8.
+struct MvTakeArgs {
+    int N, W;
+    size_t HW;
+    const long long* idx;
+};
+__global__ void __launch_bounds__(LB) mv_take_fwd_kernel(MvTakeArgs a, const float* __restrict__ normal, const float* __restrict__ dist, const float* __restrict__ w,
+                                                         float* __restrict__ pixels, float* __restrict__ normals, float* __restrict__ dists, float* __restrict__ wout) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= a.N) return;
+    const size_t p = (size_t)a.idx[i];
+    const uint32_t y = (uint32_t)(p / (size_t)a.W), x = (uint32_t)(p - (size_t)y * (size_t)a.W);
+    pixels[2 * i] = (float)x;
+    pixels[2 * i + 1] = (float)y;
+#pragma unroll
+    for (int c = 0; c < 3; c++) normals[3 * i + c] = normal[c * a.HW + p];
+    dists[i] = dist[p];
+    wout[i] = w ? w[p] : 1.0f;
+}
+__global__ void __launch_bounds__(LB) mv_take_bwd_kernel(MvTakeArgs a, const float* __restrict__ d_normals, const float* __restrict__ d_dists,
+                                                         float* __restrict__ d_normal /* (3, HW), zero-filled */, float* __restrict__ d_dist /* (HW), zero-filled */) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= a.N) return;
+    const size_t p = (size_t)a.idx[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) d_normal[c * a.HW + p] = d_normals[3 * i + c];
+    d_dist[p] = d_dists[i];
+}
+__global__ void __launch_bounds__(RB) ncc_tail_fwd_kernel(int N, const float* __restrict__ ncc, const float* __restrict__ w, float* __restrict__ out,
+                                                          float* __restrict__ ws, uint32_t* __restrict__ ticket) {
+    float v[2] = {0.f, 0.f};
+    for (int i = blockIdx.x * RB + threadIdx.x; i < N; i += LG * RB) {
+        const float c = ncc[i];
+        const bool m = c < 0.9f;
+        v[0] += m ? c * w[i] : 0.f;
+        v[1] += m ? 1.0f : 0.f;
+    }
+    if (publish_partials<2>(v, ws, ticket, 0)) {
+        const double s = final_sum(ws, 0), n = final_sum(ws, 1);
+        if (threadIdx.x == 0) {
+            out[0] = (float)(s / (n > 1.0 ? n : 1.0));
+            out[1] = (float)n;
+        }
+    }
+}
+__global__ void __launch_bounds__(LB) ncc_tail_bwd_kernel(int N, const float* __restrict__ ncc, const float* __restrict__ w, const float* __restrict__ out,
+                                                          const float* __restrict__ g_loss, float* __restrict__ d_ncc) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= N) return;
+    const float n = out[1];
+    d_ncc[i] = ncc[i] < 0.9f ? g_loss[0] * w[i] / (n > 1.0f ? n : 1.0f) : 0.f;
+}
+
 // The geometric part of multi_view_loss, utils/loss_utils.py:277-291, from the per-pixel quantities of mv_geo (csrc/mvs.hip):
 //   pixel_valid = valid & (noise < 1),  angle_valid = valid & (angle < angle_threshold),  geo_w = exp(-decay noise) on
 //   pixel_valid (detached),  loss = weight (sum geo_w noise / #pixel_valid + sum geo_w factor angle [angle_valid] / #angle_valid)
@@ -619,6 +676,35 @@ int gs2m_mv_geo_loss_backward(int n, const float* noise, const float* angle, con
     if (n < 1 || !noise || !angle || !valid || !out || !g_loss || !d_noise || !d_angle) return GS2M_ERR_INVALID_ARG;
     const MvGeoArgs a = {n, noise, angle, valid, angle_threshold, decay, factor, weight};
     mv_geo_loss_bwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(a, out, g_loss, d_noise, d_angle);
+    return launched();
+}
+
+int gs2m_mv_take_forward(int n, const long long* idx, int width, int height, const float* normal_map, const float* dist_map, const float* w_map,
+                         float* pixels, float* normals, float* dists, float* w, void* stream) {
+    if (n < 1 || width < 1 || height < 1 || !idx || !normal_map || !dist_map || !pixels || !normals || !dists || !w) return GS2M_ERR_INVALID_ARG;
+    const MvTakeArgs a = {n, width, (size_t)width * height, idx};
+    mv_take_fwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(a, normal_map, dist_map, w_map, pixels, normals, dists, w);
+    return launched();
+}
+
+int gs2m_mv_take_backward(int n, const long long* idx, int width, int height, const float* d_normals, const float* d_dists, float* d_normal_map,
+                          float* d_dist_map, void* stream) {
+    if (n < 1 || width < 1 || height < 1 || !idx || !d_normals || !d_dists || !d_normal_map || !d_dist_map) return GS2M_ERR_INVALID_ARG;
+    const MvTakeArgs a = {n, width, (size_t)width * height, idx};
+    mv_take_bwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(a, d_normals, d_dists, d_normal_map, d_dist_map);
+    return launched();
+}
+
+int gs2m_ncc_tail_forward(int n, const float* ncc, const float* w, float* out, void* workspace, void* stream) {
+    if (n < 1 || !ncc || !w || !out || !workspace) return GS2M_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    ncc_tail_fwd_kernel<<<LG, RB, 0, (hipStream_t)stream>>>(n, ncc, w, out, ws, (uint32_t*)(ws + WS_K * LG));
+    return launched();
+}
+
+int gs2m_ncc_tail_backward(int n, const float* ncc, const float* w, const float* out, const float* g_loss, float* d_ncc, void* stream) {
+    if (n < 1 || !ncc || !w || !out || !g_loss || !d_ncc) return GS2M_ERR_INVALID_ARG;
+    ncc_tail_bwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(n, ncc, w, out, g_loss, d_ncc);
     return launched();
 }
 

@@ -428,6 +428,69 @@ def _sample_normal_map(pixels, normal_map, fused=True):
     return F.grid_sample(normal_map.unsqueeze(0), grid, mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
 
 
+class _MVTake(torch.autograd.Function):
+    """What the sampled pixels hand the NCC kernel, in one launch (include/gs2m_loss.h: gs2m_mv_take_*): idx (n) distinct flat pixel
+    indices, local_normal_map (3,H,W), distance_map (H,W) or (1,H,W), w_map (H,W) or None -> pixels (n,2), normals (n,3), dists (n), w (n).
+    Gradients to the two maps (a scatter into zeros: the indices are distinct)."""
+
+    @staticmethod
+    def forward(ctx, idx, normal_map, dist_map, w_map):
+        normal_map, dist_map = normal_map.contiguous().float(), dist_map.contiguous().float()
+        H, W = normal_map.shape[-2:]
+        n, dev = idx.numel(), normal_map.device
+        idx = idx.contiguous().long()
+        pixels = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        normals = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        dists = torch.empty((n,), dtype=torch.float32, device=dev)
+        w = torch.empty((n,), dtype=torch.float32, device=dev)
+        wm = None if w_map is None else w_map.contiguous().float()
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gs2m_mv_take_forward(n, idx.data_ptr(), W, H, normal_map.data_ptr(), dist_map.data_ptr(),
+                                                             None if wm is None else wm.data_ptr(), pixels.data_ptr(), normals.data_ptr(),
+                                                             dists.data_ptr(), w.data_ptr(), C.c_void_p(_native.stream_ptr(dev))), "gs2m_mv_take_forward")
+        ctx.save_for_backward(idx)
+        ctx.shapes = (normal_map.shape, dist_map.shape, W, H)
+        ctx.mark_non_differentiable(pixels, w)
+        return pixels, normals, dists, w
+
+    @staticmethod
+    def backward(ctx, _gp, g_normals, g_dists, _gw):
+        (idx,) = ctx.saved_tensors
+        nshape, dshape, W, H = ctx.shapes
+        dev = g_normals.device
+        maps = torch.zeros((4, H, W), dtype=torch.float32, device=dev)  # one fill for both maps
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gs2m_mv_take_backward(idx.numel(), idx.data_ptr(), W, H, g_normals.contiguous().float().data_ptr(),
+                                                              g_dists.contiguous().float().data_ptr(), maps[:3].data_ptr(), maps[3].data_ptr(),
+                                                              C.c_void_p(_native.stream_ptr(dev))), "gs2m_mv_take_backward")
+        return None, maps[:3].reshape(nshape), maps[3].reshape(dshape), None
+
+
+class _NCCTail(torch.autograd.Function):
+    """sum(ncc w [ncc < 0.9]) / max(#[ncc < 0.9], 1) (utils/loss_utils.py:345-349), one launch each way; w carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, ncc, w):
+        import gs2m_losses
+        ncc, w = ncc.contiguous().float().reshape(-1), w.contiguous().float().reshape(-1)
+        dev = ncc.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gs2m_ncc_tail_forward(ncc.numel(), ncc.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                                              gs2m_losses._workspace(dev).data_ptr(), C.c_void_p(_native.stream_ptr(dev))), "gs2m_ncc_tail_forward")
+        ctx.save_for_backward(ncc, w, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ncc, w, out = ctx.saved_tensors
+        d = torch.empty_like(ncc)
+        with _native.device_guard(ncc.device):
+            _native.check(_native.lib().gs2m_ncc_tail_backward(ncc.numel(), ncc.data_ptr(), w.data_ptr(), out.data_ptr(), g.contiguous().float().data_ptr(),
+                                                               d.data_ptr(), C.c_void_p(_native.stream_ptr(ncc.device))), "gs2m_ncc_tail_backward")
+        return d.reshape(-1, 1), None
+
+
 class _TakeDistinct(torch.autograd.Function):
     """x[idx] along dim 0 for DISTINCT indices (random_subset's): the backward is a plain scatter into zeros.  torch's indexing backward
     cannot know the indices are distinct and sorts them first to add duplicates up deterministically: two 100 k-key merge sorts per
@@ -511,7 +574,16 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
         idx = random_subset(pixel_valid, opt.multi_view_sample_num)
         if idx.numel() == 0:
             return w_geo_loss
-        w_ncc = (w_ncc_map if w_ncc_map is not None else torch.where(pixel_valid, torch.exp(-pixel_noise), 0.0)).reshape(-1)[idx]
+        w_map = w_ncc_map if w_ncc_map is not None else torch.where(pixel_valid, torch.exp(-pixel_noise), 0.0)
+    if fused and w_map.is_cuda:  # the samples' inputs in one launch, the masked mean in one (include/gs2m_loss.h: gs2m_mv_take_*, gs2m_ncc_tail_*)
+        pixels, local_n, local_d, w_ncc = _MVTake.apply(idx, render_pkg["local_normal_map"], render_pkg["distance_map"], w_map)
+        if material_stage:
+            w_ncc = w_ncc * (render_pkg["roughness_map"].detach().squeeze().clamp(0, 1) ** 2.0).reshape(-1)[idx]
+        M, b, Kinv = _homography_constants(viewpoint_cam, near, scene.ncc_scale)
+        ncc = _PatchNCC.apply(pixels, local_n, local_d, viewpoint_cam.gray_image, near.gray_image, M, b, Kinv, scene.ncc_scale, opt.multi_view_patch_size)
+        return w_geo_loss + opt.multi_view_ncc_weight * _NCCTail.apply(ncc, w_ncc)
+    with torch.no_grad():
+        w_ncc = w_map.reshape(-1)[idx]
         if material_stage:
             w_ncc = w_ncc * (render_pkg["roughness_map"].squeeze().clamp(0, 1) ** 2.0).reshape(-1)[idx]
         pixels = scene.pixels.reshape(-1, 2)[idx]

@@ -68,6 +68,18 @@ int gs2m_mv_geo_loss_backward(int n, const float* noise, const float* angle, con
                               float factor, float weight, const float* out, const float* g_loss, float* d_noise, float* d_angle,
                               void* stream);
 
+/* The photometric part of multi_view_loss around the patch NCC (utils/loss_utils.py:293-300, 345-349; gs-2m_amd/gs2m_mvs.py).
+ * mv_take: for n DISTINCT pixel indices idx (int64, y * width + x) -> pixels (n,2) = (x, y), normals (n,3) from normal_map (3,H,W),
+ * dists (n) from dist_map (H,W), w (n) from w_map (H,W; NULL: ones).  The backward writes d_normals / d_dists into d_normal_map (3,H,W) /
+ * d_dist_map (H,W), which the caller has zero-filled.
+ * ncc_tail: out[0] = sum(ncc w [ncc < 0.9]) / max(#[ncc < 0.9], 1), out[1] = that count; the backward writes d_ncc (w carries no gradient). */
+int gs2m_mv_take_forward(int n, const long long* idx, int width, int height, const float* normal_map, const float* dist_map, const float* w_map,
+                         float* pixels, float* normals, float* dists, float* w, void* stream);
+int gs2m_mv_take_backward(int n, const long long* idx, int width, int height, const float* d_normals, const float* d_dists, float* d_normal_map,
+                          float* d_dist_map, void* stream);
+int gs2m_ncc_tail_forward(int n, const float* ncc, const float* w, float* out, void* workspace, void* stream);
+int gs2m_ncc_tail_backward(int n, const float* ncc, const float* w, const float* out, const float* g_loss, float* d_ncc, void* stream);
+
 /* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
  * fused_ssim/__init__.py:40-41) and the D-SSIM term lambda * (1 - ssim) of train.py:103 (a = lambda, b = -lambda). */
 int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream);

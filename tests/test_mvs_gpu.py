@@ -230,3 +230,33 @@ def test_fused_geo_loss_equals_the_masked_means(N):
     assert abs(float(got.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) + 1e-12
     assert torch.allclose(n1.grad, n0.grad, rtol=1e-5, atol=1e-14) and torch.allclose(a1.grad, a0.grad, rtol=1e-5, atol=1e-14)
     assert torch.equal(M.mv_geo_loss(noise, angle, valid, opt)[0], got.detach()), "fixed-order reduction"
+
+
+def test_mv_take_and_ncc_tail_match_the_framework_ops():
+    """gs2m_mv_take_* / gs2m_ncc_tail_* (include/gs2m_loss.h) against the indexing and reduction expressions they replace in
+    multi_view_loss (utils/loss_utils.py:293-300, 345-349): values bit for bit, gradients bit for bit (distinct indices: nothing is added up)"""
+    import gs2m_mvs
+    g = torch.Generator().manual_seed(11)
+    H, W, n = 97, 131, 4000
+    dev = "cuda"
+    nm = torch.randn(3, H, W, generator=g).to(dev).requires_grad_(True)
+    dm = torch.rand(1, H, W, generator=g).to(dev).requires_grad_(True)
+    wm = torch.rand(H, W, generator=g).to(dev)
+    idx = torch.randperm(H * W, generator=g)[:n].to(dev)
+    px, ln, ld, w = gs2m_mvs._MVTake.apply(idx, nm, dm, wm)
+    ix, iy = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy")
+    grid = torch.stack([ix, iy], dim=-1).float().to(dev).reshape(-1, 2)
+    assert torch.equal(px, grid[idx]) and torch.equal(ln, nm.permute(1, 2, 0).reshape(-1, 3)[idx]) and torch.equal(ld, dm.reshape(-1)[idx]) and torch.equal(w, wm.reshape(-1)[idx])
+    gn, gd = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    a = torch.autograd.grad((ln * gn).sum() + (ld * gd).sum(), (nm, dm))
+    b = torch.autograd.grad((nm.permute(1, 2, 0).reshape(-1, 3)[idx] * gn).sum() + (dm.reshape(-1)[idx] * gd).sum(), (nm, dm))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    ncc = (2.0 * torch.rand(n, 1, generator=g)).to(dev).requires_grad_(True)
+    la = gs2m_mvs._NCCTail.apply(ncc, w)
+    m = (ncc < 0.9).reshape(-1)
+    lb = (ncc.reshape(-1) * w * m).sum() / m.sum().clamp(min=1)
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    (ga,), (gb,) = torch.autograd.grad(3.0 * la, ncc), torch.autograd.grad(3.0 * lb, ncc)
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=0)
+    none = torch.full((50, 1), 1.5, device=dev, requires_grad=True)  # no sample below 0.9: 0 / max(0, 1)
+    assert float(gs2m_mvs._NCCTail.apply(none, torch.ones(50, device=dev))) == 0.0
