@@ -23,7 +23,7 @@ __device__ __constant__ const float SSIM_W[11] = {0.001028380123898387f, 0.00759
                                                   0.21300552785396576f,  0.10936068743467331f,   0.036000773310661316f,
                                                   0.0075987582094967365f, 0.001028380123898387f};
 
-constexpr int SSIM_ROWS = 45;   // output rows per strip (1080 = 24 * 45); +10 halo rows of input
+constexpr int SSIM_ROWS = 45;   // output rows per strip at most (1080 = 24 * 45); +10 halo rows of input.  ssim_rows() below picks fewer on small frames
 constexpr int SSIM_LDSW = 80;   // 64 + 10 halo columns, padded
 constexpr int SSIM_PF_FWD = 3;  // input rows in flight ahead of the row being consumed: the strip walk is a chain of
 constexpr int SSIM_PF_BWD = 5;  // dependent HBM round trips (~1 us each) with only ~2 waves per SIMD to hide them
@@ -34,13 +34,13 @@ struct Ring {  // NQ quantities x 11 vertical accumulators
 };
 
 // ---------------------------------------------------------------- forward
-__global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
+__global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, int rows, float C1, float C2, const float* __restrict__ img1,
                                                       const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                       float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                       float* __restrict__ dm_dsigma12) {
     __shared__ float s_a[2][SSIM_LDSW], s_b[2][SSIM_LDSW];
     const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * SSIM_ROWS;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * rows;
     const size_t plane = (size_t)blockIdx.z * H * W;
     const float* __restrict__ A = img1 + plane;
     const float* __restrict__ Bm = img2 + plane;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, fl
 #pragma unroll
         for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
 
-    const int nrows = min(SSIM_ROWS, H - y0) + 10;  // input rows y0-5 .. y0+rows+4
+    const int nrows = min(rows, H - y0) + 10;  // input rows y0-5 .. y0+rows+4
     float pf[SSIM_PF_FWD][4];  // queue of fetched rows: pf[0] is the next one to consume
 #pragma unroll
     for (int d = 0; d < SSIM_PF_FWD; d++) fetch(d < nrows ? y0 - 5 + d : -1, pf[d][0], pf[d][1], pf[d][2], pf[d][3]);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) ssim_fwd_kernel(int H, int W, float C1, fl
 
 // ---------------------------------------------------------------- backward
 // dL/dimg1 = conv(dL dm/dmu1) + 2 img1 conv(dL dm/dsigma1_sq) + img2 conv(dL dm/dsigma12)   (the window is symmetric)
-__global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
+__global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, int rows, const float* __restrict__ img1,
                                                       const float* __restrict__ img2, const float* __restrict__ dL_dmap,
                                                       const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
                                                       const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1,
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
     // dL_dmap == nullptr: the map's gradient is the same at every element, dL_dvalue[0] * mul / div (the mean's backward)
     const float gu = dL_dmap == nullptr ? (dL_dvalue[0] * mul) / div : 0.f;
     const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * SSIM_ROWS;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * rows;
     const size_t plane = (size_t)blockIdx.z * H * W;
     float w[11];
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
     for (int q = 0; q < 3; q++)
 #pragma unroll
         for (int j = 0; j < 11; j++) R.a[q][j] = 0.f;
-    const int nrows = min(SSIM_ROWS, H - y0) + 10;
+    const int nrows = min(rows, H - y0) + 10;
     float pf[SSIM_PF_BWD][8];
 #pragma unroll
     for (int d = 0; d < SSIM_PF_BWD; d++) fetch(d < nrows ? y0 - 5 + d : -1, pf[d]);
@@ -217,8 +217,16 @@ __global__ void __launch_bounds__(64) ssim_bwd_kernel(int H, int W, const float*
     }
 }
 
+// Rows per strip: a strip is ONE wave walking its rows as a chain of dependent memory round trips, so a frame has to be cut into
+// enough strips to fill the chip (~2000 waves): 45 rows at 1080p (2160 strips), 12 at 777 x 581 (1900 strips instead of 507, whose
+// 55-row chains made the kernels 55 us each on a frame a fifth of 1080p's size).  The halo (10 input rows per strip) is re-read from L2.
+inline int ssim_rows(int B, int CH, int H, int W) {
+    const long long cols = (W + 63) / 64;
+    const long long r = (cols * H * (long long)B * CH) / 2048;
+    return (int)(r < 12 ? 12 : (r > SSIM_ROWS ? SSIM_ROWS : r));
+}
 inline bool ssim_dims_ok(int B, int CH, int H, int W) {
-    return B > 0 && CH > 0 && H > 0 && W > 0 && (long long)B * CH <= 65535 && (H + SSIM_ROWS - 1) / SSIM_ROWS <= 65535;
+    return B > 0 && CH > 0 && H > 0 && W > 0 && (long long)B * CH <= 65535 && (H + 11) / 12 <= 65535;
 }
 
 }  // namespace
@@ -230,8 +238,9 @@ extern "C" int gs2m_ssim_forward(int B, int CH, int H, int W, float C1, float C2
     const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
     if (train && !(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12)) return GS2M_ERR_INVALID_ARG;
     if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
-    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
-    ssim_fwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq,
+    const int rows = ssim_rows(B, CH, H, W);
+    dim3 grid((W + 63) / 64, (H + rows - 1) / rows, B * CH);
+    ssim_fwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, rows, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq,
                                                          dm_dsigma12);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
@@ -243,8 +252,9 @@ extern "C" int gs2m_ssim_backward(int B, int CH, int H, int W, const float* img1
     if (B < 0 || CH < 0 || H < 0 || W < 0 || !img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
         return GS2M_ERR_INVALID_ARG;
     if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
-    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
-    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+    const int rows = ssim_rows(B, CH, H, W);
+    dim3 grid((W + 63) / 64, (H + rows - 1) / rows, B * CH);
+    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, rows, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                                                          dL_dimg1, nullptr, 0.f, 1.f);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
@@ -256,8 +266,9 @@ extern "C" int gs2m_ssim_backward_uniform(int B, int CH, int H, int W, const flo
     if (B < 0 || CH < 0 || H < 0 || W < 0 || !img1 || !img2 || !dL_dvalue || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1 || div == 0.f)
         return GS2M_ERR_INVALID_ARG;
     if (!ssim_dims_ok(B, CH, H, W)) return GS2M_ERR_UNSUPPORTED;
-    dim3 grid((W + 63) / 64, (H + SSIM_ROWS - 1) / SSIM_ROWS, B * CH);
-    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, img1, img2, nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+    const int rows = ssim_rows(B, CH, H, W);
+    dim3 grid((W + 63) / 64, (H + rows - 1) / rows, B * CH);
+    ssim_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(H, W, rows, img1, img2, nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                                                          dL_dimg1, dL_dvalue, mul, div);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
