@@ -3,7 +3,7 @@
 // Semantics: renderCUDA (bwd), diff-gaussian-rasterization/cuda_rasterizer/backward.cu:413-598 -- same per-pixel tests,
 // same gradients.  The reference walks a tile's list back to front with one thread per pixel and adds every
 // (pixel, Gaussian) pair's 11 + fc gradient components to global memory with atomicAdd (:551-595).  Here:
-//  * a wave owns one 8x8 quadrant and walks the quadrant's own list (binning.hip: quad_lists_kernel) from the
+//  * a wave owns one 8x8 quadrant and walks the quadrant's own list (tile_sort.hip) from the
 //    quadrant's last contributor backwards, 16 entries ("survivors": every entry passed the quadrant test when the list
 //    was built) per group;
 //  * lane = (survivor j = lane & 15, pixel column r = lane >> 4): a group walks the 64 pixels in 8 double-steps, each
@@ -23,7 +23,7 @@
 //    gradient row from the list (round 5: it used to be two dependent gathers through the record's binning quad); the loads
 //    for the next group are issued before the current group's epilogue and land behind it.
 // One wave per quadrant (64-thread workgroups, no barriers), XCD-aware block ids, one partial-gradient row per
-// (instance, quadrant) in the DENSE numbering fill_kernel prepared (binning.hip): the rows of a Gaussian are one
+// (instance, quadrant) in the numbering emit_kernel / emit_heavy_kernel prepared (binning.hip): the rows of a Gaussian are one
 // contiguous run, every row is written (zeros for the entries behind a quadrant's last contributor), and
 // gaussian_bwd.hip streams them.  No float atomics anywhere: gradients are bitwise reproducible.
 // Measured and not kept in round 3: one workgroup per TILE whose four quadrant waves combine an
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         float2 g1;       // C, opacity
         float ch[KK];
         uint32_t pos1;   // position in the tile list + 1
-        uint32_t row;    // gradient row of (instance, quadrant): dense numbering per Gaussian (binning.hip: fill_kernel)
+        uint32_t row;    // gradient row of (instance, quadrant): numbered per Gaussian (binning.hip: emit_kernel, emit_heavy_kernel)
     };
     struct Entry {
         uint2 e;

@@ -1,7 +1,7 @@
 // Per-quadrant front-to-back alpha compositing (forward) for gfx950.
 //
 // Semantics: renderCUDA, diff-gaussian-rasterization/cuda_rasterizer/forward.cu:246-372 -- the same per-pixel
-// sequence of tests and updates, on the per-quadrant lists binning.hip:quad_lists_kernel builds.
+// sequence of tests and updates, on the per-quadrant lists tile_sort.hip builds.
 //
 // One wave per 8x8 quadrant, pixel per lane, no workgroup barriers: every list entry survives the quadrant test by
 // construction, so the wave walks its list straight down, 16 entries per chunk.  The chunk's blend records are

@@ -69,13 +69,13 @@ struct GeomState {
     uint32_t* depth_key;     // P: fp32 bits of the view depth, 0xFFFFFFFF when culled
     uint8_t* clamped;        // P
     float* sh_dir;           // P * 9: d(SH colour)/d(view direction) of a visible Gaussian, {dRdx, dRdy, dRdz}[rgb] (preprocess -> gaussian_bwd)
-    uint32_t* counters;      // 64 u32 (counters[0] = num_rendered as fill_kernel's offsets add up: debug mode compares)
+    uint32_t* counters;      // 64 u32 (GS2M_CNT_* below; counters[0] = num_rendered as emit_kernel's offsets add up: debug mode compares)
     uint32_t* gauss_rows;    // P: gradient rows of each Gaussian, or GS2M_ROWS_BIG | first unit of a heavy one (emit_kernel)
     uint32_t* block_tt;      // ceil(P / 256): tiles_touched summed over blocks of 256 Gaussians (preprocess kernel)
     uint32_t* block_pref;    // ceil(P / 256): exclusive prefix of block_tt (scan kernel): first emission offset of a block
     uint32_t* block_hu;      // ceil(P / 256): heavy units of the block's Gaussians (preprocess kernel)
     uint32_t* block_hupref;  // ceil(P / 256): exclusive prefix of block_hu (scan kernel)
-    uint32_t* wave_rows;     // ceil(P / 64): gradient rows of each wave of 64 consecutive Gaussians (fill_kernel)
+    uint32_t* wave_rows;     // ceil(P / 64): gradient rows of each wave of 64 consecutive Gaussians, heavy ones not counted (emit_kernel)
     uint32_t* wave_rowbase;  // ceil(P / 64): exclusive prefix of wave_rows (rowscan_kernel): first gradient row of the wave
     uint32_t* tile_hist;     // GS2M_HIST_COPIES x 1024: the tile sort's digit histograms, counted by emit_kernel (zeroed by the preprocess kernel)
     size_t total_bytes;      // including alignment slack

@@ -51,7 +51,7 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 
 // Phase 1 of the kernel below: the sum of the partial-gradient rows of each of the workgroup's 256 Gaussians, into LDS.
 // The backward blend (blend_bwd_q.hip) numbers its rows DENSELY in index order: wave w of this workgroup (the same 64
-// consecutive Gaussians fill_kernel's wave w owned) has its rows from wave_rowbase[w] on, Gaussian by Gaussian
+// consecutive Gaussians emit_kernel's wave w owned) has its rows from wave_rowbase[w] on, Gaussian by Gaussian
 // (gauss_rows[] rows each), and every row is written.  So a wave STREAMS one contiguous range: 64 rows per window as RQ
 // fully coalesced float4 loads per lane (lane l takes float4 l, l + 64, ... of the window), parked in LDS, then RQ lanes per
 // Gaussian add the rows of their Gaussians -- no validity bytes, no holes, no per-instance gather.  Fixed summation order

@@ -48,7 +48,6 @@ def main():
     rec = view(geomB, go + lay.rec, P * 32, np.float32).reshape(P, 32)
     tt = view(geomB, go + lay.tiles_touched, P, np.uint32)
     dk = view(geomB, go + lay.depth_key, P, np.uint32)
-    sg = view(geomB, go + lay.sorted_gid, P, np.uint32)
     vis = f.radii > 0
     print("radii equal:", np.array_equal(radii.cpu().numpy(), f.radii), " tiles_touched equal:", np.array_equal(tt, f.tiles_touched))
     print("depth key equal (visible):", np.array_equal(dk[vis], f.depths[vis].view(np.uint32)), " culled keys all FFFFFFFF:", bool((dk[~vis] == 0xFFFFFFFF).all()))

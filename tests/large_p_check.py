@@ -30,13 +30,7 @@ for refbin in (False, True):
     al = lambda t: (-t.data_ptr()) % 256
     view = lambda t, off, n, dt: t[al(t) + off: al(t) + off + n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
     tt = view(geomB, lay.tiles_touched, P, np.uint32).astype(np.int64)
-    sg = view(geomB, lay.sorted_gid, P, np.uint32).astype(np.int64)
-    so = view(geomB, lay.sorted_off, P, np.uint32).astype(np.int64)
     dk = view(geomB, lay.depth_key, P, np.uint32).astype(np.int64)
-    assert np.array_equal(np.sort(sg), np.arange(P)), "sorted_gid is a permutation"
-    assert np.all(np.diff(dk[sg]) >= 0), "depth order"
-    ex = np.concatenate([[0], np.cumsum(tt[sg])[:-1]])
-    assert np.array_equal(so, ex), "emission offsets = exclusive prefix sum of tiles_touched in depth order"
     assert int(tt.sum()) == R
     tk = view(binB, lay.tile_keys, R, np.uint32).astype(np.int64)
     pl = view(binB, lay.point_list, R, np.uint32) & np.uint32(0x0FFFFFFF)
