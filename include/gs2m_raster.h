@@ -310,8 +310,9 @@ int gs2m_set_debug(int on);
 int gs2m_set_markers(int on);
 const char* gs2m_stage_name(int stage);
 
-/* Limits: num_rendered (the emitted instance count) must stay below 2^30 -- slots, gradient rows (up to 4 per instance)
- * and list offsets are 32-bit; P below 2^28 (a 4-bit quadrant mask rides above the Gaussian id); at most 2^28 tiles.
+/* Limits: num_rendered (the emitted instance count) must stay below 2^29 -- slots and list offsets are 32-bit, gradient rows (up to 4
+ * per instance, 256 per unit of a heavy Gaussian) stay below 2^31 --; P below 2^28 (a 4-bit quadrant mask rides above the Gaussian id);
+ * at most 2^28 tiles, 2^22 heavy units.
  * gs2m_raster_forward returns GS2M_ERR_UNSUPPORTED beyond that. */
 
 /* ---- backward scratch sized by what the forward actually binned -------------------------------------------------------
