@@ -434,7 +434,7 @@ __device__ __forceinline__ void network_wg(uint32_t (&k)[E], uint32_t (&x)[E], c
     xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
 }
 
-constexpr int WG_MAX = 2048;
+constexpr int WG_MAX = 4096;
 template <int E, int LE>
 __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
                                              const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase,
@@ -450,30 +450,34 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
 #define TS_CLK() do {} while (0)
 #endif
     uint32_t key[E], idx[E], rb[E];
-    {   // span position p = e * 256 + tid: coalesced slot loads, one 16-byte gather per element, all E in flight
-        uint32_t slot[E];
+    // span position p = e * 256 + tid: coalesced slot loads, one 16-byte gather per element, batches of up to 8 elements per lane in flight
+    constexpr int BATCH = E < 8 ? E : 8;
+    static_for<0, E / BATCH>([&](auto bc) {
+        constexpr int e0 = BATCH * decltype(bc)::value;
+        uint32_t slot[BATCH];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t p = (uint32_t)(e * 256 + tid);
+        for (int e = 0; e < BATCH; e++) {
+            const uint32_t p = (uint32_t)((e0 + e) * 256 + tid);
             slot[e] = p < n ? slot_sorted[start + p] : 0u;
         }
-        uint4 rc[E];
+        uint4 rc[BATCH];
 #pragma unroll
 #ifdef GS2M_KO_TS_GATHER  // timing only
-        for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * 256 + tid) < n ? e_rec[start + e * 256 + tid + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        for (int e = 0; e < BATCH; e++) rc[e] = (uint32_t)((e0 + e) * 256 + tid) < n ? e_rec[start + (e0 + e) * 256 + tid + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
 #else
-        for (int e = 0; e < E; e++) rc[e] = (uint32_t)(e * 256 + tid) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        for (int e = 0; e < BATCH; e++) rc[e] = (uint32_t)((e0 + e) * 256 + tid) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
 #endif
-        static_for<0, E>([&](auto ec) {
+        static_for<0, BATCH>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
-            const uint32_t p = (uint32_t)(e * 256 + tid);
-            key[e] = rc[e].z;
-            idx[e] = p;
+            const uint32_t p = (uint32_t)((e0 + e) * 256 + tid);
+            key[e0 + e] = rc[e].z;
+            idx[e0 + e] = p;
             s_v[skew((int)p)] = rc[e].x;
             s_r[skew((int)p)] = rc[e].y & ~GS2M_ROWS_BIG;
-            rb[e] = p < n && (rc[e].y & GS2M_ROWS_BIG) == 0u ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;  // (a heavy instance's row is absolute)
+            rb[e0 + e] = p < n && (rc[e].y & GS2M_ROWS_BIG) == 0u ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;  // (a heavy instance's row is absolute)
         });
-    }
+        asm volatile("" ::: "memory");  // the next batch's loads stay behind this batch's staging (registers: one batch in flight)
+    });
     TS_CLK();  // 0: records staged (loads done)
 #ifndef GS2M_KO_TS_SORT
     network_wg<E, LE, false>(key, idx, tid, s_x);
@@ -560,8 +564,9 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
 #endif
 }
 
-// more than 2048 entries: the same network over LDS (up to 4096 entries) or, beyond, over the tile's own (still unused) quadrant-list
-// region in global memory -- slow, correct, exercised by the dense-scene tests
+// more than 4096 entries: a bitonic network over the tile's own (still unused) quadrant-list region in global memory (over LDS up to
+// BIG_LDS entries: the path the register kernels replaced, still reachable through the test hook's small sizes) -- slow (0.4 ms for
+// 4200..8000 entries, 1.3 ms for 9000..20000), correct, exercised by the dense-scene tests
 constexpr int BIG_LDS = 4096;
 __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
                                               const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
@@ -645,7 +650,7 @@ __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t sta
 
 
 // A workgroup per tile, in two launches: spans of up to 1024 entries (MAXE = 4: 13 KB of LDS and 80 registers, six workgroups per CU;
-// this launch also writes ranges[] -- it is the frame's first when it runs at all) and the longer ones (MAXE = 8; launched on every
+// this launch also writes ranges[] -- it is the frame's first when it runs at all) and the longer ones (MAXE = 16: 8 elements per lane up to 2048 entries, 16 up to 4096, 50 KB of LDS; launched on every
 // frame).  A fixed grid walks the tiles: on a frame without such spans a launch costs what ~1000 workgroups cost to look at a few tile
 // ranges each.
 #ifndef GS2M_TS_WG_OCC
@@ -657,7 +662,7 @@ struct WgCfg {
     static constexpr int kLds = MAXE >= 8 ? (3 * kWords > 2 * BIG_LDS ? 3 * kWords : 2 * BIG_LDS) : 3 * kWords;
 };
 template <int MAXE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >= 8 ? 4 : GS2M_TS_WG_OCC, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >= 8 ? 3 : GS2M_TS_WG_OCC, 8)))
 tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
                     const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
                     uint32_t* __restrict__ row_tmp, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
@@ -682,7 +687,8 @@ tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__
             else sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
         } else {
             if (n <= 1024u) continue;
-            if (n <= (uint32_t)WG_MAX) sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            if (n <= 2048u) sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            else if (n <= (uint32_t)WG_MAX) sort_tile_wg<16, 4>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
             else sort_tile_big(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, row_tmp, qlist, qrow, qcount, s_all);
         }
         gs2m_sync();  // the LDS arrays are the next tile's
@@ -716,6 +722,6 @@ void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const Binning
                                                        im.qcount, tiles_x, tiles_y, grid);
     }
     // spans of more than 1024 entries: none on the bench scenes (the workgroups look at their tiles' ranges and leave)
-    tile_sort_wg_kernel<8><<<wg_grid < 1024u ? wg_grid : 1024u, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
+    tile_sort_wg_kernel<16><<<wg_grid < 1024u ? wg_grid : 1024u, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
                                                                              b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid);
 }
