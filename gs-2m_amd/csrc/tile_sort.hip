@@ -5,20 +5,22 @@
 // order: what its 45-bit radix sort of (tile << 32 | depth) keys over the id-ordered duplicateWithKeys output produces
 // (rasterizer_impl.cu:288-296) -- writes ranges[] (identifyTileRanges: the sort's last pass recorded where
 // every tile's run starts and ends) and splits the sorted list into the four per-quadrant lists the blend kernels walk.
-//   * spans of up to 1024 entries (every tile of the bench scenes): ONE WAVE per tile, the span in registers as (depth, position
-//     in the span) pairs, lane-major (lane l holds elements l E .. l E + E - 1, E = 8 or 16), sorted by a bitonic network in its
-//     all-ascending form (each merge starts with a mirrored compare, so that padding with +inf needs no direction bits):
-//     strides inside a lane are register renaming + compare-exchange, strides across lanes are DPP moves (quad_perm,
-//     row_half_mirror / row_mirror, row_ror:8, a masked row_shl:4 / row_shr:4 pair) and, for the three strides that cross a
-//     DPP row, ds_bpermute; levels above the span's length are skipped (their input is already in order);
-//   * equal depths (two Gaussians at exactly the same view depth): the network compares depths only; when the sorted span holds
-//     equal neighbours (rare, wave-uniform) it is run again with (depth, position) as the key -- positions are in id order;
+//   * the span in registers as (depth, position in the span) pairs, lane-major (lane l holds elements l E .. l E + E - 1), sorted
+//     by a bitonic network in its all-ascending form (each merge starts with a mirrored compare, so that padding with +inf needs no
+//     direction bits): strides inside a lane are register renaming + compare-exchange, strides across lanes are DPP moves (quad_perm,
+//     row_half_mirror / row_mirror, row_ror:8, a masked row_shl:4 / row_shr:4 pair) and, for the strides that cross a DPP row,
+//     ds_bpermute; strides across the waves of a workgroup go through LDS;
+//   * who sorts which span (gs2m_launch_tile_sort below): ONE WAVE per tile (8 or 16 elements per lane: spans of up to 512 / 1024
+//     entries) on frames of many tiles, a WORKGROUP per tile (1 to 16 elements per lane: up to 4096 entries) on frames of few tiles and
+//     for long spans everywhere; beyond 4096 entries sorted runs of 4096 from the same network, merged over global memory;
+//   * equal depths (coincident Gaussians: a quarter of a trained model's tiles hold such a pair): the network compares depths only;
+//     the members of a run of equal depths then look along the run for their place in span order = id order (tie_positions);
 //   * ids and rows wait in LDS under their span position and are picked up in sorted order, then ballots give every instance
 //     its place in each of the four quadrant lists with coalesced stores; the gradient row of a list entry = the instance's
 //     first row (relative to its emit wave, emit_kernel; absolute and flagged GS2M_ROWS_BIG for a heavy Gaussian's) + the wave's base
-//     (rowscan_kernel) + its quadrants before this one;
-//   * longer spans are queued and sorted by a workgroup each: the same network over LDS (up to 4096 entries) or, beyond, over
-//     the tile's own (still unused) quadrant-list region in global memory -- slow, correct, exercised by the dense-scene tests.
+//     (rowscan_kernel) + its quadrants before this one.
+// (The TIE variants of the network's building blocks -- (depth, position) as a two-word key -- have no caller any more; they are what
+// the equal-depth handling replaced and what tools/ts_micro.py's comparisons were made against.)
 #include "common.h"
 #include <atomic>
 #include <cstdlib>
@@ -564,90 +566,147 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
 #endif
 }
 
-// more than 4096 entries: a bitonic network over the tile's own (still unused) quadrant-list region in global memory (over LDS up to
-// BIG_LDS entries: the path the register kernels replaced, still reachable through the test hook's small sizes) -- slow (0.4 ms for
-// 4200..8000 entries, 1.3 ms for 9000..20000), correct, exercised by the dense-scene tests
-constexpr int BIG_LDS = 4096;
+// More than 4096 entries (a tile under thousands of Gaussians: dense foliage in a multi-million-Gaussian scene).  The span is sorted in
+// the tile's own (still unused) quadrant-list region in global memory (32 n bytes: keys K[n], span positions I[n], and I2[n] for the
+// last step), but almost all of the network still runs in registers:
+//   A. every chunk of 4096 entries is gathered and sorted by depth with the register network above (16 per lane), written out as a run;
+//   B. merge level by level (runs of 4096 -> 8192 -> ...): the mirrored compare of a level and its strides of 4096 and more run over
+//      global memory (one step for two runs, three for four, ...), the strides 2048 .. 1 again in registers, a chunk at a time;
+//   C. equal depths: every entry looks along its run for its place (tie_positions' rule).
+// Exercised by tests/test_tile_sort_gpu.py (spans of up to 20000 entries, with equal depths) and the dense-scene tests.
+constexpr int BIG_CHUNK = 4096;
 __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t start, const uint32_t n, const uint32_t* __restrict__ slot_sorted,
                                               const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
                                               uint32_t* __restrict__ row_tmp /* R words: sorted rows on their way to the lists */,
                                               uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
-                                              uint32_t* s_all /* 2 * BIG_LDS words */) {
+                                              uint32_t* s_x /* BIG_CHUNK + BIG_CHUNK / 32 words: the register network's exchange array */) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t* const s_key = s_all;
-    uint32_t* const s_idx = s_all + BIG_LDS;
-    {
-        // working arrays: LDS, or -- beyond its capacity -- the tile's own quadrant-list region (32 n bytes, written only at the end)
-        const bool glob = n > (uint32_t)BIG_LDS;
-        uint32_t* const K = glob ? reinterpret_cast<uint32_t*>(qlist + (size_t)4 * start) : s_key;
-        uint32_t* const I = glob ? K + n : s_idx;
-        auto barrier = [&]() {
-            if (glob) __threadfence_block();
-            gs2m_sync();
-        };
-        for (uint32_t p = tid; p < n; p += 256) {
-            K[p] = e_rec[slot_sorted[start + p]].z;
-            I[p] = p;
+    uint32_t* const K = reinterpret_cast<uint32_t*>(qlist + (size_t)4 * start);
+    uint32_t* const I = K + n;
+    auto barrier = [&]() {
+        __threadfence_block();
+        gs2m_sync();
+    };
+    constexpr int E = 16, LE = 4;
+    // ---- A: sorted runs of 4096 ----
+    for (uint32_t base = 0; base < n; base += BIG_CHUNK) {
+        uint32_t key[E], idx[E];
+        static_for<0, E / 8>([&](auto bc) {  // gathers in batches of 8 per lane
+            constexpr int e0 = 8 * decltype(bc)::value;
+            uint32_t slot[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t p = base + (uint32_t)((e0 + e) * 256 + tid);
+                slot[e] = p < n ? slot_sorted[start + p] : 0u;
+            }
+            static_for<0, 8>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                const uint32_t p = base + (uint32_t)((e0 + e) * 256 + tid);
+                key[e0 + e] = p < n ? e_rec[slot[e]].z : 0xFFFFFFFFu;  // (a real key is the bit pattern of a depth > 0.2: never all ones)
+                idx[e0 + e] = p;
+            });
+        });
+        network_wg<E, LE, false>(key, idx, tid, s_x);
+#pragma unroll
+        for (int e = 0; e < E; e++) {  // the padding sorts behind every real entry of the chunk
+            const uint32_t i = base + (uint32_t)(tid * E + e);
+            if (i < n) { K[i] = key[e]; I[i] = idx[e]; }
+        }
+    }
+    barrier();
+    // ---- B: merge levels ----
+    auto cex = [&](uint32_t i, uint32_t p) {
+        const uint32_t a = K[i], b = K[p];
+        if (b < a) {
+            const uint32_t xa = I[i], xb = I[p];
+            K[i] = b; K[p] = a; I[i] = xb; I[p] = xa;
+        }
+    };
+    for (int kb = 13; (1u << (kb - 1)) < n; kb++) {
+        const uint32_t half = 1u << (kb - 1), mask = (1u << kb) - 1u;
+        for (uint32_t q = tid;; q += 256) {  // mirrored compare inside blocks of 2^kb; pairs with the partner in the (virtual, +inf) padding are no-ops
+            const uint32_t i = ((q >> (kb - 1)) << kb) | (q & (half - 1u));
+            if (i >= n) break;
+            const uint32_t p = i ^ mask;
+            if (p < n) cex(i, p);
         }
         barrier();
-        int nlev = 0;
-        while ((1u << nlev) < n) nlev++;
-        auto cex = [&](uint32_t i, uint32_t p) {  // (depth, span position): a total order; positions are in Gaussian-id order
-            const uint32_t a = K[i], b = K[p], xa = I[i], xb = I[p];
-            if (b < a || (b == a && xb < xa)) { K[i] = b; K[p] = a; I[i] = xb; I[p] = xa; }
-        };
-        for (int kb = 1; kb <= nlev; kb++) {
-            const uint32_t half = 1u << (kb - 1), mask = (1u << kb) - 1u;
-            for (uint32_t q = tid;; q += 256) {  // mirrored compare inside blocks of 2^kb; pairs with the partner in the (virtual, +inf) padding are no-ops
-                const uint32_t i = ((q >> (kb - 1)) << kb) | (q & (half - 1u));
+        for (int jb = kb - 2; jb >= 12; jb--) {  // strides of 4096 and more
+            const uint32_t j = 1u << jb;
+            for (uint32_t q = tid;; q += 256) {
+                const uint32_t i = ((q >> jb) << (jb + 1)) | (q & (j - 1u));
                 if (i >= n) break;
-                const uint32_t p = i ^ mask;
+                const uint32_t p = i | j;
                 if (p < n) cex(i, p);
             }
             barrier();
-            for (int jb = kb - 2; jb >= 0; jb--) {
-                const uint32_t j = 1u << jb;
-                for (uint32_t q = tid;; q += 256) {
-                    const uint32_t i = ((q >> jb) << (jb + 1)) | (q & (j - 1u));
-                    if (i >= n) break;
-                    const uint32_t p = i | j;
-                    if (p < n) cex(i, p);
-                }
-                barrier();
+        }
+        for (uint32_t base = 0; base < n; base += BIG_CHUNK) {  // strides 2048 .. 1 inside every chunk, element tid * 16 + e of the chunk in register e
+            uint32_t key[E], idx[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t i = base + (uint32_t)(tid * E + e);
+                key[e] = i < n ? K[i] : 0xFFFFFFFFu;
+                idx[e] = i < n ? I[i] : i;
+            }
+            cross_wave<E, false>(key, idx, tid, tid ^ 128, false, (wave & 2) == 0, s_x);
+            cross_wave<E, false>(key, idx, tid, tid ^ 64, false, (wave & 1) == 0, s_x);
+            xor_steps<E, LE, LE + 5, false>(key, idx, lane);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t i = base + (uint32_t)(tid * E + e);
+                if (i < n) { K[i] = key[e]; I[i] = idx[e]; }
             }
         }
-        // sorted ids -> point_list (final), absolute rows -> row_tmp
-        for (uint32_t p = tid; p < n; p += 256) {
-            const uint4 rc = e_rec[slot_sorted[start + I[p]]];
-            point_list[start + p] = rc.x;
-            row_tmp[start + p] = (rc.y & GS2M_ROWS_BIG) != 0u ? (rc.y & ~GS2M_ROWS_BIG) : rc.y + wave_rowbase[(rc.x & GS2M_GID_MASK) >> 6];
-        }
-        __threadfence_block();
-        gs2m_sync();
-        // quadrant lists: wave q compacts quadrant q (the scratch in the list region is dead behind the barrier above)
-        const int q = wave;
-        uint2* out = qlist + (size_t)4 * start + (size_t)q * n;
-        uint32_t* orow = qrow + (size_t)4 * start + (size_t)q * n;
-        uint32_t run = 0;
-        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        for (uint32_t base = 0; base < n; base += GS2M_WAVE) {
-            const uint32_t k = base + (uint32_t)lane;
-            uint32_t v = 0, r = 0;
-            if (k < n) { v = point_list[start + k]; r = row_tmp[start + k]; }
-            const uint32_t mask = v >> GS2M_GID_BITS;
-            const bool hit = ((mask >> q) & 1u) != 0u;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-            if (hit) {
-                const uint32_t o = run + (uint32_t)__popcll(m & lt);
-                out[o] = make_uint2(v, k);
-                orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
-            }
-            run += (uint32_t)__popcll(m);
-        }
-        if (lane == 0) qcount[tile * 4 + q] = run;
+        barrier();
     }
+    // ---- C: equal depths in span order ----
+    uint32_t* const I2 = I + n;
+    for (uint32_t p = tid; p < n; p += 256) {
+        const uint32_t Kp = K[p], X = I[p];
+        uint32_t a = p, cnt = 0;
+        for (uint32_t j = p; j > 0u;) {
+            j--;
+            if (K[j] != Kp) break;
+            a = j;
+            cnt += I[j] < X ? 1u : 0u;
+        }
+        for (uint32_t j = p + 1u; j < n; j++) {
+            if (K[j] != Kp) break;
+            cnt += I[j] < X ? 1u : 0u;
+        }
+        I2[a + cnt] = X;
+    }
+    barrier();
+    // sorted ids -> point_list (final), absolute rows -> row_tmp
+    for (uint32_t p = tid; p < n; p += 256) {
+        const uint4 rc = e_rec[slot_sorted[start + I2[p]]];
+        point_list[start + p] = rc.x;
+        row_tmp[start + p] = (rc.y & GS2M_ROWS_BIG) != 0u ? (rc.y & ~GS2M_ROWS_BIG) : rc.y + wave_rowbase[(rc.x & GS2M_GID_MASK) >> 6];
+    }
+    barrier();
+    // quadrant lists: wave q compacts quadrant q (the scratch in the list region is dead behind the barrier above)
+    const int q = wave;
+    uint2* out = qlist + (size_t)4 * start + (size_t)q * n;
+    uint32_t* orow = qrow + (size_t)4 * start + (size_t)q * n;
+    uint32_t run = 0;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t base = 0; base < n; base += GS2M_WAVE) {
+        const uint32_t k = base + (uint32_t)lane;
+        uint32_t v = 0, r = 0;
+        if (k < n) { v = point_list[start + k]; r = row_tmp[start + k]; }
+        const uint32_t mask = v >> GS2M_GID_BITS;
+        const bool hit = ((mask >> q) & 1u) != 0u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) {
+            const uint32_t o = run + (uint32_t)__popcll(m & lt);
+            out[o] = make_uint2(v, k);
+            orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
+        }
+        run += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) qcount[tile * 4 + q] = run;
 }
-
 
 // A workgroup per tile, in two launches: spans of up to 1024 entries (MAXE = 4: 13 KB of LDS and 80 registers, six workgroups per CU;
 // this launch also writes ranges[] -- it is the frame's first when it runs at all) and the longer ones (MAXE = 16: 8 elements per lane up to 2048 entries, 16 up to 4096, 50 KB of LDS; launched on every
@@ -659,7 +718,7 @@ __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t sta
 template <int MAXE>
 struct WgCfg {
     static constexpr int kMax = 256 * MAXE, kWords = kMax + kMax / 32;
-    static constexpr int kLds = MAXE >= 8 ? (3 * kWords > 2 * BIG_LDS ? 3 * kWords : 2 * BIG_LDS) : 3 * kWords;
+    static constexpr int kLds = 3 * kWords;
 };
 template <int MAXE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >= 8 ? 3 : GS2M_TS_WG_OCC, 8)))
