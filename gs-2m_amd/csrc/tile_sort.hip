@@ -781,6 +781,6 @@ void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const Binning
                                                        im.qcount, tiles_x, tiles_y, grid);
     }
     // spans of more than 1024 entries: none on the bench scenes (the workgroups look at their tiles' ranges and leave)
-    tile_sort_wg_kernel<16><<<wg_grid < 1024u ? wg_grid : 1024u, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
+    tile_sort_wg_kernel<16><<<wg_grid < 768u ? wg_grid : 768u /* three workgroups per CU: all resident at once */, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
                                                                              b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid);
 }
