@@ -253,7 +253,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
         }
         // slots, list offsets, look-back words; gradient rows (4 per instance, heavy units padded to 64 instances) stay below the
         // GS2M_ROWS_BIG bit
-        if (land[GS2M_LAND_R] >= (1u << 29) || land[GS2M_LAND_HUNITS] >= (1u << 22)) return GS2M_ERR_UNSUPPORTED;
+        if (land[GS2M_LAND_R] >= (1u << 29)) return GS2M_ERR_UNSUPPORTED;
         R = (int)land[GS2M_LAND_R];
         U = land[GS2M_LAND_HUNITS];  // (published with num_rendered in one store)
         // The crowded-wave rule (common.h) repairs IMBALANCE between waves.  A frame whose Gaussians all cover a dozen tiles has every
@@ -268,9 +268,10 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
             gs2m_launch_blockscan(P, g, land_dev, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(s));  // (the rare path: no polling)
-            if (land[GS2M_LAND_R] != (uint32_t)R || land[GS2M_LAND_HUNITS] >= (1u << 22)) return GS2M_ERR_STAGE(ST_SCAN);
+            if (land[GS2M_LAND_R] != (uint32_t)R) return GS2M_ERR_STAGE(ST_SCAN);
             U = land[GS2M_LAND_HUNITS];
         }
+        if (U >= (1u << 22)) return GS2M_ERR_UNSUPPORTED;
     }
 
     const int tile_bits = (int)higher_msb((uint32_t)tiles);
