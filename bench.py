@@ -300,6 +300,28 @@ def bench_c4(a):
     print(json.dumps(out_line), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` typed as such (no launcher, WORLD_SIZE unset): start the N ranks as a CHILD process --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>` --
+    before this process has made any GPU call (importing torch does not initialise HIP), relay what the ranks print (rank 0's
+    JSON line among it) and return the child's exit code.  No exec: the parent stays a plain waiting process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between the ranks' processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +357,8 @@ def main():
     ap.add_argument("--no-reference-binning", action="store_true", help="skip the second timing of the same workload in reference-binning mode")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if a.config is None:
@@ -659,4 +683,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -64,3 +64,21 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     rf = d["roofline"]  # small frame: either blend kernel may be the longer one; the line says which and how it was timed
     assert rf["kernel"] in ("blend_bwd", "blend_fwd") and rf["avg_launch_ms"] > 0
     assert rf["measured"] == ("timed region" if rf["kernel"] == "blend_bwd" else "stage pass (untimed, same step)")
+
+
+def test_bench_gpus_2_as_typed_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --steps 3 --warmup 2` exactly as the driver would type it -- no launcher, WORLD_SIZE unset:
+    bench.py starts `torch.distributed.run` as a child before it touches the GPU, relays rank 0's line and the child's
+    exit code (BASELINE configs[4]; here both ranks share the box's one GPU over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GS2M_DIST_BACKEND="gloo", GS2M_BENCH_WATCHDOG_S="500")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["views_per_rank"] == 1 and d["views_per_step"] == 2
+    for key in ("pipelined", "equal_work", "accumulate_v2", "compute_only"):
+        assert d[key + "_ms_per_step"] > 0 and d[key + "_value"] > 0, key
