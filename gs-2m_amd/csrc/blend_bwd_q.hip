@@ -8,11 +8,17 @@
 //    was built) per group;
 //  * lane = (survivor j = lane & 15, pixel column r = lane >> 4): a group walks the 64 pixels in 8 double-steps, each
 //    lane evaluating its two pixels (r, y) and (r + 4, y) of one image row as ONE packed fp32 pair;
-//  * with w_i = alpha_i T_i the reference's recurrence for the colour behind a survivor (backward.cu:530-550) becomes
-//    dL/dalpha_i = T_i (c_i . g) - S_i / (1 - alpha_i), S_i = sum over the survivors BEHIND i of w_k (c_k . g) + the
-//    background term: ONE scalar recurrence per pixel instead of one per channel.  T_i (a running product of
-//    1 / (1 - alpha)) and S_i (a running sum) across the 16 survivors of a group are Kogge-Stone scans over the 16 lanes
-//    of a DPP row; their values at the group's front are carried to the next group through LDS (s_T2, s_S2);
+//  * the reference's per-channel "colour behind" recurrence (backward.cu:530-550: accum_rec = alpha_k c_k + (1 - alpha_k)
+//    accum_rec, dL/dalpha += (c - accum_rec) dL/dpixel) is projected on the pixel's gradient g: with b_i = (colour behind
+//    survivor i) . g, seeded with bg . g (backward.cu:562-566), dL/dalpha_i = T_i ((c_i . g) - b_i) and b obeys the AFFINE
+//    recurrence b_i = (1 - alpha_k) b_k + alpha_k (c_k . g), k the survivor right behind i: ONE scalar recurrence per pixel
+//    instead of one per channel, a convex blend like the reference's (its rounding errors do not accumulate along the
+//    list; rounds 1-5 carried the suffix SUM S_i = sum w_k (c_k . g) and formed T_i (c_i . g) - S_i / (1 - alpha_i): the same
+//    number as the difference of two running quantities, 6-10 x the reference's error in the far tail).  The maps of the 16
+//    survivors of a group are composed by a Kogge-Stone scan over the 16 lanes of a DPP row (row_scan_affine2); the product
+//    part of the scanned map is prod (1 - alpha): T_i = (transmittance behind the group) / that product -- one reciprocal
+//    per pair, of the scanned product (the reference divides entry by entry, backward.cu:532); the values at the group's
+//    front are carried to the next group through LDS (s_T2, s_B2);
 //  * the sums over pixels are fp32 MFMAs (v_mfma_f32_16x16x4_f32): dL/dcolour,feature[survivor][channel] =
 //    W[survivor][pixel] x Ggrad[pixel][channel], and the colour . gradient dots (c_i . g)[pixel][survivor] =
 //    Ggrad x C^T in an accumulator layout that needs no transposition (see scB / gA below);
@@ -41,44 +47,31 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GS2M_BWDQ_UNROLL_B 1
 #endif
 
-// Inclusive prefix product / sum over the 16 lanes of a DPP row, for a PAIR of independent values with the two
-// chains interleaved.  One v_mul/add_f32_dpp per level and value: lanes whose source falls outside the row are
-// disabled by the DPP and keep x (product) or add 0 (sum, bound_ctrl:1); hipcc does not fold mov_dpp + mul for a
-// float identity, hence the asm.  A DPP read needs 2 wait states after the VALU write of its source, and the
-// other chain's instruction is one of them: one `s_nop 0` per level (the compiler does not track the hazard
-// through inline asm, so the nops are explicit).
-__device__ __forceinline__ void row_scan_mul2(float& x, float& y) {
+// Inclusive scan of AFFINE maps b -> A b + B over the 16 lanes of a DPP row (Kogge-Stone), for a PAIR of independent pixels with
+// the two chains interleaved.  Lane j holds survivor j's map (A = 1 - alpha, B = alpha (c . g)); afterwards it holds the
+// composition of the maps of lanes 0..j, lane 0's applied first: A = prod (1 - alpha), B = the colour . gradient blended over
+// survivors 0..j with nothing behind them.  One level with stride d: (A, B) <- (A A[-d], A B[-d] + B) -- one v_fmac_f32_dpp
+// (B first: it reads this lane's A of the level before) and one v_mul_f32_dpp per chain; lanes whose source falls outside the
+// row are disabled by the DPP and keep their map (the identity composed in front).  A DPP read needs 2 wait states after the
+// VALU write of its source: with two chains of two registers every register is read three instructions after it was written,
+// so only the first level needs the `s_nop` (the compiler does not track the hazard through inline asm).
+__device__ __forceinline__ void row_scan_affine2(float& Ax, float& Ay, float& Bx, float& By) {
+#define GS2M_AFFINE_LEVEL(D)                                                             \
+        "v_fmac_f32_dpp %2, %2, %0 row_shr:" #D " row_mask:0xf bank_mask:0xf\n\t"          \
+        "v_fmac_f32_dpp %3, %3, %1 row_shr:" #D " row_mask:0xf bank_mask:0xf\n\t"          \
+        "v_mul_f32_dpp %0, %0, %0 row_shr:" #D " row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_mul_f32_dpp %1, %1, %1 row_shr:" #D " row_mask:0xf bank_mask:0xf\n\t"
     asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf"
-        : "+v"(x), "+v"(y));
+        GS2M_AFFINE_LEVEL(1)
+        GS2M_AFFINE_LEVEL(2)
+        GS2M_AFFINE_LEVEL(4)
+        GS2M_AFFINE_LEVEL(8)
+        : "+v"(Ax), "+v"(Ay), "+v"(Bx), "+v"(By));
+#undef GS2M_AFFINE_LEVEL
 }
-// The sum scan leaves its inputs alone: with bound_ctrl:1 a lane without a source reads 0, so the first level can write a
-// fresh register (x shifted + x) -- no copies in front of the chain (the product scan needs them: its identity is 1).
-__device__ __forceinline__ void row_scan_add2(const float x, const float y, float& ox, float& oy) {
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(ox), "=&v"(oy)
-        : "v"(x), "v"(y));
+// value of the lane below in the DPP row; lane 0 of the row takes `first`
+__device__ __forceinline__ float row_shr1(float first, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
 }
 
 template <int FC>
@@ -99,9 +92,9 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #endif
     constexpr int GST = GS2M_BWDQ_GSTRIDE;
     __shared__ __align__(16) float s_g[64][GST];   // per pixel: dL/dcolour (3), dL/dfeature (FC), zero pad
-    // per pixel pair {(x, y), (x + 4, y)}, index 4 y + (x & 3): running T, running suffix sum Sg, n_contrib
+    // per pixel pair {(x, y), (x + 4, y)}, index 4 y + (x & 3): running T, running (colour behind) . g, n_contrib
     __shared__ float2 s_T2[32];
-    __shared__ float2 s_S2[32];
+    __shared__ float2 s_B2[32];
     __shared__ uint2 s_N2[32];
     __shared__ __align__(16) float s_out[16][ROWF];  // the group's 16 gradient rows, assembled here and stored as whole float4s
     __shared__ uint32_t s_rowg[16];                  // gradient-row index of each survivor of the current group
@@ -135,17 +128,17 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++)
             *reinterpret_cast<float4*>(&s_g[lane][4 * q]) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-        // suffix sum seeded with the background term (backward.cu:562-566)
+        // behind everything: the background (backward.cu:562-566)
         const int pe = ((lane >> 3) * 4 + (lane & 3)) * 2 + ((lane >> 2) & 1);  // pair index * 2 + element
         reinterpret_cast<float*>(s_T2)[pe] = Tf;
-        reinterpret_cast<float*>(s_S2)[pe] = Tf * (bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2]);
+        reinterpret_cast<float*>(s_B2)[pe] = bg[0] * g[0] + bg[1] * g[1] + bg[2] * g[2];
         reinterpret_cast<uint32_t*>(s_N2)[pe] = lastp;
     }
     gs2m_sync();
 
     // ---- survivor-per-lane state ----
     const int j = lane & 15, r = lane >> 4;
-    // The running per-pixel transmittance / suffix sum live in LDS (s_T2, s_S2): read by the 16 survivor lanes
+    // The running per-pixel transmittance / colour . gradient behind live in LDS (s_T2, s_B2): read by the 16 survivor lanes
     // of the pixel's row each step, written back by its last lane.  LDS operations of one wave execute
     // in order, so the next group's read sees this group's write.
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
@@ -246,12 +239,8 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         v2f m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
         auto gc_block = [&](int b) {
             v4f a = {0.f, 0.f, 0.f, 0.f};
-#ifndef GS2M_KO_GC
 #pragma unroll
             for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gA[(16 * b) * GST + 4 * k], scB[k], a, 0, 0, 0);
-#else
-            a[0] = gA[(16 * b) * GST] * scB[0]; a[1] = a[0]; a[2] = a[0]; a[3] = a[0];
-#endif
             return a;
         };
         v4f gnext = gc_block(0);
@@ -260,30 +249,26 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         for (int b = 0; b < 4; b++) {
             const v4f gcur = gnext;
             const float pyb = qyf + (float)(2 * b);
-            // the block's LDS operands up front: the compiler cannot move these reads above the s_T2/s_S2 writes
+            // the block's LDS operands up front: the compiler cannot move these reads above the s_T2/s_B2 writes
             // of earlier steps on its own (it cannot see that the pixels differ), and every step would wait out
             // a full LDS latency twice
-            v2f T2[2], S2[2];
+            v2f T2[2], B2[2];
             uint2 N2[2];
             float gBv[4];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int pi = (2 * b + h) * 4 + r;
-                const float2 t = s_T2[pi], q = s_S2[pi];
+                const float2 t = s_T2[pi], q = s_B2[pi];
                 T2[h] = v2f{t.x, t.y};
-                S2[h] = v2f{q.x, q.y};
+                B2[h] = v2f{q.x, q.y};
                 N2[h] = s_N2[pi];
             }
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) gBv[rr] = s_g[16 * b + 4 * rr + r][j];
             float gAn[KK];  // A operand of the NEXT block's colour . gradient product
 #pragma unroll
-#ifdef GS2M_BWDQ_OLD_GAN
-            for (int k = 0; k < KK; k++) gAn[k] = b < 3 ? gA[(16 * (b + 1)) * GST + 4 * k] : 0.f;  // the last block has no successor
-#else
             // (the last block has no successor: it reads its own rows again -- an address select instead of a branch per operand)
             for (int k = 0; k < KK; k++) gAn[k] = gA[(16 * (b < 3 ? b + 1 : 3)) * GST + 4 * k];
-#endif
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // image row 2b + h: pixels (r, 2b + h) and (r + 4, 2b + h) as one packed pair
                 const int pi = (2 * b + h) * 4 + r;
@@ -297,71 +282,50 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f t3 = (sB2 * dx) * dy;
                 const v2f power = (-0.5f * (t1 + t2)) - t3;
                 const v2f e = power * GS2M_LOG2E;
-#ifndef GS2M_KO_TRANS
                 const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-#else
-                const v2f G = e * 0.001f;
-#endif
                 const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
                 const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
                 const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
                 const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
                 const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
                 const v2f om = 1.0f - am;
-#ifndef GS2M_KO_TRANS
-                const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-#else
-                const v2f inv = om * 1.01f;
-#endif
-                float Px = inv.x, Py = inv.y;
-#ifndef GS2M_KO_SCAN
-                row_scan_mul2(Px, Py);
-#endif
-                const v2f Pinc = {Px, Py};
-                const v2f Ti = T2[h] * Pinc;  // transmittance in front of survivor j at the two pixels
-                const v2f w = am * Ti;
                 const v2f gc = {gcur[2 * h], gcur[2 * h + 1]};
-                const v2f qv = gc * w;
-                float Sx, Sy;
-#ifndef GS2M_KO_SCAN
-                row_scan_add2(qv.x, qv.y, Sx, Sy);
-#else
-                Sx = qv.x + gc.x; Sy = qv.y + gc.y;
+                // survivor j's map of the colour-behind recurrence (backward.cu:530-550 projected on the pixel's gradient):
+                // b -> (1 - alpha) b + alpha (c . g); a pair that does not contribute is the identity
+                const v2f bq = am * gc;
+                float Ax = om.x, Ay = om.y, Bx = bq.x, By = bq.y;
+                row_scan_affine2(Ax, Ay, Bx, By);
+                const v2f Ainc = {Ax, Ay}, Binc = {Bx, By};
+                // (colour . gradient) behind survivor j + 1 = the scanned map applied to what lies behind the group
+                const v2f binc = __builtin_elementwise_fma(Ainc, B2[h], Binc);
+                const v2f bex = {row_shr1(B2[h].x, binc.x), row_shr1(B2[h].y, binc.y)};  // ... behind survivor j itself
+                // transmittance in front of survivor j: what is left behind the group / prod (1 - alpha) over survivors 0..j
+                // (backward.cu:532 divides once per entry; here ONE reciprocal of the scanned product)
+                v2f rP = {__builtin_amdgcn_rcpf(Ainc.x), __builtin_amdgcn_rcpf(Ainc.y)};
+#ifdef GS2M_BWDQ_NEWTON
+                rP = __builtin_elementwise_fma(rP, __builtin_elementwise_fma(-Ainc, rP, v2f{1.0f, 1.0f}), rP);
 #endif
-                const v2f Sinc = {Sx, Sy};
-                const v2f Sprev = S2[h] + (Sinc - qv);  // contributions of everything behind survivor j
-                const v2f da = Ti * gc - Sprev * inv;     // dL/dalpha (header of this file)
+                const v2f Ti = T2[h] * rP;
+                const v2f w = am * Ti;
+                const v2f da = Ti * (gc - bex);  // dL/dalpha (header of this file)
                 if (j == 15) {
-                    const v2f Sn = S2[h] + Sinc;
                     s_T2[pi] = make_float2(Ti.x, Ti.y);
-                    s_S2[pi] = make_float2(Sn.x, Sn.y);
+                    s_B2[pi] = make_float2(binc.x, binc.y);
                 }
                 const v2f sv = da * sg;  // s = opacity * dL/dalpha * G
                 const v2f u1 = dx * sA2 + dy * sB, u2 = cdy + dx * sB2;
                 const v2f a1 = sv * u1, a2 = sv * u2;
-#ifndef GS2M_KO_ABS
                 U1 += fabsf(a1.x); U1 += fabsf(a1.y);
                 U2 += fabsf(a2.x); U2 += fabsf(a2.y);
-#else
-                U1 += sv.x; U2 += sv.y;
-#endif
-#ifndef GS2M_KO_WG
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, gBv[2 * h], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, gBv[2 * h + 1], acc1, 0, 0, 0);
-#else
-                acc1[0] += w.x * gBv[2 * h]; acc1[1] += w.y * gBv[2 * h + 1];
-#endif
                 m0 += sv;
                 m1 = __builtin_elementwise_fma(sv, v2f{dy, dy}, m1);
                 m2 = __builtin_elementwise_fma(sv, v2f{dy * dy, dy * dy}, m2);
                 if (h == 0 && b < 3) {  // one block ahead, operands long since loaded: the result is there when the next block starts
                     v4f a = {0.f, 0.f, 0.f, 0.f};
-#ifndef GS2M_KO_GC
 #pragma unroll
                     for (int k = 0; k < KK; k++) a = __builtin_amdgcn_mfma_f32_16x16x4f32(gAn[k], scB[k], a, 0, 0, 0);
-#else
-                    a[0] = gAn[0] * scB[0]; a[1] = a[0]; a[2] = a[0]; a[3] = a[0];
-#endif
                     gnext = a;
                 }
             }

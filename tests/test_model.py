@@ -203,144 +203,101 @@ def test_blender_dataset_reader(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# densification / pruning / opacity reset against a functional restatement of scene/gaussian_model.py:372-567
-def _restated_build_rotation(r):  # utils/general_utils.py:76-98
-    q = r / torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])[:, None]
-    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    R = torch.zeros((q.size(0), 3, 3), device=r.device)
-    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
-    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
-    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
-    return R
-
-
-class _RestatedModel:
-    """The reference's densification written as plain tensor bookkeeping: a dict of parameters, a dict of Adam moments
-    per parameter, the three statistics and max_radii2D.  Each step cites the reference lines it follows."""
-    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "albedo", "roughness", "metallic")
-
-    def __init__(self, params, moments, percent_dense):
-        self.p = {k: v.clone() for k, v in params.items()}
-        self.m = {k: (a.clone(), b.clone()) for k, (a, b) in moments.items()}
-        self.percent_dense = percent_dense
-        self.dev = params["xyz"].device
-        n = self.p["xyz"].shape[0]
-        self._reset(n)
-
-    def _reset(self, n):
-        z = lambda *sh: torch.zeros(*sh, device=self.dev)
-        self.accum, self.accum_abs, self.denom = z(n, 1), z(n, 1), z(n, 1)
-        self.max_radii = z(n)
-
-    def _append(self, new):  # cat_tensors_to_optimizer GM:430-455 + densification_postfix GM:459-492
-        for k in self.NAMES:
-            self.p[k] = torch.cat((self.p[k], new[k]), dim=0)
-            a, b = self.m[k]
-            self.m[k] = (torch.cat((a, torch.zeros_like(new[k])), dim=0), torch.cat((b, torch.zeros_like(new[k])), dim=0))
-        self._reset(self.p["xyz"].shape[0])
-
-    def _prune(self, mask):  # prune_points GM:396-415 (+ _prune_optimizer GM:378-394)
-        keep = ~mask
-        for k in self.NAMES:
-            self.p[k] = self.p[k][keep]
-            self.m[k] = (self.m[k][0][keep], self.m[k][1][keep])
-        self.accum, self.accum_abs, self.denom = self.accum[keep], self.accum_abs[keep], self.denom[keep]
-        self.max_radii = self.max_radii[keep]
-
-    def densify_and_prune(self, max_grad, max_grad_abs, min_opacity, extent, max_screen_size=None):  # GM:538-560
-        grads = self.accum / self.denom
-        grads[grads.isnan()] = 0.0
-        grads_abs = self.accum_abs / self.denom
-        grads_abs[grads_abs.isnan()] = 0.0
-        # densify_and_clone GM:516-536
-        big = torch.max(torch.exp(self.p["scaling"]), dim=1).values
-        sel = (torch.norm(grads, dim=-1) >= max_grad) & (big <= self.percent_dense * extent)
-        self._append({k: self.p[k][sel] for k in self.NAMES})
-        # densify_and_split GM:489-514, N = 2
-        N = 2
-        n = self.p["xyz"].shape[0]
-        padded = torch.zeros(n, device=self.dev)
-        padded[:grads_abs.shape[0]] = grads_abs.squeeze()
-        act = torch.exp(self.p["scaling"])
-        sel = (padded >= max_grad_abs) & (torch.max(act, dim=1).values > self.percent_dense * extent)
-        stds = act[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=self.dev), std=stds)
-        rots = _restated_build_rotation(self.p["rotation"][sel]).repeat(N, 1, 1)
-        new = {k: self.p[k][sel].repeat(N, *([1] * (self.p[k].dim() - 1))) for k in self.NAMES}
-        new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.p["xyz"][sel].repeat(N, 1)
-        new["scaling"] = torch.log(act[sel].repeat(N, 1) / (0.8 * N))
-        self._append(new)
-        self._prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool, device=self.dev))))
-        # transparent / large GM:549-558 (max_radii2D was just reset by the postfix, as in the reference)
-        prune = (torch.sigmoid(self.p["opacity"]) < min_opacity).squeeze()
-        if max_screen_size:
-            prune = prune | (self.max_radii > max_screen_size) | (torch.exp(self.p["scaling"]).max(dim=1).values > 0.1 * extent)
-        self._prune(prune)
-
-    def reset_opacity(self):  # GM:362-365 + replace_tensor_to_optimizer GM:372-386
-        s = torch.sigmoid(self.p["opacity"])
-        v = torch.min(s, torch.ones_like(s) * 0.01)
-        self.p["opacity"] = torch.log(v / (1 - v))
-        self.m["opacity"] = (torch.zeros_like(self.p["opacity"]), torch.zeros_like(self.p["opacity"]))
+# densification / pruning / opacity reset / Adam-state surgery against the REFERENCE'S OWN CLASS (scene/gaussian_model.py:362-573):
+# tests/golden/ref_densify.npz holds every tensor of the reference's GaussianModel before and after each operation
+# (tests/golden/make_densify_golden.py imports the class from /root/reference in the build container and drives it on the CPU)
+DENSIFY_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_densify.npz")
+_NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "albedo", "roughness", "metallic")
 
 
 @pytest.mark.parametrize("device", DEVICES)
-def test_densify_prune_reset_match_the_restated_reference(device):
-    """clone + split (torch.normal under a fixed generator) + prune with the Adam-moment surgery, then an opacity reset
-    and a second round with max_screen_size: GaussianModel vs the restatement above on the same device, bit for bit.
-    On the GPU the optimizer is the product's fused Adam (gs2m_optim.Adam), whose state the surgery edits in training."""
+def test_densify_prune_reset_match_the_reference_class(device, monkeypatch):
+    """clone + split + prune with the Adam-moment surgery, an opacity reset, a second round with max_screen_size, reduce_opacity,
+    prune_points, add_densification_stats and prune_init_points: gs2m_model.GaussianModel against the reference class's own
+    tensors after every step -- bit for bit on the CPU; on the GPU (the product's fused Adam, whose state the surgery edits in
+    training) the same Gaussians selected at every step and values to 1e-6 (the device's exp / log / sigmoid).  The split's
+    torch.normal draws are the reference run's, replayed: the product must ask for them with the reference's `std`."""
     from gs2m_model import GaussianModel, OptimizationParams
-    g = torch.Generator().manual_seed(11)
-    n, extent = 400, 4.0
-    prm = dict(xyz=torch.randn(n, 3, generator=g), f_dc=torch.randn(n, 1, 3, generator=g), f_rest=torch.randn(n, 15, 3, generator=g),
-               opacity=torch.randn(n, 1, generator=g) * 2.5, scaling=torch.randn(n, 3, generator=g) * 0.8 - 3.0,
-               rotation=torch.randn(n, 4, generator=g), albedo=torch.randn(n, 3, generator=g), roughness=torch.randn(n, 1, generator=g),
-               metallic=torch.randn(n, 1, generator=g))
+    z = np.load(DENSIFY_GOLD)
+    max_grad, max_grad_abs, min_opacity, extent, percent_dense, lr_scale = (float(v) for v in z["args"])
+    t = lambda a: torch.tensor(a).to(device)
     model = GaussianModel(3, device)
-    model.parameterize([prm[k].clone() for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
+    model.spatial_lr_scale = lr_scale
+    model.parameterize([t(z[f"s0/p/{k}"]) for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "albedo", "roughness", "metallic")])
 
     class Opt(OptimizationParams):
         prune_init_points = False
-        percent_dense = 0.01
+    Opt.percent_dense = percent_dense
     model.training_setup(Opt, optimizer_cls=torch.optim.Adam if device == "cpu" else None)
-    # one optimizer step so that every parameter has non-trivial Adam moments
+    # the optimizer's moments: a step on zero gradients creates the state without moving anything, then the reference's values go in
     for grp in model.optimizer.param_groups:
-        p = grp["params"][0]
-        p.grad = torch.randn(p.shape, generator=g).to(device)
+        grp["params"][0].grad = torch.zeros_like(grp["params"][0])
     model.optimizer.step()
     model.optimizer.zero_grad(set_to_none=True)
-    params = {grp["name"]: grp["params"][0].detach().clone() for grp in model.optimizer.param_groups}
-    moments = {grp["name"]: (model.optimizer.state[grp["params"][0]]["exp_avg"].clone(),
-                             model.optimizer.state[grp["params"][0]]["exp_avg_sq"].clone()) for grp in model.optimizer.param_groups}
-    ref = _RestatedModel(params, moments, Opt.percent_dense)
+    for grp in model.optimizer.param_groups:
+        p = grp["params"][0]
+        assert torch.equal(p.detach(), t(z[f"s0/p/{grp['name']}"])), "a step on zero gradients moves nothing"
+        st = model.optimizer.state[p]
+        st["exp_avg"].copy_(t(z[f"s0/m/{grp['name']}"]))
+        st["exp_avg_sq"].copy_(t(z[f"s0/v/{grp['name']}"]))
+
+    def same(a, want, what):
+        want = t(want)
+        assert a.shape == want.shape, (what, tuple(a.shape), tuple(want.shape))
+        if device == "cpu":
+            assert torch.equal(a, want), what
+        else:
+            torch.testing.assert_close(a, want, rtol=1e-6, atol=1e-7, msg=lambda m: f"{what}: {m}")
 
     def check(tag):
-        assert model.get_xyz.shape[0] == ref.p["xyz"].shape[0], tag
+        assert model.get_xyz.shape[0] == z[f"{tag}/p/xyz"].shape[0], tag
+        attrs = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling", rotation="_rotation",
+                     albedo="_albedo", roughness="_roughness", metallic="_metallic")
         for grp in model.optimizer.param_groups:
             k, p = grp["name"], grp["params"][0]
-            assert torch.equal(p.detach(), ref.p[k]), (tag, k)
+            assert getattr(model, attrs[k]) is p, (tag, k, "the model's attribute is the optimizer's parameter")
+            same(p.detach(), z[f"{tag}/p/{k}"], (tag, "param", k))
             st = model.optimizer.state.get(p)
-            assert st is not None and torch.equal(st["exp_avg"], ref.m[k][0]) and torch.equal(st["exp_avg_sq"], ref.m[k][1]), (tag, k)
-        assert torch.equal(model.max_radii2D, ref.max_radii) and torch.equal(model.denom, ref.denom)
+            assert st is not None, (tag, k)
+            same(st["exp_avg"], z[f"{tag}/m/{k}"], (tag, "exp_avg", k))
+            same(st["exp_avg_sq"], z[f"{tag}/v/{k}"], (tag, "exp_avg_sq", k))
+        same(model.xyz_gradient_accum, z[f"{tag}/accum"], (tag, "accum"))
+        same(model.xyz_gradient_accum_abs, z[f"{tag}/accum_abs"], (tag, "accum_abs"))
+        same(model.denom, z[f"{tag}/denom"], (tag, "denom"))
+        same(model.max_radii2D, z[f"{tag}/max_radii"], (tag, "max_radii"))
 
+    check("s0")
+    draws = []
+    def replay_normal(*a, **k):
+        i = len(draws)
+        assert not a and set(k) == {"mean", "std"} and float(k["mean"].abs().max()) == 0.0
+        same(k["std"].detach(), z[f"normal{i}/std"], ("split", i, "std of the draw"))
+        draws.append(i)
+        return t(z[f"normal{i}/out"])
+    monkeypatch.setattr(torch, "normal", replay_normal)
+    stage = 0
     for rnd, screen in ((0, None), (1, 20)):
-        m = model.get_xyz.shape[0]
-        acc = (torch.rand(m, 1, generator=g) * 6e-4).to(device)
-        acc_abs = (torch.rand(m, 1, generator=g) * 2.4e-3).to(device)
-        den = ((torch.rand(m, 1, generator=g) > 0.1).float() * 3).to(device)  # some Gaussians never seen: 0 / 0 -> NaN -> 0
-        rad = (torch.rand(m, generator=g) * 40).to(device)
-        model.xyz_gradient_accum, model.xyz_gradient_accum_abs, model.denom, model.max_radii2D = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
-        ref.accum, ref.accum_abs, ref.denom, ref.max_radii = acc.clone(), acc_abs.clone(), den.clone(), rad.clone()
-        torch.manual_seed(500 + rnd)
-        model.densify_and_prune(0.0002, 0.0008, 0.005, extent, screen)
-        torch.manual_seed(500 + rnd)
-        ref.densify_and_prune(0.0002, 0.0008, 0.005, extent, screen)
-        check(f"round {rnd}")
-        assert model.get_xyz.shape[0] != m
+        model.xyz_gradient_accum, model.xyz_gradient_accum_abs = t(z[f"in{rnd}/accum"]), t(z[f"in{rnd}/accum_abs"])
+        model.denom, model.max_radii2D = t(z[f"in{rnd}/denom"]), t(z[f"in{rnd}/max_radii"])
+        model.densify_and_prune(max_grad, max_grad_abs, min_opacity, extent, screen)
+        stage += 1
+        check(f"s{stage}")
         if rnd == 0:
             model.reset_opacity()
-            ref.reset_opacity()
-            check("reset")
+            stage += 1
+            check(f"s{stage}")
+    assert draws == [0, 1], "one draw per split"
+    model.reduce_opacity()
+    check("s4")
+    model.prune_points(t(z["in5/mask"]))
+    check("s5")
+    vs = torch.zeros(model.get_xyz.shape[0], 4, device=device, requires_grad=True)
+    vs.grad = t(z["in6/grad"])
+    model.add_densification_stats(vs, t(z["in6/filter"]))
+    model.add_densification_stats(vs, t(z["in6/filter"]))
+    check("s6")
+    model.prune_init_points()
+    check("s7")
 
 
 @pytest.mark.parametrize("device", DEVICES)
