@@ -39,6 +39,13 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+// floats per partial-gradient row: 11 + fc padded to whole float4s (80 B at fc 9).  GS2M_ROW_SECTORS (A/B builds, profiles/r06_rows_ab.md):
+// whole 32-byte sectors (96 B at fc 9) -- no partial-sector writes, 20 % more bytes both ways.
+#ifdef GS2M_ROW_SECTORS
+#define GS2M_ROW_ROUND(nv) ((((nv) + 7) / 8) * 8)
+#else
+#define GS2M_ROW_ROUND(nv) ((((nv) + 3) / 4) * 4)
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef GS2M_BWDQ_WAVES
 #define GS2M_BWDQ_WAVES
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ grad_color,
     const float* __restrict__ grad_buffer, float* __restrict__ rows) {
     constexpr int NV = ROW_FEAT + FC;
-    constexpr int ROWF = ((NV + 3) / 4) * 4;
+    constexpr int ROWF = GS2M_ROW_ROUND(NV);
     constexpr int RSTRIDE = ROWF;  // rows are packed (a 128-B stride was tried: random single lines read no faster)
     constexpr int NC = 3 + FC;  // colour + feature columns of the W x Ggrad product
     constexpr int KK = (NC + 3) / 4;  // k-steps of the colour . gradient product (4 channels each) = channel quads
@@ -144,7 +151,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
     const float halfW = 0.5f * W, halfH = 0.5f * H;
 
-    float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f;
+    float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f, sthr = 1.0f;
     // colour . gradient dot products gc[survivor][pixel] come from the matrix pipe as well:
     //   D[i][n] = sum_k A[i][k] B[k][n],  i = pixel slot of a 16-pixel block, n = survivor, k = channel.
     // Lane (j, r) receives D[4r + rr][j] in accumulator element rr, so with pixel slot 4r + rr := the pixel
@@ -170,7 +177,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     // what a lane takes from its survivor's list entry and record: geometry, its channel of every quad, the gradient row
     struct Fill {
         float4 g0;       // x, y, A, B
-        float2 g1;       // C, opacity
+        float4 g1;       // C, opacity, power threshold of alpha >= 1/255 (preprocess.hip), -
         float ch[KK];
         uint32_t pos1;   // position in the tile list + 1
         uint32_t row;    // gradient row of (instance, quadrant): numbered per Gaussian (binning.hip: emit_kernel, emit_heavy_kernel)
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         Fill f;
         const float4* p = rec + (size_t)(en.e.x & GS2M_GID_MASK) * REC_Q;
         f.g0 = p[REC_GEO0];
-        f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
+        f.g1 = p[REC_GEO1];
 #pragma unroll
         for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
         f.pos1 = en.e.y;
@@ -283,9 +290,10 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f power = (-0.5f * (t1 + t2)) - t3;
                 const v2f e = power * GS2M_LOG2E;
                 const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-                const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
-                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
-                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
+                const v2f soG = so2 * G;  // alpha before the 0.99 clamp
+                // alpha >= 1/255 (backward.cu:526) decided on `power` against the survivor's threshold, as the forward decides it
+                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (power.x >= sthr);
+                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (power.y >= sthr);
                 const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
                 const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
                 const v2f om = 1.0f - am;
@@ -295,17 +303,22 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f bq = am * gc;
                 float Ax = om.x, Ay = om.y, Bx = bq.x, By = bq.y;
                 row_scan_affine2(Ax, Ay, Bx, By);
-                const v2f Ainc = {Ax, Ay}, Binc = {Bx, By};
-                // (colour . gradient) behind survivor j + 1 = the scanned map applied to what lies behind the group
-                const v2f binc = __builtin_elementwise_fma(Ainc, B2[h], Binc);
-                const v2f bex = {row_shr1(B2[h].x, binc.x), row_shr1(B2[h].y, binc.y)};  // ... behind survivor j itself
+                // (colour . gradient) behind survivor j + 1 = the scanned map applied to what lies behind the group; behind survivor j
+                // itself: the lane below (plain fp32 instructions on the scan's four registers: as a packed pair they would have to be
+                // moved into an aligned register pair first, and a packed instruction is no cheaper than two plain ones on gfx950)
+#ifndef GS2M_BWDQ_PK_SCAN
+                const v2f binc = {__builtin_fmaf(Ax, B2[h].x, Bx), __builtin_fmaf(Ay, B2[h].y, By)};
+                const v2f bex = {row_shr1(B2[h].x, binc.x), row_shr1(B2[h].y, binc.y)};
                 // transmittance in front of survivor j: what is left behind the group / prod (1 - alpha) over survivors 0..j
                 // (backward.cu:532 divides once per entry; here ONE reciprocal of the scanned product)
-                v2f rP = {__builtin_amdgcn_rcpf(Ainc.x), __builtin_amdgcn_rcpf(Ainc.y)};
-#ifdef GS2M_BWDQ_NEWTON
-                rP = __builtin_elementwise_fma(rP, __builtin_elementwise_fma(-Ainc, rP, v2f{1.0f, 1.0f}), rP);
-#endif
+                const v2f Ti = {T2[h].x * __builtin_amdgcn_rcpf(Ax), T2[h].y * __builtin_amdgcn_rcpf(Ay)};
+#else
+                const v2f Ainc = {Ax, Ay}, Binc = {Bx, By};
+                const v2f binc = __builtin_elementwise_fma(Ainc, B2[h], Binc);
+                const v2f bex = {row_shr1(B2[h].x, binc.x), row_shr1(B2[h].y, binc.y)};
+                const v2f rP = {__builtin_amdgcn_rcpf(Ainc.x), __builtin_amdgcn_rcpf(Ainc.y)};
                 const v2f Ti = T2[h] * rP;
+#endif
                 const v2f w = am * Ti;
                 const v2f da = Ti * (gc - bex);  // dL/dalpha (header of this file)
                 if (j == 15) {
@@ -382,7 +395,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         e_next = load_entry(1);
         for (g_cur = 0; g_cur < ngroups; g_cur++) {
             // install the group's survivors
-            sx = f.g0.x; sy = f.g0.y; sA = f.g0.z; sB = f.g0.w; sC = f.g1.x; so = f.g1.y;
+            sx = f.g0.x; sy = f.g0.y; sA = f.g0.z; sB = f.g0.w; sC = f.g1.x; so = f.g1.y; sthr = f.g1.z;
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;
@@ -398,7 +411,7 @@ int fc_template(int fc) { return fc <= 1 ? 1 : (fc <= 5 ? 5 : (fc <= 9 ? 9 : 10)
 
 }  // namespace
 
-int gs2m_row_floats(int fc) { return ((ROW_FEAT + fc_template(fc) + 3) / 4) * 4; }
+int gs2m_row_floats(int fc) { return GS2M_ROW_ROUND(ROW_FEAT + fc_template(fc)); }
 
 // every row of the dense numbering is written (zeros behind a quadrant's last contributor)
 void gs2m_launch_blend_bwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

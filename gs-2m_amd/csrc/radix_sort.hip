@@ -281,9 +281,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_onesweep_kernel(
         {
             int p = (int)grp - 1;
             bool found = p < 0;
-#ifdef GS2M_KO_LOOKBACK
-            found = true;  // timing only: wrong output positions
-#endif
             while (!found) {
                 uint32_t w[LB2_WIN];
 #pragma unroll

@@ -19,8 +19,6 @@
 //     its place in each of the four quadrant lists with coalesced stores; the gradient row of a list entry = the instance's
 //     first row (relative to its emit wave, emit_kernel; absolute and flagged GS2M_ROWS_BIG for a heavy Gaussian's) + the wave's base
 //     (rowscan_kernel) + its quadrants before this one.
-// (The TIE variants of the network's building blocks -- (depth, position) as a two-word key -- have no caller any more; they are what
-// the equal-depth handling replaced and what tools/ts_micro.py's comparisons were made against.)
 #include "common.h"
 #include <atomic>
 #include <cstdlib>
@@ -69,90 +67,74 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
-template <int E, bool TIE, int a, int b>  // TIE: equal keys are ordered by x (the span position)
+template <int E, int a, int b>
 __device__ __forceinline__ void ce(uint32_t (&k)[E], uint32_t (&x)[E]) {  // a < b: the smaller key to a
-    if constexpr (TIE) {
-        const bool sw = k[b] < k[a] || (k[b] == k[a] && x[b] < x[a]);
-        const uint32_t ka = sw ? k[b] : k[a], kb = sw ? k[a] : k[b], xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
-        k[a] = ka; k[b] = kb; x[a] = xa; x[b] = xb;
-    } else {  // min / max for the keys, one compare for the two payload selects: 5 vector instructions, no mask arithmetic
-        const bool sw = k[b] < k[a];
-        const uint32_t mn = min(k[a], k[b]), mx = max(k[a], k[b]);
-        const uint32_t xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
-        k[a] = mn; k[b] = mx; x[a] = xa; x[b] = xb;
-    }
+    // min / max for the keys, one compare for the two payload selects: 5 vector instructions, no mask arithmetic
+    const bool sw = k[b] < k[a];
+    const uint32_t mn = min(k[a], k[b]), mx = max(k[a], k[b]);
+    const uint32_t xa = sw ? x[b] : x[a], xb = sw ? x[a] : x[b];
+    k[a] = mn; k[b] = mx; x[a] = xa; x[b] = xb;
 }
-template <int E, int KB, bool TIE>  // mirrored compare inside blocks of 2^KB elements of one lane
+template <int E, int KB>  // mirrored compare inside blocks of 2^KB elements of one lane
 __device__ __forceinline__ void inlane_flip(uint32_t (&k)[E], uint32_t (&x)[E]) {
     static_for<0, E>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
-        if constexpr (((e >> (KB - 1)) & 1) == 0) ce<E, TIE, e, (e ^ ((1 << KB) - 1))>(k, x);
+        if constexpr (((e >> (KB - 1)) & 1) == 0) ce<E, e, (e ^ ((1 << KB) - 1))>(k, x);
     });
 }
-template <int E, int JB, bool TIE>
+template <int E, int JB>
 __device__ __forceinline__ void inlane_xor(uint32_t (&k)[E], uint32_t (&x)[E]) {
     static_for<0, E>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
-        if constexpr (((e >> JB) & 1) == 0) ce<E, TIE, e, (e | (1 << JB))>(k, x);
+        if constexpr (((e >> JB) & 1) == 0) ce<E, e, (e | (1 << JB))>(k, x);
     });
 }
 // Across lanes: the lane with the lower number keeps the smaller keys.  On equal keys both keep their own (consistent on
-// both sides; the order of equal depths is settled by a second run with TIE).
-template <int E, int T, bool TIE>
+// both sides; runs of equal depths are put into span order afterwards: tie_positions).
+template <int E, int T>
 __device__ __forceinline__ void cross_flip(uint32_t (&k)[E], uint32_t (&x)[E], int lane) {
     const bool lower = ((lane >> (T - 1)) & 1) == 0;
     uint32_t nk[E], nx[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t ok = lane_flip<T>(k[E - 1 - e], lane), ox = lane_flip<T>(x[E - 1 - e], lane);
-        if constexpr (TIE) {
-            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
-            nk[e] = take ? ok : k[e];
-            nx[e] = take ? ox : x[e];
-        } else {  // the lower lane keeps the minimum, the upper one the maximum; the payload follows the key (equal keys: each keeps its own)
-            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
-            nk[e] = lower ? mn : mx;
-            nx[e] = nk[e] == k[e] ? x[e] : ox;
-        }
+        // the lower lane keeps the minimum, the upper one the maximum; the payload follows the key (equal keys: each keeps its own)
+        const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+        nk[e] = lower ? mn : mx;
+        nx[e] = nk[e] == k[e] ? x[e] : ox;
     }
 #pragma unroll
     for (int e = 0; e < E; e++) { k[e] = nk[e]; x[e] = nx[e]; }
 }
-template <int E, int B, bool TIE>
+template <int E, int B>
 __device__ __forceinline__ void cross_xor(uint32_t (&k)[E], uint32_t (&x)[E], int lane) {
     const bool lower = ((lane >> B) & 1) == 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t ok = lane_xor<B>(k[e], lane), ox = lane_xor<B>(x[e], lane);
-        if constexpr (TIE) {
-            const bool take = lower ? (ok < k[e] || (ok == k[e] && ox < x[e])) : (ok > k[e] || (ok == k[e] && ox > x[e]));
-            k[e] = take ? ok : k[e];
-            x[e] = take ? ox : x[e];
-        } else {
-            const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
-            const uint32_t nk = lower ? mn : mx;
-            x[e] = nk == k[e] ? x[e] : ox;
-            k[e] = nk;
-        }
+        const uint32_t mn = min(k[e], ok), mx = max(k[e], ok);
+        const uint32_t nk = lower ? mn : mx;
+        x[e] = nk == k[e] ? x[e] : ox;
+        k[e] = nk;
     }
 }
-template <int E, int LE, int JB, bool TIE>  // compare-exchange steps with strides 2^JB ... 2^0
+template <int E, int LE, int JB>  // compare-exchange steps with strides 2^JB ... 2^0
 __device__ __forceinline__ void xor_steps(uint32_t (&k)[E], uint32_t (&x)[E], int lane) {
     if constexpr (JB >= 0) {
-        if constexpr (JB >= LE) cross_xor<E, JB - LE, TIE>(k, x, lane);
-        else inlane_xor<E, JB, TIE>(k, x);
-        xor_steps<E, LE, JB - 1, TIE>(k, x, lane);
+        if constexpr (JB >= LE) cross_xor<E, JB - LE>(k, x, lane);
+        else inlane_xor<E, JB>(k, x);
+        xor_steps<E, LE, JB - 1>(k, x, lane);
     }
 }
-template <int E, int LE, int KB, bool TIE>  // merge levels KB ... LE + 6 (sorted blocks of 2^(KB-1) -> 2^KB); a level whose blocks are longer than the data is a no-op
+template <int E, int LE, int KB>  // merge levels KB ... LE + 6 (sorted blocks of 2^(KB-1) -> 2^KB); a level whose blocks are longer than the data is a no-op
 __device__ __forceinline__ void levels(uint32_t (&k)[E], uint32_t (&x)[E], int lane, uint32_t n) {
     if constexpr (KB <= LE + 6) {
         if (n > (1u << (KB - 1))) {  // (wave-uniform) below that the upper half of every block is padding: already in order
-            if constexpr (KB <= LE) inlane_flip<E, KB, TIE>(k, x);
-            else cross_flip<E, KB - LE, TIE>(k, x, lane);
-            xor_steps<E, LE, KB - 2, TIE>(k, x, lane);
+            if constexpr (KB <= LE) inlane_flip<E, KB>(k, x);
+            else cross_flip<E, KB - LE>(k, x, lane);
+            xor_steps<E, LE, KB - 2>(k, x, lane);
         }
-        levels<E, LE, KB + 1, TIE>(k, x, lane, n);
+        levels<E, LE, KB + 1>(k, x, lane, n);
     }
 }
 
@@ -208,11 +190,7 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
         }
         uint4 rc[8];  // {id | mask, relative first row, depth key, -}
 #pragma unroll
-#ifdef GS2M_KO_TS_GATHER  // timing only: the records read in span order (coalesced) instead of gathered by slot
-        for (int e = 0; e < 8; e++) rc[e] = (uint32_t)((e0 + e) * GS2M_WAVE + lane) < n ? e_rec[start + (e0 + e) * GS2M_WAVE + lane + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
-#else
         for (int e = 0; e < 8; e++) rc[e] = (uint32_t)((e0 + e) * GS2M_WAVE + lane) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
-#endif
         static_for<0, 8>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const uint32_t p = (uint32_t)((e0 + e) * GS2M_WAVE + lane);
@@ -222,18 +200,12 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
             // for now and added behind the sort: its latency disappears behind the network
             s_v[skew((int)p)] = rc[e].x;
             s_r[skew((int)p)] = rc[e].y & ~GS2M_ROWS_BIG;
-#ifndef GS2M_KO_TS_ROWBASE
             rb[e0 + e] = p < n && (rc[e].y & GS2M_ROWS_BIG) == 0u ? wave_rowbase[(rc[e].x & GS2M_GID_MASK) >> 6] : 0u;  // (a heavy instance's row is absolute)
-#else
-            rb[e0 + e] = 0u;
-#endif
         });
         asm volatile("" ::: "memory");  // the next batch's loads stay behind this batch's staging (registers: one batch in flight)
     });
-#ifndef GS2M_KO_TS_SORT
     // (the padding is spread over the lanes in this arrangement: every level runs)
-    levels<E, LE, 1, false>(key, idx, lane, 0xFFFFFFFFu);
-#endif
+    levels<E, LE, 1>(key, idx, lane, 0xFFFFFFFFu);
 #pragma unroll
     for (int e = 0; e < E; e++) s_r[skew(e * GS2M_WAVE + lane)] += rb[e];
     // ---- ids and rows of the sorted elements: picked up by span position (sorted element i = lane * E + e, the network's index space) ----
@@ -300,13 +272,11 @@ __device__ __forceinline__ void sort_tile_wave(const int tile, const uint32_t st
         for (int q = 0; q < 4; q++) {
             const bool hit = ((mask >> q) & 1u) != 0u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-#ifndef GS2M_KO_TS_LISTS
             if (hit) {
                 const size_t o = (size_t)q * n + run[q] + (uint32_t)__popcll(m & lt);
                 out[o] = make_uint2(v, k);
                 orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
             }
-#endif
             run[q] += (uint32_t)__popcll(m);
         }
     }
@@ -395,7 +365,7 @@ tile_sort_wave16_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t*
 // 256 lanes share a tile: element i = tid * E + e (E = 2, 4 or 8: up to 512, 1024, 2048 entries), every wave sorts its 64 E elements
 // with the network above, and the two merge levels that span the four waves exchange registers through LDS -- three exchanges in
 // all (the mirrored compare of either level and the stride-of-one-wave step of the last), everything else stays inside a wave.
-template <int E, bool TIE>
+template <int E>
 __device__ __forceinline__ void cross_wave(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, const int partner, const bool mirrored, const bool lower,
                                            uint32_t* s_x) {  // one exchange array: the keys go across first, then the positions
     uint32_t ok[E], ox[E];
@@ -413,27 +383,21 @@ __device__ __forceinline__ void cross_wave(uint32_t (&k)[E], uint32_t (&x)[E], c
     gs2m_sync();  // the exchange array is rewritten by the next exchange
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        if constexpr (TIE) {
-            const bool take = lower ? (ok[e] < k[e] || (ok[e] == k[e] && ox[e] < x[e])) : (ok[e] > k[e] || (ok[e] == k[e] && ox[e] > x[e]));
-            k[e] = take ? ok[e] : k[e];
-            x[e] = take ? ox[e] : x[e];
-        } else {
-            const uint32_t mn = min(k[e], ok[e]), mx = max(k[e], ok[e]);
-            const uint32_t nk = lower ? mn : mx;
-            x[e] = nk == k[e] ? x[e] : ox[e];
-            k[e] = nk;
-        }
+        const uint32_t mn = min(k[e], ok[e]), mx = max(k[e], ok[e]);
+        const uint32_t nk = lower ? mn : mx;
+        x[e] = nk == k[e] ? x[e] : ox[e];
+        k[e] = nk;
     }
 }
-template <int E, int LE, bool TIE>
+template <int E, int LE>
 __device__ __forceinline__ void network_wg(uint32_t (&k)[E], uint32_t (&x)[E], const int tid, uint32_t* s_x) {
     const int lane = tid & 63, wave = tid >> 6;
-    levels<E, LE, 1, TIE>(k, x, lane, 0xFFFFFFFFu);                                        // sorted runs of 64 E: one per wave
-    cross_wave<E, TIE>(k, x, tid, tid ^ 127, true, (wave & 1) == 0, s_x);            // level LE + 7: mirrored compare across a pair of waves
-    xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
-    cross_wave<E, TIE>(k, x, tid, tid ^ 255, true, wave < 2, s_x);                   // level LE + 8: across all four
-    cross_wave<E, TIE>(k, x, tid, tid ^ 64, false, (wave & 1) == 0, s_x);            //   stride of one wave
-    xor_steps<E, LE, LE + 5, TIE>(k, x, lane);
+    levels<E, LE, 1>(k, x, lane, 0xFFFFFFFFu);                                        // sorted runs of 64 E: one per wave
+    cross_wave<E>(k, x, tid, tid ^ 127, true, (wave & 1) == 0, s_x);            // level LE + 7: mirrored compare across a pair of waves
+    xor_steps<E, LE, LE + 5>(k, x, lane);
+    cross_wave<E>(k, x, tid, tid ^ 255, true, wave < 2, s_x);                   // level LE + 8: across all four
+    cross_wave<E>(k, x, tid, tid ^ 64, false, (wave & 1) == 0, s_x);            //   stride of one wave
+    xor_steps<E, LE, LE + 5>(k, x, lane);
 }
 
 constexpr int WG_MAX = 4096;
@@ -464,11 +428,7 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
         }
         uint4 rc[BATCH];
 #pragma unroll
-#ifdef GS2M_KO_TS_GATHER  // timing only
-        for (int e = 0; e < BATCH; e++) rc[e] = (uint32_t)((e0 + e) * 256 + tid) < n ? e_rec[start + (e0 + e) * 256 + tid + (slot[e] & 0u)] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
-#else
         for (int e = 0; e < BATCH; e++) rc[e] = (uint32_t)((e0 + e) * 256 + tid) < n ? e_rec[slot[e]] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
-#endif
         static_for<0, BATCH>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const uint32_t p = (uint32_t)((e0 + e) * 256 + tid);
@@ -481,11 +441,7 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
         asm volatile("" ::: "memory");  // the next batch's loads stay behind this batch's staging (registers: one batch in flight)
     });
     TS_CLK();  // 0: records staged (loads done)
-#ifndef GS2M_KO_TS_SORT
-    network_wg<E, LE, false>(key, idx, tid, s_x);
-#else
-    gs2m_sync();
-#endif
+    network_wg<E, LE>(key, idx, tid, s_x);
     TS_CLK();  // 1: sorted
 #pragma unroll
     for (int e = 0; e < E; e++) s_r[skew(e * 256 + tid)] += rb[e];  // (this thread parked it: LDS operations of one wave execute in order)
@@ -550,13 +506,11 @@ __device__ __forceinline__ void sort_tile_wg(const int tile, const uint32_t star
         const uint32_t mask = v >> GS2M_GID_BITS;
         const bool hit = ((mask >> q) & 1u) != 0u;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-#ifndef GS2M_KO_TS_LISTS
         if (hit) {
             const uint32_t o = run + (uint32_t)__popcll(m & lt);
             out[o] = make_uint2(v, k);
             orow[o] = r + (uint32_t)__popc(mask & ((1u << q) - 1u));
         }
-#endif
         run += (uint32_t)__popcll(m);
     }
     if (lane == 0) qcount[tile * 4 + q] = run;
@@ -606,7 +560,7 @@ __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t sta
                 idx[e0 + e] = p;
             });
         });
-        network_wg<E, LE, false>(key, idx, tid, s_x);
+        network_wg<E, LE>(key, idx, tid, s_x);
 #pragma unroll
         for (int e = 0; e < E; e++) {  // the padding sorts behind every real entry of the chunk
             const uint32_t i = base + (uint32_t)(tid * E + e);
@@ -649,9 +603,9 @@ __device__ __forceinline__ void sort_tile_big(const int tile, const uint32_t sta
                 key[e] = i < n ? K[i] : 0xFFFFFFFFu;
                 idx[e] = i < n ? I[i] : i;
             }
-            cross_wave<E, false>(key, idx, tid, tid ^ 128, false, (wave & 2) == 0, s_x);
-            cross_wave<E, false>(key, idx, tid, tid ^ 64, false, (wave & 1) == 0, s_x);
-            xor_steps<E, LE, LE + 5, false>(key, idx, lane);
+            cross_wave<E>(key, idx, tid, tid ^ 128, false, (wave & 2) == 0, s_x);
+            cross_wave<E>(key, idx, tid, tid ^ 64, false, (wave & 1) == 0, s_x);
+            xor_steps<E, LE, LE + 5>(key, idx, lane);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const uint32_t i = base + (uint32_t)(tid * E + e);

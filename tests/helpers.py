@@ -331,6 +331,7 @@ def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS, max_exceptions=None, fl
     assert worst <= rel, f"{name}: max-norm relative error {worst:.3e} > {rel:g}"
 
 
+ROW_FLOOR_FRAC = 1e-6  # see assert_sum_close
 SUM_GROSS_MAX = 2e-2  # max-norm bound on blend sums whose exceptions are PROVEN threshold events (ref_special_sizes: 2.0e-3; C4 view: 1.15e-3)
 
 
@@ -348,14 +349,20 @@ def assert_sum_close(name, got, ref, f, rel=REL_TOL_GRADS, floor_frac=1e-5, max_
     got = np.asarray(got); ref = np.asarray(ref)
     assert got.shape == ref.shape and np.all(np.isfinite(got)), name
     frac, worst, floor = grad_stats(got, ref, rel, floor_frac)
+    # An element of a Gaussian's row that CANCELS (one colour channel of a splat whose other channels sum to ~10: 5.8e-4 +- 3e-6 in
+    # fp32, whichever implementation adds it up -- the reference build's own value moves by that much with its atomics' order) is held
+    # to ROW_FLOOR_FRAC of the row's largest element (~16 ulp), not to 1e-3 of itself.
+    a = got.reshape(got.shape[0], -1).astype(np.float64); b = ref.reshape(ref.shape[0], -1).astype(np.float64)
+    bound = rel * np.abs(b) + np.maximum(floor, ROW_FLOOR_FRAC * np.abs(b).max(1, keepdims=True))
+    outside = np.abs(a - b) > bound
+    frac = float(outside.mean())
     # A threshold pixel can sit on the Gaussian that owns the tensor's LARGEST element (1 run in 8 of the C4 training view: 1.15e-3 in the
     # max norm): beyond `rel` in the max norm is not a failure by itself, it sends EVERY row outside the element-wise bound to the proof
     # below, whatever the budget; a gross bound stays (a wrong kernel is off by O(1)).
     assert worst <= SUM_GROSS_MAX, f"{name}: max-norm relative error {worst:.3e} > {SUM_GROSS_MAX:g}"
     if worst <= rel and frac <= (max(budget, 2.0 / max(got.size, 1)) if budget > 0 else 0.0):
         return
-    a = got.reshape(got.shape[0], -1).astype(np.float64); b = ref.reshape(ref.shape[0], -1).astype(np.float64)
-    rows = np.nonzero((np.abs(a - b) > rel * np.abs(b) + floor).any(1))[0]
+    rows = np.nonzero(outside.any(1))[0]
     assert len(rows) <= max_proofs, f"{name}: {frac:.3e} of the elements are outside {rel:g}*|ref| + {floor:.3g} ({len(rows)} Gaussians: more than a proof is attempted for)"
     budget = 5 * PROOF_BUDGET
     for r in rows:

@@ -39,9 +39,8 @@ ll = rg[:, 1] - rg[:, 0]
 q = [50, 90, 99, 99.9, 99.99, 100]
 print(f"workload {P} Gaussians {W}x{H} fc {fc}: R {R} visible {int((radii > 0).sum().item())} emitting {int((tt > 0).sum())}")
 print("instances/Gaussian percentiles", q, np.percentile(tt[tt > 0], q))
-sg = view(geomB, lay.sorted_gid, P, np.uint32)
-w = tt[sg][: (P // 64) * 64].reshape(-1, 64)  # depth-sorted order = the emit / row-sum waves
-print("per-wave64 (depth order): mean of max", w.max(1).mean(), "mean of mean", w.mean(1).mean(), "max of max", w.max())
+w = tt[: (P // 64) * 64].reshape(-1, 64)  # index order = the emit / row-sum waves (round 5 on)
+print("per-wave64 (index order): mean of max", w.max(1).mean(), "mean of mean", w.mean(1).mean(), "max of max", w.max())
 print("tile list length percentiles", q, np.percentile(ll, q), "mean", ll.mean())
 print("observe>0", int((observe > 0).sum().item()))
 N = W * H
@@ -61,6 +60,8 @@ rec = view(geomB, lay.rec, P * 32, np.float32).reshape(P, 32)
 rng = np.random.default_rng(0)
 sample = rng.choice(np.nonzero(ll > 0)[0], size=min(NSAMPLE, int((ll > 0).sum())), replace=False)
 ev = live = ev84 = 0
+nent = dead_ent = 0
+hist_live = np.zeros(65, np.int64)
 px = torch.arange(16, device=dev, dtype=torch.float32)
 for t in sample:
     lo, hi = rg[t]
@@ -79,7 +80,13 @@ for t in sample:
         aq = a[sel][:, ys, xs] & inimg[ys, xs]
         ev += int(sel.sum()) * 64
         live += int(aq.sum())
+        cnt = aq.sum((1, 2))
+        nent += int(sel.sum())
+        dead_ent += int((cnt == 0).sum())
+        hist_live += np.bincount(cnt.cpu().numpy(), minlength=65)
         # 8x4 units: a half of the quadrant is evaluated only if the entry has a live pixel in it (lower bound on an exact test)
         ev84 += int(aq[:, :4].any((1, 2)).sum() + aq[:, 4:].any((1, 2)).sum()) * 32
 print(f"lane efficiency over {len(sample)} sampled tiles: {live} live of {ev} evaluated pixel x entry pairs = {live / max(ev, 1):.3f}"
       f"; with 8x4 units at most {ev84} pairs evaluated ({ev84 / max(ev, 1):.3f} of today's)")
+print(f"list entries without ANY pixel of alpha >= 1/255 in their quadrant: {dead_ent} of {nent} = {dead_ent / max(nent, 1):.3f}")
+print("live pixels per (entry, quadrant), cumulative share at 0, 4, 8, 16, 32, 48, 64:", [round(float(hist_live[:k + 1].sum()) / max(nent, 1), 3) for k in (0, 4, 8, 16, 32, 48, 64)])
