@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     const float qxr = (float)(qx0 + r), qyf = (float)qy0;
     const float halfW = 0.5f * W, halfH = 0.5f * H;
 
-    float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f, sthr = 1.0f;
+    float sx = 0.f, sy = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, so = 0.f;
     // colour . gradient dot products gc[survivor][pixel] come from the matrix pipe as well:
     //   D[i][n] = sum_k A[i][k] B[k][n],  i = pixel slot of a 16-pixel block, n = survivor, k = channel.
     // Lane (j, r) receives D[4r + rr][j] in accumulator element rr, so with pixel slot 4r + rr := the pixel
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
     // what a lane takes from its survivor's list entry and record: geometry, its channel of every quad, the gradient row
     struct Fill {
         float4 g0;       // x, y, A, B
-        float4 g1;       // C, opacity, power threshold of alpha >= 1/255 (preprocess.hip), -
+        float2 g1;       // C, opacity
         float ch[KK];
         uint32_t pos1;   // position in the tile list + 1
         uint32_t row;    // gradient row of (instance, quadrant): numbered per Gaussian (binning.hip: emit_kernel, emit_heavy_kernel)
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         Fill f;
         const float4* p = rec + (size_t)(en.e.x & GS2M_GID_MASK) * REC_Q;
         f.g0 = p[REC_GEO0];
-        f.g1 = p[REC_GEO1];
+        f.g1 = *reinterpret_cast<const float2*>(p + REC_GEO1);
 #pragma unroll
         for (int k = 0; k < KK; k++) f.ch[k] = reinterpret_cast<const float*>(p + REC_CH + k)[r];
         f.pos1 = en.e.y;
@@ -290,10 +290,9 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
                 const v2f power = (-0.5f * (t1 + t2)) - t3;
                 const v2f e = power * GS2M_LOG2E;
                 const v2f G = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-                const v2f soG = so2 * G;  // alpha before the 0.99 clamp
-                // alpha >= 1/255 (backward.cu:526) decided on `power` against the survivor's threshold, as the forward decides it
-                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (power.x >= sthr);
-                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (power.y >= sthr);
+                const v2f soG = so2 * G;  // alpha before the 0.99 clamp; alpha >= 1/255 <=> soG >= 1/255
+                const bool c0 = (spos <= N2[h].x) && (power.x <= 0.0f) && (soG.x >= 1.0f / 255.0f);
+                const bool c1 = (spos <= N2[h].y) && (power.y <= 0.0f) && (soG.y >= 1.0f / 255.0f);
                 const v2f sg = {c0 ? soG.x : 0.f, c1 ? soG.y : 0.f};    // opacity * G of contributing pairs, else 0
                 const v2f am = {fminf(0.99f, sg.x), fminf(0.99f, sg.y)};  // their alpha, else 0
                 const v2f om = 1.0f - am;
@@ -395,7 +394,7 @@ __global__ void __launch_bounds__(64) GS2M_BWDQ_WAVES blend_bwd_q_kernel(
         e_next = load_entry(1);
         for (g_cur = 0; g_cur < ngroups; g_cur++) {
             // install the group's survivors
-            sx = f.g0.x; sy = f.g0.y; sA = f.g0.z; sB = f.g0.w; sC = f.g1.x; so = f.g1.y; sthr = f.g1.z;
+            sx = f.g0.x; sy = f.g0.y; sA = f.g0.z; sB = f.g0.w; sC = f.g1.x; so = f.g1.y;
 #pragma unroll
             for (int k = 0; k < KK; k++) scB[k] = f.ch[k];
             spos = f.pos1;

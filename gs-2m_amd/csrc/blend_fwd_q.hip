@@ -20,19 +20,13 @@
 // a pixel with T > 0.5, straight into the output tensor (zeroed by the preprocess kernel): only the first few
 // entries of a list do, and the wave stops looking once no live pixel has T > 0.5.
 #include "common.h"
-#include <type_traits>
 
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifdef GS2M_FWD_WAVES8
-#define GS2M_FWD_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
-#define GS2M_FWD_OCC
-#endif
 template <int FC>  // feature channels blended (compile time); runtime fc <= FC
-__global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
+__global__ void __launch_bounds__(64) blend_fwd_q_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ qlist, const uint32_t* __restrict__ qcount,
     const float4* __restrict__ rec, int W, int H, int tiles_x, int tiles, const float* __restrict__ bg, int fc,
     float* __restrict__ out_color, float* __restrict__ out_buffer, float* __restrict__ final_T,
@@ -61,7 +55,7 @@ __global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
     // record quads parked per entry: geo0, geo1, channel quads (the bin quad is only needed on the rare observe path)
     constexpr int CH = 16;       // entries per chunk
     constexpr int NS = 2 + KQ;   // quads staged
-    // one LDS block, [buffer][NS quads + per entry of the chunk {power threshold, position in the tile list + 1}][CH],
+    // one LDS block, [buffer][NS quads + the chunk's list entries {Gaussian id, position in the tile list + 1}][CH],
     // addressed from ONE per-buffer base kept in a VGPR the compiler cannot rematerialise: with separate arrays at
     // known addresses it re-creates two address registers from SGPRs for every entry (2 of 32 vector instructions)
     constexpr int BUFQ = NS * CH + CH / 2;  // float4 per buffer
@@ -88,20 +82,18 @@ __global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
     int ilast = 0;      // list entries up to and including the last one some pixel accepted (wave-uniform)
 
     // one list entry (index i of the list, slot jj of LDS buffer `buf`): returns true when every pixel has finished
-    auto eval = [&](auto watching, const int i, const int buf, const int jj) {  // watching: std::true_type while `watch` may still hold
+    auto eval = [&](const int i, const int buf, const int jj) {
         const float4 a = q_at(buf, 0, jj);
         const float2 b = *reinterpret_cast<const float2*>(&q_at(buf, 1, jj));
         float4 c[KQ];
 #pragma unroll
         for (int q = 0; q < KQ; q++) c[q] = q_at(buf, 2 + q, jj);
-        const uint2 ec = e_at(buf, jj);  // {bits of the entry's power threshold, position in the tile list + 1}
+        const uint2 ec = e_at(buf, jj);
         const float dx = a.x - pxf, dy = a.y - pyf;
         const float p2 = gs2m_power(dx, dy, a.z, a.w, b.x);
         const float alpha = fminf(0.99f, b.y * gs2m_exp(p2));
         const float test_T = T * (1.0f - alpha);
-        // alpha >= 1/255 (forward.cu:336) decided on `power` against the Gaussian's own threshold ln((1/255) / opacity)
-        // (preprocess.hip: REC_PTHR): the same decision in the backward by construction, and independent of how exp rounds
-        const mask_t cand = live & __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(p2 >= __uint_as_float(ec.x));
+        const mask_t cand = live & __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
         const mask_t fin = cand & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);  // these pixels stop here, without this entry
         const mask_t contrib = cand & ~fin;
         live &= ~fin;
@@ -117,11 +109,10 @@ __global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
         }
         const uint32_t pos1 = ec.y;  // position in the tile list + 1 (parked that way), as the reference counts contributors
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(last_contributor) : "v"(pos1), "s"(contrib));
-        if (decltype(watching)::value && watch) {
+        if (watch) {
             const mask_t half = contrib & __builtin_amdgcn_ballot_w64(T > 0.5f);
             if (half != 0ull) {  // rare: only the front of a list
-                // (the entry's id is not parked: this path is rare enough to read it from the list again)
-                if (lane == 0) atomicAdd(&observe[list[i].x & GS2M_GID_MASK], (int)__popcll(half));  // integer: the order does not matter
+                if (lane == 0) atomicAdd(&observe[__builtin_amdgcn_readfirstlane(ec.x)], (int)__popcll(half));  // integer: the order does not matter
             }
             // T only falls: once no live pixel is above 0.5 nothing later can be
             watch = (live & __builtin_amdgcn_ballot_w64(T > 0.5f)) != 0ull;
@@ -148,8 +139,7 @@ __global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
     auto park = [&](int buf, const uint2 e, const Stage& st) {
         q_at(buf, eq, ej) = st.a;
         if (eq + 4 < NS) q_at(buf, eq + 4, ej) = st.b;
-        if (eq == 0) e_at(buf, ej).y = e.y + 1u;
-        if (eq == 1) e_at(buf, ej).x = __float_as_uint(st.a.z);  // REC_GEO1.z: the power threshold
+        if (eq == 0) e_at(buf, ej) = make_uint2(e.x & GS2M_GID_MASK, e.y + 1u);
     };
     if (nchunks > 0) {
         uint2 e1 = load_entry(0);
@@ -162,27 +152,11 @@ __global__ void __launch_bounds__(64) GS2M_FWD_OCC blend_fwd_q_kernel(
             if (c + 1 < nchunks) st = load_quads(ecur);
             if (c + 2 < nchunks) e1 = load_entry(c + 2);
             const int base = c * CH, buf = c & 1;
-#ifdef GS2M_FWD_TWO_COPIES  // (A/B, profiles/r06_forward_ab.md: the `observe` test compiled out of a second copy of the chunk's evaluation)
-            if (watch) {
-#pragma unroll
-                for (int jj = 0; jj < CH; jj++) {
-                    if (base + jj >= n) break;
-                    if (eval(std::true_type{}, base + jj, buf, jj)) { stop = true; break; }
-                }
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < CH; jj++) {
-                    if (base + jj >= n) break;
-                    if (eval(std::false_type{}, base + jj, buf, jj)) { stop = true; break; }
-                }
-            }
-#else
 #pragma unroll
             for (int jj = 0; jj < CH; jj++) {
                 if (base + jj >= n) break;
-                if (eval(std::true_type{}, base + jj, buf, jj)) { stop = true; break; }
+                if (eval(base + jj, buf, jj)) { stop = true; break; }
             }
-#endif
             if (c + 1 < nchunks && !stop) park(buf ^ 1, ecur, st);
         }
     }

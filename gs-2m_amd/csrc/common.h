@@ -11,8 +11,7 @@
 
 // ---- blend record: 8 x float4 = 128 B per Gaussian (one aligned HBM line) -------------
 // q0: x, y, A, B          pixel-space mean, conic (A = conic.x, B = conic.y)
-// q1: C, opacity, pthr, hy  conic.z, opacity, pthr = the smallest float >= ln(fl(1/255) / opacity): alpha >= 1/255 <=> power >= pthr
-//                        (what the blend kernels test; +1 when opacity < 1/255: never), hy = half extent of that ellipse (diagnostic)
+// q1: C, opacity, hx, hy  conic.z, opacity, half extents of the alpha >= 1/255 ellipse (the extents: diagnostic only since round 5)
 // q2: 0, rmin, rwh, t2    (unused), tile rect min (x | y << 16), rect (w | h << 16) -- also in GeomState::rect --,
 //                        t2 = upper bound of A dx^2 + 2B dx dy + C dy^2 where alpha can reach 1/255
 // q3..q6: the 13 blended channels, contiguous: r, g, b (SH-evaluated or precomputed), features[0..9], 3 pad

@@ -14,8 +14,51 @@
 // chains through h to n and d (the reference image, the pixel positions and the poses get no gradient, as there).
 #include "common.h"
 #include "../../include/gs2m_mvs.h"
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
+
+// ---------------------------------------------------------------- deterministic scatter (round 6)
+// The two bilinear backwards below scatter every sample's gradient into four texels.  With fp32 atomics the order of the
+// additions -- and so the last bits of every texel, and over a few hundred training iterations the Gaussian count of a run --
+// differs from run to run.  Deterministic mode (the default; gs2m_mvs_set_deterministic): the kernel runs twice over its samples,
+// first for the largest magnitude it will scatter (an integer atomicMax on the float's bits: order-independent), then adding
+// llrint(value x 2^shift) into 64-bit integers -- integer addition is associative, so the sum does not depend on the order --
+// with shift chosen from that maximum so that as many contributions as the call has samples cannot overflow; a third kernel
+// adds the sums, converted back, to the output and clears the integers for the next call.  Resolution: 2^-40 of the largest
+// contribution or better (the float atomics round every addition to 2^-24 of the running sum).
+enum { SCATTER_FLOAT = 0, SCATTER_MAX = 1, SCATTER_FIXED = 2 };
+struct DetScale {
+    const uint32_t* maxbits;  // float bits of the largest |value| (SCATTER_MAX pass)
+    int headroom;             // bits kept free for the number of contributions
+};
+__device__ __forceinline__ int det_shift(const DetScale d) {
+    const uint32_t b = *d.maxbits;
+    const int e = (int)((b >> 23) & 0xFFu) - 127;  // largest |value| < 2^(e + 1)
+    return 62 - d.headroom - (e + 1);
+}
+__device__ __forceinline__ void det_note_max(uint32_t* maxbits, float v) {  // one atomic per wave
+    uint32_t m = __float_as_uint(fabsf(v));
+    if (m >= 0x7F800000u) m = 0u;  // inf / NaN: nothing sensible to scale by (the float path would poison the texel as well)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(maxbits, m);
+}
+__device__ __forceinline__ void det_add(long long* acc, float v, double scale) {
+    if (v != 0.f && fabsf(v) < __builtin_inff()) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn((double)v * scale));
+}
+__global__ void __launch_bounds__(256) det_finalize_kernel(size_t n, long long* __restrict__ acc, DetScale d, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long a = acc[i];
+    if (a != 0) {
+        out[i] += (float)((double)a * ldexp(1.0, -det_shift(d)));
+        acc[i] = 0;
+    }
+}
 
 struct NccConst {
     float M[9];     // K_near R_rn K_ref^-1, row major
@@ -226,12 +269,24 @@ __global__ void __launch_bounds__(ROUGH_THREADS) patch_ncc_rough_kernel(int N, N
 // view is rendered with gradients, and the positions depend on the rendered depth).  PyTorch's backward kernel for this op
 // takes 69 ms for the 2M pixels of a 1080p view on this stack -- 90 % of multi_view_loss; with hardware fp32 atomics it is
 // a ~0.1 ms scatter (one position touches four texels, and the positions are a warped pixel grid: little contention).
-template <int C, bool BWD>
+template <int C, bool BWD, int MODE = SCATTER_FLOAT>
 __global__ void __launch_bounds__(256) grid_border_kernel(int N, int H, int W, const float* __restrict__ img, const float* __restrict__ grid,
                                                           float* __restrict__ out, const float* __restrict__ d_out,
-                                                          float* __restrict__ d_img, float* __restrict__ d_grid) {
+                                                          float* __restrict__ d_img, float* __restrict__ d_grid,
+                                                          long long* __restrict__ acc = nullptr, uint32_t* __restrict__ maxbits = nullptr, int headroom = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (MODE == SCATTER_MAX) {  // the largest |d_out| bounds every contribution (the bilinear weights are <= 1)
+        float m = 0.f;
+        if (i < N) {
+#pragma unroll
+            for (int c = 0; c < C; c++) m = fmaxf(m, fabsf(d_out[(size_t)i * C + c]));
+        }
+        det_note_max(maxbits, m);
+        return;
+    }
     if (i >= N) return;
+    double scale = 0.0;
+    if (MODE == SCATTER_FIXED) scale = ldexp(1.0, det_shift(DetScale{maxbits, headroom}));
     // unnormalise (align_corners), then clip to the border; the clip zeroes the position gradient where it binds
     float x = (grid[2 * (size_t)i] + 1.f) * 0.5f * (float)(W - 1), y = (grid[2 * (size_t)i + 1] + 1.f) * 0.5f * (float)(H - 1);
     float mx = 0.5f * (float)(W - 1), my = 0.5f * (float)(H - 1);
@@ -255,10 +310,17 @@ __global__ void __launch_bounds__(256) grid_border_kernel(int N, int H, int W, c
         } else {
             const float g = d_out[(size_t)i * C + c];
             if (d_img != nullptr && g != 0.f) {
-                unsafeAtomicAdd(&d_img[p + (size_t)y0 * W + x0], g * w00);
-                if (bx) unsafeAtomicAdd(&d_img[p + (size_t)y0 * W + x1], g * w10);
-                if (by) unsafeAtomicAdd(&d_img[p + (size_t)y1 * W + x0], g * w01);
-                if (bx && by) unsafeAtomicAdd(&d_img[p + (size_t)y1 * W + x1], g * w11);
+                if (MODE == SCATTER_FIXED) {
+                    det_add(&acc[p + (size_t)y0 * W + x0], g * w00, scale);
+                    if (bx) det_add(&acc[p + (size_t)y0 * W + x1], g * w10, scale);
+                    if (by) det_add(&acc[p + (size_t)y1 * W + x0], g * w01, scale);
+                    if (bx && by) det_add(&acc[p + (size_t)y1 * W + x1], g * w11, scale);
+                } else {
+                    unsafeAtomicAdd(&d_img[p + (size_t)y0 * W + x0], g * w00);
+                    if (bx) unsafeAtomicAdd(&d_img[p + (size_t)y0 * W + x1], g * w10);
+                    if (by) unsafeAtomicAdd(&d_img[p + (size_t)y1 * W + x0], g * w01);
+                    if (bx && by) unsafeAtomicAdd(&d_img[p + (size_t)y1 * W + x1], g * w11);
+                }
             }
             gx += g * ((v10 - v00) * (1.f - fy) + (v11 - v01) * fy);
             gy += g * ((v01 - v00) * (1.f - fx) + (v11 - v10) * fx);
@@ -343,15 +405,17 @@ __device__ __forceinline__ GeoPix geo_eval(const GeoConst& C, int u, int v, cons
     return g;
 }
 
-template <bool BWD>
+template <bool BWD, int MODE = SCATTER_FLOAT>
 __global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __restrict__ depth, const float* __restrict__ normal,
                                                      const float* __restrict__ depth_n, const float* __restrict__ normal_n,
                                                      float* __restrict__ noise, float* __restrict__ angle, uint8_t* __restrict__ valid,
                                                      const float* __restrict__ d_noise, const float* __restrict__ d_angle,
                                                      float* __restrict__ d_depth, float* __restrict__ d_normal,
-                                                     float* __restrict__ d_depth_n, float* __restrict__ d_normal_n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C.W * C.H) return;
+                                                     float* __restrict__ d_depth_n, float* __restrict__ d_normal_n,
+                                                     long long* __restrict__ acc = nullptr, uint32_t* __restrict__ maxbits = nullptr, int headroom = 0) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (MODE != SCATTER_MAX && i0 >= C.W * C.H) return;
+    const int i = min(i0, C.W * C.H - 1);  // (SCATTER_MAX: whole waves stay for the wave-wide maximum; the surplus lanes note 0)
     const int u = i % C.W, v = i / C.W;
     const GeoPix g = geo_eval(C, u, v, depth, normal, depth_n, normal_n);
     const float lo = -1.0f + 1e-6f, hi = 1.0f - 1e-6f;
@@ -395,16 +459,31 @@ __global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __
 #pragma unroll
     for (int k = 0; k < 3; k++) { dqx += dnraw[k] * g.gnx[k]; dqy += dnraw[k] * g.gny[k]; }
     const float w00 = (1.f - g.fx) * (1.f - g.fy), w10 = g.fx * (1.f - g.fy), w01 = (1.f - g.fx) * g.fy, w11 = g.fx * g.fy;
-    auto scatter = [&](float* img, float gv) {
+    if (MODE == SCATTER_MAX) {  // what this sample will scatter is bounded by these four (the bilinear weights are <= 1)
+        const float m = fmaxf(fmaxf(fabsf(dzs), fabsf(dnraw[0])), fmaxf(fabsf(dnraw[1]), fabsf(dnraw[2])));
+        det_note_max(maxbits, i0 < C.W * C.H ? m : 0.f);
+        return;
+    }
+    double scale = 0.0;
+    if (MODE == SCATTER_FIXED) scale = ldexp(1.0, det_shift(DetScale{maxbits, headroom}));
+    auto scatter = [&](float* img, long long* ai, float gv) {  // ai: the texel plane's integer sums (SCATTER_FIXED)
         if (gv == 0.f) return;
-        unsafeAtomicAdd(&img[(size_t)g.y0 * C.Wn + g.x0], gv * w00);
-        if (g.bx) unsafeAtomicAdd(&img[(size_t)g.y0 * C.Wn + g.x0 + 1], gv * w10);
-        if (g.by) unsafeAtomicAdd(&img[(size_t)(g.y0 + 1) * C.Wn + g.x0], gv * w01);
-        if (g.bx && g.by) unsafeAtomicAdd(&img[(size_t)(g.y0 + 1) * C.Wn + g.x0 + 1], gv * w11);
+        const size_t o = (size_t)g.y0 * C.Wn + g.x0;
+        if (MODE == SCATTER_FIXED) {
+            det_add(&ai[o], gv * w00, scale);
+            if (g.bx) det_add(&ai[o + 1], gv * w10, scale);
+            if (g.by) det_add(&ai[o + C.Wn], gv * w01, scale);
+            if (g.bx && g.by) det_add(&ai[o + C.Wn + 1], gv * w11, scale);
+        } else {
+            unsafeAtomicAdd(&img[o], gv * w00);
+            if (g.bx) unsafeAtomicAdd(&img[o + 1], gv * w10);
+            if (g.by) unsafeAtomicAdd(&img[o + C.Wn], gv * w01);
+            if (g.bx && g.by) unsafeAtomicAdd(&img[o + C.Wn + 1], gv * w11);
+        }
     };
-    scatter(d_depth_n, dzs);
+    scatter(d_depth_n, acc, dzs);
 #pragma unroll
-    for (int k = 0; k < 3; k++) scatter(d_normal_n + k * HWn, dnraw[k]);
+    for (int k = 0; k < 3; k++) scatter(d_normal_n + k * HWn, acc + (size_t)(k + 1) * HWn, dnraw[k]);
     // q = (Y.x fxn / Y.z + cxn, Y.y fyn / Y.z + cyn)
     dY[0] += dqx * C.fxn * g.iz;
     dY[1] += dqy * C.fyn * g.iz;
@@ -423,6 +502,40 @@ int fill(NccConst& C, const float* M, const float* b, const float* Kinv, float n
     for (int k = 0; k < 3; k++) C.b[k] = b[k];
     C.inv_scale = 1.0f / ncc_scale; C.P = patch; C.w = w; C.h = h;
     return GS2M_OK;
+}
+
+// ---- deterministic mode: the integer sums of one call, per (device, stream); kept all-zero between calls (det_finalize_kernel clears what it reads)
+std::atomic<int> g_mvs_deterministic{1};
+struct DetWorkspace {
+    long long* acc = nullptr;
+    size_t words = 0;
+    uint32_t* maxbits = nullptr;
+};
+std::mutex g_det_mutex;
+std::map<std::pair<int, hipStream_t>, DetWorkspace> g_det_ws;
+// -> the workspace for `words` 64-bit sums on this stream (grown and zeroed when needed), or nullptr when the allocation fails
+DetWorkspace* det_workspace(size_t words, hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    DetWorkspace& w = g_det_ws[std::make_pair(dev, s)];
+    if (w.words < words) {
+        if (w.acc != nullptr) {
+            (void)hipStreamSynchronize(s);  // the smaller buffer may still be read by a finalize kernel in flight
+            (void)hipFree(w.acc);
+            w.acc = nullptr; w.words = 0;
+        }
+        if (hipMalloc((void**)&w.acc, words * sizeof(long long)) != hipSuccess) { w.acc = nullptr; return nullptr; }
+        if (hipMemsetAsync(w.acc, 0, words * sizeof(long long), s) != hipSuccess) return nullptr;
+        w.words = words;
+    }
+    if (w.maxbits == nullptr && hipMalloc((void**)&w.maxbits, 256) != hipSuccess) { w.maxbits = nullptr; return nullptr; }
+    return &w;
+}
+int det_headroom(long long samples) {  // bits kept free: every sample may add 4 contributions to one texel
+    int b = 3;
+    while ((1ll << (b - 2)) < samples && b < 40) b++;
+    return b;
 }
 
 }  // namespace
@@ -485,18 +598,40 @@ int gs2m_grid_sample_border_forward(int N, int channels, int height, int width, 
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 
+void gs2m_mvs_set_deterministic(int on) { g_mvs_deterministic.store(on ? 1 : 0); }
+int gs2m_mvs_get_deterministic(void) { return g_mvs_deterministic.load(); }
+
 int gs2m_grid_sample_border_backward(int N, int channels, int height, int width, const float* image, const float* grid,
                                      const float* dL_dout, float* dL_dimage, float* dL_dgrid, void* stream) {
     if (N == 0) return GS2M_OK;
     if (N < 0 || height < 1 || width < 1 || !image || !grid || !dL_dout) return GS2M_ERR_INVALID_ARG;
+    if (channels < 1 || channels > 4) return GS2M_ERR_UNSUPPORTED;
     const dim3 g((N + 255) / 256), b(256);
-    switch (channels) {
-        case 1: grid_border_kernel<1, true><<<g, b, 0, (hipStream_t)stream>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid); break;
-        case 2: grid_border_kernel<2, true><<<g, b, 0, (hipStream_t)stream>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid); break;
-        case 3: grid_border_kernel<3, true><<<g, b, 0, (hipStream_t)stream>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid); break;
-        case 4: grid_border_kernel<4, true><<<g, b, 0, (hipStream_t)stream>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid); break;
-        default: return GS2M_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const bool det = g_mvs_deterministic.load() != 0 && dL_dimage != nullptr;
+    DetWorkspace* ws = nullptr;
+    const size_t words = (size_t)channels * height * width;
+    if (det) {
+        ws = det_workspace(words, s);
+        if (ws == nullptr) return GS2M_ERR_ALLOC;
+        if (hipMemsetAsync(ws->maxbits, 0, sizeof(uint32_t), s) != hipSuccess) return GS2M_ERR_HIP;
     }
+    const int hb = det_headroom(N);
+#define GS2M_GB_BWD(CH)                                                                                                                   \
+    if (det) {                                                                                                                            \
+        grid_border_kernel<CH, true, SCATTER_MAX><<<g, b, 0, s>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid, ws->acc, ws->maxbits, hb);   \
+        grid_border_kernel<CH, true, SCATTER_FIXED><<<g, b, 0, s>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid, ws->acc, ws->maxbits, hb); \
+    } else {                                                                                                                              \
+        grid_border_kernel<CH, true><<<g, b, 0, s>>>(N, height, width, image, grid, nullptr, dL_dout, dL_dimage, dL_dgrid);               \
+    }
+    switch (channels) {
+        case 1: GS2M_GB_BWD(1); break;
+        case 2: GS2M_GB_BWD(2); break;
+        case 3: GS2M_GB_BWD(3); break;
+        default: GS2M_GB_BWD(4); break;
+    }
+#undef GS2M_GB_BWD
+    if (det) det_finalize_kernel<<<(unsigned)((words + 255) / 256), 256, 0, s>>>(words, ws->acc, DetScale{ws->maxbits, hb}, dL_dimage);
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 
@@ -534,8 +669,24 @@ int gs2m_mv_geo_backward(int width, int height, int width_n, int height_n, const
     const int rc = fill_geo(C, A, b, A2, b2, intr_ref, intr_near, width, height, width_n, height_n, occlusion);
     if (rc != GS2M_OK) return rc;
     const int n = width * height;
-    mv_geo_kernel<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise,
-                                                                         dL_dangle, dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_mvs_deterministic.load() != 0) {
+        const size_t words = (size_t)4 * height_n * width_n;  // depth + three normal planes of the neighbour
+        DetWorkspace* ws = det_workspace(words, s);
+        if (ws == nullptr) return GS2M_ERR_ALLOC;
+        if (hipMemsetAsync(ws->maxbits, 0, sizeof(uint32_t), s) != hipSuccess) return GS2M_ERR_HIP;
+        const int hb = det_headroom(n);
+        mv_geo_kernel<true, SCATTER_MAX><<<(n + 255) / 256, 256, 0, s>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise, dL_dangle,
+                                                                         dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n, ws->acc, ws->maxbits, hb);
+        mv_geo_kernel<true, SCATTER_FIXED><<<(n + 255) / 256, 256, 0, s>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise, dL_dangle,
+                                                                           dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n, ws->acc, ws->maxbits, hb);
+        const size_t plane = (size_t)height_n * width_n;
+        det_finalize_kernel<<<(unsigned)((plane + 255) / 256), 256, 0, s>>>(plane, ws->acc, DetScale{ws->maxbits, hb}, dL_ddepth_n);
+        det_finalize_kernel<<<(unsigned)((3 * plane + 255) / 256), 256, 0, s>>>(3 * plane, ws->acc + plane, DetScale{ws->maxbits, hb}, dL_dnormal_n);
+    } else {
+        mv_geo_kernel<true><<<(n + 255) / 256, 256, 0, s>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise,
+                                                            dL_dangle, dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n);
+    }
     return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP;
 }
 

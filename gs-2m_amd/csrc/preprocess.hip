@@ -231,25 +231,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 const float op = in_op;
                 float ex, ey;
                 float tau2f = __builtin_inff();  // bound on A dx^2 + 2B dx dy + C dy^2 inside the ellipse
-                // alpha = opacity exp(power) >= 1/255 (forward.cu:336, backward.cu:526) as a threshold on `power`: pthr = the smallest
-                // float >= ln(fl(1/255) / opacity), from double arithmetic -- for a float `power`, power >= pthr is exactly
-                // opacity e^power >= fl(1/255) in real arithmetic.  Both blend kernels test `power` against it: their decisions agree by
-                // construction and do not depend on how an implementation of exp rounds next to the threshold (two correct fp32
-                // evaluations of the reference's expression differ there too: tests/helpers.py, threshold proofs).
-                float pthr = 1.0f;  // opacity < 1/255 (or NaN): alpha < 1/255 everywhere, no power <= 0 reaches the threshold
                 if (op < 1.0f / 255.0f) {
                     ex = ey = -1.0f;  // alpha <= opacity < 1/255 everywhere: never contributes
                     tau2f = -1.0f;
                 } else {
-                    const double lthr = log((double)(1.0f / 255.0f) / (double)op);  // <= 0
-                    pthr = (float)lthr;
-                    if ((double)pthr < lthr) pthr = __uint_as_float(__float_as_uint(pthr) - 1u);  // negative: one step towards zero
                     const double dA = cA, dB = cB, dC = cC;
                     const double ddet = dA * dC - dB * dB;
                     if (!(ddet > 0.0) || !(dA > 0.0) || !(dC > 0.0) || dA * dC > 1.0e4 * ddet) {
                         ex = ey = __builtin_inff();
                     } else {
-                        const double tau2 = 2.0 * fmax(0.0, 1.0e-3 - lthr);
+                        const double tau2 = 2.0 * fmax(0.0, log(255.0 * (double)op) + 1.0e-3);
                         ex = (float)(sqrt(tau2 * dC / ddet) * 1.001 + 0.01);
                         ey = (float)(sqrt(tau2 * dA / ddet) * 1.001 + 0.01);
                         tau2f = (float)(tau2 * 1.002 + 1.0e-3);
@@ -278,7 +269,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 const uint32_t ew = (uint32_t)(ex1 - ex0), eh = (uint32_t)(ey1 - ey0);
                 float4* r4 = rq;
                 r4[REC_GEO0] = make_float4(pix, piy, cA, cB);
-                r4[REC_GEO1] = make_float4(cC, op, pthr, ey);
+                r4[REC_GEO1] = make_float4(cC, op, ex, ey);
                 r4[REC_BIN] = make_float4(u2f(0u), u2f((uint32_t)ex0 | ((uint32_t)ey0 << 16)), u2f(ew | (eh << 16)), tau2f);
                 float f[GS2M_NUM_FEATURES];
 #pragma unroll

@@ -109,6 +109,16 @@ class _GridSampleBorder(torch.autograd.Function):
         return d_img, d_grid
 
 
+def set_deterministic(on=True):
+    """The scatters of grid_sample_border's and mv_geo's backwards in 64-bit fixed point (integer atomics: bitwise reproducible, the
+    default) or with fp32 atomics (include/gs2m_mvs.h)."""
+    _native.lib().gs2m_mvs_set_deterministic(1 if on else 0)
+
+
+def is_deterministic():
+    return bool(_native.lib().gs2m_mvs_get_deterministic())
+
+
 def grid_sample_border(image, grid):
     """F.grid_sample(image[None], grid.view(1, -1, 1, 2), mode='bilinear', padding_mode='border', align_corners=True) for a
     (C, H, W) image, C <= 4, returned as (N, C); gradients to both."""

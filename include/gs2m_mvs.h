@@ -30,6 +30,13 @@ int gs2m_patch_ncc_roughness(int N, const float* pixels, const float* normals, c
                              const float* near_gray, int width, int height, const float* M, const float* b, const float* Kinv,
                              float ncc_scale, int patch, float* ncc_gray, float* ncc_grad, float* ref_var, void* stream);
 
+/* The two backwards below scatter bilinear footprints into the neighbour's maps.  Deterministic mode (default ON): the sums are
+ * formed in 64-bit fixed point scaled by the call's largest contribution (integer atomics: independent of the order of the
+ * additions, bitwise reproducible run to run) in a per-(device, stream) workspace of the library's own; off: fp32 atomics (the
+ * last bits of a texel then depend on the order in which the hardware retires them).  Process-wide. */
+void gs2m_mvs_set_deterministic(int on);
+int gs2m_mvs_get_deterministic(void);
+
 /* torch.nn.functional.grid_sample(image[None], grid.view(1, N, 1, 2), mode='bilinear', padding_mode='border',
  * align_corners=True) for a (channels, height, width) image at N normalised positions -- how _sample_depth_normal
  * (utils/loss_utils.py:368-409) looks the neighbour's depth and normal maps up; out, dL_dout: (N, channels), channels <= 4.

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 ITERS = 4000
 SNAP_IT = 449        # determinism snapshot: after the first densification rounds (they start at iteration 100 here)
+SNAP2_IT = 949       # a second one inside the GEOMETRY stage (from iteration 667 here): depth-normal and multi-view terms with their
+                     # bilinear scatters (64-bit fixed-point sums, include/gs2m_mvs.h), three more densification rounds
 PARITY_IT = 1800     # mid-run parity spot check (the model is near its largest here)
 
 
@@ -63,6 +65,8 @@ def test_c4_full_loop_at_stated_size(tmp_path):
     def cb(it, g, cams_, gts_):
         if it == SNAP_IT:
             snap["a"] = [p.detach().clone() for p in g.parameters()]
+        if it == SNAP2_IT:
+            snap["a2"] = [p.detach().clone() for p in g.parameters()]
         if it == PARITY_IT:
             parity["P"] = g.get_xyz.shape[0]
             parity["scene"] = _capture_rasterizer_call(cams_[0], g, geometry_stage=True)
@@ -78,10 +82,14 @@ def test_c4_full_loop_at_stated_size(tmp_path):
     def cb2(it, g, cams_, gts_):
         if it == SNAP_IT:
             snap["b"] = [p.detach().clone() for p in g.parameters()]
+        if it == SNAP2_IT:
+            snap["b2"] = [p.detach().clone() for p in g.parameters()]
 
-    gs2m_train.c4_run(None, iterations=SNAP_IT + 1, schedule_iterations=ITERS, scene=scene, callback=cb2)
+    _, st2 = gs2m_train.c4_run(None, iterations=SNAP2_IT + 1, schedule_iterations=ITERS, scene=scene, callback=cb2)
     assert snap["a"][0].shape[0] > st["points_start"], "the snapshot lies behind the first densification rounds"
     assert all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(snap["a"], snap["b"])), "two runs differ: densification is not deterministic"
+    assert len(st2["mv_loss"]) > 100, "the second snapshot lies inside the geometry stage (the multi-view term has run)"
+    assert all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(snap["a2"], snap["b2"])), "two runs differ inside the geometry stage"
 
     # mid-run parity at the then-current P: this view's forward + backward against the reference's own kernels
     assert parity["P"] > 100_000, parity["P"]

@@ -205,6 +205,86 @@ def test_mv_geo_matches_op_by_op():
     assert a2[2].float().mean().item() < a[2].float().mean().item()
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-11, 3e7])
+def test_scatter_backwards_are_bitwise_reproducible(scale):
+    """The bilinear scatters of grid_sample_border's and mv_geo's backwards (include/gs2m_mvs.h, deterministic mode = the default:
+    64-bit fixed-point sums scaled by the call's largest contribution): the same bits on every run, whatever the magnitude of the
+    upstream gradients, and the float-atomic mode's values to fp32 accumulation accuracy.  Many samples per texel: 200 k samples on a
+    37 x 53 image (~100 contributions per texel, in whatever order the hardware retires them)."""
+    assert torch.cuda.is_available()
+    import gs2m_mvs as MV
+    g = torch.Generator().manual_seed(3)
+    C, H, W, N = 4, 37, 53, 200_000
+    img = torch.randn(C, H, W, generator=g).cuda().requires_grad_(True)
+    grid = (torch.rand(N, 2, generator=g) * 2.2 - 1.1).cuda().requires_grad_(True)
+    G = (torch.randn(N, C, generator=g) * scale).cuda()
+
+    def run():
+        img.grad = grid.grad = None
+        (MV.grid_sample_border(img, grid) * G).sum().backward()
+        return img.grad.clone(), grid.grad.clone()
+
+    assert MV.is_deterministic()
+    a = [run() for _ in range(4)]
+    for b in a[1:]:
+        assert torch.equal(a[0][0], b[0]) and torch.equal(a[0][1], b[1]), "deterministic mode: identical bits run to run"
+    try:
+        MV.set_deterministic(False)
+        f = run()
+    finally:
+        MV.set_deterministic(True)
+    assert torch.isfinite(a[0][0]).all()
+    assert (a[0][0] - f[0]).abs().max().item() <= 2e-5 * f[0].abs().max().item(), "fixed-point sums vs fp32 atomics"
+    assert torch.equal(a[0][1], f[1]), "the position gradient is not scattered: the same in both modes"
+    # the fixed-point sums against a float64 scatter of the same contributions (torch's op on double inputs)
+    import torch.nn.functional as F
+    imgd, gridd = img.detach().double().requires_grad_(True), grid.detach().double()
+    ref = F.grid_sample(imgd[None], gridd.view(1, -1, 1, 2), mode="bilinear", padding_mode="border", align_corners=True)[0, :, :, 0].permute(1, 0)
+    (ref * G.double()).sum().backward()
+    err_det = (a[0][0].double() - imgd.grad).abs().max().item()
+    err_flt = (f[0].double() - imgd.grad).abs().max().item()
+    assert err_det <= 4e-6 * imgd.grad.abs().max().item(), (err_det, imgd.grad.abs().max().item())
+    assert err_det <= err_flt * 1.5 + 1e-30, "one rounding per texel instead of one per addition"
+
+
+def test_mv_geo_backward_is_bitwise_reproducible():
+    assert torch.cuda.is_available()
+    import gs2m_synth as S
+    import gs2m_mvs as MV
+    from gs2m_scene import Camera
+    W, H = 320, 192
+    ref = Camera(S.look_at_camera(W, H, (0.0, 0.0, 0.0), (0.0, 0.0, 6.0), fx=1.1 * W), "cuda")
+    near = Camera(S.look_at_camera(W, H, (0.5, -0.2, 0.3), (0.0, 0.0, 6.0), fx=1.1 * W), "cuda")
+    g = torch.Generator().manual_seed(1)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    mk = lambda t: t.cuda().requires_grad_(True)
+    depth = mk((5.5 + 0.4 * torch.sin(2 * xx) * torch.cos(1.5 * yy))[None])
+    depth_n = mk((5.3 + 0.4 * torch.cos(1.7 * xx + 0.3) * torch.cos(1.2 * yy))[None])
+    normal = mk(torch.stack([0.3 * xx, 0.3 * yy, -torch.ones_like(xx)], 0) + 0.15 * torch.randn(3, H, W, generator=g))
+    normal_n = mk(torch.stack([0.3 * xx + 0.4, 0.3 * yy - 0.3, -torch.ones_like(xx)], 0) * 0.8 + 0.05 * torch.randn(3, H, W, generator=g))
+    G1, G2 = torch.rand(H * W, generator=g).cuda() * 1e-6, torch.rand(H * W, generator=g).cuda() * 1e-6  # (a mean-reduced loss's magnitudes)
+    leaves = (depth, normal, depth_n, normal_n)
+
+    def run():
+        for t in leaves:
+            t.grad = None
+        noise, angle, valid = MV.mv_geo(depth, normal, depth_n, normal_n, ref, near, 5.0)
+        ((noise * G1 + angle * G2) * valid).sum().backward()
+        return [t.grad.clone() for t in leaves]
+
+    a = [run() for _ in range(4)]
+    for b in a[1:]:
+        for x, y in zip(a[0], b):
+            assert torch.equal(x, y), "deterministic mode: identical bits run to run"
+    try:
+        MV.set_deterministic(False)
+        f = run()
+    finally:
+        MV.set_deterministic(True)
+    for x, y in zip(a[0], f):
+        assert torch.isfinite(x).all() and (x - y).abs().max().item() <= 2e-5 * max(y.abs().max().item(), 1e-30)
+
+
 @pytest.mark.parametrize("N", [1920 * 1080, 1000, 7])
 def test_fused_geo_loss_equals_the_masked_means(N):
     """utils/loss_utils.py:277-291: the fused reduction (include/gs2m_loss.h: gs2m_mv_geo_loss_*) against the PyTorch

@@ -314,17 +314,6 @@ def _binning_bit_exact(oracle_lib, gs2m_native, dgr):
     assert np.array_equal(dk[vis], f.depths[vis].view(np.uint32)) and np.all(dk[~vis] == 0xFFFFFFFF)
     rec = view(geomB, lay.rec, P * 32, np.float32).reshape(P, 32)
     assert np.array_equal(rec[vis, 0:2], f.means2D[vis])
-    # the record's power threshold: the smallest float >= ln(fl(1/255) / opacity) (preprocess.hip; +1 below 1/255: never)
-    c255 = np.float64(np.float32(1.0) / np.float32(255.0))
-    op = f.conic_opacity[vis, 3].astype(np.float64)
-    with np.errstate(divide="ignore"):
-        lthr = np.log(c255 / op)
-    want = lthr.astype(np.float32)
-    want = np.where(want.astype(np.float64) < lthr, np.nextafter(want, np.float32(np.inf)), want)
-    want = np.where(op < c255, np.float32(1.0), want)
-    got = rec[vis, 6]
-    assert np.all(np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)) <= 1), "power threshold of alpha >= 1/255"
-    assert np.all((got <= 0) | (got == 1.0))
     pl = view(binB, lay.point_list, R, np.uint32) & np.uint32(0x0FFFFFFF)  # list-driven kernels: quadrant mask above the id
     tk = view(binB, lay.tile_keys, R, np.uint32)
     assert np.array_equal(pl, f.vals_sorted), "sorted Gaussian ids"
