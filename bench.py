@@ -51,13 +51,31 @@ CONFIGS = {  # name -> (Gaussians, width, height, feature_count)
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources the library is built from: ties a counter file to the kernels it was taken on."""
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "gs-2m_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gs-2m_amd", "csrc", "*.h"))
-                    + [os.path.join(ROOT, "gs-2m_amd", "csrc", "Makefile")]):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 over the DEVICE code of the library the bench runs on -- the `.hip_fatbin` section of libgs2m_raster.so (every kernel's
+    code object): ties a counter file to the kernels it was taken on.  A host-side edit (api.hip's launch logic, a comment) leaves it
+    unchanged, any change of a kernel or of its compile flags changes it.  (Rounds 1-5 hashed the source FILES, so a host-only edit
+    invalidated the counters and the stamp had to be renewed by hand.)"""
+    import struct
+    path = os.environ.get("GS2M_LIB", os.path.join(ROOT, "gs-2m_amd", "csrc", "libgs2m_raster.so"))
+    try:
+        blob = open(path, "rb").read()
+        assert blob[:4] == b"\x7fELF" and blob[4] == 2  # ELF64
+        shoff, = struct.unpack_from("<Q", blob, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+        sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", blob, shoff + i * shentsize)
+        str_off = sec(shstrndx)[4]
+        h = hashlib.sha256()
+        found = False
+        for i in range(shnum):
+            name_off, _, _, _, off, size = sec(i)[:6]
+            name = blob[str_off + name_off: blob.index(b"\0", str_off + name_off)].decode()
+            if name == ".hip_fatbin":
+                h.update(blob[off: off + size])
+                found = True
+        assert found
+        return h.hexdigest()[:16]
+    except Exception:
+        return "no-device-code"
 
 
 def counters_for(kernel, workload):
@@ -270,9 +288,20 @@ def bench_c4(a):
         "config": {"workload": st["workload"], "views": len(cams), "width": W, "height": H, "points_start": st["points_start"],
                    "points_max": st["points_max"], "points_end": st["points_end"], "psnr_start": round(st["psnr_start"], 3),
                    "psnr_end": round(st["psnr_end"], 3), "scene_build_s": round(t_scene, 2)},
+        "gpu_busy_frac": None,
         "rasterizer_ms_per_iteration_at_end": round(raster_ms, 4),
         "stages_ms_at_end": {k: round(v, 5) for k, v in k_ms.items() if v},
     }
+    # GPU-busy fraction: the kernel time of exactly this run (the trajectory is deterministic) from a kernel trace of the same kernels
+    # (tools/c4_busy.sh -> profiles/c4_kernel_time.json, refused when taken on other device code) over this run's wall time
+    try:
+        kt = json.load(open(os.path.join(ROOT, "profiles", "c4_kernel_time.json")))
+        if kt.get("source_hash") == kernel_source_hash() and kt.get("iterations") == iters:
+            out_line["gpu_busy_frac"] = round(kt["kernel_ms_total"] / (1e3 * iters / st["it_per_s"]), 4)
+            out_line["gpu_busy_source"] = (f"sum of the kernel durations of the same {iters} iterations under rocprofv3 --kernel-trace ({kt['kernel_us_per_iteration']} us and "
+                                           f"{kt['launches_per_iteration']} launches per iteration; profiles/c4_kernel_time.json) / this run's untraced wall time")
+    except Exception:
+        pass
     dom = "blend_bwd"
     if not a.no_cpu_baseline:
         # the CPU oracle on what render() hands the op for view 0 of the final model (checker infrastructure, never on the product path)
@@ -636,7 +665,9 @@ def main():
                 # matrix-pipe busy cycles per SIMD over the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
                 roof["counters"]["mfma_busy_share"] = round(ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / (ctr["GRBM_GUI_ACTIVE"] / 8.0), 4)
         out = {
-            "metric": "train views/s (fwd+bwd raster) at 1M Gaussians 1080p",
+            # BASELINE.json's metric is quoted on C3 (1M Gaussians, 1080p); other configurations say what they ran
+            "metric": ("train views/s (fwd+bwd raster) at 1M Gaussians 1080p" if (P, W, H) == (1_000_000, 1920, 1080) else
+                       f"train views/s (fwd+bwd raster) at {P} Gaussians {W}x{H}"),
             "value": round(world * VPR * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 4), "median_ms_per_step": round(ms_median, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -24,8 +24,9 @@ namespace {
 // ---------------------------------------------------------------- deterministic scatter (round 6)
 // The two bilinear backwards below scatter every sample's gradient into four texels.  With fp32 atomics the order of the
 // additions -- and so the last bits of every texel, and over a few hundred training iterations the Gaussian count of a run --
-// differs from run to run.  Deterministic mode (the default; gs2m_mvs_set_deterministic): the kernel runs twice over its samples,
-// first for the largest magnitude it will scatter (an integer atomicMax on the float's bits: order-independent), then adding
+// differs from run to run.  Deterministic mode (the default; gs2m_mvs_set_deterministic): two passes over the samples, the first for
+// the largest magnitude that will be scattered (an integer atomicMax on the float's bits: order-independent; mv_geo's first pass also
+// does all the rest of its backward and parks each sample's contributions, so the chain is evaluated once), the second adding
 // llrint(value x 2^shift) into 64-bit integers -- integer addition is associative, so the sum does not depend on the order --
 // with shift chosen from that maximum so that as many contributions as the call has samples cannot overflow; a third kernel
 // adds the sums, converted back, to the output and clears the integers for the next call.  Resolution: 2^-40 of the largest
@@ -412,7 +413,8 @@ __global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __
                                                      const float* __restrict__ d_noise, const float* __restrict__ d_angle,
                                                      float* __restrict__ d_depth, float* __restrict__ d_normal,
                                                      float* __restrict__ d_depth_n, float* __restrict__ d_normal_n,
-                                                     long long* __restrict__ acc = nullptr, uint32_t* __restrict__ maxbits = nullptr, int headroom = 0) {
+                                                     long long* __restrict__ acc = nullptr, uint32_t* __restrict__ maxbits = nullptr, int headroom = 0,
+                                                     float* __restrict__ srec = nullptr /* SCATTER_MAX: 7 x n words, what each sample will scatter */) {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (MODE != SCATTER_MAX && i0 >= C.W * C.H) return;
     const int i = min(i0, C.W * C.H - 1);  // (SCATTER_MAX: whole waves stay for the wave-wide maximum; the surplus lanes note 0)
@@ -459,31 +461,30 @@ __global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __
 #pragma unroll
     for (int k = 0; k < 3; k++) { dqx += dnraw[k] * g.gnx[k]; dqy += dnraw[k] * g.gny[k]; }
     const float w00 = (1.f - g.fx) * (1.f - g.fy), w10 = g.fx * (1.f - g.fy), w01 = (1.f - g.fx) * g.fy, w11 = g.fx * g.fy;
-    if (MODE == SCATTER_MAX) {  // what this sample will scatter is bounded by these four (the bilinear weights are <= 1)
+    if (MODE == SCATTER_MAX) {
+        // Deterministic mode, first of two kernels: everything but the scatter.  What this sample will add to the neighbour's maps is
+        // parked (values, bilinear fractions, footprint) for mv_geo_scatter_kernel, and bounded by these four values (the weights are
+        // <= 1) for the scale of the integer sums.
         const float m = fmaxf(fmaxf(fabsf(dzs), fabsf(dnraw[0])), fmaxf(fabsf(dnraw[1]), fabsf(dnraw[2])));
         det_note_max(maxbits, i0 < C.W * C.H ? m : 0.f);
-        return;
-    }
-    double scale = 0.0;
-    if (MODE == SCATTER_FIXED) scale = ldexp(1.0, det_shift(DetScale{maxbits, headroom}));
-    auto scatter = [&](float* img, long long* ai, float gv) {  // ai: the texel plane's integer sums (SCATTER_FIXED)
-        if (gv == 0.f) return;
-        const size_t o = (size_t)g.y0 * C.Wn + g.x0;
-        if (MODE == SCATTER_FIXED) {
-            det_add(&ai[o], gv * w00, scale);
-            if (g.bx) det_add(&ai[o + 1], gv * w10, scale);
-            if (g.by) det_add(&ai[o + C.Wn], gv * w01, scale);
-            if (g.bx && g.by) det_add(&ai[o + C.Wn + 1], gv * w11, scale);
-        } else {
+        if (i0 >= C.W * C.H) return;
+        const size_t n = (size_t)C.W * C.H;
+        srec[i] = dzs; srec[n + i] = dnraw[0]; srec[2 * n + i] = dnraw[1]; srec[3 * n + i] = dnraw[2];
+        srec[4 * n + i] = g.fx; srec[5 * n + i] = g.fy;
+        reinterpret_cast<uint32_t*>(srec)[6 * n + i] = (uint32_t)g.x0 | ((uint32_t)g.y0 << 15) | (g.bx ? 1u << 30 : 0u) | (g.by ? 1u << 31 : 0u);
+    } else {
+        auto scatter = [&](float* img, float gv) {
+            if (gv == 0.f) return;
+            const size_t o = (size_t)g.y0 * C.Wn + g.x0;
             unsafeAtomicAdd(&img[o], gv * w00);
             if (g.bx) unsafeAtomicAdd(&img[o + 1], gv * w10);
             if (g.by) unsafeAtomicAdd(&img[o + C.Wn], gv * w01);
             if (g.bx && g.by) unsafeAtomicAdd(&img[o + C.Wn + 1], gv * w11);
-        }
-    };
-    scatter(d_depth_n, acc, dzs);
+        };
+        scatter(d_depth_n, dzs);
 #pragma unroll
-    for (int k = 0; k < 3; k++) scatter(d_normal_n + k * HWn, acc + (size_t)(k + 1) * HWn, dnraw[k]);
+        for (int k = 0; k < 3; k++) scatter(d_normal_n + k * HWn, dnraw[k]);
+    }
     // q = (Y.x fxn / Y.z + cxn, Y.y fyn / Y.z + cyn)
     dY[0] += dqx * C.fxn * g.iz;
     dY[1] += dqy * C.fyn * g.iz;
@@ -494,6 +495,29 @@ __global__ void __launch_bounds__(256) mv_geo_kernel(GeoConst C, const float* __
     d_depth[i] = dP[0] * g.rx + dP[1] * g.ry + dP[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) d_normal[k * HW + i] = dnr[k];
+}
+
+// Deterministic mode, second kernel: the parked contributions into the 64-bit sums (depth plane, then the three normal planes).
+__global__ void __launch_bounds__(256) mv_geo_scatter_kernel(size_t n, int Wn, size_t HWn, const float* __restrict__ srec, long long* __restrict__ acc,
+                                                             DetScale d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v[4] = {srec[i], srec[n + i], srec[2 * n + i], srec[3 * n + i]};
+    if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) return;
+    const float fx = srec[4 * n + i], fy = srec[5 * n + i];
+    const uint32_t pk = reinterpret_cast<const uint32_t*>(srec)[6 * n + i];
+    const bool bx = (pk >> 30) & 1u, by = (pk >> 31) & 1u;
+    const size_t o = (size_t)((pk >> 15) & 0x7FFFu) * Wn + (pk & 0x7FFFu);
+    const float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+    const double scale = ldexp(1.0, det_shift(d));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long* a = acc + (size_t)k * HWn + o;
+        det_add(a, v[k] * w00, scale);
+        if (bx) det_add(a + 1, v[k] * w10, scale);
+        if (by) det_add(a + Wn, v[k] * w01, scale);
+        if (bx && by) det_add(a + Wn + 1, v[k] * w11, scale);
+    }
 }
 
 int fill(NccConst& C, const float* M, const float* b, const float* Kinv, float ncc_scale, int patch, int w, int h) {
@@ -510,11 +534,13 @@ struct DetWorkspace {
     long long* acc = nullptr;
     size_t words = 0;
     uint32_t* maxbits = nullptr;
+    float* scratch = nullptr;  // plain scratch (mv_geo's parked contributions)
+    size_t scratch_words = 0;
 };
 std::mutex g_det_mutex;
 std::map<std::pair<int, hipStream_t>, DetWorkspace> g_det_ws;
 // -> the workspace for `words` 64-bit sums on this stream (grown and zeroed when needed), or nullptr when the allocation fails
-DetWorkspace* det_workspace(size_t words, hipStream_t s) {
+DetWorkspace* det_workspace(size_t words, hipStream_t s, size_t scratch_words = 0) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_det_mutex);
@@ -530,6 +556,15 @@ DetWorkspace* det_workspace(size_t words, hipStream_t s) {
         w.words = words;
     }
     if (w.maxbits == nullptr && hipMalloc((void**)&w.maxbits, 256) != hipSuccess) { w.maxbits = nullptr; return nullptr; }
+    if (w.scratch_words < scratch_words) {
+        if (w.scratch != nullptr) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(w.scratch);
+            w.scratch = nullptr; w.scratch_words = 0;
+        }
+        if (hipMalloc((void**)&w.scratch, scratch_words * sizeof(float)) != hipSuccess) { w.scratch = nullptr; return nullptr; }
+        w.scratch_words = scratch_words;
+    }
     return &w;
 }
 int det_headroom(long long samples) {  // bits kept free: every sample may add 4 contributions to one texel
@@ -672,14 +707,14 @@ int gs2m_mv_geo_backward(int width, int height, int width_n, int height_n, const
     hipStream_t s = (hipStream_t)stream;
     if (g_mvs_deterministic.load() != 0) {
         const size_t words = (size_t)4 * height_n * width_n;  // depth + three normal planes of the neighbour
-        DetWorkspace* ws = det_workspace(words, s);
+        if (width_n >= (1 << 15) || height_n >= (1 << 15)) return GS2M_ERR_UNSUPPORTED;  // (the parked footprint: 15 bits per coordinate)
+        DetWorkspace* ws = det_workspace(words, s, (size_t)7 * n);
         if (ws == nullptr) return GS2M_ERR_ALLOC;
         if (hipMemsetAsync(ws->maxbits, 0, sizeof(uint32_t), s) != hipSuccess) return GS2M_ERR_HIP;
         const int hb = det_headroom(n);
         mv_geo_kernel<true, SCATTER_MAX><<<(n + 255) / 256, 256, 0, s>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise, dL_dangle,
-                                                                         dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n, ws->acc, ws->maxbits, hb);
-        mv_geo_kernel<true, SCATTER_FIXED><<<(n + 255) / 256, 256, 0, s>>>(C, depth, normal, depth_n, normal_n, nullptr, nullptr, nullptr, dL_dnoise, dL_dangle,
-                                                                           dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n, ws->acc, ws->maxbits, hb);
+                                                                         dL_ddepth, dL_dnormal, dL_ddepth_n, dL_dnormal_n, ws->acc, ws->maxbits, hb, ws->scratch);
+        mv_geo_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>((size_t)n, width_n, (size_t)height_n * width_n, ws->scratch, ws->acc, DetScale{ws->maxbits, hb});
         const size_t plane = (size_t)height_n * width_n;
         det_finalize_kernel<<<(unsigned)((plane + 255) / 256), 256, 0, s>>>(plane, ws->acc, DetScale{ws->maxbits, hb}, dL_ddepth_n);
         det_finalize_kernel<<<(unsigned)((3 * plane + 255) / 256), 256, 0, s>>>(3 * plane, ws->acc + plane, DetScale{ws->maxbits, hb}, dL_dnormal_n);

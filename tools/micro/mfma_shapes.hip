@@ -52,6 +52,28 @@ __global__ void k_scan(float* out, float a, float b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = Ax + Ay + Bx + By;
 }
 
+// (3) issue cost of the instruction kinds of the backward's block loop at its occupancy: 16 instructions per iteration on 4 registers
+template <int KIND>  // 0: v_mul_f32 (plain), 1: v_mul_f32_dpp row_shr:1, 2: v_fmac_f32_dpp row_shr:1, 3: v_pk_mul_f32, 4: v_exp_f32, 5: v_rcp_f32
+__global__ void k_op(float* out, float a, float b) {
+    float x0 = a + threadIdx.x * 1e-6f, x1 = a, x2 = b, x3 = b + threadIdx.x * 1e-6f;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f p0 = {x0, x1}, p1 = {x2, x3};
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (KIND == 0) asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b));
+            if (KIND == 1) asm volatile("v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                        "v_mul_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            if (KIND == 2) asm volatile("v_fmac_f32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                        "v_fmac_f32_dpp %2, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %3, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b));
+            if (KIND == 3) asm volatile("v_pk_mul_f32 %0, %0, %2\n\tv_pk_mul_f32 %1, %1, %2\n\tv_pk_mul_f32 %0, %0, %2\n\tv_pk_mul_f32 %1, %1, %2" : "+v"(p0), "+v"(p1) : "v"(p1));
+            if (KIND == 4) asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            if (KIND == 5) asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + p0.x + p0.y + p1.x + p1.y;
+}
+
 template <typename F>
 float timeit(F f) {
     hipEvent_t e0, e1;
@@ -77,5 +99,14 @@ int main() {
     const float s32 = per * timeit([&] { k_scan<32><<<grid, block>>>(out, 0.9f, 0.1f); });
     printf("affine scan of 2 chains over 16 lanes (16 DPP + 4 plain) : %.1f\n", s16);
     printf("affine scan of 2 chains over 32 lanes (20 DPP + 4 plain) : %.1f\n", s32);
+    const char* names[6] = {"v_mul_f32", "v_mul_f32_dpp row_shr:1", "v_fmac_f32_dpp row_shr:1", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32"};
+    float t[6];
+    t[0] = per * timeit([&] { k_op<0><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    t[1] = per * timeit([&] { k_op<1><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    t[2] = per * timeit([&] { k_op<2><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    t[3] = per * timeit([&] { k_op<3><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    t[4] = per * timeit([&] { k_op<4><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    t[5] = per * timeit([&] { k_op<5><<<grid, block>>>(out, 0.999f, 1.0001f); });
+    for (int i = 0; i < 6; i++) printf("16 x %-26s: %.1f  (%.2f per instruction)\n", names[i], t[i], t[i] / 16);
     return 0;
 }
