@@ -342,8 +342,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (!dL_dmeans2D || !dL_dopacities || !dL_dmeans3D || !dL_dscales || !dL_drots || !dL_dfeatures) return GS2M_ERR_INVALID_ARG;
     // dL_dcolors / dL_dcov3D may be NULL when the corresponding input was not given (nobody reads them then)
     if ((colors_precomp && !dL_dcolors) || (cov3D_precomp && !dL_dcov3D)) return GS2M_ERR_INVALID_ARG;
-    if (shs && M > 0 && !dL_dshs) return GS2M_ERR_INVALID_ARG;
-    if (shs_rest && (M != 16 || !dL_dshs_rest || ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15))) return GS2M_ERR_UNSUPPORTED;
+    // dL_dshs (and dL_dshs_rest) may be NULL with SH input: dL/dSH is then not computed (a view whose colour gradient is identically zero)
+    if (shs_rest && (M != 16 || ((dL_dshs == nullptr) != (dL_dshs_rest == nullptr)) || ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15))) return GS2M_ERR_UNSUPPORTED;
 
     const int tiles_x = (width + GS2M_TILE - 1) / GS2M_TILE, tiles_y = (height + GS2M_TILE - 1) / GS2M_TILE;
     const size_t tiles = (size_t)tiles_x * tiles_y, N = (size_t)width * height;

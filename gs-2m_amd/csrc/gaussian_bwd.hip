@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     float tan_fovy, const int* __restrict__ radii, int fc, const float4* __restrict__ rec,
     const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ wave_rowbase,
     const uint8_t* __restrict__ clamped,
-    const float* __restrict__ sh_dir, const float* __restrict__ rows /* nullptr: nothing was rendered, every sum is zero */,
+    const float* __restrict__ sh_dir, const float* __restrict__ rows /* nullptr: nothing was rendered, every sum is zero */, int want_sh,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconics,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
@@ -450,7 +450,8 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     } while (0)
             float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
             if (D > 1) { xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z; }
-            // pass 2: dL/dSH_k = basis_k(dir) * dL/dRGB
+            // pass 2: dL/dSH_k = basis_k(dir) * dL/dRGB (skipped when the caller did not ask for dL/dSH: include/gs2m_raster.h)
+            if (want_sh) {
             DSH(0, SH_C0);
             if (D > 0) {
                 DSH(1, -SH_C1 * y);
@@ -475,6 +476,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             }
             // coefficients above the active degree receive no gradient
             for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+            }
 #undef DSH
             const float ddx = dRdx[0] * g[0] + dRdx[1] * g[1] + dRdx[2] * g[2];
             const float ddy = dRdy[0] * g[0] + dRdy[1] * g[1] + dRdy[2] * g[2];
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             drot[3] = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
 #undef Dm
         }
-    } else if (shs != nullptr && M > 0) {
+    } else if (shs != nullptr && M > 0 && want_sh) {
         float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
     }
@@ -547,7 +549,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
     gaussian_bwd_kernel<LDS, RQ><<<(P + 255) / 256, 256, 0, s>>>(                                                       \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
         projmatrix, campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.gauss_rows, g.tiles_touched, g.wave_rowbase, g.clamped, \
-        g.sh_dir, have_rows ? rows : nullptr, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, \
+        g.sh_dir, have_rows ? rows : nullptr, want_sh, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, \
         dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures)
 #define GS2M_GBQ(LDS)                                                                                                   \
     switch (rowf >> 2) {                                                                                                \
@@ -556,7 +558,10 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
         case 5: GS2M_GB(LDS, 5); break;                                                                                 \
         default: GS2M_GB(LDS, 6); break;                                                                                \
     }
-    const bool lds = shs != nullptr && M == 16 &&
+    // dL_dshs == NULL with SH input: the caller does not want dL/dSH (its colour gradient is identically zero, e.g. a view rendered for
+    // its depth and normals only): the per-Gaussian kernel skips the 48 stores per Gaussian; everything else is computed as usual
+    const int want_sh = dL_dshs != nullptr ? 1 : 0;
+    const bool lds = want_sh && shs != nullptr && M == 16 &&
                      (shs_rest ? ((((uintptr_t)shs_rest) | ((uintptr_t)dL_dshs_rest)) & 15) == 0
                                : ((((uintptr_t)shs) | ((uintptr_t)dL_dshs)) & 15) == 0);
     if (lds) { GS2M_GBQ(true) } else { GS2M_GBQ(false) }

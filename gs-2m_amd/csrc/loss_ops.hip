@@ -593,6 +593,95 @@ __global__ void __launch_bounds__(RB) affine_mean_kernel(size_t n, const float* 
     }
 }
 
+// ---------------------------------------------------------------- random subset of the set elements of a mask (gs2m_mvs.random_subset)
+// The reference draws its patch samples with idx[torch.randperm(idx.numel())[:k]] (utils/loss_utils.py:283-286).  gs2m_mvs.random_subset
+// (round 5) does without the sort of one random key per valid pixel -- thinning to k + 4 sqrt(k) expected survivors, then the ~1 % in excess
+// removed one per stratum -- but as ~27 framework operators of a few microseconds each (`nonzero` alone is seven launches).  The same two
+// steps as four launches: counter-based uniform numbers (a 64-bit mix of seed and element index: no generator state, no ordering between
+// threads), an ORDERED compaction (the samples stay in pixel order: what keeps the NCC kernels' gathers coherent).
+__device__ __forceinline__ unsigned long long subset_mix(unsigned long long x) {  // splitmix64's finalizer
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ bool subset_survives(const unsigned char* __restrict__ mask, int i, int n, unsigned long long seed, float p) {
+    if (i >= n || mask[i] == 0) return false;
+    const float u = (float)(subset_mix(seed ^ ((unsigned long long)i * 0xD1342543DE82EF95ull)) >> 40) * (1.0f / 16777216.0f);
+    return u < p;
+}
+__device__ __forceinline__ float subset_p(int k, int set) {  // (k + 4 sqrt(k)) / count, at most 1: as gs2m_mvs.random_subset computes it
+    return fminf(((float)k + 4.0f * sqrtf((float)k)) / (float)max(set, 1), 1.0f);
+}
+constexpr int SUB_B = 1024;
+__global__ void __launch_bounds__(SUB_B) subset_count_kernel(int n, const unsigned char* __restrict__ mask, int* __restrict__ counts) {
+    __shared__ int s_w[SUB_B / 64];
+    const int i = blockIdx.x * SUB_B + threadIdx.x;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(i < n && mask[i] != 0);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(b);
+    gs2m_sync();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SUB_B / 64; w++) t += s_w[w];
+        if (t) atomicAdd(&counts[0], t);  // (integers: the order does not matter)
+    }
+}
+__global__ void __launch_bounds__(SUB_B) subset_block_kernel(int n, const unsigned char* __restrict__ mask, int k, unsigned long long seed,
+                                                              const int* __restrict__ counts, int* __restrict__ block_counts) {
+    __shared__ int s_w[SUB_B / 64];
+    const int i = blockIdx.x * SUB_B + threadIdx.x;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(subset_survives(mask, i, n, seed, subset_p(k, counts[0])));
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(b);
+    gs2m_sync();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SUB_B / 64; w++) t += s_w[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(SUB_B) subset_write_kernel(int n, const unsigned char* __restrict__ mask, int k, unsigned long long seed, int* __restrict__ counts,
+                                                              const int* __restrict__ block_counts, long long* __restrict__ idx, int cap) {
+    __shared__ int s_w[SUB_B / 64], s_part[SUB_B / 64];
+    int before = 0;  // survivors in the blocks in front (chain-free: every block adds them up itself)
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SUB_B) before += block_counts[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+    const int i = blockIdx.x * SUB_B + threadIdx.x;
+    const bool keep = subset_survives(mask, i, n, seed, subset_p(k, counts[0]));
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_w[wave] = __popcll(b); s_part[wave] = before; }
+    gs2m_sync();
+    int base = 0, off = 0, tot = 0;
+    for (int w = 0; w < SUB_B / 64; w++) {
+        base += s_part[w];
+        if (w < wave) off += s_w[w];
+        tot += s_w[w];
+    }
+    const int pos = base + off + __popcll(b & ((1ull << lane) - 1ull));
+    if (keep && pos < cap) idx[pos] = i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[1] = base + tot;  // all survivors (may exceed cap: the caller looks)
+}
+// out[j] = idx[j + #{i < e : removed_i - i <= j}], removed_i = min(m - 1, floor((i + U_i) m / e)): the j-th survivor that is kept
+__global__ void __launch_bounds__(LB) subset_remove_kernel(int m, int k, unsigned long long seed, const long long* __restrict__ idx, long long* __restrict__ out) {
+    const int j = blockIdx.x * LB + threadIdx.x;
+    if (j >= k) return;
+    const int e = m - k;
+    const double step = (double)m / (double)e;
+    auto key = [&](int i) {  // removed_i - i (non-decreasing in i)
+        const double u = (double)(subset_mix(seed ^ ((unsigned long long)i * 0xD1342543DE82EF95ull)) >> 11) * (1.0 / 9007199254740992.0);
+        long long r = (long long)(((double)i + u) * step);
+        if (r > m - 1) r = m - 1;
+        return r - i;
+    };
+    int lo = 0, hi = e;  // first i whose key exceeds j = the number of keys <= j (searchsorted right=True)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key(mid) <= (long long)j) lo = mid + 1; else hi = mid;
+    }
+    out[j] = idx[j + lo];
+}
+
 inline int launched() { return hipGetLastError() == hipSuccess ? GS2M_OK : GS2M_ERR_HIP; }
 inline bool too_large(int W, int H) { return (long long)W * H >= (1ll << 31); }  // the kernels split a pixel index with 32-bit arithmetic
 
@@ -692,6 +781,23 @@ int gs2m_mv_take_backward(int n, const long long* idx, int width, int height, co
     if (n < 1 || width < 1 || height < 1 || !idx || !d_normals || !d_dists || !d_normal_map || !d_dist_map) return GS2M_ERR_INVALID_ARG;
     const MvTakeArgs a = {n, width, (size_t)width * height, idx};
     mv_take_bwd_kernel<<<(n + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(a, d_normals, d_dists, d_normal_map, d_dist_map);
+    return launched();
+}
+
+int gs2m_subset_thin(int n, const unsigned char* mask, int k, unsigned long long seed, long long* idx, int cap, int* counts, int* block_counts, void* stream) {
+    if (n < 1 || k < 1 || cap < 1 || !mask || !idx || !counts || !block_counts) return GS2M_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (n + SUB_B - 1) / SUB_B;
+    if (gs2m_zero_async(counts, 2 * sizeof(int), s) != hipSuccess) return GS2M_ERR_HIP;
+    subset_count_kernel<<<blocks, SUB_B, 0, s>>>(n, mask, counts);
+    subset_block_kernel<<<blocks, SUB_B, 0, s>>>(n, mask, k, seed, counts, block_counts);
+    subset_write_kernel<<<blocks, SUB_B, 0, s>>>(n, mask, k, seed, counts, block_counts, idx, cap);
+    return launched();
+}
+
+int gs2m_subset_remove(int m, int k, unsigned long long seed, const long long* idx, long long* out, void* stream) {
+    if (k < 1 || m <= k || !idx || !out) return GS2M_ERR_INVALID_ARG;
+    subset_remove_kernel<<<(k + LB - 1) / LB, LB, 0, (hipStream_t)stream>>>(m, k, seed, idx, out);
     return launched();
 }
 

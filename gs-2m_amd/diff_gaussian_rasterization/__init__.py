@@ -17,6 +17,8 @@ from typing import NamedTuple
 import ctypes as C
 import threading
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -298,10 +300,11 @@ class _CModule:
     def rasterize_gaussians_backward(background, means3D, radii, buffer, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, features, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_colors,
                                      grad_buffer, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                     featureCount, return_conics=False, sh_rest=None, unused_input_grads=True):
+                                     featureCount, return_conics=False, sh_rest=None, unused_input_grads=True, want_sh_grad=True):
         """`unused_input_grads=False`: dL/dcolors_precomp and dL/dcov3D_precomp are not computed (None in the result) when
         those inputs were not given -- the reference's extension writes them regardless and its autograd Function drops
-        them (diff_gaussian_rasterization/__init__.py:127-139); the Function below asks for this form."""
+        them (diff_gaussian_rasterization/__init__.py:127-139); the Function below asks for this form.  `want_sh_grad=False`:
+        dL/dSH is not computed either (None in the result): the caller knows the colour gradient to be identically zero."""
         L = _native.lib()
         device = means3D.device
         means3D = _f32c(means3D, "means3D")
@@ -331,9 +334,11 @@ class _CModule:
         # what densification accumulates, train.py:223-227), and the gradients of inputs that are usually absent
         # (precomputed colours / covariances, scene/gaussian_model.py:230-240 has no such parameter), dL/dconic.
         entries = [("means3D", (P, 3)), ("opacities", (P, 1)), ("scales", (P, 3)), ("rotations", (P, 4)),
-                   ("features", (P, NUM_FEATURES)), ("shs", (P, 1 if split else M, 3))]
-        if split:
-            entries.append(("shs_rest", (P, M - 1, 3)))
+                   ("features", (P, NUM_FEATURES))]
+        if want_sh_grad:
+            entries.append(("shs", (P, 1 if split else M, 3)))
+            if split:
+                entries.append(("shs_rest", (P, M - 1, 3)))
         want_colors = unused_input_grads or (colors is not None and colors.numel() != 0)
         want_cov3D = unused_input_grads or (cov3D_precomp is not None and cov3D_precomp.numel() != 0)
         entries += [("means2D", (P, 4))] + ([("colors", (P, NUM_CHANNELS))] if want_colors else []) + ([("cov3D", (P, 6))] if want_cov3D else [])
@@ -342,7 +347,7 @@ class _CModule:
         arena = _arena.GradArena(device, entries, zero=(P == 0), key="rasterizer")
         dL_dmeans3D = arena["means3D"]; dL_dmeans2D = arena["means2D"]; dL_dcolors = arena.get("colors")
         dL_dfeatures = arena["features"]; dL_dopacities = arena["opacities"]; dL_dcov3D = arena.get("cov3D")
-        dL_dshs = arena["shs"]; dL_dscales = arena["scales"]; dL_drotations = arena["rotations"]
+        dL_dshs = arena.get("shs"); dL_dscales = arena["scales"]; dL_drotations = arena["rotations"]
         dL_dshs_rest = arena.get("shs_rest")
         dL_dconics = arena.get("conics")
         scratch = _ScratchCache.get(device, _stream())
@@ -397,6 +402,20 @@ def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales
                                      cov3Ds_precomp, features, raster_settings, shs_rest)
 
 
+_zero_image_cache = {}
+
+
+def _zero_image(buffer):
+    """(3,H,W) zeros on buffer's device, cached per shape (read-only input of the backward kernels: no fill per call)"""
+    key = (buffer.device, buffer.shape[1], buffer.shape[2])
+    z = _zero_image_cache.get(key)
+    if z is None:
+        if len(_zero_image_cache) > 8:
+            _zero_image_cache.clear()
+        z = _zero_image_cache[key] = torch.zeros((NUM_CHANNELS, buffer.shape[1], buffer.shape[2]), dtype=torch.float32, device=buffer.device)
+    return z
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, features,
@@ -430,8 +449,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         raster_settings = ctx.raster_settings
         (buffer, features, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, shs, geomBuffer,
          binningBuffer, imgBuffer, shs_rest) = ctx.saved_tensors
+        # No gradient reached the colour output (materialize_grads is off): a view rendered for its G-buffer only -- the multi-view
+        # term's neighbour view (train.py:121-130 uses its depth and normal maps).  dL/dcolour is then identically zero for every
+        # Gaussian, and with it dL/dSH: the kernel is told not to write the (P,16,3) tensor, and autograd gets None (no zeros to add
+        # to the other view's SH gradient: 0.06 ms of accumulation per training iteration at 590 k Gaussians).
+        color_dead = grad_out_color is None and os.environ.get("GS2M_KEEP_DEAD_SH") is None  # (env: A/B of this shortcut)
         if grad_out_color is None:
-            grad_out_color = torch.zeros_like(buffer[:NUM_CHANNELS])
+            grad_out_color = _zero_image(buffer)
         if grad_out_buffer is None:
             grad_out_buffer = torch.zeros_like(buffer)
         args = (raster_settings.bg, means3D, radii, buffer, colors_precomp, scales, rotations,
@@ -443,7 +467,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dense_rows = L.gs2m_raster_dense_rows(ctx.forward_token)  # -1: no longer available (worst-case sizing: 4 rows per instance)
         if dense_rows >= 0:
             L.gs2m_raster_backward_rows_hint(dense_rows)  # consumed by this thread's next backward call, i.e. the one below
-        res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest, unused_input_grads=False)
+        res = _C.rasterize_gaussians_backward(*args, sh_rest=shs_rest, unused_input_grads=False, want_sh_grad=not color_dead)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_features) = res[:9]
         grad_sh_rest = res[9] if len(res) > 9 else None

@@ -31,9 +31,25 @@ def _zero_points(P, dtype, device):
     return z
 
 
+_zero_colors_cache = {}
+
+
+def _zero_colors(P, device):
+    key = (P, device)
+    z = _zero_colors_cache.get(key)
+    if z is None:
+        _zero_colors_cache.clear()
+        z = _zero_colors_cache[key] = torch.zeros((P, 3), dtype=torch.float32, device=device)
+    return z
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=False, material_stage=False,
-           sobel_normal=False, blend_metallic=False):
-    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+           sobel_normal=False, blend_metallic=False, shade=True):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU.
+    `shade=False` (this repository's extension; the reference has no such argument): the caller wants the G-buffer only -- the
+    multi-view term's neighbour view, whose depth and normal maps alone enter the loss (utils/loss_utils.py:253-276).  The colours go in
+    as precomputed zeros instead of SH coefficients: `render` comes out black, and the forward does not read the (P,16,3) coefficients
+    nor the backward write their gradient."""
     device = pc.get_xyz.device
     # zero tensor whose gradient carries the 2D (screen-space) mean gradients: the first two columns as
     # in 3DGS, the last two accumulate absolute values (GR:38-43)
@@ -78,7 +94,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, geometry_stage=Fa
     shs = None
     shs_rest = None
     colors_precomp = None
-    if pipe.convert_SHs_python:
+    if not shade and device.type == "cuda":
+        colors_precomp = _zero_colors(pc.get_xyz.shape[0], device)
+    elif pipe.convert_SHs_python:
         shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
         dir_pp = (pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1))
         dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)

@@ -524,16 +524,57 @@ def take_distinct(x, idx):
     return _TakeDistinct.apply(x, idx) if x.requires_grad else x[idx]
 
 
-def random_subset(mask, k):
+_subset_scratch = {}
+
+
+def _subset_device(flat, k, rng):
+    """random_subset's two steps as four launches (include/gs2m_loss.h: gs2m_subset_thin / gs2m_subset_remove) with counter-based random
+    numbers; the seeds come from `rng` (Python's `random`: seeded by the training run, no device generator state).  -> indices, or None
+    when the rare plain path is needed (the thinning came out short, or most survivors would have to be removed)."""
+    dev = flat.device
+    n = flat.shape[0]
+    cap = int(k + 12.0 * math.sqrt(k) + 64)
+    key = (dev, _native.stream_ptr(dev))
+    sc = _subset_scratch.get(key)
+    if sc is None or sc[0].shape[0] < cap or sc[2].shape[0] < (n + 1023) // 1024:
+        sc = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(2, dtype=torch.int32, device=dev),
+              torch.empty((n + 1023) // 1024 + 1, dtype=torch.int32, device=dev), torch.empty(2, dtype=torch.int32).pin_memory())
+        _subset_scratch[key] = sc
+    idx, counts, blocks, host = sc
+    s1, s2 = rng.getrandbits(63), rng.getrandbits(63)
+    with _native.device_guard(dev):
+        _native.check(_native.lib().gs2m_subset_thin(n, flat.data_ptr(), int(k), s1, idx.data_ptr(), cap, counts.data_ptr(), blocks.data_ptr(),
+                                                     C.c_void_p(_native.stream_ptr(dev))), "gs2m_subset_thin")
+        host.copy_(counts, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()  # (the one host wait `nonzero` always had)
+        total, m = int(host[0]), int(host[1])
+        if m > cap or (m < k and total > m):
+            return None
+        if m <= k:
+            return idx[:m].clone()
+        if 4 * (m - k) > m:
+            return None
+        out = torch.empty(int(k), dtype=torch.int64, device=dev)
+        _native.check(_native.lib().gs2m_subset_remove(m, int(k), s2, idx.data_ptr(), out.data_ptr(), C.c_void_p(_native.stream_ptr(dev))),
+                      "gs2m_subset_remove")
+    return out
+
+
+def random_subset(mask, k, rng=random):
     """-> indices of a random subset of exactly min(k, count) set elements of the flat bool `mask`, every set element equally likely --
     what the reference draws with `idx[torch.randperm(idx.numel())[:k]]` (utils/loss_utils.py:283-286, 172-175), without sorting one
     random key per VALID PIXEL (450 k keys per iteration at DTU's size: 0.18 ms of merge-sort kernels; the sort's ~12 launches cost
-    nearly as much for 100 k keys).  Two steps, no sort: the mask is thinned to k + 4 sqrt(k) expected survivors (one fused compare
+    nearly as much for 100 k keys).  Two steps, no sort: the mask is thinned to k + 4 sqrt(k) expected survivors (one compare
     against uniform numbers), then the ~1 % in excess are removed one per stratum of the survivor list (position (j + U_j) m / e for
     the j-th of e removals: distinct, increasing, uniform over the list), and the kept positions follow from a searchsorted.  Not the
-    uniform distribution over k-subsets (the removals are stratified), but uniform inclusion probabilities and exactly k samples.
-    (One host wait, as `nonzero` always had.)"""
+    uniform distribution over k-subsets (the removals are stratified), but uniform inclusion probabilities and exactly k samples, in
+    element order.  On the GPU: four launches of this repository's kernels (`_subset_device`; round 5: ~27 framework operators);
+    GS2M_SUBSET_TORCH=1 or a CPU mask: the PyTorch formulation below.  (One host wait, as `nonzero` always had.)"""
     flat = mask.reshape(-1)
+    if flat.is_cuda and flat.dtype == torch.bool and flat.is_contiguous() and flat.shape[0] > 0 and k >= 1 and os.environ.get("GS2M_SUBSET_TORCH") is None:
+        out = _subset_device(flat, k, rng)
+        if out is not None:
+            return out
     n = flat.sum()
     p = ((k + 4.0 * math.sqrt(k)) / n.clamp(min=1).to(torch.float32)).clamp(max=1.0)
     idx = torch.nonzero(flat & (torch.rand(flat.shape[0], device=flat.device) < p)).squeeze(1)
@@ -559,7 +600,10 @@ def multi_view_loss(scene, viewpoint_cam, opt, render_pkg, pipe, bg_color, mater
     if len(viewpoint_cam.nearest_indices) == 0:
         return 0.0
     near = cams[rng.sample(viewpoint_cam.nearest_indices, 1)[0]]
-    near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False)
+    # only the neighbour's depth and normal maps enter the loss: this repository's render() takes `shade=False` (no SH evaluation, no
+    # dL/dSH); any other render function (the reference's signature) is called as the reference calls it
+    extra = {"shade": False} if (getattr(render_fn, "__module__", "") == "gaussian_renderer" and os.environ.get("GS2M_SHADE_NEIGHBOUR") is None) else {}
+    near_pkg = render_fn(near, scene.gaussians, pipe, bg_color, geometry_stage=True, material_stage=False, sobel_normal=False, **extra)
     if fused and os.environ.get("GS2M_MV_GEO_TORCH") is None:  # (env: debugging aid, the op-by-op geometric chain with the fused NCC)
         pixel_noise, angle, valid = mv_geo(render_pkg["depth_map"], render_pkg["normal_map"], near_pkg["depth_map"], near_pkg["normal_map"],
                                            viewpoint_cam, near, opt.mv_occlusion_threshold)

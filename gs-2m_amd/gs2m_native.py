@@ -18,7 +18,7 @@ EXPORTS = ("gs2m_raster_forward", "gs2m_raster_backward", "gs2m_raster_mark_visi
            "gs2m_debug_layout", "gs2m_debug_tile_sort", "gs2m_raster_forward_token", "gs2m_raster_dense_rows", "gs2m_raster_backward_rows_hint", "gs2m_prealloc_alloc", "gs2m_set_debug", "gs2m_set_markers", "gs2m_stage_name", "gs2m_set_reference_binning", "gs2m_set_spin_wait", "gs2m_set_sort_tickets", "gs2m_set_tile_sort_policy", "gs2m_pack_features_forward", "gs2m_pack_features_backward", "gs2m_gbuffer_post_forward",
            "gs2m_gbuffer_post_backward", "gs2m_gbuffer_maps_backward", "gs2m_sobel_normal_forward", "gs2m_sobel_normal_backward", "gs2m_activate_forward", "gs2m_activate_backward", "gs2m_texture_cube_forward", "gs2m_texture_cube_backward", "gs2m_texture_2d_clamp_forward", "gs2m_texture_2d_clamp_backward", "gs2m_diffuse_cubemap_forward", "gs2m_diffuse_cubemap_backward", "gs2m_cubemap_texel_table", "gs2m_specular_cubemap_forward", "gs2m_specular_cubemap_backward", "gs2m_specular_cubemap_normalized_forward", "gs2m_specular_cubemap_normalized_backward", "gs2m_pbr_shade_forward", "gs2m_pbr_shade_backward", "gs2m_patch_ncc_forward", "gs2m_patch_ncc_backward", "gs2m_patch_ncc_roughness", "gs2m_grid_sample_border_forward", "gs2m_grid_sample_border_backward", "gs2m_mv_geo_forward", "gs2m_mv_geo_backward", "gs2m_mvs_set_deterministic", "gs2m_mvs_get_deterministic", "gs2m_adam_step", "gs2m_ssim_forward", "gs2m_ssim_backward", "gs2m_profile_mode", "gs2m_profile_sampling", "gs2m_profile_collect", "gs2m_version",
            # include/gs2m_loss.h (round 3: the loss tail of the training iteration)
-           "gs2m_affine_mean", "gs2m_densification_stats", "gs2m_edge_gradient", "gs2m_image_loss_backward", "gs2m_image_loss_forward", "gs2m_loss_workspace_bytes", "gs2m_mv_geo_loss_backward", "gs2m_mv_geo_loss_forward", "gs2m_mv_take_backward", "gs2m_mv_take_forward", "gs2m_ncc_tail_backward", "gs2m_ncc_tail_forward", "gs2m_pbr_inputs_backward", "gs2m_pbr_inputs_forward", "gs2m_plane_loss_backward", "gs2m_plane_loss_forward", "gs2m_ssim_backward_uniform", "gs2m_tv_loss_backward", "gs2m_tv_loss_forward")
+           "gs2m_affine_mean", "gs2m_densification_stats", "gs2m_edge_gradient", "gs2m_image_loss_backward", "gs2m_image_loss_forward", "gs2m_loss_workspace_bytes", "gs2m_mv_geo_loss_backward", "gs2m_mv_geo_loss_forward", "gs2m_mv_take_backward", "gs2m_mv_take_forward", "gs2m_ncc_tail_backward", "gs2m_ncc_tail_forward", "gs2m_subset_thin", "gs2m_subset_remove", "gs2m_pbr_inputs_backward", "gs2m_pbr_inputs_forward", "gs2m_plane_loss_backward", "gs2m_plane_loss_forward", "gs2m_ssim_backward_uniform", "gs2m_tv_loss_backward", "gs2m_tv_loss_forward")
 
 STAGES = ("preprocess", "unused1", "scan", "emit", "tile_sort", "lists", "blend_fwd", "unused7", "blend_bwd",
           "gaussian_bwd")
@@ -195,6 +195,10 @@ def lib():
     L.gs2m_ncc_tail_forward.restype = i
     L.gs2m_ncc_tail_backward.argtypes = [i, p, p, p, p, p, p]
     L.gs2m_ncc_tail_backward.restype = i
+    L.gs2m_subset_thin.argtypes = [i, p, i, C.c_ulonglong, p, i, p, p, p]
+    L.gs2m_subset_thin.restype = i
+    L.gs2m_subset_remove.argtypes = [i, i, C.c_ulonglong, p, p, p]
+    L.gs2m_subset_remove.restype = i
     L.gs2m_affine_mean.argtypes = [C.c_longlong, p, f, f, p, p, p]
     L.gs2m_affine_mean.restype = i
     L.gs2m_ssim_backward_uniform.argtypes = [i, i, i, i, p, p, p, f, f, p, p, p, p, p]

@@ -80,6 +80,18 @@ int gs2m_mv_take_backward(int n, const long long* idx, int width, int height, co
 int gs2m_ncc_tail_forward(int n, const float* ncc, const float* w, float* out, void* workspace, void* stream);
 int gs2m_ncc_tail_backward(int n, const float* ncc, const float* w, const float* out, const float* g_loss, float* d_ncc, void* stream);
 
+/* The patch samples of multi_view_loss / roughness_loss: a random subset of exactly k set elements of a mask, every set element equally
+ * likely (the reference: idx[torch.randperm(idx.numel())[:k]], utils/loss_utils.py:283-286; gs-2m_amd/gs2m_mvs.py: random_subset), in
+ * element order, in two steps with counter-based random numbers (a 64-bit mix of `seed` and the element index).
+ * subset_thin: element i of mask (n bytes) survives when set and u(seed, i) < (k + 4 sqrt(k)) / count(mask); the survivors' indices,
+ * ascending, go to idx (capacity cap: those beyond it are dropped), counts[0] = count(mask), counts[1] = number of survivors (device ints:
+ * the caller reads them); block_counts: ceil(n / 1024) ints of scratch.
+ * subset_remove (m survivors > k): out[j] = idx[j + #{i < m - k : removed_i - i <= j}], removed_i = min(m - 1, floor((i + u(seed, i)) m / (m - k))):
+ * one survivor removed per stratum, k kept. */
+int gs2m_subset_thin(int n, const unsigned char* mask, int k, unsigned long long seed, long long* idx, int cap, int* counts, int* block_counts,
+                     void* stream);
+int gs2m_subset_remove(int m, int k, unsigned long long seed, const long long* idx, long long* out, void* stream);
+
 /* out[0] = a + b * mean(x) over n contiguous floats (x 16-byte aligned): `ssim_map.mean()` (a = 0, b = 1,
  * fused_ssim/__init__.py:40-41) and the D-SSIM term lambda * (1 - ssim) of train.py:103 (a = lambda, b = -lambda). */
 int gs2m_affine_mean(long long n, const float* x, float a, float b, float* out, void* workspace, void* stream);

@@ -128,7 +128,7 @@ int gs2m_raster_backward(
     float* dL_dcolors,    /* (P,3), or NULL without colors_precomp */
     float* dL_dmeans3D,   /* (P,3) */
     float* dL_dcov3D,     /* (P,6), or NULL without cov3D_precomp */
-    float* dL_dshs,       /* (P,M,3) */
+    float* dL_dshs,       /* (P,M,3); NULL: dL/dSH is not wanted (a view whose colour gradient is identically zero: the 48 stores per Gaussian are skipped) */
     float* dL_dscales,    /* (P,3) */
     float* dL_drots,      /* (P,4) */
     float* dL_dfeatures,  /* (P,10) */

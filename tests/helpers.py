@@ -332,7 +332,9 @@ def assert_grad_close(name, got, ref, rel=REL_TOL_GRADS, max_exceptions=None, fl
 
 
 ROW_FLOOR_FRAC = 1e-6  # see assert_sum_close
-SUM_GROSS_MAX = 2e-2  # max-norm bound on blend sums whose exceptions are PROVEN threshold events (ref_special_sizes: 2.0e-3; C4 view: 1.15e-3)
+SUM_GROSS_MAX = 5e-3  # tensor-wide max-norm bound on blend sums whose exceptions are PROVEN threshold events (worst seen: ref_special_sizes 2.0e-3, a C4
+                      # view 1.15e-3; round 5 had 2e-2 here.  Relative to a small Gaussian's OWN row a threshold pixel moves far more -- 2e-1 at 2M / 4K,
+                      # for the reference build against the oracle too: profiles/r06_error_tail.md -- but not relative to the tensor's largest element)
 
 
 def assert_sum_close(name, got, ref, f, rel=REL_TOL_GRADS, floor_frac=1e-5, max_proofs=48, budget=MAX_GRAD_EXCEPTIONS):

@@ -340,3 +340,37 @@ def test_mv_take_and_ncc_tail_match_the_framework_ops():
     assert torch.allclose(ga, gb, rtol=1e-6, atol=0)
     none = torch.full((50, 1), 1.5, device=dev, requires_grad=True)  # no sample below 0.9: 0 / max(0, 1)
     assert float(gs2m_mvs._NCCTail.apply(none, torch.ones(50, device=dev))) == 0.0
+
+
+def test_random_subset_on_the_device_is_an_exact_uniform_draw():
+    """gs2m_mvs.random_subset on a CUDA mask (include/gs2m_loss.h: gs2m_subset_thin / gs2m_subset_remove, counter-based random numbers):
+    exactly min(k, count) indices of set elements, ascending, no duplicates, every set element equally likely, the same draw for the same
+    seeds; the small-count and near-k cases as in the CPU test (tests/test_losses.py)."""
+    assert torch.cuda.is_available()
+    import random
+    import gs2m_mvs
+    g = torch.Generator().manual_seed(0)
+    mask = (torch.rand(200_000, generator=g) < 0.6).cuda()
+    n = int(mask.sum())
+    k = 30_000
+    hits = torch.zeros(200_000, device="cuda")
+    rng = random.Random(5)
+    for _ in range(100):
+        idx = gs2m_mvs.random_subset(mask, k, rng=rng)
+        assert idx.dtype == torch.int64 and idx.numel() == k and bool((idx[1:] > idx[:-1]).all()) and bool(mask[idx].all())
+        hits[idx] += 1
+    freq = hits[mask] / 100.0
+    assert abs(float(freq.mean()) - k / n) < 1e-6 and float(freq.std()) < 1.5 * (k / n * (1 - k / n) / 100.0) ** 0.5
+    a = gs2m_mvs.random_subset(mask, k, rng=random.Random(7))
+    b = gs2m_mvs.random_subset(mask, k, rng=random.Random(7))
+    c = gs2m_mvs.random_subset(mask, k, rng=random.Random(8))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    few = torch.zeros(5000, dtype=torch.bool); few[::50] = True
+    idx = gs2m_mvs.random_subset(few.cuda(), 3000)
+    assert idx.numel() == 100 and bool(few.cuda()[idx].all())
+    assert gs2m_mvs.random_subset(torch.zeros(100, dtype=torch.bool, device="cuda"), 10).numel() == 0
+    near = torch.ones(3100, dtype=torch.bool, device="cuda")  # count within 4 sigma of k: everything is kept by the thinning, 100 removed
+    idx = gs2m_mvs.random_subset(near, 3000)
+    assert idx.numel() == 3000 and len(torch.unique(idx)) == 3000
+    tiny = torch.ones(40, dtype=torch.bool, device="cuda")   # most survivors would have to go: the plain path
+    assert gs2m_mvs.random_subset(tiny, 5).numel() == 5

@@ -488,3 +488,43 @@ def test_two_forwards_before_their_backwards_and_a_retained_graph():
     assert np.array_equal(first.cpu().numpy(), ga["means3D"]) and torch.equal(pa["means3D"].grad, first)
     assert np.array_equal(pb["means3D"].grad.cpu().numpy(), gb["means3D"])
     assert np.array_equal(pc["means3D"].grad.cpu().numpy(), gb["means3D"])
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_backward_without_colour_gradient_skips_dL_dSH(split):
+    """A view whose colour output receives no gradient (the multi-view term's neighbour view: only its depth and normal maps enter
+    the loss): dL/dcolour is identically zero, so the op hands autograd None for the SH tensor(s) and the per-Gaussian kernel does
+    not write them (dL_dshs = NULL, include/gs2m_raster.h) -- every other gradient bit for bit what an explicit all-zero colour
+    gradient gives."""
+    _require_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = Hh.make_scene(20_000, 320, 200, seed=4, fc=5)
+    st = Hh.settings_for(sc, "cuda")
+    Gb = sc["Gb"].cuda()
+
+    def run(with_zero_colour_term):
+        g = {k: v.cuda().requires_grad_(True) for k, v in sc["g"].items()}
+        m2 = torch.zeros(g["means3D"].shape[0], 4, device="cuda", requires_grad=True)
+        kw = {}
+        if split:
+            dc = g["shs"][:, :1].detach().clone().contiguous().requires_grad_(True)
+            rest = g["shs"][:, 1:].detach().clone().contiguous().requires_grad_(True)
+            kw = dict(shs=dc, shs_rest=rest)
+            sh_leaves = (dc, rest)
+        else:
+            kw = dict(shs=g["shs"])
+            sh_leaves = (g["shs"],)
+        color, radii, observe, buffer = GaussianRasterizer(st)(g["means3D"], m2, g["opacities"], scales=g["scales"], rotations=g["rotations"],
+                                                               features=g["features"], **kw)
+        loss = (buffer * Gb).sum()
+        if with_zero_colour_term:
+            loss = loss + (color * 0.0).sum()
+        loss.backward()
+        return [g[k].grad for k in ("means3D", "opacities", "scales", "rotations", "features")] + [m2.grad], [t.grad for t in sh_leaves]
+
+    a, sha = run(False)
+    b, shb = run(True)
+    assert all(t is None for t in sha), "no gradient for the SH tensors when the colour output got none"
+    assert all(t is not None and float(t.abs().max()) == 0.0 for t in shb), "an all-zero colour gradient gives all-zero dL/dSH"
+    for x, y in zip(a, b):
+        assert x is not None and torch.equal(x, y)

@@ -285,3 +285,33 @@ def test_split_sh_equals_concatenated(P):
         res.append((color.detach(), buffer.detach(), gsh, leaves["means3D"].grad, leaves["scales"].grad, m2.grad))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+def test_render_without_shading_gives_the_same_geometry_and_gradients():
+    """render(..., shade=False) -- what the multi-view term asks of its neighbour view (gs2m_mvs.multi_view_loss) -- against the
+    ordinary call on a loss that reads the depth and normal maps only: the maps and every parameter gradient bit for bit (the SH
+    gradients: zeros in one case, absent in the other), the image black."""
+    import gaussian_renderer
+    import gs2m_scene
+    import helpers as Hh
+    sc = Hh.make_scene(15_000, 320, 200, seed=9, fc=10)
+    cam = gs2m_scene.Camera(sc["cam"], "cuda")
+    Gd, Gn = sc["Gb"][1:2].cuda(), sc["Gb"][2:5].cuda()
+
+    def run(shade):
+        pc = Hh.model_from_scene(sc, "cuda", requires_grad=True)
+        out = gaussian_renderer.render(cam, pc, gs2m_scene.PipelineParams(), sc["bg"].cuda(), geometry_stage=True, material_stage=False, shade=shade)
+        ((out["depth_map"] * Gd).sum() + (out["normal_map"] * Gn).sum()).backward()
+        return out, pc
+
+    a, pa = run(True)
+    b, pb = run(False)
+    assert float(b["render"].abs().max()) == 0.0 and float(a["render"].abs().max()) > 0.0
+    for k in ("depth_map", "normal_map", "alpha_map", "radii", "observe"):
+        assert torch.equal(a[k], b[k]), k
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        assert torch.equal(getattr(pa, name).grad, getattr(pb, name).grad), name
+    for name in ("_features_dc", "_features_rest"):
+        ga, gb = getattr(pa, name).grad, getattr(pb, name).grad
+        assert gb is None and (ga is None or float(ga.abs().max()) == 0.0), name
+    assert torch.equal(a["viewspace_points"].grad, b["viewspace_points"].grad)
