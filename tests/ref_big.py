@@ -14,7 +14,7 @@ for (P, W, H, fc, hi, big) in ((2_000_000, 3840, 2160, 9, 0.02, 0.0), (3_000_000
     if big > 0:  # a heavy tail: splats over hundreds to thousands of tiles
         sel = torch.rand(P, generator=torch.Generator().manual_seed(3)) < big
         sc["g"]["scales"] = torch.where(sel[:, None], sc["g"]["scales"] * 40.0, sc["g"]["scales"])
-    Hh.PROOF_BUDGET = 60_000 * (40 if big > 0 else 1)  # splats over hundreds of tiles: a proof walks every instance's tile list (minutes, not seconds)
+    Hh.PROOF_BUDGET = 60_000 * 40  # 4K frames, splats over hundreds of tiles: a proof walks every instance's tile list (minutes, not the tests' seconds)
     for refbin in (False, True):
         t0 = time.time()
         try:
