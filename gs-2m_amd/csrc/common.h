@@ -6,6 +6,25 @@
 #include <stddef.h>
 #include "../../include/gs2m_raster.h"
 
+// Non-temporal ("nt") global accesses for the big read-once / write-once streams: the SH coefficients on their way into the
+// preprocess kernel (192 B per Gaussian), the gradient rows on their way into the per-Gaussian backward, dL/dSH on its way out.
+// Without the hint such a stream pushes the lines other kernels come back for (the blend records the preprocess kernel is
+// writing, which the emit kernel reads next) out of the caches: preprocess 88 -> 79 us and emit 42 -> 39 us for the SH loads alone,
+// per-Gaussian backward 160 -> 156 us (same-box A/B, NOTEBOOK.md round 6).  Measured WITHOUT effect or worse, and left as plain
+// accesses: the small per-Gaussian inputs, record / sh_dir / image stores, list and pixel-gradient loads of the blend kernels
+// (ALU-bound), key loads of the radix sort, slot loads of the tile sort; nt STORES of the gradient rows make their reader slower.
+typedef float gs2m_v4f __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T gs2m_ldnt(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float4 gs2m_ldnt(const float4* p) {
+    const gs2m_v4f t = __builtin_nontemporal_load(reinterpret_cast<const gs2m_v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+template <typename T> __device__ __forceinline__ void gs2m_stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void gs2m_stnt(float4* p, float4 v) {
+    const gs2m_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<gs2m_v4f*>(p));
+}
+
 #define GS2M_ALIGN 256
 #define GS2M_WAVE 64
 
@@ -138,7 +157,7 @@ __device__ __forceinline__ void gs2m_stage_sh(const float* __restrict__ shs, con
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const size_t k = base4 + tid + 256 * i;
-            t[i] = k < lim4 ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            t[i] = k < lim4 ? gs2m_ldnt(g4 + k) : make_float4(0.f, 0.f, 0.f, 0.f);  // 192 bytes per Gaussian, read once (see gs2m_ldnt)
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -165,8 +184,8 @@ __device__ __forceinline__ void gs2m_stage_sh(const float* __restrict__ shs, con
         if (full) {
             const float4* g4 = reinterpret_cast<const float4*>(rest + rbase);
 #pragma unroll
-            for (int i = 0; i < 11; i++) t[i] = g4[tid + 256 * i];
-            t[11] = tid < 64 ? g4[tid + 2816] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 11; i++) t[i] = gs2m_ldnt(g4 + tid + 256 * i);
+            t[11] = tid < 64 ? gs2m_ldnt(g4 + tid + 2816) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
 #pragma unroll
             for (int i = 0; i < 12; i++) {
@@ -211,7 +230,7 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
             const int e = 4 * (tid + 256 * i);
             const int row = e / 48, col = e - row * 48;
             const float* d = s_sh + row * 49 + col;
-            if (k < lim4) o4[k] = make_float4(d[0], d[1], d[2], d[3]);
+            if (k < lim4) gs2m_stnt(o4 + k, make_float4(d[0], d[1], d[2], d[3]));
         }
     } else {
         const size_t dbase = (size_t)blockIdx.x * 768, dlim = (size_t)P * 3;
@@ -232,7 +251,7 @@ __device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float*
                 for (int c = 0; c < 4; c++) v[c] = s_sh[a + c + (c >= left ? 4 : 0)];
                 const size_t ge = rbase + 4 * (size_t)(tid + 256 * i);
                 if (full || ge + 3 < rlim) {
-                    *reinterpret_cast<float4*>(drest + ge) = make_float4(v[0], v[1], v[2], v[3]);
+                    gs2m_stnt(reinterpret_cast<float4*>(drest + ge), make_float4(v[0], v[1], v[2], v[3]));
                 } else {
                     if (ge < rlim) drest[ge] = v[0];
                     if (ge + 1 < rlim) drest[ge + 1] = v[1];

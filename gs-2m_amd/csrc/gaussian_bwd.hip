@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __
 #pragma unroll
         for (int e = 0; e < MAXQ; e++) {
             const uint32_t q = w * (GS2M_WAVE * (uint32_t)rq) + (uint32_t)e * GS2M_WAVE + lane;
-            a[e] = q < nq ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[e] = q < nq ? gs2m_ldnt(r4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);  // read once: common.h, gs2m_ldnt
         }
     };
     // One window: park the loaded rows in LDS, then every group adds the rows of its Gaussians that lie in the window.
