@@ -59,10 +59,11 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 template <int RQ>  // float4 per row (rowf / 4: 3, 4, 5 or 6)
 struct ReduceLds {
     float4 s_row[4][GS2M_WAVE * RQ];  // one window per wave: 64 rows x RQ float4, row-major
-    float4 s_sum[256 * RQ];           // the result: RQ float4 per Gaussian of the workgroup
-    uint32_t s_excl[4][GS2M_WAVE], s_cnt[4][GS2M_WAVE];
+    float4 s_sum[256 * RQ];           // the result: RQ float4 per Gaussian of the workgroup.  Until a Gaussian's sum is written, the first
+                                      // two words of its slot hold its first row inside the wave's run and its row count -- whoever needs
+                                      // them is working towards that very sum -- which keeps the block at 40 KB at RQ = 5: four workgroups per CU
 };
-template <int RQ>  // -> the thread's own gauss_rows entry
+template <int RQ, int WIN>  // WIN: windows in flight (2 or 3) -> the thread's own gauss_rows entry
 __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __restrict__ gauss_rows, const uint32_t* __restrict__ wave_rowbase,
                                                        const float* __restrict__ rows, ReduceLds<RQ>& L) {
     constexpr int MAXQ = RQ, rq = RQ;
@@ -78,8 +79,8 @@ __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __
     const uint32_t total = __shfl(incl, 63, 64);                      // rows of this wave's Gaussians
     const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
     const uint32_t wb = wave_id * GS2M_WAVE < (size_t)P ? wave_rowbase[wave_id] : 0u;  // the wave's first row (binning.hip: rowscan_kernel)
-    L.s_excl[wave][lane] = incl - cnt;
-    L.s_cnt[wave][lane] = cnt;
+    uint2* const s_run = reinterpret_cast<uint2*>(&L.s_sum[(wave * GS2M_WAVE) * rq]);  // Gaussian j of the wave: s_run[j * rq * 2] = {first row, rows}
+    s_run[lane * rq * 2] = make_uint2(incl - cnt, cnt);
     const int G = GS2M_WAVE / rq, g = lane / rq, c = lane - g * rq;
     const bool worker = g < G;
     uint32_t j = worker ? (uint32_t)g : GS2M_WAVE;
@@ -110,7 +111,8 @@ __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __
         const uint32_t k0 = w * GS2M_WAVE, k1 = w < nwin ? k0 + GS2M_WAVE : 0xFFFFFFFFu;
         bool mine = false;
         if (w < nwin && j < GS2M_WAVE) {
-            const uint32_t ex = L.s_excl[wave][j], cn = L.s_cnt[wave][j];
+            const uint2 run = s_run[j * rq * 2];
+            const uint32_t ex = run.x, cn = run.y;
             mine = ex <= k0 && ex + cn >= k1;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(mine && c == 0);
@@ -142,7 +144,8 @@ __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __
             for (int e = 0; e < MAXQ; e++) s_row[e * GS2M_WAVE + lane] = a[e];
         }
         while (j < GS2M_WAVE) {
-            const uint32_t ex = L.s_excl[wave][j], cn = L.s_cnt[wave][j];
+            const uint2 run = s_run[j * rq * 2];
+            const uint32_t ex = run.x, cn = run.y;
             if (ex >= k1 && cn > 0) break;  // starts in a later window
             // rows of this Gaussian inside the window; those of windows it covered entirely are in racc already
             const uint32_t t0 = max(ex, k0), t1 = min(ex + cn, k1);
@@ -156,20 +159,25 @@ __device__ __forceinline__ uint32_t reduce_rows_to_lds(int P, const uint32_t* __
             j += (uint32_t)G;
         }
     };
-    // THREE windows in flight: the windows of a wave are a serial chain (load -> LDS -> sum); with one window in flight every
-    // one of them cost a full memory round trip.  One extra pass (w == nwin, an empty window) lets every group finish and
-    // write its remaining Gaussians.
-    float4 a0[MAXQ], a1[MAXQ], a2[MAXQ];
+    // WIN windows in flight: the windows of a wave are a serial chain (load -> LDS -> sum); with one window in flight every one of
+    // them cost a full memory round trip.  Rounds 4-6 kept three: 139 registers and 43 + 49 KB of LDS = 3 waves per SIMD.  With TWO
+    // windows -- 113 registers -- the run words inside the sum slots and dL/dSH leaving as basis x gradient, the kernel holds 4 waves per
+    // SIMD: 154 -> 143.5 us at the bench size (the same kernel pinned to 3 waves: 168 us, to 2: 196).  A launch that does not fill the
+    // chip anyway (the launcher: fewer than three workgroups per CU) keeps THREE: there the chain is all there is (10 k Gaussians:
+    // 12.1 against 15.0 us).  One extra pass (w == nwin, an empty window) lets every group finish and write its remaining Gaussians.
+    float4 a0[MAXQ], a1[MAXQ], a2[WIN > 2 ? MAXQ : 1];
     load_window(0, a0);
     load_window(1, a1);
-    load_window(2, a2);
-    for (uint32_t w = 0; w <= nwin; w += 3) {
+    if (WIN > 2) load_window(2, a2);
+    for (uint32_t w = 0; w <= nwin; w += WIN) {
         consume(w, a0);
-        load_window(w + 3, a0);
+        load_window(w + WIN, a0);
         if (w + 1 <= nwin) consume(w + 1, a1);
-        load_window(w + 4, a1);
-        if (w + 2 <= nwin) consume(w + 2, a2);
-        load_window(w + 5, a2);
+        load_window(w + WIN + 1, a1);
+        if (WIN > 2) {
+            if (w + 2 <= nwin) consume(w + 2, a2);
+            load_window(w + WIN + 2, a2);
+        }
     }
     return own;
 }
@@ -218,7 +226,63 @@ __global__ void __launch_bounds__(256) heavy_reduce_kernel(float* __restrict__ r
     }
 }
 
-template <bool SH_LDS, int RQ>
+// dL/dSH on its way out: every thread of the workgroup has left basis[16] and dL/dRGB[3] of its Gaussian in LDS (row stride
+// SHO_STRIDE = 19 floats: odd, conflict-free); element (k, c) of a Gaussian's (16,3) gradient is basis[k] * dL/dRGB[c].  The block's
+// 256 rows are one contiguous run of the output tensor(s): written as fully coalesced non-temporal float4 stores, the products formed
+// here.  Coefficients at or above `nact` (= (D + 1)^2) are +0.  Packed form (P,16,3) or the model's split form (P,1,3) + (P,15,3).
+#define SHO_STRIDE 19
+__device__ __forceinline__ float sh_outer_val(const float* __restrict__ s_bg, int row, int cc /* 0..47: 3 k + c */, int nact) {
+    const int k = cc / 3, c = cc - 3 * k;
+    const float* r = s_bg + row * SHO_STRIDE;
+    return k < nact ? r[k] * r[16 + c] : 0.f;
+}
+__device__ __forceinline__ void sh_outer_store(float* __restrict__ dshs, float* __restrict__ drest, int P, const float* __restrict__ s_bg, int nact) {
+    const int tid = threadIdx.x;
+    if (drest == nullptr) {
+        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
+        float4* o4 = reinterpret_cast<float4*>(dshs);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const size_t k = base4 + tid + 256 * i;
+            const int e = 4 * (tid + 256 * i);
+            const int row = e / 48, col = e - row * 48;
+            if (k < lim4) gs2m_stnt(o4 + k, make_float4(sh_outer_val(s_bg, row, col, nact), sh_outer_val(s_bg, row, col + 1, nact),
+                                                        sh_outer_val(s_bg, row, col + 2, nact), sh_outer_val(s_bg, row, col + 3, nact)));
+        }
+    } else {
+        const size_t dbase = (size_t)blockIdx.x * 768, dlim = (size_t)P * 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int e = tid + 256 * i;
+            if (dbase + e < dlim) dshs[dbase + e] = sh_outer_val(s_bg, e / 3, e % 3, nact);
+        }
+        // rest: float4 k4 = tid + 256 i of the block's 2880; element e = 4 k4 + j sits in row e / 45 at coefficient 3 + e % 45
+        const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
+        const bool full = rbase + 11520 <= rlim;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int k4 = tid + 256 * i;
+            if (k4 < 2880) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = 4 * k4 + j, row = e / 45;
+                    v[j] = sh_outer_val(s_bg, row, 3 + (e - 45 * row), nact);
+                }
+                const size_t ge = rbase + 4 * (size_t)k4;
+                if (full || ge + 3 < rlim) {
+                    gs2m_stnt(reinterpret_cast<float4*>(drest + ge), make_float4(v[0], v[1], v[2], v[3]));
+                } else {
+                    if (ge < rlim) drest[ge] = v[0];
+                    if (ge + 1 < rlim) drest[ge + 1] = v[1];
+                    if (ge + 2 < rlim) drest[ge + 2] = v[2];
+                }
+            }
+        }
+    }
+}
+
+template <bool SH_LDS, int RQ, int WIN>
 __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ scales, float scale_modifier,
@@ -236,7 +300,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     // preprocess.hip); row stride 49 floats.  The coefficients themselves are not read here: all the backward needs of them is
     // d(colour)/d(direction), 9 floats per Gaussian that the forward's preprocess kernel left in GeomState::sh_dir.
     // one LDS block, two lives: the row sums (phase 1), then the block's dL/dSH rows on their way out
-    constexpr size_t kShBytes = SH_LDS ? 256 * 49 * sizeof(float) : 16, kRedBytes = sizeof(ReduceLds<RQ>);
+    constexpr size_t kShBytes = SH_LDS ? 256 * SHO_STRIDE * sizeof(float) : 16, kRedBytes = sizeof(ReduceLds<RQ>);
     __shared__ __align__(16) unsigned char s_raw[kShBytes > kRedBytes ? kShBytes : kRedBytes];
     float* const s_sh = reinterpret_cast<float*>(s_raw);
     ReduceLds<RQ>& red = *reinterpret_cast<ReduceLds<RQ>*>(s_raw);
@@ -244,7 +308,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 24; k++) acc[k] = 0.f;
     if (rows != nullptr) {
-        const uint32_t gr = reduce_rows_to_lds<RQ>(P, gauss_rows, wave_rowbase, rows, red);
+        const uint32_t gr = reduce_rows_to_lds<RQ, WIN>(P, gauss_rows, wave_rowbase, rows, red);
         gs2m_sync();
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
@@ -435,18 +499,25 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
             const float ox = mx - campos[0], oy = my - campos[1], oz = mz - campos[2];
             const float len = sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox / len, y = oy / len, z = oz / len;
-            float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
+            float* dsh = SH_LDS ? (s_sh + threadIdx.x * SHO_STRIDE) : (dL_dshs + (size_t)idx * M * 3);
             const uint8_t cl = clamped[idx];
             float g[3] = {acc[ROW_COL] * ((cl & 1) ? 0.f : 1.f), acc[ROW_COL + 1] * ((cl & 2) ? 0.f : 1.f),
                           acc[ROW_COL + 2] * ((cl & 4) ? 0.f : 1.f)};
             // d(colour)/d(direction), evaluated by the forward (preprocess.hip) with the reference's expressions (backward.cu:62-146)
             const float dRdx[3] = {sdv[0], sdv[1], sdv[2]}, dRdy[3] = {sdv[3], sdv[4], sdv[5]}, dRdz[3] = {sdv[6], sdv[7], sdv[8]};
+            // dL/dSH_k = basis_k(direction) x dL/dRGB: with the LDS path a thread leaves its 16 basis values and the three gradient
+            // components (19 floats instead of the 48 products: 19 KB per workgroup instead of 49) and the products are formed by the
+            // coalesced store pass (sh_outer_store below) -- the same fp32 multiplications
 #define DSH(k, val)                                           \
     do {                                                      \
         const float v_ = (val);                               \
-        dsh[(k) * 3 + 0] = v_ * g[0];                         \
-        dsh[(k) * 3 + 1] = v_ * g[1];                         \
-        dsh[(k) * 3 + 2] = v_ * g[2];                         \
+        if (SH_LDS) {                                         \
+            dsh[(k)] = v_;                                    \
+        } else {                                              \
+            dsh[(k) * 3 + 0] = v_ * g[0];                     \
+            dsh[(k) * 3 + 1] = v_ * g[1];                     \
+            dsh[(k) * 3 + 2] = v_ * g[2];                     \
+        }                                                     \
     } while (0)
             float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
             if (D > 1) { xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z; }
@@ -475,7 +546,12 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
                 }
             }
             // coefficients above the active degree receive no gradient
-            for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+            if (SH_LDS) {
+                for (int k = (D + 1) * (D + 1); k < M; k++) dsh[k] = 0.f;  // (sh_outer_store writes +0 for them whatever the gradient's sign)
+                dsh[16] = g[0]; dsh[17] = g[1]; dsh[18] = g[2];
+            } else {
+                for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+            }
             }
 #undef DSH
             const float ddx = dRdx[0] * g[0] + dRdx[1] * g[1] + dRdx[2] * g[2];
@@ -515,8 +591,13 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
 #undef Dm
         }
     } else if (shs != nullptr && M > 0 && want_sh) {
-        float* dsh = SH_LDS ? (s_sh + threadIdx.x * 49) : (dL_dshs + (size_t)idx * M * 3);
-        for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        if (SH_LDS) {
+            float* dsh = s_sh + threadIdx.x * SHO_STRIDE;
+            for (int k = 0; k < SHO_STRIDE; k++) dsh[k] = 0.f;
+        } else {
+            float* dsh = dL_dshs + (size_t)idx * M * 3;
+            for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+        }
     }
 
     dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
@@ -529,7 +610,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     }  // in_range
     if (SH_LDS) {
         gs2m_sync();  // every thread has replaced its LDS row by its dL/dSH row
-        gs2m_unstage_sh(dL_dshs, dL_dshs_rest, P, s_sh);
+        sh_outer_store(dL_dshs, dL_dshs_rest, P, s_sh, (D + 1) * (D + 1));
     }
 }
 
@@ -545,19 +626,22 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                               float* dL_dmeans3D, float* dL_dcov3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dscales,
                               float* dL_drots, float* dL_dfeatures, hipStream_t s) {
     const float h_x = W / (2.0f * tan_fovx), h_y = H / (2.0f * tan_fovy);
-#define GS2M_GB(LDS, RQ)                                                                                                \
-    gaussian_bwd_kernel<LDS, RQ><<<(P + 255) / 256, 256, 0, s>>>(                                                       \
+#define GS2M_GB(LDS, RQ, WIN)                                                                                           \
+    gaussian_bwd_kernel<LDS, RQ, WIN><<<(P + 255) / 256, 256, 0, s>>>(                                                  \
         P, D, M, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,   \
         projmatrix, campos, h_x, h_y, tan_fovx, tan_fovy, radii, fc, g.rec, g.gauss_rows, g.tiles_touched, g.wave_rowbase, g.clamped, \
         g.sh_dir, have_rows ? rows : nullptr, want_sh, dL_dmeans2D, dL_dconics, dL_dopacities, dL_dcolors, dL_dmeans3D, dL_dcov3D, \
         dL_dshs, dL_dshs_rest, dL_dscales, dL_drots, dL_dfeatures)
+#define GS2M_GBW(LDS, RQ)                                                                                               \
+    if (few) GS2M_GB(LDS, RQ, 3); else GS2M_GB(LDS, RQ, 2)
 #define GS2M_GBQ(LDS)                                                                                                   \
     switch (rowf >> 2) {                                                                                                \
-        case 3: GS2M_GB(LDS, 3); break;                                                                                 \
-        case 4: GS2M_GB(LDS, 4); break;                                                                                 \
-        case 5: GS2M_GB(LDS, 5); break;                                                                                 \
-        default: GS2M_GB(LDS, 6); break;                                                                                \
+        case 3: GS2M_GBW(LDS, 3); break;                                                                                \
+        case 4: GS2M_GBW(LDS, 4); break;                                                                                \
+        case 5: GS2M_GBW(LDS, 5); break;                                                                                \
+        default: GS2M_GBW(LDS, 6); break;                                                                               \
     }
+    const bool few = (P + 255) / 256 < 3 * 256;  // fewer workgroups than three per CU: occupancy is not the limit, the wave's chain is
     // dL_dshs == NULL with SH input: the caller does not want dL/dSH (its colour gradient is identically zero, e.g. a view rendered for
     // its depth and normals only): the per-Gaussian kernel skips the 48 stores per Gaussian; everything else is computed as usual
     const int want_sh = dL_dshs != nullptr ? 1 : 0;
@@ -566,6 +650,7 @@ void gs2m_launch_gaussian_bwd(int P, int D, int M, const float* means3D, const f
                                : ((((uintptr_t)shs) | ((uintptr_t)dL_dshs)) & 15) == 0);
     if (lds) { GS2M_GBQ(true) } else { GS2M_GBQ(false) }
 #undef GS2M_GBQ
+#undef GS2M_GBW
 #undef GS2M_GB
 }
 
