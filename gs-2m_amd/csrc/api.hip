@@ -593,6 +593,14 @@ int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges
     im.qcount = qcount;
     GeomState g = {};
     g.wave_rowbase = const_cast<uint32_t*>(wave_rowbase);
+    // the span-class words the sort's kernels pass on to each other (common.h: GS2M_CNT_SPAN_*): zeroed per call, as blockscan_kernel does
+    static uint32_t* dbg_counters[64] = {nullptr};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return GS2M_ERR_UNSUPPORTED;
+    if (dbg_counters[dev] == nullptr) HIP_TRY(hipMalloc(&dbg_counters[dev], 64 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(dbg_counters[dev], 0, 64 * sizeof(uint32_t), (hipStream_t)stream_));
+    g.counters = dbg_counters[dev];
     gs2m_launch_tile_sort((size_t)tiles, tiles, 1, b, im, g, (hipStream_t)stream_);  // (a one-row tile grid)
     HIP_TRY(hipGetLastError());
     return GS2M_OK;

@@ -206,6 +206,8 @@ __global__ void __launch_bounds__(1024) blockscan_kernel(const uint32_t* __restr
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         counters[1] = r32;
         counters[GS2M_CNT_HUNITS] = u32;
+        counters[GS2M_CNT_SPAN_MID] = 0u;
+        counters[GS2M_CNT_SPAN_LONG] = 0u;
     }
 }
 

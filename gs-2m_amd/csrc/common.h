@@ -141,7 +141,8 @@ __device__ __forceinline__ void gs2m_zero_jobs(const ZeroJobs& z, size_t thread,
 #endif
 
 #ifdef __HIPCC__
-// ---- SH rows of a 256-Gaussian block <-> LDS (row stride 49 floats: conflict-free column reads) -------------------
+// ---- SH rows of a 256-Gaussian block -> LDS (row stride 49 floats: conflict-free column reads) --------------------
+// (the way back, dL/dSH, leaves as basis x gradient: gaussian_bwd.hip, sh_outer_store)
 // SH coefficients are 192 B per Gaussian (M = 16): a thread-per-Gaussian access has a 192-B lane stride, so the block
 // streams its rows with coalesced float4 accesses and every thread then works on its own LDS row.  Two source
 // layouts: one (P,16,3) tensor, or -- as the reference model stores its parameters (scene/gaussian_model.py:
@@ -217,52 +218,6 @@ __device__ __forceinline__ void gs2m_stage_sh(const float* __restrict__ shs, con
         }
     }
 }
-// the reverse: every thread has replaced its LDS row by its dL/dSH row
-__device__ __forceinline__ void gs2m_unstage_sh(float* __restrict__ dshs, float* __restrict__ drest, int P,
-                                                const float* __restrict__ s_sh) {
-    const int tid = threadIdx.x;
-    if (drest == nullptr) {
-        const size_t base4 = (size_t)blockIdx.x * 256 * 12, lim4 = (size_t)P * 12;
-        float4* o4 = reinterpret_cast<float4*>(dshs);
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const size_t k = base4 + tid + 256 * i;
-            const int e = 4 * (tid + 256 * i);
-            const int row = e / 48, col = e - row * 48;
-            const float* d = s_sh + row * 49 + col;
-            if (k < lim4) gs2m_stnt(o4 + k, make_float4(d[0], d[1], d[2], d[3]));
-        }
-    } else {
-        const size_t dbase = (size_t)blockIdx.x * 768, dlim = (size_t)P * 3;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int e = tid + 256 * i;
-            if (dbase + e < dlim) dshs[dbase + e] = s_sh[(e / 3) * 49 + (e % 3)];
-        }
-        const size_t rbase = (size_t)blockIdx.x * 11520, rlim = (size_t)P * 45;
-        const bool full = rbase + 11520 <= rlim;
-        int row = (4 * tid) / 45, col = 4 * tid - 45 * row;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            if (i < 11 || tid < 64) {
-                const int a = row * 49 + 3 + col, left = 45 - col;
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = s_sh[a + c + (c >= left ? 4 : 0)];
-                const size_t ge = rbase + 4 * (size_t)(tid + 256 * i);
-                if (full || ge + 3 < rlim) {
-                    gs2m_stnt(reinterpret_cast<float4*>(drest + ge), make_float4(v[0], v[1], v[2], v[3]));
-                } else {
-                    if (ge < rlim) drest[ge] = v[0];
-                    if (ge + 1 < rlim) drest[ge + 1] = v[1];
-                    if (ge + 2 < rlim) drest[ge + 2] = v[2];
-                }
-            }
-            row += 22; col += 34;
-            if (col >= 45) { col -= 45; row += 1; }
-        }
-    }
-}
 #endif
 
 // carve typed arrays out of one byte buffer (base may be unaligned; pass nullptr to size)
@@ -303,6 +258,10 @@ void gs2m_radix_zero_region(void* temp, size_t n, int total_bits, uint32_t** ptr
 // GeomState::counters: [0] num_rendered as the emit kernel's offsets add up (debug mode), [1] num_rendered, [2] gradient rows, [3] heavy units
 #define GS2M_CNT_ROWS 2
 #define GS2M_CNT_HUNITS 3
+// a tile span of 513 .. 1024 entries exists / one beyond 1024 (set by the first kernel of tile_sort.hip with plain stores of 1, zeroed by
+// blockscan_kernel): the kernels for those spans, launched over all tiles whatever the frame, leave at once when there is none
+#define GS2M_CNT_SPAN_MID 4
+#define GS2M_CNT_SPAN_LONG 5
 
 // kernel launchers
 void gs2m_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ wave_rowbase,
                                                             uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
                                                             uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y,
-                                                            uint32_t wave_max /* 512: longer spans are another kernel's */) {
+                                                            uint32_t wave_max /* 512: longer spans are another kernel's */, uint32_t* __restrict__ counters) {
     constexpr int M = 64 * 8;
     __shared__ uint32_t s_v[M + M / 32], s_r[M + M / 32];
     const int lane = threadIdx.x;
@@ -338,6 +338,8 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
         if (lane < 4) qcount[tile * 4 + lane] = 0u;
     } else if (n <= wave_max) {
         sort_tile_wave<8, 3>(tile, range.x, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, lane);
+    } else if (lane == 0) {  // tells the kernels behind this one that they have work (a plain store of 1: any number of writers)
+        counters[n <= 1024u ? GS2M_CNT_SPAN_MID : GS2M_CNT_SPAN_LONG] = 1u;
     }
 }
 
@@ -347,9 +349,10 @@ __global__ void __launch_bounds__(64) tile_sort_wave_kernel(const uint32_t* __re
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 tile_sort_wave16_kernel(const uint32_t* __restrict__ ranges_raw, const uint32_t* __restrict__ slot_sorted, const uint4* __restrict__ e_rec,
                         const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list, uint2* __restrict__ qlist,
-                        uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y) {
+                        uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount, int tiles_x, int tiles_y, const uint32_t* __restrict__ counters) {
     constexpr int M16 = 64 * 16, W16 = M16 + M16 / 32;
     __shared__ uint32_t s_v[W16], s_r[W16];
+    if (counters[GS2M_CNT_SPAN_MID] == 0u) return;  // no such span in this frame (tile_sort_wave_kernel looked)
     const int lane = threadIdx.x;
     const int tile = tile_of_block(blockIdx.x, tiles_x, tiles_y);
     if (tile < 0) return;
@@ -679,9 +682,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >
 tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
                     const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
                     uint32_t* __restrict__ row_tmp, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
-                    int tiles_x, int tiles_y, uint32_t nblocks) {
+                    int tiles_x, int tiles_y, uint32_t nblocks, uint32_t* __restrict__ counters) {
     constexpr int WORDS = WgCfg<MAXE>::kWords;
     __shared__ uint32_t s_all[WgCfg<MAXE>::kLds];
+    if constexpr (MAXE >= 8) {
+        if (counters[GS2M_CNT_SPAN_LONG] == 0u) return;  // no span beyond 1024 entries in this frame (the kernel in front looked)
+    }
     uint32_t* const s_v = s_all, * const s_r = s_all + WORDS, * const s_x = s_all + 2 * WORDS;
     const int tid = threadIdx.x;
     for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {  // (gridDim.x is a multiple of 8: a workgroup stays on its XCD's tiles)
@@ -694,6 +700,7 @@ tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__
                 if (tid == 0) ranges[tile] = raw.y != 0u ? make_uint2(start, raw.y) : make_uint2(0u, 0u);
                 if (n == 0u && tid < 4) qcount[tile * 4 + tid] = 0u;
             }
+            if (n > 1024u && tid == 0) counters[GS2M_CNT_SPAN_LONG] = 1u;
             if (n == 0u || n > 1024u) continue;
             if (n <= 256u) sort_tile_wg<1, 0>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
             else if (n <= 512u) sort_tile_wg<2, 1>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
@@ -728,13 +735,13 @@ void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const Binning
     const unsigned wg_grid = grid < 2048u ? grid : 2048u;  // (both multiples of 8)
     if (waves) {
         tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
-                                                  tiles_x, tiles_y, 512u);
-        tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y);
+                                                  tiles_x, tiles_y, 512u, g.counters);
+        tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, g.counters);
     } else {
         tile_sort_wg_kernel<4><<<wg_grid, 256, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                                       im.qcount, tiles_x, tiles_y, grid);
+                                                       im.qcount, tiles_x, tiles_y, grid, g.counters);
     }
-    // spans of more than 1024 entries: none on the bench scenes (the workgroups look at their tiles' ranges and leave)
+    // spans of more than 1024 entries: none on the bench scenes (the kernel in front says so: the workgroups leave at once)
     tile_sort_wg_kernel<16><<<wg_grid < 768u ? wg_grid : 768u /* three workgroups per CU: all resident at once */, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
-                                                                             b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid);
+                                                                             b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid, g.counters);
 }
