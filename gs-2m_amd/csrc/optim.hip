@@ -51,6 +51,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = __builtin_fmaf(nss, m / denom, p);
 }
 
+template <bool NT>  // non-temporal access for everything but p's store (see below): the launcher's choice by the size of the step
 __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(const AdamLaunch L) {
     // which tensor: a scalar walk over <= 16 block offsets
     int ti = 0;
@@ -69,10 +70,19 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(const AdamLaunch L) 
             // g, m, v: read here and not again before the next step; p: read again by the next view's preprocess kernel (its
             // STORE below is the one plain access).  nt on all four loads + the m / v stores: 0.301 -> 0.264 ms at 1M Gaussians
             // (6.8 TB/s of the 28 B per element), the training iteration 1.866 -> 1.810 ms; with p's store nt as well: 0.287.
-            g[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.g) + q);
-            p[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.p) + q);
-            m[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.m) + q);
-            v[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.v) + q);
+            // At C4's size (420 k Gaussians: a tensor set is 99 MB, the step's 0.7 GB partly live in the 256-MB Infinity Cache from
+            // one iteration to the next) the hint LOSES 7 %: the launcher takes it from 160 MB per tensor set on.
+            if (NT) {
+                g[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.g) + q);
+                p[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.p) + q);
+                m[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.m) + q);
+                v[u] = gs2m_ldnt(reinterpret_cast<const float4*>(T.v) + q);
+            } else {
+                g[u] = reinterpret_cast<const float4*>(T.g)[q];
+                p[u] = reinterpret_cast<const float4*>(T.p)[q];
+                m[u] = reinterpret_cast<const float4*>(T.m)[q];
+                v[u] = reinterpret_cast<const float4*>(T.v)[q];
+            }
         }
         // An element whose gradient and both moments are zero comes out bit-identical (p + nss * 0 / eps = p): the
         // Gaussians a run has never seen, and every SH band above the active degree until the schedule reaches it
@@ -97,8 +107,13 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(const AdamLaunch L) 
             const size_t q = q0 + (size_t)u * ADAM_THREADS;
             if (!same[u]) {
                 reinterpret_cast<float4*>(T.p)[q] = p[u];
-                gs2m_stnt(reinterpret_cast<float4*>(T.m) + q, m[u]);
-                gs2m_stnt(reinterpret_cast<float4*>(T.v) + q, v[u]);
+                if (NT) {
+                    gs2m_stnt(reinterpret_cast<float4*>(T.m) + q, m[u]);
+                    gs2m_stnt(reinterpret_cast<float4*>(T.v) + q, v[u]);
+                } else {
+                    reinterpret_cast<float4*>(T.m)[q] = m[u];
+                    reinterpret_cast<float4*>(T.v)[q] = v[u];
+                }
             }
         }
     } else {  // ragged tail or an unaligned tensor
@@ -144,7 +159,12 @@ extern "C" int gs2m_adam_step(int n_tensors, const gs2m_adam_tensor* tensors, do
             if (blocks > 0x7fffffffull) return GS2M_ERR_UNSUPPORTED;
         }
         if (L.count == 0) continue;
-        adam_kernel<<<(unsigned int)blocks, ADAM_THREADS, 0, (hipStream_t)stream>>>(L);
+        unsigned long long elements = 0;
+        for (int k = 0; k < L.count; k++) elements += L.t[k].n;
+        if (elements * 4ull > 160ull * 1024 * 1024)
+            adam_kernel<true><<<(unsigned int)blocks, ADAM_THREADS, 0, (hipStream_t)stream>>>(L);
+        else
+            adam_kernel<false><<<(unsigned int)blocks, ADAM_THREADS, 0, (hipStream_t)stream>>>(L);
         if (hipGetLastError() != hipSuccess) return GS2M_ERR_HIP;
     }
     return GS2M_OK;
