@@ -296,10 +296,11 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dfeatures) {
-    // dL/dSH rows go out through LDS so that every global access of the (P,16,3) tensor is a coalesced stream (see
-    // preprocess.hip); row stride 49 floats.  The coefficients themselves are not read here: all the backward needs of them is
-    // d(colour)/d(direction), 9 floats per Gaussian that the forward's preprocess kernel left in GeomState::sh_dir.
-    // one LDS block, two lives: the row sums (phase 1), then the block's dL/dSH rows on their way out
+    // dL/dSH goes out through LDS so that every global access of the (P,16,3) tensor is a coalesced stream: per Gaussian the 16 basis
+    // values and dL/dRGB (row stride SHO_STRIDE = 19 floats), multiplied out by the store pass (sh_outer_store).  The coefficients
+    // themselves are not read here: all the backward needs of them is d(colour)/d(direction), 9 floats per Gaussian that the
+    // forward's preprocess kernel left in GeomState::sh_dir.
+    // one LDS block, two lives: the row sums (phase 1), then the block's dL/dSH factors on their way out
     constexpr size_t kShBytes = SH_LDS ? 256 * SHO_STRIDE * sizeof(float) : 16, kRedBytes = sizeof(ReduceLds<RQ>);
     __shared__ __align__(16) unsigned char s_raw[kShBytes > kRedBytes ? kShBytes : kRedBytes];
     float* const s_sh = reinterpret_cast<float*>(s_raw);
