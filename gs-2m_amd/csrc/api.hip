@@ -310,7 +310,7 @@ static int forward_impl(gs2m_alloc_fn geometry_alloc, void* geometry_user, gs2m_
     DEBUG_CHECK();
     {
         StageTimer t(ST_LISTS, s, &failed_stage);  // per-tile (depth, id) order, ranges, the quadrant lists
-        gs2m_launch_tile_sort(tiles, tiles_x, tiles_y, b, im, g, s);
+        gs2m_launch_tile_sort(tiles, tiles_x, tiles_y, (size_t)(R > 0 ? R : 0), b, im, g, s);
     }
     {
         StageTimer t(ST_BLEND_FWD, s, &failed_stage);
@@ -460,7 +460,7 @@ int gs2m_set_reference_binning(int on) {
 }
 
 int gs2m_set_tile_sort_policy(int policy) {
-    if (policy < 0 || policy > 2) return GS2M_ERR_INVALID_ARG;
+    if (policy < 0 || policy > 3) return GS2M_ERR_INVALID_ARG;
     gs2m_set_tile_sort_policy_impl(policy);
     return GS2M_OK;
 }
@@ -601,7 +601,7 @@ int gs2m_debug_tile_sort(int tiles, const unsigned* ranges_raw, unsigned* ranges
     if (dbg_counters[dev] == nullptr) HIP_TRY(hipMalloc(&dbg_counters[dev], 64 * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(dbg_counters[dev], 0, 64 * sizeof(uint32_t), (hipStream_t)stream_));
     g.counters = dbg_counters[dev];
-    gs2m_launch_tile_sort((size_t)tiles, tiles, 1, b, im, g, (hipStream_t)stream_);  // (a one-row tile grid)
+    gs2m_launch_tile_sort((size_t)tiles, tiles, 1, SIZE_MAX, b, im, g, (hipStream_t)stream_);  // (a one-row tile grid; the number of entries is not known here)
     HIP_TRY(hipGetLastError());
     return GS2M_OK;
 }

@@ -283,7 +283,7 @@ void gs2m_launch_heavy_reduce(float* rows, int rowf, const BinningState& b, cons
 // tile_sort.hip: every tile's span (stable radix sort by tile: index order) sorted by (depth, id) on chip, then split into the four
 // quadrant lists; writes ranges[] from ranges_raw
 void gs2m_set_tile_sort_policy_impl(int policy);
-void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
+void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, size_t R, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s);
 hipError_t gs2m_zero_async(void* p, size_t bytes, hipStream_t s);
 
 void gs2m_launch_blend_fwd_q(int W, int H, int tiles_x, int tiles_y, int fc, const float* bg, const GeomState& g,

@@ -682,11 +682,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXE >
 tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__ ranges, const uint32_t* __restrict__ slot_sorted,
                     const uint4* __restrict__ e_rec, const uint32_t* __restrict__ wave_rowbase, uint32_t* __restrict__ point_list,
                     uint32_t* __restrict__ row_tmp, uint2* __restrict__ qlist, uint32_t* __restrict__ qrow, uint32_t* __restrict__ qcount,
-                    int tiles_x, int tiles_y, uint32_t nblocks, uint32_t* __restrict__ counters) {
+                    int tiles_x, int tiles_y, uint32_t nblocks, uint32_t* __restrict__ counters, int take_mid) {
     constexpr int WORDS = WgCfg<MAXE>::kWords;
     __shared__ uint32_t s_all[WgCfg<MAXE>::kLds];
     if constexpr (MAXE >= 8) {
-        if (counters[GS2M_CNT_SPAN_LONG] == 0u) return;  // no span beyond 1024 entries in this frame (the kernel in front looked)
+        // no span beyond 1024 entries in this frame (the kernel in front looked) -- and, when the spans of 513 .. 1024 entries are this
+        // kernel's as well (take_mid: a frame whose average span is short has too few of them for a launch of their own), none of those
+        if (counters[GS2M_CNT_SPAN_LONG] == 0u && !(take_mid && counters[GS2M_CNT_SPAN_MID] != 0u)) return;
     }
     uint32_t* const s_v = s_all, * const s_r = s_all + WORDS, * const s_x = s_all + 2 * WORDS;
     const int tid = threadIdx.x;
@@ -706,8 +708,9 @@ tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__
             else if (n <= 512u) sort_tile_wg<2, 1>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
             else sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
         } else {
-            if (n <= 1024u) continue;
-            if (n <= 2048u) sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            if (n <= 512u || (n <= 1024u && !take_mid)) continue;
+            if (n <= 1024u) sort_tile_wg<4, 2>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
+            else if (n <= 2048u) sort_tile_wg<8, 3>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
             else if (n <= (uint32_t)WG_MAX) sort_tile_wg<16, 4>(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, qlist, qrow, qcount, s_v, s_r, s_x, tid, row_tmp);
             else sort_tile_big(tile, start, n, slot_sorted, e_rec, wave_rowbase, point_list, row_tmp, qlist, qrow, qcount, s_all);
         }
@@ -720,7 +723,8 @@ tile_sort_wg_kernel(const uint32_t* __restrict__ ranges_raw, uint2* __restrict__
 static std::atomic<int> g_ts_policy{0};
 void gs2m_set_tile_sort_policy_impl(int policy) { g_ts_policy = policy; }
 
-void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const BinningState& b, const ImageState& im, const GeomState& g, hipStream_t s) {
+void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, size_t R /* instances of the frame; SIZE_MAX: unknown */, const BinningState& b, const ImageState& im,
+                           const GeomState& g, hipStream_t s) {
     if (tiles == 0) return;
     const unsigned grid = tile_grid(tiles_x, tiles_y);
     // Who sorts which span.  A frame of many tiles (1080p: 8160) fills the chip with one wave per tile (8 elements per lane up to 512
@@ -728,20 +732,27 @@ void gs2m_launch_tile_sort(size_t tiles, int tiles_x, int tiles_y, const Binning
     // gathers).  A frame of few tiles (a 777 x 581 training view: 1813) leaves such a kernel one or two waves per SIMD, each a serial
     // chain of ~40 / ~90 us: there every tile gets a workgroup (27 + 18 us instead of 40 + 99 + 55 on that view; on 8160 tiles of 400 to
     // 900 entries the workgroup kernels lose, 315 against 173 us: 1536 tiles resident instead of 4096).  policy: 0 = by tile count,
-    // 1 = workgroups, 2 = waves.
+    // 1 = workgroups, 2 = waves, 3 = waves with the spans of 513 .. 1024 entries left to the workgroup kernel behind (what 0 and 2 do
+    // by themselves in a frame whose AVERAGE span is short: see below).
     static const int env_policy = getenv("GS2M_TS_POLICY") ? atoi(getenv("GS2M_TS_POLICY")) : 0;  // (experiments)
     const int set_policy = g_ts_policy.load(std::memory_order_relaxed), policy = set_policy != 0 ? set_policy : env_policy;
-    const bool waves = policy == 2 || (policy == 0 && tiles >= 2560);
+    const bool waves = policy == 2 || policy == 3 || (policy == 0 && tiles >= 2560);
+    // Spans of 513 .. 1024 entries under the wave policy: a kernel of their own, one wave per tile with 16 elements per lane -- launched
+    // over ALL tiles, 5.4 us of dispatch when it finds nothing -- where they are common (an average span above 400: at C5's 660 every
+    // tile is one); in a frame of short spans (the bench cloud: 332 on average, none above 512) the few that may exist go to the
+    // workgroup kernel that takes the spans beyond 1024 anyway, which leaves at once when there is neither.
+    const bool mid_own_kernel = policy != 3 && (R == SIZE_MAX || R > (size_t)400 * tiles);
     const unsigned wg_grid = grid < 2048u ? grid : 2048u;  // (both multiples of 8)
     if (waves) {
         tile_sort_wave_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount,
                                                   tiles_x, tiles_y, 512u, g.counters);
-        tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, g.counters);
+        if (mid_own_kernel)
+            tile_sort_wave16_kernel<<<grid, 64, 0, s>>>(im.ranges_raw, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, g.counters);
     } else {
         tile_sort_wg_kernel<4><<<wg_grid, 256, 0, s>>>(im.ranges_raw, im.ranges, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA, b.qlist, b.qrow,
-                                                       im.qcount, tiles_x, tiles_y, grid, g.counters);
+                                                       im.qcount, tiles_x, tiles_y, grid, g.counters, 0);
     }
     // spans of more than 1024 entries: none on the bench scenes (the kernel in front says so: the workgroups leave at once)
     tile_sort_wg_kernel<16><<<wg_grid < 768u ? wg_grid : 768u /* three workgroups per CU: all resident at once */, 256, 0, s>>>(im.ranges_raw, nullptr, b.slot_sorted, b.e_rec, g.wave_rowbase, b.point_list, b.sort_valA,
-                                                                             b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid, g.counters);
+                                                                             b.qlist, b.qrow, im.qcount, tiles_x, tiles_y, grid, g.counters, waves && !mid_own_kernel ? 1 : 0);
 }

@@ -283,7 +283,9 @@ int gs2m_set_sort_tickets(int on);
 
 /* Which kernels put a tile's span into (depth, id) order (csrc/tile_sort.hip).  0 (default): by the number of tiles -- a frame of at
  * least 2560 tiles gives every tile one wave (spans of up to 1024 entries), a smaller frame gives every tile a workgroup; 1: workgroups
- * whatever the frame; 2: waves whatever the frame.  Spans of more than 1024 entries go to a workgroup in every setting.  Same results. */
+ * whatever the frame; 2: waves whatever the frame; 3: waves, with the spans of 513 .. 1024 entries left to the workgroup kernel that
+ * takes the longer ones (what 0 and 2 choose by themselves when a frame's average span is at most 400 entries).  Spans of more than
+ * 1024 entries go to a workgroup in every setting.  Same results. */
 int gs2m_set_tile_sort_policy(int policy);
 
 /* A ready-made gs2m_alloc_fn for callers that want the binning buffer (sized only after the forward's one host wait)

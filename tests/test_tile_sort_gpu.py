@@ -9,9 +9,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["auto", "workgroups", "waves"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "workgroups", "waves", "waves-mid-by-workgroup"], autouse=True)
 def policy(request):
-    """every arrangement of who sorts which span (gs2m_set_tile_sort_policy): by tile count; a workgroup per tile; a wave per tile"""
+    """every arrangement of who sorts which span (gs2m_set_tile_sort_policy): by tile count; a workgroup per tile; a wave per tile;
+    a wave per tile with the spans of 513 .. 1024 entries left to the workgroup kernel (a frame of short spans on average)"""
     import gs2m_native
     gs2m_native.set_tile_sort_policy(request.param)
     yield request.param
