@@ -291,7 +291,9 @@ def set_sort_tickets(on):
 
 
 def set_tile_sort_policy(policy):
-    """0: by tile count (default); 1: a workgroup per tile; 2: a wave per tile (spans of up to 1024 entries)."""
+    """0: by tile count (default); 1: a workgroup per tile; 2: a wave per tile (spans of up to 1024 entries); 3: a wave per tile, the
+    spans of 513 .. 1024 entries left to the workgroup kernel that takes the longer ones (0 and 2 choose that by themselves in a frame
+    whose average span is at most 400 entries)."""
     check(lib().gs2m_set_tile_sort_policy(int(policy)), "gs2m_set_tile_sort_policy")
 
 
